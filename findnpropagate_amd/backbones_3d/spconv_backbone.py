@@ -1,0 +1,388 @@
+"""VoxelResBackBone8x / VoxelBackBone8x on the MI355X sparse-conv kernels.
+
+Mirrors pcdet/models/backbones_3d/spconv_backbone.py: same constructor signature, module tree
+(hence the same state_dict keys: 'conv_input.0.weight', 'conv1.0.conv1.weight',
+'conv2.0.0.weight', '...bn1.running_mean', ...), same `forward(batch_dict)` contract
+(:243-295).  Two execution paths:
+
+  * module path  — module by module through findnpropagate_amd.spconv (unfused BN/ReLU in torch,
+    one host sync per strided conv, like spconv itself).  Used when `self.training`.
+  * fused path   — eval mode.  One sync-free stream of HIP launches for the whole backbone:
+    rank-grid rulebooks, implicit-GEMM convs with BatchNorm(eval)+residual+ReLU folded into
+    the epilogue, bf16 storage / fp32 accumulate on MFMA (or all-f32 validation mode), a
+    single host sync at the end to size the returned tensors.  `forward_points` additionally
+    fuses voxelisation + MeanVFE in front (points never leave the device).
+"""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import sparse as S
+from .. import spconv
+
+
+def replace_feature(out, new_features):
+    """pcdet/utils/spconv_utils.py:32-38."""
+    return out.replace_feature(new_features)
+
+
+def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0,
+                   conv_type='subm', norm_fn=None):
+    """spconv_backbone.py:8-27."""
+    if conv_type == 'subm':
+        conv = spconv.SubMConv3d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key)
+    elif conv_type == 'spconv':
+        conv = spconv.SparseConv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                   bias=False, indice_key=indice_key)
+    else:
+        raise NotImplementedError
+    return spconv.SparseSequential(conv, norm_fn(out_channels), nn.ReLU())
+
+
+class SparseBasicBlock(spconv.SparseModule):
+    """spconv_backbone.py:30-67."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, bias=None, norm_fn=None, downsample=None, indice_key=None):
+        super().__init__()
+        assert norm_fn is not None
+        if bias is None:
+            bias = norm_fn is not None
+        self.conv1 = spconv.SubMConv3d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=bias,
+                                       indice_key=indice_key)
+        self.bn1 = norm_fn(planes)
+        self.relu = nn.ReLU()
+        self.conv2 = spconv.SubMConv3d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=bias,
+                                       indice_key=indice_key)
+        self.bn2 = norm_fn(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = self.conv1(x)
+        out = replace_feature(out, self.bn1(out.features))
+        out = replace_feature(out, self.relu(out.features))
+        out = self.conv2(out)
+        out = replace_feature(out, self.bn2(out.features))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out = replace_feature(out, out.features + identity.features)
+        out = replace_feature(out, self.relu(out.features))
+        return out
+
+
+def _cfg_get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    if hasattr(cfg, "get"):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+class _BackboneBase(nn.Module):
+    def _common_init(self, model_cfg, grid_size):
+        self.model_cfg = model_cfg
+        self.sparse_shape = [int(v) for v in (list(grid_size[::-1]))]
+        self.sparse_shape[0] += 1  # grid_size[::-1] + [1, 0, 0], spconv_backbone.py:191
+        # 'bf16' (MFMA, default) or 'fp32' (validation mode, VALU fma chains)
+        self.fnp_dtype = str(_cfg_get(model_cfg, 'FNP_DTYPE', 'bf16')).lower()
+
+    def _pack_outputs(self, batch_dict, out, x1, x2, x3, x4):
+        batch_dict.update({'encoded_spconv_tensor': out, 'encoded_spconv_tensor_stride': 8})
+        batch_dict.update({'multi_scale_3d_features': {'x_conv1': x1, 'x_conv2': x2, 'x_conv3': x3, 'x_conv4': x4}})
+        batch_dict.update({'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}})
+        return batch_dict
+
+
+class VoxelBackBone8x(_BackboneBase):
+    """spconv_backbone.py:70-181 (plain variant; module path only)."""
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self._common_init(model_cfg, grid_size)
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, 16, 3, padding=1, bias=False, indice_key='subm1'), norm_fn(16), nn.ReLU())
+        block = post_act_block
+        self.conv1 = spconv.SparseSequential(block(16, 16, 3, norm_fn=norm_fn, padding=1, indice_key='subm1'))
+        self.conv2 = spconv.SparseSequential(
+            block(16, 32, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key='spconv2', conv_type='spconv'),
+            block(32, 32, 3, norm_fn=norm_fn, padding=1, indice_key='subm2'),
+            block(32, 32, 3, norm_fn=norm_fn, padding=1, indice_key='subm2'))
+        self.conv3 = spconv.SparseSequential(
+            block(32, 64, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key='spconv3', conv_type='spconv'),
+            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key='subm3'),
+            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key='subm3'))
+        self.conv4 = spconv.SparseSequential(
+            block(64, 64, 3, norm_fn=norm_fn, stride=2, padding=(0, 1, 1), indice_key='spconv4', conv_type='spconv'),
+            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key='subm4'),
+            block(64, 64, 3, norm_fn=norm_fn, padding=1, indice_key='subm4'))
+        last_pad = _cfg_get(model_cfg, 'last_pad', 0)
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv3d(64, 128, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                                indice_key='spconv_down2'), norm_fn(128), nn.ReLU())
+        self.num_point_features = 128
+        self.backbone_channels = {'x_conv1': 16, 'x_conv2': 32, 'x_conv3': 64, 'x_conv4': 64}
+
+    def forward(self, batch_dict):
+        return _module_forward(self, batch_dict)
+
+
+def _module_forward(self, batch_dict):
+    voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
+    batch_size = batch_dict['batch_size']
+    act = torch.float32 if self.fnp_dtype == 'fp32' else torch.bfloat16
+    x_in = spconv.SparseConvTensor(features=voxel_features.float().contiguous(), indices=voxel_coords.int().contiguous(),
+                                   spatial_shape=self.sparse_shape, batch_size=batch_size)
+    # first conv consumes f32 point features; activations then live in `act`
+    conv0 = self.conv_input[0]
+    x = conv0(x_in)
+    x = x.replace_feature(self.conv_input[2](self.conv_input[1](x.features.float())).to(act))
+    x_conv1 = _seq_forward(self.conv1, x, act)
+    x_conv2 = _seq_forward(self.conv2, x_conv1, act)
+    x_conv3 = _seq_forward(self.conv3, x_conv2, act)
+    x_conv4 = _seq_forward(self.conv4, x_conv3, act)
+    out = _seq_forward(self.conv_out, x_conv4, act)
+    return self._pack_outputs(batch_dict, out, x_conv1, x_conv2, x_conv3, x_conv4)
+
+
+def _seq_forward(seq, x, act):
+    """SparseSequential forward with dense modules evaluated in f32 and stored back in `act`."""
+    for m in seq._modules.values():
+        if isinstance(m, spconv.SparseSequential):
+            x = _seq_forward(m, x, act)
+        elif isinstance(m, SparseBasicBlock):
+            identity = x
+            o = m.conv1(x)
+            o = o.replace_feature(m.relu(m.bn1(o.features.float())).to(act))
+            o = m.conv2(o)
+            f = m.bn2(o.features.float()).to(act)
+            f = (f.float() + identity.features.float())
+            x = o.replace_feature(m.relu(f).to(act))
+        elif isinstance(m, spconv.SparseModule):
+            x = m(x)
+        else:
+            x = x.replace_feature(m(x.features.float()).to(act))
+    return x
+
+
+class VoxelResBackBone8x(_BackboneBase):
+    """spconv_backbone.py:184-295."""
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self._common_init(model_cfg, grid_size)
+        use_bias = _cfg_get(model_cfg, 'USE_BIAS', None)
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.input_channels = input_channels
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, 16, 3, padding=1, bias=False, indice_key='subm1'), norm_fn(16), nn.ReLU())
+        block = post_act_block
+        self.conv1 = spconv.SparseSequential(
+            SparseBasicBlock(16, 16, bias=use_bias, norm_fn=norm_fn, indice_key='res1'),
+            SparseBasicBlock(16, 16, bias=use_bias, norm_fn=norm_fn, indice_key='res1'))
+        self.conv2 = spconv.SparseSequential(
+            block(16, 32, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key='spconv2', conv_type='spconv'),
+            SparseBasicBlock(32, 32, bias=use_bias, norm_fn=norm_fn, indice_key='res2'),
+            SparseBasicBlock(32, 32, bias=use_bias, norm_fn=norm_fn, indice_key='res2'))
+        self.conv3 = spconv.SparseSequential(
+            block(32, 64, 3, norm_fn=norm_fn, stride=2, padding=1, indice_key='spconv3', conv_type='spconv'),
+            SparseBasicBlock(64, 64, bias=use_bias, norm_fn=norm_fn, indice_key='res3'),
+            SparseBasicBlock(64, 64, bias=use_bias, norm_fn=norm_fn, indice_key='res3'))
+        self.conv4 = spconv.SparseSequential(
+            block(64, 128, 3, norm_fn=norm_fn, stride=2, padding=(0, 1, 1), indice_key='spconv4', conv_type='spconv'),
+            SparseBasicBlock(128, 128, bias=use_bias, norm_fn=norm_fn, indice_key='res4'),
+            SparseBasicBlock(128, 128, bias=use_bias, norm_fn=norm_fn, indice_key='res4'))
+        last_pad = _cfg_get(model_cfg, 'last_pad', 0)
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv3d(128, 128, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                                indice_key='spconv_down2'), norm_fn(128), nn.ReLU())
+        self.num_point_features = 128
+        self.backbone_channels = {'x_conv1': 16, 'x_conv2': 32, 'x_conv3': 64, 'x_conv4': 128}
+        self._engine = None
+
+    # ---------------------------------------------------------------- reference contract
+    def forward(self, batch_dict):
+        """batch_dict: batch_size, voxel_features (M,C), voxel_coords (M,4) [b,z,y,x] ->
+        encoded_spconv_tensor (+stride 8), multi_scale_3d_features, multi_scale_3d_strides."""
+        if self.training:
+            return _module_forward(self, batch_dict)
+        feats = batch_dict['voxel_features']
+        coords = batch_dict['voxel_coords']
+        batch_size = int(batch_dict['batch_size'])
+        dev = feats.device
+        feats = feats.detach().float().contiguous()
+        coords = coords.int().contiguous()
+        n = S.device_scalar(feats.shape[0], dev)
+        res = self.engine().run(feats, coords, n, batch_size, grid1=None)
+        return self._pack_outputs(batch_dict, res['out'], res['x_conv1'], res['x_conv2'], res['x_conv3'], res['x_conv4'])
+
+    # ---------------------------------------------------------------- fused device path
+    def engine(self):
+        if self._engine is None:
+            self._engine = FusedResBackbone(self)
+        return self._engine
+
+    def forward_points(self, points, batch_offsets, batch_size, voxel_cfg, sync=True):
+        """points (N,C) f32 device (scenes concatenated), batch_offsets (B+1,) int32 device.
+        Voxelise + MeanVFE + backbone without leaving the device.  Returns the same dict of
+        SparseConvTensors as forward() produces plus 'voxel_coords', 'voxel_num_points',
+        'voxel_features'."""
+        return self.engine().run_points(points, batch_offsets, batch_size, voxel_cfg, sync=sync)
+
+
+class FusedResBackbone:
+    """Sync-free executor of VoxelResBackBone8x in eval mode (see module docstring)."""
+
+    def __init__(self, module: VoxelResBackBone8x):
+        self.m = module
+        self.act = torch.float32 if module.fnp_dtype == 'fp32' else torch.bfloat16
+        self._prep = None
+        self._prep_key = None
+        self._grids = {}
+        # capacity of stage l (l = 2..5) as a multiple of the stage-1 capacity; grown on overflow
+        self.cap_factor = [3.0, 2.0, 1.0, 1.0]
+        self._vox_ws = None
+
+    # ---- weights --------------------------------------------------------------------------
+    def _fold(self, conv, bn, dtype):
+        w = conv.packed_weight(dtype)
+        inv = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+        scale = (bn.weight.detach().float() * inv).contiguous()
+        shift = (bn.bias.detach().float() - bn.running_mean.detach().float() * scale)
+        if conv.bias is not None:
+            shift = shift + conv.bias.detach().float() * scale
+        return w, scale, shift.contiguous()
+
+    def prepare(self):
+        m = self.m
+        key = tuple((p.data_ptr(), p._version) for p in list(m.parameters()) + list(m.buffers())) + (self.act,)
+        if self._prep_key == key:
+            return self._prep
+        P = {}
+        P['in'] = self._fold(m.conv_input[0], m.conv_input[1], torch.float32)  # f32 features in
+        for name, seq, first in (('1', m.conv1, 0), ('2', m.conv2, 1), ('3', m.conv3, 1), ('4', m.conv4, 1)):
+            if first:
+                P['down' + name] = self._fold(seq[0][0], seq[0][1], self.act)
+            blocks = []
+            for blk in list(seq._modules.values())[first:]:
+                blocks.append((self._fold(blk.conv1, blk.bn1, self.act), self._fold(blk.conv2, blk.bn2, self.act)))
+            P['blocks' + name] = blocks
+        P['out'] = self._fold(m.conv_out[0], m.conv_out[1], self.act)
+        self._prep, self._prep_key = P, key
+        return P
+
+    # ---- persistent rank grids (zero between calls; cleared sparsely after use) -----------
+    def _stage_shapes(self):
+        m = self.m
+        shapes = [list(m.sparse_shape)]
+        for conv in (m.conv2[0][0], m.conv3[0][0], m.conv4[0][0], m.conv_out[0]):
+            s = shapes[-1]
+            shapes.append([(s[d] + 2 * conv.padding[d] - conv.kernel_size[d]) // conv.stride[d] + 1 for d in range(3)])
+        return shapes
+
+    def _get_grids(self, batch_size, device):
+        key = (batch_size, str(device))
+        g = self._grids.get(key)
+        if g is None:
+            g = [S.alloc_grid(batch_size, shp, device) for shp in self._stage_shapes()]
+            self._grids[key] = g
+        return g
+
+    # ---- execution ------------------------------------------------------------------------
+    def run_points(self, points, batch_offsets, batch_size, voxel_cfg, sync=True):
+        grids = self._get_grids(batch_size, points.device)
+        vox = S.voxelize(points, batch_offsets, batch_size, voxel_cfg, grid=grids[0], workspace=self._vox_ws)
+        self._vox_ws = vox['workspace']
+        res = self.run(vox['mean'], vox['coords'], vox['n'], batch_size, grid1=grids[0], sync=sync)
+        res['voxel_coords'], res['voxel_num_points'], res['voxel_features'] = vox['coords'], vox['num_points'], vox['mean']
+        if sync:
+            n1 = res['counts'][0]
+            res['voxel_coords'] = vox['coords'][:n1]
+            res['voxel_num_points'] = vox['num_points'][:n1]
+            res['voxel_features'] = vox['mean'][:n1]
+        return res
+
+    def run(self, feats, indices, n1, batch_size, grid1=None, sync=True):
+        """feats (cap1,Cin) f32, indices (cap1,4) i32, n1 (1,) i32 device."""
+        while True:
+            res = self._run_once(feats, indices, n1, batch_size, grid1, sync)
+            if res is not None:
+                return res
+            # overflow: capacities were grown and grids cleared; rebuild grid1 from the indices
+            grid1 = None
+
+    def _run_once(self, feats, indices, n1, batch_size, grid1, sync):
+        m, P, act = self.m, self.prepare(), self.act
+        dev = feats.device
+        grids = self._get_grids(batch_size, dev)
+        cap1 = max(indices.shape[0], 1)
+        if grid1 is None:
+            grid1 = S.build_grid(indices, n1, batch_size, m.sparse_shape, keep_order=True, grid=_with_perm(grids[0], cap1, dev))
+        caps = [cap1] + [max(256, int(cap1 * f)) for f in self.cap_factor]
+
+        def conv(x, prm, rb, n, residual=None, out_dtype=act):
+            w, sc, sh = prm
+            return S.conv_forward(x, w, rb, n, out_dtype=out_dtype, scale=sc, shift=sh, residual=residual, relu=True)
+
+        def blocks(x, rb, n, prms):
+            for p1, p2 in prms:
+                t = conv(x, p1, rb, n)
+                x = conv(t, p2, rb, n, residual=x)
+            return x
+
+        # stage 1 (conv_input + conv1): one SubM rulebook serves indice_keys 'subm1' and 'res1'
+        rb1 = S.rulebook_subm(indices, n1, grid1, 3)
+        x = conv(feats, P['in'], rb1, n1)
+        x1 = blocks(x, rb1, n1, P['blocks1'])
+        stage = [(x1, indices, n1, grid1)]
+        x_prev, idx_prev, n_prev, g_prev = x1, indices, n1, grid1
+        for li, (down_key, blk_key, dconv) in enumerate((('down2', 'blocks2', m.conv2[0][0]),
+                                                          ('down3', 'blocks3', m.conv3[0][0]),
+                                                          ('down4', 'blocks4', m.conv4[0][0]))):
+            rbs = S.rulebook_strided(idx_prev, n_prev, g_prev, dconv.kernel_size, dconv.stride, dconv.padding,
+                                     caps[li + 1], out_grid=grids[li + 1])
+            x = conv(x_prev, P[down_key], rbs, rbs.out_n)
+            rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3)
+            x = blocks(x, rb, rbs.out_n, P[blk_key])
+            stage.append((x, rbs.out_indices, rbs.out_n, rbs.out_grid))
+            x_prev, idx_prev, n_prev, g_prev = x, rbs.out_indices, rbs.out_n, rbs.out_grid
+        oconv = m.conv_out[0]
+        rbo = S.rulebook_strided(idx_prev, n_prev, g_prev, oconv.kernel_size, oconv.stride, oconv.padding, caps[4],
+                                 out_grid=grids[4])
+        xo = conv(x_prev, P['out'], rbo, rbo.out_n)
+        stage.append((xo, rbo.out_indices, rbo.out_n, rbo.out_grid))
+
+        # leave every persistent grid zeroed for the next call (O(rows) sparse clear)
+        for (_, idx, n, g) in stage:
+            S.clear_grid(g, idx, n)
+
+        shapes = self._stage_shapes()
+        if not sync:
+            return {'stages': stage, 'shapes': shapes, 'caps': caps, 'batch_size': batch_size}
+        counts = torch.cat([s[2] for s in stage]).cpu().tolist()   # the one host sync
+        overflow = False
+        for l in range(1, 5):
+            if counts[l] > caps[l]:
+                self.cap_factor[l - 1] = max(self.cap_factor[l - 1] * 2.0, counts[l] * 1.25 / cap1)
+                overflow = True
+        if overflow:
+            # rows beyond a capacity were never emitted, so the sparse clear missed their cells:
+            # wipe the persistent grids before the retry with larger buffers
+            for g in grids:
+                g.bits.zero_()
+            return None
+        tensors = []
+        for l, (x, idx, n, g) in enumerate(stage):
+            c = counts[l]
+            tensors.append(spconv.SparseConvTensor(x[:c], idx[:c], shapes[l], batch_size, n_dev=n))
+        return {'x_conv1': tensors[0], 'x_conv2': tensors[1], 'x_conv3': tensors[2], 'x_conv4': tensors[3],
+                'out': tensors[4], 'counts': counts}
+
+
+def _with_perm(grid, cap, device):
+    if grid.perm is None or grid.perm.numel() < cap:
+        grid.perm = torch.empty((cap,), dtype=torch.int32, device=device)
+    return grid

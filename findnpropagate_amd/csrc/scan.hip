@@ -1,0 +1,127 @@
+// Device-wide exclusive scans (wave shuffles + LDS) used for order-preserving compaction:
+// popcount prefixes of the rank-grid occupancy words and first-point flags of the voxeliser.
+// Three launches: tile reduce -> scan of tile sums (one workgroup) -> tile scan + offset.
+#include "rankgrid.cuh"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kItems = fnp_scan::kTile / kThreads;  // 16
+
+struct LoadPopc {
+    const unsigned long long *p;
+    __device__ __forceinline__ unsigned operator()(long long i) const { return (unsigned)__popcll(p[i]); }
+};
+struct LoadInt {
+    const int *p;
+    __device__ __forceinline__ unsigned operator()(long long i) const { return (unsigned)p[i]; }
+};
+
+__device__ __forceinline__ unsigned wave_inclusive(unsigned v) {
+    const int lane = fnp_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across the 256-thread workgroup; returns the
+// exclusive prefix, *total receives the workgroup sum.  wsum: 4 LDS words.
+__device__ __forceinline__ unsigned block_exclusive(unsigned v, unsigned *wsum, unsigned &total) {
+    const int wave = threadIdx.x >> 6, lane = fnp_lane();
+    const unsigned inc = wave_inclusive(v);
+    __syncthreads();  // protect wsum reuse
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned off = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; ++w) {
+        const unsigned s = wsum[w];
+        if (w < wave) off += s;
+    }
+    total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return off + inc - v;
+}
+
+template <class L>
+__global__ __launch_bounds__(kThreads) void tile_reduce_kernel(L load, long long n, unsigned *__restrict__ partial) {
+    __shared__ unsigned wsum[4];
+    const long long base = (long long)blockIdx.x * fnp_scan::kTile;
+    unsigned s = 0;
+#pragma unroll
+    for (int j = 0; j < kItems; ++j) {
+        const long long i = base + j * kThreads + threadIdx.x;
+        if (i < n) s += load(i);
+    }
+    unsigned total;
+    block_exclusive(s, wsum, total);
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
+// one workgroup: in-place exclusive scan of the tile sums, grand total to *total.
+__global__ __launch_bounds__(kThreads) void partial_scan_kernel(unsigned *__restrict__ partial, int np,
+                                                                int *__restrict__ total_out) {
+    __shared__ unsigned wsum[4];
+    unsigned carry = 0;
+    for (int base = 0; base < np; base += kThreads) {
+        const int i = base + threadIdx.x;
+        const unsigned v = i < np ? partial[i] : 0u;
+        unsigned total;
+        const unsigned ex = block_exclusive(v, wsum, total);
+        if (i < np) partial[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = (int)carry;
+}
+
+template <class L, class TOut>
+__global__ __launch_bounds__(kThreads) void tile_scan_kernel(L load, long long n, const unsigned *__restrict__ partial,
+                                                             TOut *__restrict__ out) {
+    __shared__ unsigned wsum[4];
+    const long long base = (long long)blockIdx.x * fnp_scan::kTile;
+    unsigned carry = partial[blockIdx.x];
+#pragma unroll 1
+    for (int j = 0; j < kItems; ++j) {
+        const long long i = base + j * kThreads + threadIdx.x;
+        const unsigned v = i < n ? load(i) : 0u;
+        unsigned total;
+        const unsigned ex = block_exclusive(v, wsum, total);
+        if (i < n) out[i] = (TOut)(carry + ex);
+        carry += total;
+    }
+}
+
+template <class L, class TOut>
+int run_scan(L load, long long n, TOut *out, int *total, void *ws, hipStream_t s) {
+    if (n < 0 || !total) return FNP_ERR_ARG;
+    if (n == 0) {
+        FNP_HIP_TRY(hipMemsetAsync(total, 0, sizeof(int), s));
+        return FNP_OK;
+    }
+    if (!out || !ws) return FNP_ERR_ARG;
+    const int tiles = fnp_divup(n, fnp_scan::kTile);
+    unsigned *partial = (unsigned *)ws;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tile_reduce_kernel<L>), dim3(tiles), dim3(kThreads), 0, s, load, n, partial);
+    FNP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(partial_scan_kernel, dim3(1), dim3(kThreads), 0, s, partial, tiles, total);
+    FNP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tile_scan_kernel<L, TOut>), dim3(tiles), dim3(kThreads), 0, s, load, n, partial, out);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+}  // namespace
+
+namespace fnp_scan {
+long long workspace_bytes(long long n) { return ((n + kTile - 1) / kTile + 1) * 4 + 64; }
+int popcount_u64(const unsigned long long *bits, long long n, unsigned *out, int *total, void *ws, hipStream_t s) {
+    return run_scan(LoadPopc{bits}, n, out, total, ws, s);
+}
+int int32(const int *in, long long n, int *out, int *total, void *ws, hipStream_t s) {
+    return run_scan(LoadInt{in}, n, out, total, ws, s);
+}
+}  // namespace fnp_scan
+
+extern "C" int64_t fnp_scan_workspace_bytes(int64_t n) { return fnp_scan::workspace_bytes(n); }

@@ -1,0 +1,329 @@
+// GPU voxelisation with the sequential semantics of spconv's Point2VoxelCPU3d.point_to_voxel
+// (call site pcdet/datasets/processor/data_processor.py:38-61; semantics SURVEY.md App. A.1)
+// fused with MeanVFE (pcdet/models/backbones_3d/vfe/mean_vfe.py:25-29).
+//
+// The reference is a single-threaded loop whose outputs depend on point order:
+//   voxel row order   = order of each voxel's first point,
+//   points per voxel  = the first max_points points of the voxel, in point order,
+//   max_voxels        = voxels whose first-come rank >= max_voxels are dropped (their points too).
+// Here the same result is produced in parallel, bit-exactly and deterministically:
+//   1. every point sets its cell's bit in the rank grid (atomicOr)             [mark]
+//   2. popcount scan -> rank of every occupied cell                            [scan.hip]
+//   3. every point bubble-inserts its index into its cell's sorted list of the max_points
+//      smallest point indices (chain of atomicMin; order independent)          [insert]
+//   4. flag "I am my cell's smallest index", scan in point order -> first-come rank
+//   5. per-scene max_voxels cut, then one pass per voxel writes coords, counts, the zero padded
+//      (M, max_points, C) block and the mean feature row                       [emit]
+// No sort, no hash probing, no floating-point atomics.
+#include "rankgrid.cuh"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kSentinel = 0x7f7f7f7f;  // memset(0x7f) pattern: larger than any point index
+constexpr int kMaxBatch = 1024;
+
+struct VoxWs {          // carve-up of the caller's workspace
+    long long *code;    // (N)   (block << 6) | bit, or -1
+    int *rank;          // (N)   sorted rank of the point's cell, or -1
+    int *flag;          // (N)   first-point flag, then exclusive scan (first-come rank)
+    int *top;           // (cap, max_points) smallest point indices per cell, ascending
+    int *cnt;           // (cap) points per cell
+    int *scene;         // (3*B + 4): fc_start[B+1], out_base[B+1], misc
+    int *n_sorted;      // (1)
+    int *n_first;       // (1)
+    void *scan_ws;
+};
+
+__host__ long long align_up(long long v) { return (v + 255) & ~255ll; }
+
+__host__ long long carve(VoxWs &w, char *base, long long n, int B, int cap, int maxp, long long nblk) {
+    long long off = 0;
+    auto take = [&](long long bytes) {
+        char *p = base ? base + off : nullptr;
+        off += align_up(bytes);
+        return p;
+    };
+    w.code = (long long *)take(8 * n);
+    w.rank = (int *)take(4 * n);
+    w.flag = (int *)take(4 * n);
+    w.top = (int *)take(4ll * cap * maxp);
+    w.cnt = (int *)take(4ll * cap);
+    w.scene = (int *)take(4ll * (3 * B + 8));
+    w.n_sorted = (int *)take(4);
+    w.n_first = (int *)take(4);
+    const long long m = nblk > n ? nblk : n;
+    w.scan_ws = take(fnp_scan::workspace_bytes(m));
+    return off;
+}
+
+__device__ __forceinline__ int batch_of(const int *__restrict__ off, int B, int i) {
+    int lo = 0, hi = B;  // off[lo] <= i < off[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kThreads) void vox_mark_kernel(const float *__restrict__ pts, int n, int C,
+                                                            const int *__restrict__ boff, int B, fnp_voxel_cfg cfg,
+                                                            RankGridDims g, unsigned long long *__restrict__ bits,
+                                                            long long *__restrict__ code) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float *p = pts + (size_t)i * C;
+    int c[3];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        // f32 subtract, f32 divide (IEEE, correctly rounded), floor -> int: same as the reference loop
+        const float q = (p[j] - cfg.range_min[j]) / cfg.voxel_size[j];
+        const float f = floorf(q);
+        ok = ok && (f >= 0.f) && (f < (float)cfg.grid[j]);
+        c[j] = (int)f;
+    }
+    long long cd = -1;
+    if (ok) {
+        const int b = batch_of(boff, B, i);
+        const long long blk = rg_block_of(g, b, c[2], c[1], c[0]);
+        const int bit = rg_bit_of(c[2], c[1], c[0]);
+        atomicOr(&bits[blk], 1ull << bit);
+        cd = (blk << 6) | bit;
+    }
+    code[i] = cd;
+}
+
+__global__ __launch_bounds__(kThreads) void vox_insert_kernel(int n, int maxp, int cap,
+                                                              const unsigned long long *__restrict__ bits,
+                                                              const unsigned *__restrict__ base,
+                                                              const long long *__restrict__ code,
+                                                              int *__restrict__ rank, int *__restrict__ top,
+                                                              int *__restrict__ cnt) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const long long cd = code[i];
+    int r = -1;
+    if (cd >= 0) {
+        const long long blk = cd >> 6;
+        const int bit = (int)(cd & 63);
+        r = (int)base[blk] + __popcll(bits[blk] & ((1ull << bit) - 1ull));
+        if (r >= cap) r = -1;  // cannot happen when cap >= n; defensive
+    }
+    rank[i] = r;
+    if (r < 0) return;
+    atomicAdd(&cnt[r], 1);
+    // bubble insert: slot j ends up holding the (j+1)-th smallest index whatever the interleaving
+    int carry = i;
+    int *slots = top + (size_t)r * maxp;
+    for (int j = 0; j < maxp; ++j) {
+        const int old = atomicMin(&slots[j], carry);
+        if (old == kSentinel) break;     // took an empty slot
+        carry = old > carry ? old : carry;  // keep pushing the larger one down
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void vox_flag_kernel(int n, int maxp, const int *__restrict__ rank,
+                                                            const int *__restrict__ top, int *__restrict__ flag) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const int r = rank[i];
+    flag[i] = (r >= 0 && top[(size_t)r * maxp] == i) ? 1 : 0;
+}
+
+// one workgroup: per-scene first-come starts and output bases after the max_voxels cut.
+__global__ void vox_scene_kernel(const int *__restrict__ boff, int B, int n, const int *__restrict__ fc,
+                                 const int *__restrict__ n_first, int max_voxels, int cap,
+                                 int *__restrict__ scene, int *__restrict__ n_voxels) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int *fc_start = scene;           // (B+1)
+    int *out_base = scene + (B + 1); // (B+1)
+    const int total = *n_first;
+    for (int b = 0; b <= B; ++b) {
+        const int o = boff[b];
+        fc_start[b] = (o < n) ? fc[o] : total;
+    }
+    int acc = 0;
+    for (int b = 0; b < B; ++b) {
+        out_base[b] = acc;
+        int c = fc_start[b + 1] - fc_start[b];
+        if (c > max_voxels) c = max_voxels;
+        acc += c;
+    }
+    out_base[B] = acc;
+    *n_voxels = acc;  // true count; consumers clamp to their capacity
+}
+
+__global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restrict__ pts, int C, int maxp,
+                                                            const int *__restrict__ boff, int B, int max_voxels,
+                                                            RankGridDims g, const long long *__restrict__ code,
+                                                            const int *__restrict__ top, const int *__restrict__ cnt,
+                                                            const int *__restrict__ fc, const int *__restrict__ scene,
+                                                            const int *__restrict__ n_sorted, int cap,
+                                                            int *__restrict__ perm, int *__restrict__ coords,
+                                                            int *__restrict__ num_points, float *__restrict__ mean,
+                                                            float *__restrict__ voxels) {
+    const int ns = min(*n_sorted, cap);
+    const int *fc_start = scene;
+    const int *out_base = scene + (B + 1);
+    for (int r = blockIdx.x * kThreads + threadIdx.x; r < ns; r += gridDim.x * kThreads) {
+        const int *slots = top + (size_t)r * maxp;
+        const int p0 = slots[0];
+        const int b = batch_of(boff, B, p0);
+        const int srank = fc[p0] - fc_start[b];
+        if (srank >= max_voxels) {
+            perm[r] = -1;
+            continue;
+        }
+        const int id = out_base[b] + srank;
+        if (id >= cap) {
+            perm[r] = -1;
+            continue;
+        }
+        perm[r] = id;
+        const long long cd = code[p0];
+        int bb, z, y, x;
+        rg_decode(g, cd >> 6, (int)(cd & 63), bb, z, y, x);
+        reinterpret_cast<int4 *>(coords)[id] = make_int4(bb, z, y, x);
+        int np = cnt[r];
+        if (np > maxp) np = maxp;
+        num_points[id] = np;
+        const float norm = (float)(np < 1 ? 1 : np);
+        for (int c = 0; c < C; ++c) {
+            float s = 0.f;
+            for (int j = 0; j < np; ++j) s += pts[(size_t)slots[j] * C + c];  // slot order, like sum(dim=1)
+            mean[(size_t)id * C + c] = s / norm;
+        }
+        if (voxels) {
+            float *v = voxels + (size_t)id * maxp * C;
+            for (int j = 0; j < maxp; ++j)
+                for (int c = 0; c < C; ++c) v[j * C + c] = j < np ? pts[(size_t)slots[j] * C + c] : 0.f;
+        }
+    }
+}
+
+// ---- rank grid from an explicit coordinate list ---------------------------------------------
+__global__ __launch_bounds__(kThreads) void rg_mark_coords_kernel(const int *__restrict__ coords,
+                                                                  const int *__restrict__ n_rows, int cap,
+                                                                  RankGridDims g, unsigned long long *__restrict__ bits,
+                                                                  int clear) {
+    const int n = min(*n_rows, cap);
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+        if (c.x < 0 || c.x >= g.B || c.y < 0 || c.y >= g.D || c.z < 0 || c.z >= g.H || c.w < 0 || c.w >= g.W) continue;
+        const long long blk = rg_block_of(g, c.x, c.y, c.z, c.w);
+        if (clear) bits[blk] = 0ull;
+        else atomicOr(&bits[blk], 1ull << rg_bit_of(c.y, c.z, c.w));
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void rg_perm_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows,
+                                                           int cap, RankGridDims g,
+                                                           const unsigned long long *__restrict__ bits,
+                                                           const unsigned *__restrict__ base, int *__restrict__ perm) {
+    const int n = min(*n_rows, cap);
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+        if (c.x < 0 || c.x >= g.B || c.y < 0 || c.y >= g.D || c.z < 0 || c.z >= g.H || c.w < 0 || c.w >= g.W) continue;
+        const int r = rg_lookup(g, bits, base, nullptr, c.x, c.y, c.z, c.w);
+        if (r >= 0 && r < cap) perm[r] = i;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t fnp_rankgrid_num_blocks(int B, int D, int H, int W) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    return fnp_num_blocks(fnp_make_dims(B, D, H, W));
+}
+
+extern "C" int64_t fnp_voxelize_workspace_bytes(int64_t n_points, int B, const fnp_voxel_cfg *cfg) {
+    if (!cfg || n_points < 0 || B <= 0) return FNP_ERR_ARG;
+    VoxWs w;
+    const RankGridDims g = fnp_make_dims(B, cfg->grid[2], cfg->grid[1], cfg->grid[0]);
+    const long long n = n_points > 0 ? n_points : 1;
+    return carve(w, nullptr, n, B, (int)n, cfg->max_points, fnp_num_blocks(g));
+}
+
+extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets, int B, const fnp_voxel_cfg *cfg,
+                            uint64_t *grid_bits, uint32_t *grid_base, int *grid_perm, void *workspace,
+                            int64_t workspace_bytes, int *coords, int *num_points, float *mean_feats, float *voxels,
+                            int *n_voxels, int cap, fnp_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!cfg || n < 0 || B <= 0 || B > kMaxBatch || cap <= 0 || !n_voxels) return FNP_ERR_ARG;
+    if (cfg->num_features < 3 || cfg->max_points <= 0 || cfg->max_points > 64 || cfg->max_voxels <= 0) return FNP_ERR_ARG;
+    if (n == 0) {
+        FNP_HIP_TRY(hipMemsetAsync(n_voxels, 0, sizeof(int), s));
+        return FNP_OK;
+    }
+    if (!points || !batch_offsets || !grid_bits || !grid_base || !grid_perm || !workspace || !coords || !num_points ||
+        !mean_feats)
+        return FNP_ERR_ARG;
+    if (cap < n) return FNP_ERR_ARG;  // every point could open a voxel
+    const RankGridDims g = fnp_make_dims(B, cfg->grid[2], cfg->grid[1], cfg->grid[0]);
+    const long long nblk = fnp_num_blocks(g);
+    VoxWs w;
+    const long long need = carve(w, (char *)workspace, n, B, n, cfg->max_points, nblk);
+    if (need > workspace_bytes) return FNP_ERR_WORKSPACE;
+    const int maxp = cfg->max_points, C = cfg->num_features;
+    const int pgrid = fnp_divup(n, kThreads);
+
+    FNP_HIP_TRY(hipMemsetAsync(w.top, 0x7f, sizeof(int) * (size_t)n * maxp, s));
+    FNP_HIP_TRY(hipMemsetAsync(w.cnt, 0, sizeof(int) * (size_t)n, s));
+    hipLaunchKernelGGL(vox_mark_kernel, dim3(pgrid), dim3(kThreads), 0, s, points, n, C, batch_offsets, B, *cfg, g,
+                       (unsigned long long *)grid_bits, w.code);
+    FNP_LAUNCH_CHECK();
+    int rc = fnp_scan::popcount_u64((const unsigned long long *)grid_bits, nblk, grid_base, w.n_sorted, w.scan_ws, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vox_insert_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, n,
+                       (const unsigned long long *)grid_bits, grid_base, w.code, w.rank, w.top, w.cnt);
+    FNP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vox_flag_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, w.rank, w.top, w.flag);
+    FNP_LAUNCH_CHECK();
+    rc = fnp_scan::int32(w.flag, n, w.flag, w.n_first, w.scan_ws, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(vox_scene_kernel, dim3(1), dim3(64), 0, s, batch_offsets, B, n, w.flag, w.n_first,
+                       cfg->max_voxels, cap, w.scene, n_voxels);
+    FNP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vox_emit_kernel, dim3(fnp_grid_for(n, kThreads)), dim3(kThreads), 0, s, points, C, maxp,
+                       batch_offsets, B, cfg->max_voxels, g, w.code, w.top, w.cnt, w.flag, w.scene, w.n_sorted, n,
+                       grid_perm, coords, num_points, mean_feats, voxels);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+extern "C" int fnp_rankgrid_build(const int *coords, const int *n_rows, int cap, int B, int D, int H, int W,
+                                  uint64_t *grid_bits, uint32_t *grid_base, int *grid_perm, void *workspace,
+                                  int64_t workspace_bytes, fnp_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!coords || !n_rows || cap <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || !grid_bits || !grid_base || !workspace)
+        return FNP_ERR_ARG;
+    const RankGridDims g = fnp_make_dims(B, D, H, W);
+    const long long nblk = fnp_num_blocks(g);
+    if (fnp_scan::workspace_bytes(nblk) + 256 > workspace_bytes) return FNP_ERR_WORKSPACE;
+    int *total = (int *)workspace;
+    void *scan_ws = (char *)workspace + 256;
+    const int grid = fnp_grid_for(cap, kThreads);
+    hipLaunchKernelGGL(rg_mark_coords_kernel, dim3(grid), dim3(kThreads), 0, s, coords, n_rows, cap, g,
+                       (unsigned long long *)grid_bits, 0);
+    FNP_LAUNCH_CHECK();
+    int rc = fnp_scan::popcount_u64((const unsigned long long *)grid_bits, nblk, grid_base, total, scan_ws, s);
+    if (rc) return rc;
+    if (grid_perm) {
+        FNP_HIP_TRY(hipMemsetAsync(grid_perm, 0xff, sizeof(int) * (size_t)cap, s));
+        hipLaunchKernelGGL(rg_perm_kernel, dim3(grid), dim3(kThreads), 0, s, coords, n_rows, cap, g,
+                           (const unsigned long long *)grid_bits, grid_base, grid_perm);
+        FNP_LAUNCH_CHECK();
+    }
+    return FNP_OK;
+}
+
+extern "C" int fnp_rankgrid_clear(const int *coords, const int *n_rows, int cap, int B, int D, int H, int W,
+                                  uint64_t *grid_bits, fnp_stream_t stream) {
+    if (!coords || !n_rows || cap <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || !grid_bits) return FNP_ERR_ARG;
+    const RankGridDims g = fnp_make_dims(B, D, H, W);
+    hipLaunchKernelGGL(rg_mark_coords_kernel, dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       coords, n_rows, cap, g, (unsigned long long *)grid_bits, 1);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}

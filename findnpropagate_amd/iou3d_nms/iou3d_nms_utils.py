@@ -1,0 +1,66 @@
+"""pcdet/ops/iou3d_nms/iou3d_nms_utils.py:12-152 with the same names, arguments and returns."""
+import torch
+
+from . import iou3d_nms_cuda
+
+
+def boxes_iou_bev(boxes_a, boxes_b):
+    """boxes (N,7),(M,7) [x,y,z,dx,dy,dz,heading] -> (N,M) rotated BEV IoU."""
+    assert boxes_a.shape[1] == boxes_b.shape[1] == 7
+    ans_iou = torch.zeros((boxes_a.shape[0], boxes_b.shape[0]), dtype=torch.float32, device=boxes_a.device)
+    iou3d_nms_cuda.boxes_iou_bev_gpu(boxes_a.contiguous(), boxes_b.contiguous(), ans_iou)
+    return ans_iou
+
+
+def boxes_iou3d_gpu(boxes_a, boxes_b):
+    """(N,7),(M,7) -> (N,M) 3D IoU (z = box centre), iou3d_nms_utils.py:48-81, one fused launch."""
+    assert boxes_a.shape[1] == boxes_b.shape[1] == 7
+    ans = torch.zeros((boxes_a.shape[0], boxes_b.shape[0]), dtype=torch.float32, device=boxes_a.device)
+    iou3d_nms_cuda.boxes_iou3d_gpu(boxes_a.contiguous(), boxes_b.contiguous(), ans)
+    return ans
+
+
+def boxes_aligned_iou3d_gpu(boxes_a, boxes_b):
+    """(N,7),(N,7) -> (N,1), iou3d_nms_utils.py:83-117."""
+    assert boxes_a.shape[0] == boxes_b.shape[0]
+    assert boxes_a.shape[1] == boxes_b.shape[1] == 7
+    boxes_a_height_max = (boxes_a[:, 2] + boxes_a[:, 5] / 2).view(-1, 1)
+    boxes_a_height_min = (boxes_a[:, 2] - boxes_a[:, 5] / 2).view(-1, 1)
+    boxes_b_height_max = (boxes_b[:, 2] + boxes_b[:, 5] / 2).view(-1, 1)
+    boxes_b_height_min = (boxes_b[:, 2] - boxes_b[:, 5] / 2).view(-1, 1)
+    overlaps_bev = torch.zeros((boxes_a.shape[0], 1), dtype=torch.float32, device=boxes_a.device)
+    iou3d_nms_cuda.boxes_aligned_overlap_bev_gpu(boxes_a.contiguous(), boxes_b.contiguous(), overlaps_bev)
+    max_of_min = torch.max(boxes_a_height_min, boxes_b_height_min)
+    min_of_max = torch.min(boxes_a_height_max, boxes_b_height_max)
+    overlaps_h = torch.clamp(min_of_max - max_of_min, min=0)
+    overlaps_3d = overlaps_bev * overlaps_h
+    vol_a = (boxes_a[:, 3] * boxes_a[:, 4] * boxes_a[:, 5]).view(-1, 1)
+    vol_b = (boxes_b[:, 3] * boxes_b[:, 4] * boxes_b[:, 5]).view(-1, 1)
+    return overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-6)
+
+
+def _nms(boxes, scores, thresh, rotated, pre_maxsize=None):
+    assert boxes.shape[1] == 7
+    order = scores.sort(0, descending=True)[1]
+    if pre_maxsize is not None:
+        order = order[:pre_maxsize]
+    order = order.to(boxes.device)
+    boxes = boxes[order].contiguous()
+    keep, num = iou3d_nms_cuda._nms_device(boxes, thresh, rotated)
+    n = int(num.item())  # the reference synchronises here too (cudaMemcpy D2H, iou3d_nms.cpp:131)
+    return order[keep[:n]].contiguous(), None
+
+
+def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
+    """(N,7) boxes, (N,) scores -> (kept indices in score order, None), iou3d_nms_utils.py:120-135."""
+    return _nms(boxes, scores, thresh, True, pre_maxsize)
+
+
+def nms_normal_gpu(boxes, scores, thresh, **kwargs):
+    """Axis-aligned BEV NMS (heading ignored), iou3d_nms_utils.py:138-152."""
+    return _nms(boxes, scores, thresh, False)
+
+
+def boxes_bev_iou_cpu(boxes_a, boxes_b):
+    """iou3d_nms_utils.py:12-28 (host tensors; pseudo-label mixing).  Not built in this round."""
+    raise NotImplementedError("boxes_bev_iou_cpu: host-side rotated IoU is a 'next' row (SURVEY.md §8f rank 2)")

@@ -1,0 +1,158 @@
+"""ctypes binding of libfnp_hip.so — the C ABI declared in include/fnp.h.
+
+This is the only way product code reaches the GPU kernels.  There is NO CPU fallback: if the
+shared library is missing the import of any operator fails loudly (build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C findnpropagate_amd/csrc``).
+
+PyTorch is used for device memory and streams only: tensors are passed as raw device pointers
+and every call is enqueued on ``torch.cuda.current_stream()``.
+"""
+import ctypes
+import os
+import re
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfnp_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fnp.h")
+
+FNP_F32 = 0
+FNP_BF16 = 1
+
+_ERRORS = {-1: "FNP_ERR_ARG", -2: "FNP_ERR_LAUNCH", -3: "FNP_ERR_HIP", -4: "FNP_ERR_WORKSPACE"}
+
+
+class FnpError(RuntimeError):
+    pass
+
+
+class VoxelCfg(ctypes.Structure):
+    """struct fnp_voxel_cfg (include/fnp.h)."""
+
+    _fields_ = [
+        ("range_min", c_float * 3),
+        ("voxel_size", c_float * 3),
+        ("grid", c_int * 3),
+        ("num_features", c_int),
+        ("max_points", c_int),
+        ("max_voxels", c_int),
+    ]
+
+
+class ConvGeom(ctypes.Structure):
+    """struct fnp_conv_geom (include/fnp.h)."""
+
+    _fields_ = [
+        ("ksize", c_int * 3),
+        ("stride", c_int * 3),
+        ("padding", c_int * 3),
+        ("in_shape", c_int * 3),
+        ("out_shape", c_int * 3),
+    ]
+
+
+P = c_void_p  # every device pointer crosses the ABI as a plain address
+
+# name -> (restype, argtypes).  Mirrors include/fnp.h one to one; tests/test_abi.py checks that
+# the header, this table and the exported symbols agree.
+SIGNATURES = {
+    "fnp_version": (c_char_p, []),
+    "fnp_abi_version": (c_int, []),
+    "fnp_points_in_boxes": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "fnp_points_in_boxes_count": (c_int, [P, P, P, c_int, c_int, P]),
+    "fnp_points_in_boxes_dense": (c_int, [P, P, P, c_int, c_int, P]),
+    "fnp_boxes_overlap_bev": (c_int, [P, c_int, P, c_int, P, P]),
+    "fnp_boxes_iou_bev": (c_int, [P, c_int, P, c_int, P, P]),
+    "fnp_boxes_aligned_overlap_bev": (c_int, [P, P, c_int, P, P]),
+    "fnp_boxes_iou3d": (c_int, [P, c_int, P, c_int, P, P]),
+    "fnp_nms_workspace_bytes": (c_int64, [c_int]),
+    "fnp_nms_rotated": (c_int, [P, c_int, c_float, P, P, P, P]),
+    "fnp_nms_normal": (c_int, [P, c_int, c_float, P, P, P, P]),
+    "fnp_rankgrid_num_blocks": (c_int64, [c_int, c_int, c_int, c_int]),
+    "fnp_scan_workspace_bytes": (c_int64, [c_int64]),
+    "fnp_voxelize_workspace_bytes": (c_int64, [c_int64, c_int, POINTER(VoxelCfg)]),
+    "fnp_voxelize": (c_int, [P, c_int, P, c_int, POINTER(VoxelCfg), P, P, P, P, c_int64,
+                             P, P, P, P, P, c_int, P]),
+    "fnp_rankgrid_build": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int64, P]),
+    "fnp_rankgrid_clear": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "fnp_rulebook_subm": (c_int, [P, P, c_int, c_int, POINTER(ConvGeom), P, P, P, P, P]),
+    "fnp_rulebook_strided": (c_int, [P, P, c_int, c_int, POINTER(ConvGeom), P, P, P, P, P,
+                                     P, P, c_int, P, P, c_int64, P]),
+    "fnp_spconv_forward": (c_int, [P, c_int, P, P, c_int, c_int, P, c_int, P, c_int,
+                                   P, P, P, c_int, c_int, c_int, P]),
+    "fnp_sparse_to_dense": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+}
+
+
+def header_symbols():
+    """Function names declared in include/fnp.h (used by the ABI test)."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fnp_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load():
+    """dlopen libfnp_hip.so and bind every entry point.  Raises FnpError when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FnpError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "There is no CPU fallback for this path."
+        )
+    # torch ships its own libamdhip64 (same SONAME); importing it first makes this library bind
+    # to the runtime torch already loaded, so both share one HIP context and stream table.
+    import torch  # noqa: F401
+
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise FnpError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise FnpError(f"{what} failed: {_ERRORS.get(code, code)}")
+
+
+def ptr(t):
+    """Device (or host) address of a contiguous torch tensor, None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "fnp ABI takes contiguous buffers"
+    return t.data_ptr()
+
+
+def stream():
+    """hipStream_t of torch's current stream, as an integer handle for the ABI."""
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(t):
+    import torch
+
+    if t.dtype == torch.float32:
+        return FNP_F32
+    if t.dtype == torch.bfloat16:
+        return FNP_BF16
+    raise FnpError(f"unsupported feature dtype {t.dtype}")
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise FnpError("fnp kernels take device tensors; got a CPU tensor (there is no CPU path)")

@@ -1,0 +1,239 @@
+"""Functional host layer over the C ABI (include/fnp.h) for voxelisation, rank grids, rulebooks
+and sparse convolution.  torch is used for device memory and streams only; every function
+enqueues HIP kernels from libfnp_hip.so on the current stream and never synchronises unless its
+docstring says so.
+
+Data layout in HBM:
+  features  (cap, C)   row-major, bf16 or f32            rows >= n are undefined
+  indices   (cap, 4)   int32 [b, z, y, x]
+  n         (1,)       int32 device scalar: number of valid rows
+  grid      bits (nblk,) u64 occupancy, base (nblk,) u32 popcount prefix, perm (cap,) int32|None
+  rulebook  nbr (K, cap) int32: input row per (kernel offset, output row) or -1
+"""
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import lib as _l
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == 3
+        return [int(x) for x in v]
+    return [int(v)] * 3
+
+
+@dataclass
+class RankGrid:
+    bits: torch.Tensor            # (nblk,) int64 view of u64
+    base: torch.Tensor            # (nblk,) int32 view of u32
+    perm: Optional[torch.Tensor]  # (cap,) int32 or None (rows already in rank order)
+    batch_size: int
+    shape: List[int]              # [D, H, W]
+
+
+@dataclass
+class Rulebook:
+    nbr: torch.Tensor             # (K, cap_out) int32
+    K: int
+    cap_out: int
+    geom: _l.ConvGeom
+    out_indices: Optional[torch.Tensor] = None   # strided only
+    out_n: Optional[torch.Tensor] = None
+    out_grid: Optional[RankGrid] = None
+    out_shape: Optional[List[int]] = None
+
+
+def num_blocks(batch_size, shape):
+    return int(_l.load().fnp_rankgrid_num_blocks(batch_size, *shape))
+
+
+def alloc_grid(batch_size, shape, device, with_perm_cap=None):
+    """Zeroed occupancy words + uninitialised prefix (+ perm) for a (B, D, H, W) grid."""
+    nblk = num_blocks(batch_size, shape)
+    bits = torch.zeros((nblk,), dtype=torch.int64, device=device)
+    base = torch.empty((nblk,), dtype=torch.int32, device=device)
+    perm = torch.empty((with_perm_cap,), dtype=torch.int32, device=device) if with_perm_cap else None
+    return RankGrid(bits, base, perm, batch_size, list(shape))
+
+
+def make_geom(ksize, stride, padding, in_shape, out_shape=None):
+    g = _l.ConvGeom()
+    k, s, p = _triple(ksize), _triple(stride), _triple(padding)
+    if out_shape is None:
+        out_shape = [(in_shape[d] + 2 * p[d] - k[d]) // s[d] + 1 for d in range(3)]
+    for d in range(3):
+        g.ksize[d], g.stride[d], g.padding[d] = k[d], s[d], p[d]
+        g.in_shape[d], g.out_shape[d] = int(in_shape[d]), int(out_shape[d])
+    return g, [int(x) for x in out_shape]
+
+
+def device_scalar(value, device):
+    return torch.full((1,), int(value), dtype=torch.int32, device=device)
+
+
+# --------------------------------------------------------------------------------- voxelise
+def make_voxel_cfg(voxel_size, point_cloud_range, num_features, max_points, max_voxels):
+    """grid = round((max - min) / voxel_size) as in data_processor.py:257-258."""
+    import numpy as np
+
+    cfg = _l.VoxelCfg()
+    rng = np.asarray(point_cloud_range, dtype=np.float32)
+    vs = np.asarray(voxel_size, dtype=np.float32)
+    grid = np.round((rng[3:6] - rng[0:3]) / vs).astype(np.int64)
+    for d in range(3):
+        cfg.range_min[d] = float(rng[d])
+        cfg.voxel_size[d] = float(vs[d])
+        cfg.grid[d] = int(grid[d])
+    cfg.num_features = int(num_features)
+    cfg.max_points = int(max_points)
+    cfg.max_voxels = int(max_voxels)
+    return cfg
+
+
+def voxelize(points, batch_offsets, batch_size, cfg, grid=None, want_voxels=False, workspace=None):
+    """points (N,C) f32 device, batch_offsets (B+1,) int32 device.
+
+    Returns dict(coords (N,4) i32, num_points (N,), mean (N,C) f32, voxels|None, n (1,) i32 device,
+    grid RankGrid with perm).  Rows >= n are undefined.  No host sync.
+    """
+    L = _l.load()
+    _l.require_device(points, batch_offsets)
+    assert points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous()
+    assert batch_offsets.dtype == torch.int32 and batch_offsets.numel() == batch_size + 1
+    n, C = points.shape
+    assert C == cfg.num_features
+    dev = points.device
+    cap = max(n, 1)
+    shape = [cfg.grid[2], cfg.grid[1], cfg.grid[0]]
+    if grid is None:
+        grid = alloc_grid(batch_size, shape, dev, with_perm_cap=cap)
+    elif grid.perm is None or grid.perm.numel() < cap:
+        grid.perm = torch.empty((cap,), dtype=torch.int32, device=dev)
+    ws_bytes = int(L.fnp_voxelize_workspace_bytes(n, batch_size, cfg))
+    if workspace is None or workspace.numel() < ws_bytes:
+        workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    num_points = torch.empty((cap,), dtype=torch.int32, device=dev)
+    mean = torch.empty((cap, C), dtype=torch.float32, device=dev)
+    voxels = torch.empty((cap, cfg.max_points, C), dtype=torch.float32, device=dev) if want_voxels else None
+    n_vox = torch.zeros((1,), dtype=torch.int32, device=dev)
+    rc = L.fnp_voxelize(_l.ptr(points), n, _l.ptr(batch_offsets), batch_size, cfg,
+                        _l.ptr(grid.bits), _l.ptr(grid.base), _l.ptr(grid.perm),
+                        _l.ptr(workspace), workspace.numel(),
+                        _l.ptr(coords), _l.ptr(num_points), _l.ptr(mean), _l.ptr(voxels), _l.ptr(n_vox), cap,
+                        _l.stream())
+    _l.check(rc, "fnp_voxelize")
+    return dict(coords=coords, num_points=num_points, mean=mean, voxels=voxels, n=n_vox, grid=grid,
+                workspace=workspace, cap=cap)
+
+
+# --------------------------------------------------------------------------------- grids
+def build_grid(indices, n_dev, batch_size, shape, keep_order=True, grid=None):
+    """Index an explicit (cap,4) coordinate list.  perm maps rank -> row (keep_order=True)."""
+    L = _l.load()
+    _l.require_device(indices, n_dev)
+    assert indices.dtype == torch.int32 and indices.is_contiguous()
+    cap = max(indices.shape[0], 1)
+    dev = indices.device
+    if grid is None:
+        grid = alloc_grid(batch_size, shape, dev, with_perm_cap=cap if keep_order else None)
+    nblk = grid.bits.numel()
+    ws = torch.empty((int(L.fnp_scan_workspace_bytes(nblk)) + 256,), dtype=torch.uint8, device=dev)
+    rc = L.fnp_rankgrid_build(_l.ptr(indices), _l.ptr(n_dev), cap, batch_size, *shape,
+                              _l.ptr(grid.bits), _l.ptr(grid.base), _l.ptr(grid.perm), _l.ptr(ws), ws.numel(),
+                              _l.stream())
+    _l.check(rc, "fnp_rankgrid_build")
+    return grid
+
+
+def clear_grid(grid, indices, n_dev):
+    """Sparse clear of the occupancy words touched by `indices` (O(rows))."""
+    L = _l.load()
+    rc = L.fnp_rankgrid_clear(_l.ptr(indices), _l.ptr(n_dev), max(indices.shape[0], 1), grid.batch_size, *grid.shape,
+                              _l.ptr(grid.bits), _l.stream())
+    _l.check(rc, "fnp_rankgrid_clear")
+
+
+# --------------------------------------------------------------------------------- rulebooks
+def rulebook_subm(indices, n_dev, grid, ksize):
+    L = _l.load()
+    cap = max(indices.shape[0], 1)
+    geom, _ = make_geom(ksize, 1, [k // 2 for k in _triple(ksize)], grid.shape, grid.shape)
+    K = geom.ksize[0] * geom.ksize[1] * geom.ksize[2]
+    nbr = torch.empty((K, cap), dtype=torch.int32, device=indices.device)
+    rc = L.fnp_rulebook_subm(_l.ptr(indices), _l.ptr(n_dev), cap, grid.batch_size, geom,
+                             _l.ptr(grid.bits), _l.ptr(grid.base), _l.ptr(grid.perm), _l.ptr(nbr), _l.stream())
+    _l.check(rc, "fnp_rulebook_subm")
+    return Rulebook(nbr=nbr, K=K, cap_out=cap, geom=geom)
+
+
+def rulebook_strided(indices, n_dev, grid, ksize, stride, padding, cap_out, out_grid=None):
+    """Builds out grid + out indices (rank order) + nbr.  out_n is the TRUE count (may exceed
+    cap_out: the caller checks it when it synchronises)."""
+    L = _l.load()
+    dev = indices.device
+    cap_in = max(indices.shape[0], 1)
+    geom, out_shape = make_geom(ksize, stride, padding, grid.shape)
+    K = geom.ksize[0] * geom.ksize[1] * geom.ksize[2]
+    if out_grid is None:
+        out_grid = alloc_grid(grid.batch_size, out_shape, dev)
+    cap_out = max(int(cap_out), 1)
+    out_idx = torch.empty((cap_out, 4), dtype=torch.int32, device=dev)
+    out_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+    nbr = torch.empty((K, cap_out), dtype=torch.int32, device=dev)
+    ws = torch.empty((int(L.fnp_scan_workspace_bytes(out_grid.bits.numel())),), dtype=torch.uint8, device=dev)
+    rc = L.fnp_rulebook_strided(_l.ptr(indices), _l.ptr(n_dev), cap_in, grid.batch_size, geom,
+                                _l.ptr(grid.bits), _l.ptr(grid.base), _l.ptr(grid.perm),
+                                _l.ptr(out_grid.bits), _l.ptr(out_grid.base),
+                                _l.ptr(out_idx), _l.ptr(out_n), cap_out, _l.ptr(nbr), _l.ptr(ws), ws.numel(),
+                                _l.stream())
+    _l.check(rc, "fnp_rulebook_strided")
+    return Rulebook(nbr=nbr, K=K, cap_out=cap_out, geom=geom, out_indices=out_idx, out_n=out_n, out_grid=out_grid,
+                    out_shape=out_shape)
+
+
+# --------------------------------------------------------------------------------- convolution
+def pack_weight(weight, dtype):
+    """spconv 2.x layout (Cout,kD,kH,kW,Cin) -> packed (K, Cout, Cin) contiguous in `dtype`.
+    (spconv 1.x (kD,kH,kW,Cin,Cout) is converted by the module loader, see spconv/conv.py.)"""
+    Cout, Cin = weight.shape[0], weight.shape[-1]
+    K = weight.shape[1] * weight.shape[2] * weight.shape[3]
+    return weight.detach().reshape(Cout, K, Cin).permute(1, 0, 2).contiguous().to(dtype)
+
+
+def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, shift=None, residual=None, relu=False,
+                 out=None):
+    """feat_out (cap_out, Cout) = act(conv * scale + shift + residual).  No host sync."""
+    L = _l.load()
+    _l.require_device(feat_in, w_packed, rb.nbr, n_out_dev)
+    K, Cout, Cin = w_packed.shape
+    assert K == rb.K and feat_in.shape[1] == Cin and feat_in.dtype == w_packed.dtype
+    assert feat_in.is_contiguous() and w_packed.is_contiguous()
+    out_dtype = out_dtype or feat_in.dtype
+    cap_out = rb.cap_out
+    if out is None:
+        out = torch.empty((cap_out, Cout), dtype=out_dtype, device=feat_in.device)
+    if residual is not None:
+        assert residual.dtype == out.dtype and residual.shape[1] == Cout and residual.is_contiguous()
+    if scale is not None:
+        assert scale.dtype == torch.float32 and shift.dtype == torch.float32
+    rc = L.fnp_spconv_forward(_l.ptr(feat_in), _l.dtype_code(feat_in), _l.ptr(w_packed),
+                              _l.ptr(rb.nbr), rb.nbr.shape[1], K, _l.ptr(n_out_dev), cap_out,
+                              _l.ptr(out), _l.dtype_code(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual),
+                              int(bool(relu)), Cin, Cout, _l.stream())
+    _l.check(rc, "fnp_spconv_forward")
+    return out
+
+
+def to_dense(features, indices, n_dev, batch_size, shape):
+    """SparseConvTensor.dense(): (B, C, D, H, W) zeros + scatter."""
+    L = _l.load()
+    C = features.shape[1]
+    out = torch.zeros((batch_size, C, *shape), dtype=features.dtype, device=features.device)
+    rc = L.fnp_sparse_to_dense(_l.ptr(features), _l.dtype_code(features), _l.ptr(indices), _l.ptr(n_dev),
+                               max(indices.shape[0], 1), C, batch_size, *shape, _l.ptr(out), _l.stream())
+    _l.check(rc, "fnp_sparse_to_dense")
+    return out

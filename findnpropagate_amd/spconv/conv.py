@@ -1,0 +1,125 @@
+"""SubMConv3d / SparseConv3d modules (spconv_backbone.py:12-17,39-46,193-234).
+
+Parameters keep spconv 2.x names and layout so the released checkpoint loads through the
+reference's own loader (detector3d_template.py:401-433): `weight` (Cout,kD,kH,kW,Cin), `bias`.
+Forward only: the backward of the sparse convolution is not built yet and a
+training-mode call with grad enabled raises instead of silently returning a graph-less tensor.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import sparse as S
+from .core import SparseConvTensor
+from .modules import SparseModule
+
+
+def _triple(v):
+    return [int(x) for x in v] if isinstance(v, (list, tuple)) else [int(v)] * 3
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
+                 algo=None, fp32_accum=None, name=None):
+        super().__init__()
+        assert ndim == 3 and groups == 1 and not transposed and not inverse
+        assert _triple(dilation) == [1, 1, 1], "dilation is not used on this path"
+        self.ndim = ndim
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _triple(kernel_size)
+        self.stride = _triple(stride)
+        self.padding = _triple(padding)
+        self.dilation = _triple(dilation)
+        self.subm = subm
+        self.indice_key = indice_key
+        self.weight = nn.Parameter(torch.empty(out_channels, *self.kernel_size, in_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self._packed = {}
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, subm={self.subm}, indice_key={self.indice_key}")
+
+    def packed_weight(self, dtype):
+        """(K, Cout, Cin) contiguous copy in `dtype`, refreshed when the parameter changes."""
+        key = (dtype, self.weight.device)
+        ver = (self.weight._version, self.weight.data_ptr())
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, S.pack_weight(self.weight, dtype))
+            self._packed[key] = hit
+        return hit[1]
+
+    def forward(self, input: SparseConvTensor):
+        assert isinstance(input, SparseConvTensor)
+        if torch.is_grad_enabled() and self.training and self.weight.requires_grad:
+            raise NotImplementedError(
+                "findnpropagate_amd.spconv: sparse-conv backward is not built yet (forward/inference only); "
+                "call under torch.no_grad() / model.eval()")
+        feats = input.features.detach()
+        if feats.dtype not in (torch.float32, torch.bfloat16):
+            feats = feats.to(torch.bfloat16)
+        feats = feats.contiguous()
+        w = self.packed_weight(feats.dtype)
+        n_dev = input.n_dev()
+        if self.subm:
+            rb = input.find_indice_pair(self.indice_key)
+            if rb is None or rb.K != w.shape[0]:
+                rb = S.rulebook_subm(input.indices, n_dev, input.rank_grid(), self.kernel_size)
+                if self.indice_key is not None:
+                    input.indice_dict[self.indice_key] = rb
+            out_feats = S.conv_forward(feats, w, rb, n_dev)
+            if out_feats.shape[0] != feats.shape[0]:
+                out_feats = out_feats[: feats.shape[0]]
+            if self.bias is not None:
+                out_feats = out_feats + self.bias.to(out_feats.dtype)
+            out = SparseConvTensor(out_feats, input.indices, input.spatial_shape, input.batch_size, input.grid,
+                                   input.voxel_num, input.indice_dict, input.benchmark, n_dev, input._rank_grid)
+            return out
+        # strided: the output site count is data dependent -> one host sync, like spconv itself
+        n_in = feats.shape[0]
+        kvol = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+        out_shape = [(input.spatial_shape[d] + 2 * self.padding[d] - self.kernel_size[d]) // self.stride[d] + 1
+                     for d in range(3)]
+        cells = input.batch_size * out_shape[0] * out_shape[1] * out_shape[2]
+        cap_out = max(1, min(n_in * kvol, cells))
+        rb = S.rulebook_strided(input.indices, n_dev, input.rank_grid(), self.kernel_size, self.stride, self.padding,
+                                cap_out)
+        out_feats = S.conv_forward(feats, w, rb, rb.out_n)
+        n_out = int(rb.out_n.item())
+        assert n_out <= cap_out
+        out_feats = out_feats[:n_out]
+        if self.bias is not None:
+            out_feats = out_feats + self.bias.to(out_feats.dtype)
+        if self.indice_key is not None:
+            input.indice_dict[self.indice_key] = rb
+        return SparseConvTensor(out_feats, rb.out_indices[:n_out], rb.out_shape, input.batch_size, input.grid,
+                                input.voxel_num, input.indice_dict, input.benchmark, rb.out_n, rb.out_grid)
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, True,
+                         indice_key=indice_key, algo=algo, fp32_accum=fp32_accum, name=name)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, False,
+                         indice_key=indice_key, algo=algo, fp32_accum=fp32_accum, name=name)

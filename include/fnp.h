@@ -1,0 +1,206 @@
+/*
+ * fnp.h — C ABI of libfnp_hip.so, the MI355X (gfx950) drop-in for the point-cloud hot path of
+ * djamahl99/findnpropagate (an OpenPCDet fork).
+ *
+ * Every entry point is what the reference's FFI for this path binds today (pybind11 torch
+ * extensions and the third-party spconv package); the reference interface each one replaces is
+ * cited as  <file>:<line>  relative to the reference tree.
+ *
+ * Conventions:
+ *   - all pointers are DEVICE pointers borrowed from the caller (torch tensors), unless a
+ *     parameter is documented as "host"; the caller allocates every output and every workspace;
+ *   - no hidden allocation, no host synchronisation, no exit(): 0 = success, <0 = error code;
+ *   - every launch goes to the hipStream_t handed in (the reference launches on the legacy
+ *     default stream, roiaware_pool3d_kernel.cu:348, iou3d_nms_kernel.cu:394);
+ *   - row counts that are data-dependent (voxels, active output sites) live in device memory
+ *     (`const int *n_rows`), kernels grid-stride over them, so a whole forward is sync-free
+ *     and hipGraph-capturable.
+ */
+#ifndef FNP_H
+#define FNP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *fnp_stream_t; /* hipStream_t */
+
+enum {
+    FNP_OK = 0,
+    FNP_ERR_ARG = -1,      /* bad shape / null pointer / unsupported channel count */
+    FNP_ERR_LAUNCH = -2,   /* hipGetLastError() after a launch */
+    FNP_ERR_HIP = -3,      /* a HIP runtime call failed */
+    FNP_ERR_WORKSPACE = -4 /* workspace too small */
+};
+
+enum { FNP_F32 = 0, FNP_BF16 = 1 };
+
+/* Library / build identification: returns a static string "fnp-hip gfx950 <abi version>". */
+const char *fnp_version(void);
+int fnp_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * roiaware_pool3d — replaces pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:98-118
+ * (points_in_boxes_gpu) and its kernel roiaware_pool3d_kernel.cu:16-36,313-359.
+ * ------------------------------------------------------------------------------------------ */
+
+/* boxes (B,T,7) [x,y,z,dx,dy,dz,heading], pts (B,M,3); box_idx_of_points (B,M) receives the
+ * first (lowest) box index containing the point, else -1 (the reference needs the caller to
+ * pre-fill -1, roiaware_pool3d_utils.py:38; this entry point writes every element). */
+int fnp_points_in_boxes(const float *boxes, const float *pts, int *box_idx_of_points,
+                        int B, int T, int M, fnp_stream_t stream);
+
+/* Batched form of the Box Seeker's hot loop 4 (frustum_proposals_v1.py:930-932): for each of
+ * T candidate boxes count the points (M,3) inside it, with the same test as above.
+ * counts (T,) int32.  One launch instead of T launches + T host syncs. */
+int fnp_points_in_boxes_count(const float *boxes, const float *pts, int *counts,
+                              int T, int M, fnp_stream_t stream);
+
+/* Dense (T,M) 0/1 membership with the reference's CPU margin 1e-2 and z test
+ * (roiaware_pool3d.cpp:121-168, points_in_boxes_cpu) — device-side equivalent. */
+int fnp_points_in_boxes_dense(const float *boxes, const float *pts, int *pts_indices,
+                              int T, int M, fnp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * iou3d_nms — replaces pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:49-209 and
+ * iou3d_nms_kernel.cu (box_overlap :104-225, iou_bev :227-234, iou_normal :327-338,
+ * nms_kernel :280-324, nms_normal_kernel :341-385).
+ * ------------------------------------------------------------------------------------------ */
+
+/* boxes_overlap_bev_gpu (iou3d_nms.cpp:71-89): a (N,7), b (M,7) -> ans (N,M) overlap area. */
+int fnp_boxes_overlap_bev(const float *boxes_a, int num_a, const float *boxes_b, int num_b,
+                          float *ans_overlap, fnp_stream_t stream);
+/* boxes_iou_bev_gpu (iou3d_nms.cpp:91-111): -> ans (N,M) rotated BEV IoU. */
+int fnp_boxes_iou_bev(const float *boxes_a, int num_a, const float *boxes_b, int num_b,
+                      float *ans_iou, fnp_stream_t stream);
+/* boxes_aligned_overlap_bev_gpu (iou3d_nms.cpp:49-69): a (N,7), b (N,7) -> ans (N,). */
+int fnp_boxes_aligned_overlap_bev(const float *boxes_a, const float *boxes_b, int num,
+                                  float *ans_overlap, fnp_stream_t stream);
+/* Fused boxes_iou3d_gpu (iou3d_nms_utils.py:48-81): BEV overlap x height overlap / union,
+ * z = box centre.  ans (N,M). */
+int fnp_boxes_iou3d(const float *boxes_a, int num_a, const float *boxes_b, int num_b,
+                    float *ans_iou, fnp_stream_t stream);
+
+/* Bytes of the u64 suppression-mask workspace for N boxes. */
+int64_t fnp_nms_workspace_bytes(int num_boxes);
+/* nms_gpu / nms_normal_gpu (iou3d_nms.cpp:113-209): boxes (N,7) pre-sorted by score desc.
+ * keep (N,) int64 DEVICE, num_keep (1,) int32 DEVICE.  The greedy sweep that the reference
+ * runs on the host after a synchronous cudaMemcpy (iou3d_nms.cpp:139-155,189-205) runs on
+ * the device, so the call is asynchronous. */
+int fnp_nms_rotated(const float *boxes, int num_boxes, float thresh, void *workspace,
+                    int64_t *keep, int *num_keep, fnp_stream_t stream);
+int fnp_nms_normal(const float *boxes, int num_boxes, float thresh, void *workspace,
+                   int64_t *keep, int *num_keep, fnp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Rank grid — the voxel index behind voxelisation and rulebook building.  A grid of
+ * (B, D, H, W) cells is cut into 4x4x4 blocks; each block owns one u64 occupancy word
+ * (bit = (z&3)*16 + (y&3)*4 + (x&3)) and one u32 exclusive popcount prefix, so
+ * row(cell) = base[block] + popc(bits[block] & below(bit)) is a collision-free lookup.
+ * Replaces spconv's hash / direct table (call sites spconv_utils.py:3-10).
+ * ------------------------------------------------------------------------------------------ */
+int64_t fnp_rankgrid_num_blocks(int B, int D, int H, int W);
+int64_t fnp_scan_workspace_bytes(int64_t n);
+
+/* ------------------------------------------------------------------------------------------
+ * Voxelisation + MeanVFE — replaces spconv.utils.Point2VoxelCPU3d.point_to_voxel as called
+ * at pcdet/datasets/processor/data_processor.py:38-61 and MeanVFE.forward
+ * (pcdet/models/backbones_3d/vfe/mean_vfe.py:14-31).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fnp_voxel_cfg {
+    float range_min[3];  /* x,y,z of POINT_CLOUD_RANGE[0:3] */
+    float voxel_size[3]; /* x,y,z */
+    int grid[3];         /* x,y,z = round((max-min)/voxel_size), data_processor.py:257-258 */
+    int num_features;    /* C of points (N,C); xyz are columns 0..2 */
+    int max_points;      /* MAX_POINTS_PER_VOXEL (10) */
+    int max_voxels;      /* MAX_NUMBER_OF_VOXELS per scene */
+} fnp_voxel_cfg;
+
+int64_t fnp_voxelize_workspace_bytes(int64_t n_points, int B, const fnp_voxel_cfg *cfg);
+
+/* points (N,C) f32, scenes concatenated; batch_offsets (B+1,) int32 device (scene b owns
+ * points [off[b], off[b+1])).  Outputs, all capacity `cap` rows (cap >= N is always enough):
+ *   coords (cap,4) int32 [b,z,y,x] in the sequential first-come order of the reference,
+ *   num_points (cap,) int32, mean_feats (cap,C) f32 = MeanVFE, voxels (cap,max_points,C) f32
+ *   zero padded (nullable), n_voxels (1,) int32 device.
+ * grid_bits/grid_base/grid_perm describe the (B, gz, gy, gx) rank grid of the voxels for the
+ * first rulebook (grid_perm[sorted rank] = voxel row).  grid_bits must be zero on entry. */
+int fnp_voxelize(const float *points, int n_points, const int *batch_offsets, int B,
+                 const fnp_voxel_cfg *cfg,
+                 uint64_t *grid_bits, uint32_t *grid_base, int *grid_perm,
+                 void *workspace, int64_t workspace_bytes,
+                 int *coords, int *num_points, float *mean_feats, float *voxels,
+                 int *n_voxels, int cap, fnp_stream_t stream);
+
+/* Index an existing coordinate list (N,4) [b,z,y,x] into a rank grid (for SparseConvTensor
+ * built from user tensors).  grid_bits must be zero on entry. */
+int fnp_rankgrid_build(const int *coords, const int *n_rows, int cap,
+                       int B, int D, int H, int W,
+                       uint64_t *grid_bits, uint32_t *grid_base, int *grid_perm,
+                       void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
+
+/* Zero the occupancy words touched by `coords` (sparse clear, O(rows) instead of O(grid)). */
+int fnp_rankgrid_clear(const int *coords, const int *n_rows, int cap,
+                       int B, int D, int H, int W, uint64_t *grid_bits, fnp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Rulebooks — replace spconv's indice-pair generation for SubMConv3d / SparseConv3d
+ * (call sites pcdet/models/backbones_3d/spconv_backbone.py:12-17,39-46,193-234).
+ * Output-stationary layout: nbr[k*cap + o] = input row feeding output row o through kernel
+ * offset k, or -1.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fnp_conv_geom {
+    int ksize[3];   /* kD,kH,kW */
+    int stride[3];
+    int padding[3];
+    int in_shape[3];  /* D,H,W of the input grid */
+    int out_shape[3]; /* D,H,W of the output grid ( = in_shape for SubM ) */
+} fnp_conv_geom;
+
+/* SubM: outputs = inputs, same order. */
+int fnp_rulebook_subm(const int *coords, const int *n_rows, int cap, int B,
+                      const fnp_conv_geom *geom,
+                      const uint64_t *grid_bits, const uint32_t *grid_base, const int *grid_perm,
+                      int *nbr, fnp_stream_t stream);
+
+/* Strided SparseConv3d: builds the output rank grid (out_bits must be zero on entry), the
+ * output coordinate list (rows in rank-grid order: spatially blocked, deterministic) and nbr.
+ * in_perm may be NULL when the input rows are already in rank-grid order. */
+int fnp_rulebook_strided(const int *in_coords, const int *n_in, int cap_in, int B,
+                         const fnp_conv_geom *geom,
+                         const uint64_t *in_bits, const uint32_t *in_base, const int *in_perm,
+                         uint64_t *out_bits, uint32_t *out_base,
+                         int *out_coords, int *n_out, int cap_out, int *nbr,
+                         void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse convolution forward (implicit GEMM, output-stationary, no atomics) with the
+ * BatchNorm1d(eval) + residual + ReLU epilogue of spconv_backbone.py:51-67 fused in.
+ *   feat_in  (n_in, Cin)   in_dtype     weight (K, Cout, Cin) packed, w_dtype = in_dtype
+ *   feat_out (n_out, Cout) out_dtype    residual (n_out, Cout) out_dtype or NULL
+ *   scale/shift (Cout,) f32 or NULL (identity).  out = act(acc*scale + shift + residual)
+ * bf16 x bf16 -> fp32 accumulate runs on MFMA (v_mfma_f32_16x16x32_bf16); f32 runs on VALU
+ * fma chains (validation mode).
+ * ------------------------------------------------------------------------------------------ */
+int fnp_spconv_forward(const void *feat_in, int in_dtype, const void *weight,
+                       const int *nbr, int nbr_stride, int K,
+                       const int *n_out, int cap_out,
+                       void *feat_out, int out_dtype,
+                       const float *scale, const float *shift, const void *residual, int relu,
+                       int Cin, int Cout, fnp_stream_t stream);
+
+/* SparseConvTensor.dense() as used by HeightCompression (height_compression.py:20-24):
+ * feats (n,C) -> out (B,C,D,H,W) of out_dtype, which must be zero on entry. */
+int fnp_sparse_to_dense(const void *feats, int dtype, const int *coords, const int *n_rows, int cap,
+                        int C, int B, int D, int H, int W, void *out, fnp_stream_t stream);
+
+/* Capacity overflow: data-dependent counts (n_voxels, n_out) always hold the TRUE count; every
+ * kernel clamps to the capacity it was given, so a count larger than its capacity means rows
+ * were dropped and the caller must re-run with larger buffers. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FNP_H */

@@ -1,0 +1,318 @@
+"""numpy front-end of oracle/liboracle.so (oracle/fnp_oracle.c) plus the layer graph of
+VoxelResBackBone8x restated on top of it.
+
+TEST INFRASTRUCTURE ONLY — imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by findnpropagate_amd/.  Each function cites the reference file:line
+(relative to the reference tree) it follows.
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build():
+    """Compile the C restatement (and, when /root/reference exists, oracle/_ref)."""
+    subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.orc_box_overlap.restype = c_float
+        _lib.orc_iou_bev.restype = c_float
+        _lib.orc_iou_normal.restype = c_float
+        _lib.orc_nms.restype = c_int
+        _lib.orc_voxelize.restype = c_int
+        _lib.orc_rulebook_strided.restype = c_int
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(c_void_p)
+
+
+# ---------------------------------------------------------------- roiaware_pool3d
+def points_in_boxes(points, boxes):
+    """points (B,M,3), boxes (B,T,7) -> (B,M) int32: roiaware_pool3d_kernel.cu:313-336."""
+    points, boxes = _f32(points), _f32(boxes)
+    B, M, _ = points.shape
+    T = boxes.shape[1]
+    out = np.empty((B, M), np.int32)
+    lib().orc_points_in_boxes(_p(boxes), _p(points), _p(out), B, T, M)
+    return out
+
+
+def points_in_boxes_count(points, boxes):
+    """points (M,3), boxes (T,7) -> (T,) counts: frustum_proposals_v1.py:930-932."""
+    points, boxes = _f32(points), _f32(boxes)
+    out = np.empty((boxes.shape[0],), np.int32)
+    lib().orc_points_in_boxes_count(_p(boxes), _p(points), _p(out), boxes.shape[0], points.shape[0])
+    return out
+
+
+def points_in_boxes_dense(points, boxes):
+    """points (M,3), boxes (T,7) -> (T,M) 0/1: roiaware_pool3d.cpp:143-168 (MARGIN 1e-2)."""
+    points, boxes = _f32(points), _f32(boxes)
+    out = np.empty((boxes.shape[0], points.shape[0]), np.int32)
+    lib().orc_points_in_boxes_dense(_p(boxes), _p(points), _p(out), boxes.shape[0], points.shape[0])
+    return out
+
+
+# ---------------------------------------------------------------- iou3d_nms
+def _pairwise(fn, a, b):
+    a, b = _f32(a), _f32(b)
+    out = np.empty((a.shape[0], b.shape[0]), np.float32)
+    fn(_p(a), a.shape[0], _p(b), b.shape[0], _p(out))
+    return out
+
+
+def boxes_overlap_bev(a, b):
+    return _pairwise(lib().orc_boxes_overlap_bev, a, b)
+
+
+def boxes_iou_bev(a, b):
+    return _pairwise(lib().orc_boxes_iou_bev, a, b)
+
+
+def boxes_iou3d(a, b):
+    return _pairwise(lib().orc_boxes_iou3d, a, b)
+
+
+def boxes_aligned_overlap_bev(a, b):
+    a, b = _f32(a), _f32(b)
+    out = np.empty((a.shape[0],), np.float32)
+    lib().orc_boxes_aligned_overlap_bev(_p(a), _p(b), a.shape[0], _p(out))
+    return out
+
+
+def iou_normal(a, b):
+    a, b = _f32(a), _f32(b)
+    return float(lib().orc_iou_normal(_p(a), _p(b)))
+
+
+def nms(boxes_sorted, thresh, rotated):
+    """boxes pre-sorted by score desc -> kept indices (iou3d_nms.cpp:113-209)."""
+    boxes_sorted = _f32(boxes_sorted)
+    keep = np.empty((max(boxes_sorted.shape[0], 1),), np.int64)
+    n = lib().orc_nms(_p(boxes_sorted), boxes_sorted.shape[0], c_float(thresh), int(bool(rotated)), _p(keep))
+    return keep[:n].copy()
+
+
+def nms_gpu(boxes, scores, thresh, rotated=True):
+    """iou3d_nms_utils.nms_gpu / nms_normal_gpu (iou3d_nms_utils.py:120-152): stable argsort here;
+    the reference uses torch's (unstable) sort, ties are the caller's concern."""
+    order = np.argsort(-np.asarray(scores, np.float32), kind="stable")
+    keep = nms(np.asarray(boxes, np.float32)[order], thresh, rotated)
+    return order[keep]
+
+
+# ---------------------------------------------------------------- voxeliser + VFE
+def voxelize(points, voxel_size, coors_range, max_points, max_voxels):
+    """Point2VoxelCPU3d.point_to_voxel (data_processor.py:38-61): returns
+    voxels (M,max_points,C), coords (M,3)[z,y,x], num_points (M,)."""
+    points = _f32(points)
+    n, C = points.shape
+    vs = _f32(voxel_size)
+    rng = _f32(coors_range)
+    grid = np.round((rng[3:] - rng[:3]) / vs).astype(np.int32)  # data_processor.py:257-258
+    voxels = np.zeros((max_voxels, max_points, C), np.float32)
+    coords = np.zeros((max_voxels, 3), np.int32)
+    num = np.zeros((max_voxels,), np.int32)
+    m = lib().orc_voxelize(_p(points), n, C, _p(rng[:3].copy()), _p(vs), _p(grid), max_points, max_voxels,
+                           _p(voxels), _p(coords), _p(num))
+    return voxels[:m].copy(), coords[:m].copy(), num[:m].copy()
+
+
+def mean_vfe(voxels, num_points):
+    """MeanVFE.forward (mean_vfe.py:25-29)."""
+    voxels = _f32(voxels)
+    M, P, C = voxels.shape
+    out = np.empty((M, C), np.float32)
+    lib().orc_mean_vfe(_p(voxels), _p(_i32(num_points)), M, P, C, _p(out))
+    return out
+
+
+# ---------------------------------------------------------------- sparse conv
+class SparseTensor:
+    """features (N,C) f32, indices (N,4) [b,z,y,x] int32, spatial_shape [D,H,W]."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size):
+        self.features = _f32(features)
+        self.indices = _i32(indices)
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.rulebooks = {}
+
+    def dense(self):
+        """SparseConvTensor.dense() (height_compression.py:21): (B,C,D,H,W)."""
+        C = self.features.shape[1]
+        out = np.zeros((self.batch_size, C, *self.spatial_shape), np.float32)
+        shape = _i32(self.spatial_shape)
+        lib().orc_sparse_to_dense(_p(self.features), _p(self.indices), self.features.shape[0], C, _p(shape), _p(out))
+        return out
+
+
+def _triple(v):
+    return [int(v)] * 3 if np.isscalar(v) else [int(x) for x in v]
+
+
+def rulebook_subm(indices, spatial_shape, ksize):
+    indices = _i32(indices)
+    n = indices.shape[0]
+    ksize = _i32(_triple(ksize))
+    K = int(np.prod(ksize))
+    pin = np.empty((K, max(n, 1)), np.int32)
+    pout = np.empty((K, max(n, 1)), np.int32)
+    pn = np.zeros((K,), np.int32)
+    lib().orc_rulebook_subm(_p(indices), n, _p(_i32(spatial_shape)), _p(ksize), _p(pin), _p(pout), _p(pn))
+    return pin, pout, pn
+
+
+def rulebook_strided(indices, spatial_shape, ksize, stride, padding):
+    indices = _i32(indices)
+    n = indices.shape[0]
+    ksize, stride, padding = _i32(_triple(ksize)), _i32(_triple(stride)), _i32(_triple(padding))
+    shape = _i32(spatial_shape)
+    out_shape = ((shape + 2 * padding - ksize) // stride + 1).astype(np.int32)
+    K = int(np.prod(ksize))
+    cap = max(n * K, 1)
+    out_idx = np.empty((cap, 4), np.int32)
+    pin = np.empty((K, max(n, 1)), np.int32)
+    pout = np.empty((K, max(n, 1)), np.int32)
+    pn = np.zeros((K,), np.int32)
+    m = lib().orc_rulebook_strided(_p(indices), n, _p(shape), _p(ksize), _p(stride), _p(padding), _p(out_shape),
+                                   _p(out_idx), cap, _p(pin), _p(pout), _p(pn))
+    return out_idx[:m].copy(), [int(s) for s in out_shape], pin, pout, pn
+
+
+def conv_apply(features, weight, pin, pout, pn, n_out):
+    """weight (Cout, kD, kH, kW, Cin) — spconv 2.x layout (detector3d_template.py:401-433)."""
+    features = _f32(features)
+    weight = _f32(weight)
+    Cout, Cin = weight.shape[0], weight.shape[-1]
+    K = int(np.prod(weight.shape[1:4]))
+    w = weight.reshape(Cout, K, Cin)
+    out = np.zeros((n_out, Cout), np.float32)
+    lib().orc_spconv_apply(_p(features), _p(_f32(w)), _p(pin), _p(pout), _p(pn), pin.shape[1], K, Cin, Cout, _p(out))
+    return out
+
+
+def subm_conv(x, weight, indice_key=None):
+    """spconv.SubMConv3d forward (spconv_backbone.py:39-46): rulebook cached per indice_key."""
+    ksize = weight.shape[1:4]
+    key = ("subm", indice_key)
+    if indice_key is None or key not in x.rulebooks:
+        rb = rulebook_subm(x.indices, x.spatial_shape, ksize)
+        if indice_key is not None:
+            x.rulebooks[key] = rb
+    else:
+        rb = x.rulebooks[key]
+    out = SparseTensor(conv_apply(x.features, weight, *rb, x.features.shape[0]), x.indices, x.spatial_shape, x.batch_size)
+    out.rulebooks = x.rulebooks
+    return out
+
+
+def sparse_conv(x, weight, stride, padding):
+    """spconv.SparseConv3d forward (spconv_backbone.py:14-15)."""
+    ksize = weight.shape[1:4]
+    out_idx, out_shape, pin, pout, pn = rulebook_strided(x.indices, x.spatial_shape, ksize, stride, padding)
+    return SparseTensor(conv_apply(x.features, weight, pin, pout, pn, out_idx.shape[0]), out_idx, out_shape, x.batch_size)
+
+
+def bn_fold(bn, eps=1e-3):
+    """bn = dict(weight, bias, running_mean, running_var) -> (scale, shift) f32."""
+    C = bn["weight"].shape[0]
+    scale = np.empty((C,), np.float32)
+    shift = np.empty((C,), np.float32)
+    lib().orc_bn_fold(_p(_f32(bn["weight"])), _p(_f32(bn["bias"])), _p(_f32(bn["running_mean"])),
+                      _p(_f32(bn["running_var"])), c_float(eps), C, _p(scale), _p(shift))
+    return scale, shift
+
+
+def scale_shift_act(feats, scale, shift, residual=None, relu=True, bf16=False):
+    feats = np.array(feats, dtype=np.float32, order="C", copy=True)
+    n, C = feats.shape
+    lib().orc_scale_shift_act(_p(feats), n, C, _p(scale) if scale is not None else None,
+                              _p(shift) if shift is not None else None,
+                              _p(_f32(residual)) if residual is not None else None, int(relu))
+    if bf16:
+        round_bf16(feats)
+    return feats
+
+
+def round_bf16(a):
+    """In-place round-to-nearest-even to bf16 precision (emulates bf16 feature storage)."""
+    assert a.dtype == np.float32 and a.flags.c_contiguous
+    lib().orc_round_bf16(_p(a), c_size_t(a.size))
+    return a
+
+
+# ---------------------------------------------------------------- VoxelResBackBone8x
+def backbone_forward(params, voxel_features, voxel_coords, batch_size, sparse_shape, bf16=False, last_pad=0):
+    """VoxelResBackBone8x.forward (spconv_backbone.py:243-295) in eval mode.
+
+    params: dict name -> ndarray with the reference state_dict keys
+    ('conv_input.0.weight', 'conv_input.1.weight', ..., 'conv1.0.conv1.weight', ...), conv
+    weights in spconv 2.x layout (Cout,kD,kH,kW,Cin).  bf16=True emulates the MFMA path's bf16
+    storage: weights and every layer output are rounded to bf16, accumulation stays f32.
+    Returns dict of SparseTensor: x_conv1..x_conv4, out.
+    """
+
+    def W(name):
+        w = _f32(params[name]).copy()
+        return round_bf16(w) if (bf16 and name != "conv_input.0.weight") else w
+
+    def BN(prefix):
+        return bn_fold({k: params[f"{prefix}.{k}"] for k in ("weight", "bias", "running_mean", "running_var")})
+
+    def post(x, feats, bn_prefix, residual=None):
+        sc, sh = BN(bn_prefix)
+        y = SparseTensor(scale_shift_act(feats, sc, sh, residual, True, bf16), x.indices, x.spatial_shape, x.batch_size)
+        y.rulebooks = x.rulebooks
+        return y
+
+    def basic_block(x, prefix, key):  # SparseBasicBlock.forward, spconv_backbone.py:51-67
+        o = subm_conv(x, W(f"{prefix}.conv1.weight"), key)
+        o = post(o, o.features, f"{prefix}.bn1")
+        o2 = subm_conv(o, W(f"{prefix}.conv2.weight"), key)
+        return post(o2, o2.features, f"{prefix}.bn2", residual=x.features)
+
+    def down(x, prefix, stride, padding):  # post_act_block conv_type='spconv', :8-27
+        o = sparse_conv(x, W(f"{prefix}.0.weight"), stride, padding)
+        return post(o, o.features, f"{prefix}.1")
+
+    x = SparseTensor(voxel_features, voxel_coords, sparse_shape, batch_size)
+    o = subm_conv(x, W("conv_input.0.weight"), "subm1")                    # :193-197
+    x = post(o, o.features, "conv_input.1")
+    x = basic_block(x, "conv1.0", "res1")                                   # :200-203
+    x_conv1 = basic_block(x, "conv1.1", "res1")
+    x = down(x_conv1, "conv2.0", 2, 1)                                      # :205-210
+    x = basic_block(x, "conv2.1", "res2")
+    x_conv2 = basic_block(x, "conv2.2", "res2")
+    x = down(x_conv2, "conv3.0", 2, 1)                                      # :212-217
+    x = basic_block(x, "conv3.1", "res3")
+    x_conv3 = basic_block(x, "conv3.2", "res3")
+    x = down(x_conv3, "conv4.0", 2, (0, 1, 1))                              # :219-224
+    x = basic_block(x, "conv4.1", "res4")
+    x_conv4 = basic_block(x, "conv4.2", "res4")
+    o = sparse_conv(x_conv4, W("conv_out.0.weight"), (2, 1, 1), last_pad)   # :228-234, kernel (3,1,1)
+    out = post(o, o.features, "conv_out.1")
+    return {"x_conv1": x_conv1, "x_conv2": x_conv2, "x_conv3": x_conv3, "x_conv4": x_conv4, "out": out}

@@ -1,0 +1,274 @@
+"""Rulebooks + sparse convolution kernels vs the CPU oracle (rows matched by coordinate, since the
+strided output row order is implementation-defined in spconv), the spconv-shaped module API, and
+the fused VoxelResBackBone8x in f32 (<= 1e-4, the north-star tolerance) and bf16 mode."""
+import numpy as np
+import pytest
+import torch
+
+from findnpropagate_amd import sparse as S
+from findnpropagate_amd import spconv
+from findnpropagate_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_sparse(rng, B, shape, n, C):
+    cells = B * shape[0] * shape[1] * shape[2]
+    lin = rng.choice(cells, size=n, replace=False)
+    b, rem = np.divmod(lin, shape[0] * shape[1] * shape[2])
+    z, rem = np.divmod(rem, shape[1] * shape[2])
+    y, x = np.divmod(rem, shape[2])
+    return rng.standard_normal((n, C)).astype(np.float32), np.stack([b, z, y, x], 1).astype(np.int32)
+
+
+def _key(idx, shape):
+    idx = idx.astype(np.int64)
+    return ((idx[:, 0] * shape[0] + idx[:, 1]) * shape[1] + idx[:, 2]) * shape[2] + idx[:, 3]
+
+
+def _by_coord(feats, idx, shape):
+    o = np.argsort(_key(idx, shape))
+    return feats[o], idx[o]
+
+
+def _nbr_to_pairs(nbr, n_out):
+    """(K,cap) nbr -> set of (k, in, out)."""
+    nbr = nbr[:, :n_out]
+    k, o = np.nonzero(nbr >= 0)
+    return set(zip(k.tolist(), nbr[k, o].tolist(), o.tolist()))
+
+
+@pytest.mark.parametrize("ksize", [3, (3, 1, 1)])
+def test_subm_rulebook_bit_exact(cuda, oracle, rng, ksize):
+    B, shape, n = 3, [13, 50, 47], 4000
+    _, idx = _random_sparse(rng, B, shape, n, 1)
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    grid = S.build_grid(d_idx, n_dev, B, shape)
+    rb = S.rulebook_subm(d_idx, n_dev, grid, ksize)
+    pin, pout, pn = oracle.rulebook_subm(idx, shape, ksize)
+    want = set()
+    for k in range(pin.shape[0]):
+        want |= {(k, int(pin[k, p]), int(pout[k, p])) for p in range(pn[k])}
+    assert _nbr_to_pairs(rb.nbr.cpu().numpy(), n) == want
+
+
+@pytest.mark.parametrize("k,s,p", [(3, 2, 1), (3, 2, (0, 1, 1)), ((3, 1, 1), (2, 1, 1), 0), (2, 2, 0)])
+def test_strided_rulebook_bit_exact(cuda, oracle, rng, k, s, p):
+    B, shape, n = 2, [21, 40, 44], 3000
+    _, idx = _random_sparse(rng, B, shape, n, 1)
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    grid = S.build_grid(d_idx, n_dev, B, shape)
+    rb = S.rulebook_strided(d_idx, n_dev, grid, k, s, p, cap_out=n * 27)
+    n_out = int(rb.out_n.item())
+    out_idx = rb.out_indices[:n_out].cpu().numpy()
+    o_idx, o_shape, pin, pout, pn = oracle.rulebook_strided(idx, shape, k, s, p)
+    assert rb.out_shape == o_shape and n_out == o_idx.shape[0]
+    # same site set; our rows are in rank-grid (blocked) order, deterministic
+    assert np.array_equal(np.sort(_key(out_idx, o_shape)), np.sort(_key(o_idx, o_shape)))
+    # same pairs once output rows are renamed by coordinate
+    ren = {int(kk): i for i, kk in enumerate(_key(o_idx, o_shape))}
+    mine = {(kk, i, ren[int(_key(out_idx[o:o + 1], o_shape)[0])]) for (kk, i, o) in _nbr_to_pairs(rb.nbr.cpu().numpy(), n_out)}
+    want = set()
+    for kk in range(pin.shape[0]):
+        want |= {(kk, int(pin[kk, q]), int(pout[kk, q])) for q in range(pn[kk])}
+    assert mine == want
+
+
+@pytest.mark.parametrize("Cin,Cout", [(5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (24, 40)])
+def test_conv_f32_bit_exact_vs_oracle(cuda, oracle, rng, Cin, Cout):
+    """f32 validation path: k-ascending, cin-ascending fmaf chain == oracle's chain."""
+    B, shape, n = 2, [9, 30, 31], 1500
+    feats, idx = _random_sparse(rng, B, shape, n, Cin)
+    w = (rng.standard_normal((Cout, 3, 3, 3, Cin)) * 0.1).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((n, Cout)).astype(np.float32)
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    rb = S.rulebook_subm(d_idx, n_dev, S.build_grid(d_idx, n_dev, B, shape), 3)
+    wp = S.pack_weight(torch.from_numpy(w).to(cuda), torch.float32)
+    got = S.conv_forward(torch.from_numpy(feats).to(cuda), wp, rb, n_dev, scale=torch.from_numpy(scale).to(cuda),
+                         shift=torch.from_numpy(shift).to(cuda), residual=torch.from_numpy(res).to(cuda), relu=True)
+    y = oracle.subm_conv(oracle.SparseTensor(feats, idx, shape, B), w)
+    want = oracle.scale_shift_act(y.features, scale, shift, res, relu=True)
+    assert np.array_equal(got.cpu().numpy(), want)
+    raw = S.conv_forward(torch.from_numpy(feats).to(cuda), wp, rb, n_dev)
+    assert np.array_equal(raw.cpu().numpy(), y.features)
+
+
+@pytest.mark.parametrize("Cin,Cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128)])
+@pytest.mark.parametrize("n", [1, 63, 1500])
+def test_conv_bf16_mfma_vs_oracle(cuda, oracle, rng, Cin, Cout, n):
+    """bf16 x bf16 products are exact in f32; only the f32 summation order differs from the oracle
+    (which is fed the same bf16-rounded inputs): tolerance 1e-4 relative to the row scale + one bf16
+    rounding of the stored output."""
+    B, shape = 2, [9, 30, 31]
+    feats, idx = _random_sparse(rng, B, shape, n, Cin)
+    w = (rng.standard_normal((Cout, 3, 3, 3, Cin)) * 0.1).astype(np.float32)
+    oracle.round_bf16(feats)
+    oracle.round_bf16(w)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.standard_normal(Cout).astype(np.float32)
+    res = rng.standard_normal((n, Cout)).astype(np.float32)
+    oracle.round_bf16(res)
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    rb = S.rulebook_subm(d_idx, n_dev, S.build_grid(d_idx, n_dev, B, shape), 3)
+    wp = S.pack_weight(torch.from_numpy(w).to(cuda), torch.bfloat16)
+    x = torch.from_numpy(feats).to(cuda).to(torch.bfloat16)
+    y = oracle.subm_conv(oracle.SparseTensor(feats, idx, shape, B), w)
+    want = oracle.scale_shift_act(y.features, scale, shift, res, relu=True)
+    # f32 output: isolates the accumulation-order difference
+    got32 = S.conv_forward(x, wp, rb, n_dev, out_dtype=torch.float32, scale=torch.from_numpy(scale).to(cuda),
+                           shift=torch.from_numpy(shift).to(cuda), residual=torch.from_numpy(res).to(cuda), relu=True)
+    np.testing.assert_allclose(got32.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    # bf16 output: one extra rounding
+    got16 = S.conv_forward(x, wp, rb, n_dev, scale=torch.from_numpy(scale).to(cuda),
+                           shift=torch.from_numpy(shift).to(cuda),
+                           residual=torch.from_numpy(res).to(cuda).to(torch.bfloat16), relu=True)
+    assert got16.dtype == torch.bfloat16
+    np.testing.assert_allclose(got16.float().cpu().numpy(), want, rtol=1e-2, atol=1e-2)
+    # run-to-run bit stability (no atomics)
+    again = S.conv_forward(x, wp, rb, n_dev, out_dtype=torch.float32, scale=torch.from_numpy(scale).to(cuda),
+                           shift=torch.from_numpy(shift).to(cuda), residual=torch.from_numpy(res).to(cuda), relu=True)
+    assert torch.equal(got32, again)
+
+
+def test_module_api_matches_oracle_and_dense(cuda, oracle, rng):
+    """spconv-shaped modules (SubMConv3d -> SparseConv3d -> .dense()) in f32."""
+    B, shape, n = 2, [11, 24, 26], 900
+    feats, idx = _random_sparse(rng, B, shape, n, 8)
+    m1 = spconv.SubMConv3d(8, 16, 3, padding=1, bias=False, indice_key="a").to(cuda).eval()
+    m2 = spconv.SparseConv3d(16, 32, 3, stride=2, padding=(0, 1, 1), bias=True, indice_key="b").to(cuda).eval()
+    with torch.no_grad():
+        x = spconv.SparseConvTensor(torch.from_numpy(feats).to(cuda), torch.from_numpy(idx).to(cuda), shape, B)
+        y1 = m1(x)
+        y1b = m1(y1.replace_feature(x.features))          # second call reuses indice_key 'a'
+        y2 = m2(y1)
+        dense = y2.dense().cpu().numpy()
+    assert "a" in x.indice_dict and torch.equal(y1.features, y1b.features)
+    o1 = oracle.subm_conv(oracle.SparseTensor(feats, idx, shape, B), m1.weight.detach().cpu().numpy())
+    assert np.array_equal(y1.features.cpu().numpy(), o1.features)
+    o2 = oracle.sparse_conv(o1, m2.weight.detach().cpu().numpy(), 2, (0, 1, 1))
+    o2.features += m2.bias.detach().cpu().numpy()[None, :]
+    assert y2.spatial_shape == o2.spatial_shape and y2.features.shape[0] == o2.features.shape[0]
+    got_f, got_i = _by_coord(y2.features.cpu().numpy(), y2.indices.cpu().numpy(), y2.spatial_shape)
+    want_f, want_i = _by_coord(o2.features, o2.indices, o2.spatial_shape)
+    assert np.array_equal(got_i, want_i)
+    np.testing.assert_allclose(got_f, want_f, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(dense, o2.dense(), rtol=1e-6, atol=1e-6)
+    # training-mode call with autograd must fail loudly, not return a graph-less tensor
+    m1.train()
+    with pytest.raises(NotImplementedError):
+        m1(x)
+
+
+def _small_net(cuda, dtype):
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+
+    grid_size = np.array([96, 88, 40])  # x, y, z -> sparse shape [41, 88, 96]
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False, "FNP_DTYPE": dtype}, 5, grid_size), seed=1)
+    return net.to(cuda).eval()
+
+
+def _check_stage(got, want, rtol, atol):
+    gf, gi = _by_coord(got.features.float().cpu().numpy(), got.indices.cpu().numpy(), got.spatial_shape)
+    wf, wi = _by_coord(want.features, want.indices, want.spatial_shape)
+    assert got.spatial_shape == want.spatial_shape
+    assert np.array_equal(gi, wi), "active site sets differ"
+    np.testing.assert_allclose(gf, wf, rtol=rtol, atol=atol)
+
+
+def test_fused_backbone_f32_within_1e4(cuda, oracle, rng):
+    net = _small_net(cuda, "fp32")
+    shape = net.sparse_shape
+    feats, idx = _random_sparse(rng, 2, shape, 6000, 5)
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    want = oracle.backbone_forward(sd, feats, idx, 2, shape)
+    bd = {"voxel_features": torch.from_numpy(feats).to(cuda), "voxel_coords": torch.from_numpy(idx).to(cuda).float(),
+          "batch_size": 2}
+    with torch.no_grad():
+        out = net(bd)
+    assert out["encoded_spconv_tensor_stride"] == 8
+    assert out["multi_scale_3d_strides"] == {"x_conv1": 1, "x_conv2": 2, "x_conv3": 4, "x_conv4": 8}
+    x1 = out["multi_scale_3d_features"]["x_conv1"]
+    assert np.array_equal(x1.indices.cpu().numpy(), idx), "SubM keeps the input row order"
+    for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+        _check_stage(out["multi_scale_3d_features"][k], want[k], 1e-4, 1e-4)
+    _check_stage(out["encoded_spconv_tensor"], want["out"], 1e-4, 1e-4)
+    assert out["encoded_spconv_tensor"].features.shape[1] == 128
+    # HeightCompression: dense (B, 128, 2, H/8, W/8) -> (B, 256, H/8, W/8)
+    d = out["encoded_spconv_tensor"].dense()
+    assert list(d.shape) == [2, 128, 2, 11, 12]
+    np.testing.assert_allclose(d.cpu().numpy(), want["out"].dense(), rtol=1e-4, atol=1e-4)
+    # module path (unfused BN in torch) agrees with the fused path
+    net.train()
+    with torch.no_grad():
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.eval()
+        out2 = net({"voxel_features": bd["voxel_features"], "voxel_coords": bd["voxel_coords"], "batch_size": 2})
+    net.eval()
+    _check_stage(out2["encoded_spconv_tensor"], want["out"], 1e-4, 1e-4)
+
+
+def test_fused_backbone_bf16(cuda, oracle, rng):
+    net = _small_net(cuda, "bf16")
+    shape = net.sparse_shape
+    feats, idx = _random_sparse(rng, 2, shape, 6000, 5)
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    want = oracle.backbone_forward(sd, feats, idx, 2, shape, bf16=True)
+    want32 = oracle.backbone_forward(sd, feats, idx, 2, shape)
+    bd = {"voxel_features": torch.from_numpy(feats).to(cuda), "voxel_coords": torch.from_numpy(idx).to(cuda), "batch_size": 2}
+    with torch.no_grad():
+        out = net(bd)
+    assert out["encoded_spconv_tensor"].features.dtype == torch.bfloat16
+    # vs the bf16-emulating oracle: differences are isolated bf16 rounding flips (<= 1 bf16 ulp,
+    # 2^-8 relative) that propagate through 21 layers
+    for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+        _check_stage(out["multi_scale_3d_features"][k], want[k], 3e-2, 3e-2)
+    _check_stage(out["encoded_spconv_tensor"], want["out"], 3e-2, 3e-2)
+    # vs the f32 oracle: report the bf16 storage error (not a parity gate)
+    g, _ = _by_coord(out["encoded_spconv_tensor"].features.float().cpu().numpy(),
+                     out["encoded_spconv_tensor"].indices.cpu().numpy(), want32["out"].spatial_shape)
+    w, _ = _by_coord(want32["out"].features, want32["out"].indices, want32["out"].spatial_shape)
+    rel = np.abs(g - w).max() / (np.abs(w).max() + 1e-6)
+    assert rel < 0.1, rel
+    # bit-identical across runs
+    with torch.no_grad():
+        out2 = net({"voxel_features": bd["voxel_features"], "voxel_coords": bd["voxel_coords"], "batch_size": 2})
+    assert torch.equal(out["encoded_spconv_tensor"].features, out2["encoded_spconv_tensor"].features)
+
+
+def test_forward_points_full_size_properties(cuda, oracle):
+    """BASELINE-size run (3 scenes x 30k points, 41x1440x1440 grid): voxel rows bit-exact vs the
+    oracle voxeliser, stage site counts == oracle rulebook counts, SubM keeps voxel order."""
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+
+    grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), seed=0).to(cuda).eval()
+    assert net.sparse_shape == [41, 1440, 1440]
+    seeds = (11, 12, 13)
+    pts, off = syn.make_batch(seeds)
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+    with torch.no_grad():
+        res = net.forward_points(torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda), 3, cfg)
+        res2 = net.forward_points(torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda), 3, cfg)
+    coords = []
+    for b, s in enumerate(seeds):
+        _, c, _ = oracle.voxelize(syn.make_scene(s), syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 10, 160000)
+        coords.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
+    coords = np.concatenate(coords)
+    assert np.array_equal(res["voxel_coords"].cpu().numpy(), coords)
+    assert np.array_equal(res["x_conv1"].indices.cpu().numpy(), coords)
+    shape, idx = [41, 1440, 1440], coords
+    for name, (k, s, p) in (("x_conv2", (3, 2, 1)), ("x_conv3", (3, 2, 1)), ("x_conv4", (3, 2, (0, 1, 1))), ("out", ((3, 1, 1), (2, 1, 1), 0))):
+        idx, shape, _, _, _ = oracle.rulebook_strided(idx, shape, k, s, p)
+        got = res[name]
+        assert got.spatial_shape == shape and got.indices.shape[0] == idx.shape[0]
+        assert np.array_equal(np.sort(_key(got.indices.cpu().numpy(), shape)), np.sort(_key(idx, shape)))
+        assert torch.isfinite(got.features.float()).all()
+    assert res["out"].spatial_shape == [2, 180, 180]
+    assert torch.equal(res["out"].features, res2["out"].features), "persistent grids were left clean; rerun is bit-identical"

@@ -1,0 +1,108 @@
+"""GPU voxeliser + MeanVFE vs the sequential oracle: coords / order / counts / the (M,P,C) block
+bit-exact, mean features bit-exact too (same slot-order summation)."""
+import numpy as np
+import pytest
+import torch
+
+from findnpropagate_amd import sparse as S
+from findnpropagate_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(points_list, cfg_args, cuda, want_voxels=True):
+    pts = np.concatenate(points_list, 0) if points_list else np.zeros((0, cfg_args[2]), np.float32)
+    off = np.zeros(len(points_list) + 1, np.int32)
+    off[1:] = np.cumsum([p.shape[0] for p in points_list])
+    cfg = S.make_voxel_cfg(*cfg_args)
+    r = S.voxelize(torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda), len(points_list), cfg,
+                   want_voxels=want_voxels)
+    n = int(r["n"].item())
+    return {k: (r[k][:n].cpu().numpy() if r[k] is not None else None) for k in ("coords", "num_points", "mean", "voxels")}, n
+
+
+def _oracle(points_list, cfg_args, oracle):
+    vs, rg, C, mp, mv = cfg_args
+    cs, ns, vs_, ms = [], [], [], []
+    for b, p in enumerate(points_list):
+        v, c, n = oracle.voxelize(p, vs, rg, mp, mv)
+        cs.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
+        ns.append(n)
+        vs_.append(v)
+        ms.append(oracle.mean_vfe(v, n))
+    return np.concatenate(cs), np.concatenate(ns), np.concatenate(vs_), np.concatenate(ms)
+
+
+def test_voxelize_nuscenes_scene_bit_exact(cuda, oracle):
+    args = (syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+    scenes = [syn.make_scene(s) for s in (0, 1, 2)]
+    got, n = _run(scenes, args, cuda)
+    c, num, vox, mean = _oracle(scenes, args, oracle)
+    assert n == c.shape[0] and n > 50000
+    assert np.array_equal(got["coords"], c), "voxel coords / first-come order"
+    assert np.array_equal(got["num_points"], num)
+    assert np.array_equal(got["voxels"], vox)
+    assert np.array_equal(got["mean"], mean)
+
+
+@pytest.mark.parametrize("max_points,max_voxels", [(3, 100000), (10, 300), (1, 77)])
+def test_voxelize_overflow_rules(cuda, oracle, rng, max_points, max_voxels):
+    """Dense cloud: voxels overflow max_points; max_voxels cuts the first-come list per scene."""
+    scenes = []
+    for s in range(3):
+        p = rng.uniform(-3, 3, size=(5000 + 311 * s, 5)).astype(np.float32)
+        p[:, 2] = rng.uniform(-1.2, 1.2, size=p.shape[0])
+        p[::11, 1] = -50.0   # out of range
+        scenes.append(p)
+    args = ([0.25, 0.25, 0.5], [-2.5, -2.5, -1.0, 2.5, 2.5, 1.0], 5, max_points, max_voxels)
+    got, n = _run(scenes, args, cuda)
+    c, num, vox, mean = _oracle(scenes, args, oracle)
+    assert n == c.shape[0]
+    assert np.array_equal(got["coords"], c) and np.array_equal(got["num_points"], num)
+    assert np.array_equal(got["voxels"], vox) and np.array_equal(got["mean"], mean)
+    assert num.max() == max_points
+
+
+def test_voxelize_shuffled_points_follow_point_order(cuda, oracle, rng):
+    """The reference shuffles points before voxelising (data_processor.py:96-106): order matters."""
+    p = syn.make_scene(5)
+    p = p[rng.permutation(p.shape[0])]
+    args = (syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+    got, n = _run([p], args, cuda)
+    c, num, vox, mean = _oracle([p], args, oracle)
+    assert np.array_equal(got["coords"], c) and np.array_equal(got["voxels"], vox)
+
+
+def test_voxelize_edge_inputs(cuda, oracle):
+    args = ([0.1, 0.1, 0.1], [0, 0, 0, 1, 1, 1], 5, 10, 100)
+    got, n = _run([np.zeros((0, 5), np.float32)], args, cuda)
+    assert n == 0
+    p = np.array([[0.55, 0.25, 0.95, 7, 0], [1.0, 0.5, 0.5, 0, 0], [-1e-9, 0.5, 0.5, 0, 0], [0.55, 0.25, 0.95, 9, 1]], np.float32)
+    got, n = _run([p], args, cuda)
+    assert n == 1 and got["coords"].tolist() == [[0, 9, 2, 5]] and got["num_points"].tolist() == [2]
+    assert got["mean"][0, 3] == 8.0
+    # a scene with no valid point between two non-empty scenes
+    got, n = _run([p, np.full((3, 5), 50.0, np.float32), p], args, cuda)
+    assert got["coords"].tolist() == [[0, 9, 2, 5], [2, 9, 2, 5]]
+
+
+def test_voxel_generator_wrapper_dropin(cuda, oracle):
+    """VoxelGeneratorWrapper with the reference's signature (data_processor.py:17-62)."""
+    from findnpropagate_amd.processor import VoxelGeneratorWrapper
+
+    p = syn.make_scene(3)
+    g = VoxelGeneratorWrapper(vsize_xyz=syn.VOXEL_SIZE, coors_range_xyz=syn.POINT_CLOUD_RANGE, num_point_features=5,
+                              max_num_points_per_voxel=10, max_num_voxels=120000)
+    voxels, coords, num = g.generate(p)
+    v, c, n = oracle.voxelize(p, syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 10, 120000)
+    assert coords.dtype == np.int32 and coords.shape[1] == 3
+    assert np.array_equal(coords, c) and np.array_equal(num, n) and np.array_equal(voxels, v)
+
+
+def test_rerun_is_deterministic(cuda):
+    args = (syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+    scenes = [syn.make_scene(7)]
+    a, _ = _run(scenes, args, cuda)
+    b, _ = _run(scenes, args, cuda)
+    for k in a:
+        assert np.array_equal(a[k], b[k])

@@ -1,0 +1,217 @@
+"""Self-pinning of the oracle's spconv restatement (voxeliser, rulebooks, sparse conv, dense):
+spconv itself is absent and unpinned by the reference ("parity unpinned"), so the
+restatement is checked against torch.nn.functional.conv3d on densified grids, a dict-based
+sequential voxeliser and hand-computed cases.  CPU only."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def _random_sparse(rng, B, shape, n, C):
+    cells = B * shape[0] * shape[1] * shape[2]
+    lin = rng.choice(cells, size=n, replace=False)
+    b, rem = np.divmod(lin, shape[0] * shape[1] * shape[2])
+    z, rem = np.divmod(rem, shape[1] * shape[2])
+    y, x = np.divmod(rem, shape[2])
+    idx = np.stack([b, z, y, x], 1).astype(np.int32)
+    feats = rng.standard_normal((n, C)).astype(np.float32)
+    return feats, idx
+
+
+def _densify(feats, idx, B, shape):
+    d = np.zeros((B, feats.shape[1], *shape), np.float32)
+    d[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]] = feats
+    return d
+
+
+def _w_torch(w):  # (Cout,kD,kH,kW,Cin) -> (Cout,Cin,kD,kH,kW)
+    return torch.from_numpy(w).permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("ksize", [3, (3, 1, 1), (1, 3, 3)])
+def test_subm_equals_dense_conv_on_input_sites(oracle, rng, ksize):
+    B, shape, n, Cin, Cout = 2, [6, 9, 10], 150, 5, 7
+    feats, idx = _random_sparse(rng, B, shape, n, Cin)
+    k = [ksize] * 3 if np.isscalar(ksize) else list(ksize)
+    w = rng.standard_normal((Cout, *k, Cin)).astype(np.float32)
+    x = oracle.SparseTensor(feats, idx, shape, B)
+    y = oracle.subm_conv(x, w, "k")
+    dense = F.conv3d(torch.from_numpy(_densify(feats, idx, B, shape)), _w_torch(w), padding=[kk // 2 for kk in k]).numpy()
+    want = dense[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]]
+    assert np.array_equal(y.indices, idx)
+    np.testing.assert_allclose(y.features, want, rtol=1e-5, atol=1e-5)
+    # rulebook is cached per indice_key
+    assert ("subm", "k") in x.rulebooks
+
+
+@pytest.mark.parametrize("k,s,p", [(3, 2, 1), (3, 2, (0, 1, 1)), ((3, 1, 1), (2, 1, 1), 0), (2, 2, 0), (3, 1, 0)])
+def test_strided_equals_dense_conv_masked_to_generated_sites(oracle, rng, k, s, p):
+    B, shape, n, Cin, Cout = 2, [9, 12, 11], 200, 4, 6
+    feats, idx = _random_sparse(rng, B, shape, n, Cin)
+    kk = [k] * 3 if np.isscalar(k) else list(k)
+    ss = [s] * 3 if np.isscalar(s) else list(s)
+    pp = [p] * 3 if np.isscalar(p) else list(p)
+    w = rng.standard_normal((Cout, *kk, Cin)).astype(np.float32)
+    y = oracle.sparse_conv(oracle.SparseTensor(feats, idx, shape, B), w, ss, pp)
+    dense_in = torch.from_numpy(_densify(feats, idx, B, shape))
+    dense = F.conv3d(dense_in, _w_torch(w), stride=ss, padding=pp).numpy()
+    assert list(dense.shape[2:]) == y.spatial_shape
+    occ = torch.from_numpy(_densify(np.ones((n, 1), np.float32), idx, B, shape))
+    reach = F.conv3d(occ, torch.ones((1, 1, *kk)), stride=ss, padding=pp).numpy()[:, 0] > 0
+    got_mask = np.zeros_like(reach)
+    oi = y.indices
+    got_mask[oi[:, 0], oi[:, 1], oi[:, 2], oi[:, 3]] = True
+    assert np.array_equal(got_mask, reach), "output site set = cells with an input in their receptive field"
+    assert len({tuple(r) for r in oi.tolist()}) == oi.shape[0], "no duplicate output rows"
+    np.testing.assert_allclose(y.features, dense[oi[:, 0], :, oi[:, 1], oi[:, 2], oi[:, 3]], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(y.dense(), dense * reach[:, None], rtol=1e-5, atol=1e-5)
+
+
+def test_known_answer_two_voxels(oracle):
+    """Two x-adjacent voxels, 1 channel, weight = kernel offset index: hand-computed."""
+    idx = np.array([[0, 1, 1, 1], [0, 1, 1, 2]], np.int32)
+    feats = np.array([[1.0], [10.0]], np.float32)
+    w = np.arange(27, dtype=np.float32).reshape(1, 3, 3, 3, 1)
+    y = oracle.subm_conv(oracle.SparseTensor(feats, idx, [3, 3, 4], 1), w)
+    # site 0 sees itself through the centre (k=13) and its +x neighbour through k=14
+    assert y.features[:, 0].tolist() == [13 * 1 + 14 * 10, 12 * 1 + 13 * 10]
+    # stride 2, pad 1: outputs at floor((i+1-k)/2); cells (1,1,1)->o in {(0|1,0|1,0|1)}...
+    z = oracle.sparse_conv(oracle.SparseTensor(feats, idx, [3, 3, 4], 1), w, 2, 1)
+    assert z.spatial_shape == [2, 2, 2]
+    assert z.indices.shape[0] == 8  # x=1 (odd) reaches ox 0 and 1; x=2 reaches ox 1 only; y,z=1 reach 0 and 1
+    d = z.dense()[0, 0]
+    # output (1,1,1): input coord = 2*o - 1 + k -> site (1,1,1) via k=(0,0,0)=0, site (1,1,2) via k=(0,0,1)=1
+    assert d[1, 1, 1] == 0 * 1 + 1 * 10
+    # output (0,0,0): site (1,1,1) via k=(2,2,2)=26 only (x=2 would need kx=3)
+    assert d[0, 0, 0] == 26 * 1
+
+
+def test_boundary_voxel_and_batch_separation(oracle):
+    idx = np.array([[0, 0, 0, 0], [1, 0, 0, 1]], np.int32)   # neighbours in space but different batch
+    feats = np.array([[2.0], [3.0]], np.float32)
+    w = np.ones((1, 3, 3, 3, 1), np.float32)
+    y = oracle.subm_conv(oracle.SparseTensor(feats, idx, [2, 2, 2], 2), w)
+    assert y.features[:, 0].tolist() == [2.0, 3.0]
+
+
+def _voxelize_py(points, vs, rng_, max_points, max_voxels):
+    vs = np.asarray(vs, np.float32)
+    lo = np.asarray(rng_[:3], np.float32)
+    grid = np.round((np.asarray(rng_[3:], np.float32) - lo) / vs).astype(np.int64)
+    table, coords, num, vox = {}, [], [], []
+    for p in points:
+        c = np.floor((p[:3] - lo) / vs)
+        if (c < 0).any() or (c >= grid).any():
+            continue
+        key = (int(c[2]), int(c[1]), int(c[0]))
+        v = table.get(key)
+        if v is None:
+            if len(coords) >= max_voxels:
+                continue
+            v = len(coords)
+            table[key] = v
+            coords.append(key)
+            num.append(0)
+            vox.append(np.zeros((max_points, points.shape[1]), np.float32))
+        if num[v] < max_points:
+            vox[v][num[v]] = p
+            num[v] += 1
+    return np.array(vox, np.float32).reshape(-1, max_points, points.shape[1]), np.array(coords, np.int32).reshape(-1, 3), np.array(num, np.int32)
+
+
+@pytest.mark.parametrize("max_points,max_voxels", [(10, 100000), (3, 100000), (10, 50)])
+def test_voxelizer_sequential_semantics(oracle, rng, max_points, max_voxels):
+    pts = rng.uniform(-3, 3, size=(3000, 5)).astype(np.float32)
+    pts[:, 2] = rng.uniform(-1.2, 1.2, size=3000)
+    pts[::7, 0] = 100.0                       # out of range points are skipped
+    vs, rg = [0.25, 0.25, 0.5], [-2.5, -2.5, -1.0, 2.5, 2.5, 1.0]
+    v, c, n = oracle.voxelize(pts, vs, rg, max_points, max_voxels)
+    v2, c2, n2 = _voxelize_py(pts, vs, rg, max_points, max_voxels)
+    assert np.array_equal(c, c2) and np.array_equal(n, n2) and np.array_equal(v, v2)
+    assert c.shape[0] <= max_voxels and n.max() <= max_points
+    if max_points == 3:
+        assert (n == 3).any(), "overflowing voxels keep their first max_points points"
+    mean = oracle.mean_vfe(v, n)
+    want = v.sum(1) / np.maximum(n, 1)[:, None].astype(np.float32)
+    np.testing.assert_allclose(mean, want, rtol=1e-6, atol=1e-6)
+
+
+def test_voxelizer_empty_and_single(oracle):
+    v, c, n = oracle.voxelize(np.zeros((0, 5), np.float32), [0.1, 0.1, 0.1], [0, 0, 0, 1, 1, 1], 10, 100)
+    assert v.shape == (0, 10, 5) and c.shape == (0, 3) and n.shape == (0,)
+    p = np.array([[0.55, 0.25, 0.95, 7, 0]], np.float32)
+    v, c, n = oracle.voxelize(p, [0.1, 0.1, 0.1], [0, 0, 0, 1, 1, 1], 10, 100)
+    assert c.tolist() == [[9, 2, 5]] and n.tolist() == [1]      # [z, y, x]
+    # upper range bound is exclusive: x == max -> c == grid -> dropped
+    p = np.array([[1.0, 0.5, 0.5, 0, 0]], np.float32)
+    assert oracle.voxelize(p, [0.1, 0.1, 0.1], [0, 0, 0, 1, 1, 1], 10, 100)[1].shape[0] == 0
+
+
+def test_bn_fold_matches_torch_batchnorm_eval(oracle, rng):
+    C, n = 16, 200
+    bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(rng.standard_normal(C).astype(np.float32)))
+        bn.bias.copy_(torch.from_numpy(rng.standard_normal(C).astype(np.float32)))
+        bn.running_mean.copy_(torch.from_numpy(rng.standard_normal(C).astype(np.float32)))
+        bn.running_var.copy_(torch.from_numpy(rng.uniform(0.5, 2, C).astype(np.float32)))
+    x = rng.standard_normal((n, C)).astype(np.float32)
+    sc, sh = oracle.bn_fold({k: getattr(bn, k).detach().numpy() for k in ("weight", "bias", "running_mean", "running_var")})
+    got = oracle.scale_shift_act(x, sc, sh, None, relu=True)
+    want = torch.relu(bn(torch.from_numpy(x))).detach().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def test_backbone_graph_shapes_and_dense_equivalence(oracle, rng):
+    """Whole VoxelResBackBone8x graph on a small grid vs the same graph evaluated with dense
+    torch convs masked to the active sites (SubM) / reachable sites (strided)."""
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    from findnpropagate_amd import synthetic as syn
+
+    grid_size = np.array([24, 20, 40])  # x, y, z
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid_size), seed=3).eval()
+    sd = {k: v.detach().numpy() for k, v in net.state_dict().items() if "num_batches" not in k}
+    shape = net.sparse_shape
+    assert shape == [41, 20, 24]
+    feats, idx = _random_sparse(rng, 2, shape, 400, 5)
+    res = oracle.backbone_forward(sd, feats, idx, 2, shape)
+    assert res["x_conv2"].spatial_shape == [21, 10, 12]
+    assert res["x_conv3"].spatial_shape == [11, 5, 6]
+    assert res["x_conv4"].spatial_shape == [5, 3, 3]
+    assert res["out"].spatial_shape == [2, 3, 3]
+    # dense restatement
+    def bn(x, p):
+        g = lambda k: torch.from_numpy(sd[f"{p}.{k}"]).view(1, -1, 1, 1, 1)
+        return (x - g("running_mean")) / torch.sqrt(g("running_var") + 1e-3) * g("weight") + g("bias")
+
+    def subm(x, mask, name, bnp, res_=None):
+        y = bn(F.conv3d(x, _w_torch(sd[name]), padding=1), bnp)
+        if res_ is not None:
+            y = y + res_
+        return torch.relu(y) * mask
+
+    def block(x, mask, p):
+        t = subm(x, mask, f"{p}.conv1.weight", f"{p}.bn1")
+        return subm(t, mask, f"{p}.conv2.weight", f"{p}.bn2", res_=x)
+
+    def down(x, mask, p, s, pad, k=(3, 3, 3)):
+        m = (F.conv3d(mask, torch.ones((1, 1, *k)), stride=s, padding=pad) > 0).float()
+        return torch.relu(bn(F.conv3d(x, _w_torch(sd[f"{p}.0.weight"]), stride=s, padding=pad), f"{p}.1")) * m, m
+
+    x = torch.from_numpy(_densify(feats, idx, 2, shape))
+    m1 = torch.from_numpy(_densify(np.ones((400, 1), np.float32), idx, 2, shape))
+    x = subm(x, m1, "conv_input.0.weight", "conv_input.1")
+    x = block(block(x, m1, "conv1.0"), m1, "conv1.1")
+    np.testing.assert_allclose(res["x_conv1"].dense(), x.numpy(), rtol=1e-4, atol=1e-4)
+    x, m2 = down(x, m1, "conv2.0", 2, 1)
+    x = block(block(x, m2, "conv2.1"), m2, "conv2.2")
+    np.testing.assert_allclose(res["x_conv2"].dense(), x.numpy(), rtol=1e-4, atol=1e-4)
+    x, m3 = down(x, m2, "conv3.0", 2, 1)
+    x = block(block(x, m3, "conv3.1"), m3, "conv3.2")
+    x, m4 = down(x, m3, "conv4.0", 2, (0, 1, 1))
+    x = block(block(x, m4, "conv4.1"), m4, "conv4.2")
+    np.testing.assert_allclose(res["x_conv4"].dense(), x.numpy(), rtol=1e-4, atol=1e-4)
+    mo = (F.conv3d(m4, torch.ones((1, 1, 3, 1, 1)), stride=(2, 1, 1)) > 0).float()
+    x = torch.relu(bn(F.conv3d(x, _w_torch(sd["conv_out.0.weight"]), stride=(2, 1, 1)), "conv_out.1")) * mo
+    np.testing.assert_allclose(res["out"].dense(), x.numpy(), rtol=1e-4, atol=1e-4)
