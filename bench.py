@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — NuScenes scenes/s through voxelise -> MeanVFE -> VoxelResBackBone8x on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
+driver launches it under torch.distributed.run, one rank per GPU.  A step = one pass of the hot
+path over one batch of B synthetic 30k-point scenes already resident in HBM (workload =
+BASELINE.json configs[1]).  Scenes shard across ranks with no data-path collective (weak scaling).
+Rank 0 prints ONE JSON line with the whole-job scenes/s plus:
+  roofline     — the dominant kernel's algorithmic bytes per launch (SURVEY.md §8d formula, counts
+                 taken from this run's rulebooks) / its mean launch duration measured with HIP
+                 events on the launch stream, against the 8 TB/s HBM peak;
+  cpu_baseline — oracle/ (CPU restatement, "port") timed on this host, 1 thread, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="scenes per step per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--no-events", action="store_true", help="do not bracket conv launches with events")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(tag, P, n_out, b):
+    """P*(Cin*b + 8) + N_out*Cout*b + K*Cin*Cout*b (+ N_out*Cout*b residual read)."""
+    cin, cout, K, res = tag
+    v = P * (cin * b + 8) + n_out * cout * b + K * cin * cout * b
+    if res:
+        v += n_out * cout * b
+    return v
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path for the product)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)
+
+    from findnpropagate_amd import lib, sparse as S, synthetic as syn
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+
+    lib.load()
+    B = args.batch
+    grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False, "FNP_DTYPE": args.dtype}, 5, grid), seed=0)
+    net = net.to(dev).eval()
+    seeds = [rank * B + i for i in range(B)]
+    pts_np, off_np = syn.make_batch(seeds)
+    pts = torch.from_numpy(pts_np).to(dev)
+    off = torch.from_numpy(off_np).to(dev)
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, syn.MAX_VOXELS_TEST)
+    eng = net.engine()
+
+    def step():
+        with torch.no_grad():
+            return net.forward_points(pts, off, B, cfg)  # ends with the one host sync that sizes the outputs
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    # rulebook statistics for the roofline (outside the timed region)
+    eng.rulebook_log = []
+    res = step()
+    rb_log, eng.rulebook_log = eng.rulebook_log, None
+    counts = res["counts"]
+    stats = {}
+    for tag, rb, n_dev in rb_log:
+        n = int(n_dev.item())
+        key = id(rb.nbr)
+        if key not in stats:
+            stats[key] = int((rb.nbr[:, :n] >= 0).sum().item())
+        stats.setdefault(("tags", tag), []).append((stats[key], n))
+    torch.cuda.synchronize()
+
+    if not args.no_events:
+        eng.profile = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof, eng.profile = eng.profile, None
+
+    out = {
+        "metric": "NuScenes scenes/s (30k pts, Transfusion voxel backbone)",
+        "value": world * B * args.steps / elapsed,
+        "unit": "scenes/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {"workload": "synthetic 30k-point nuScenes-like scenes: voxelize + MeanVFE + VoxelResBackBone8x "
+                               "(BASELINE.json configs[1])",
+                   "scenes_per_step_per_gpu": B, "points_per_scene": int(pts_np.shape[0] // B),
+                   "voxels_per_scene": int(counts[0] // B), "sparse_shape": [41, 1440, 1440],
+                   "site_counts": [int(c) for c in counts], "weights": "seeded random init",
+                   "parallelism": f"scenes sharded {world}x, no data-path collective"},
+    }
+
+    if rank == 0 and prof:
+        b = 2 if args.dtype == "bf16" else 4
+        per = {}
+        for tag, e0, e1 in prof:
+            per.setdefault(tag[:3], []).append((e0.elapsed_time(e1), tag))
+        # dominant layer class = largest total time; one class = one kernel name (template instance)
+        cls = max(per, key=lambda k: sum(x[0] for x in per[k]))
+        ms = [x[0] for x in per[cls]]
+        byts = []
+        for _, tag in per[cls]:
+            P, n = stats[("tags", tag)][0]
+            byts.append(algorithmic_bytes(tag, P, n, b))
+        avg_ms = float(np.mean(ms))
+        avg_bytes = float(np.mean(byts))
+        achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
+        cin, cout, K = cls
+        flops = 2.0 * float(np.mean([stats[("tags", tag)][0][0] for _, tag in per[cls]])) * cin * cout
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "traffic": None,
+            "kernel": f"spconv_mfma_kernel<{cin},{cout},4,{K if K == 27 else 0}>" if args.dtype == "bf16" else "spconv_valu_kernel",
+            "avg_launch_ms": avg_ms, "launches_timed": len(ms), "algorithmic_bytes_per_launch": avg_bytes,
+            "mfma_tflops_algorithmic": flops / (avg_ms * 1e-3) / 1e12,
+            "time_share_of_step": sum(ms) / (1e3 * elapsed),
+            "all_conv_classes_ms_per_step": {f"{k[0]}x{k[1]}k{k[2]}": sum(x[0] for x in v) / args.steps for k, v in per.items()},
+        }
+
+    if rank == 0 and args.cpu_scenes > 0:
+        from oracle import oracle as O
+
+        sd = {k: t.detach().cpu().numpy() for k, t in net.state_dict().items()}
+        O.lib()
+        tc0 = time.perf_counter()
+        for s in range(args.cpu_scenes):
+            p = syn.make_scene(s)
+            v, c, n = O.voxelize(p, syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, syn.MAX_POINTS_PER_VOXEL, syn.MAX_VOXELS_TEST)
+            f = O.mean_vfe(v, n)
+            idx = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+            O.backbone_forward(sd, f, idx, 1, net.sparse_shape)
+        tc = time.perf_counter() - tc0
+        out["cpu_baseline"] = {"value": args.cpu_scenes / tc, "unit": "scenes/s", "cores": 1, "kind": "port",
+                               "sample": f"{args.cpu_scenes} of the same synthetic scenes, batch 1, f32, voxelize + "
+                                         f"MeanVFE + VoxelResBackBone8x through oracle/ (gather-GEMM-scatter), {tc:.1f} s"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

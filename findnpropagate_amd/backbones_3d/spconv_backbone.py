@@ -245,6 +245,10 @@ class FusedResBackbone:
         # capacity of stage l (l = 2..5) as a multiple of the stage-1 capacity; grown on overflow
         self.cap_factor = [3.0, 2.0, 1.0, 1.0]
         self._vox_ws = None
+        # measurement hooks (bench.py): when `profile` is a list every conv launch is bracketed by
+        # stream events, (tag, start, end) appended; `rulebook_log` receives (tag, Rulebook, n_dev)
+        self.profile = None
+        self.rulebook_log = None
 
     # ---- weights --------------------------------------------------------------------------
     def _fold(self, conv, bn, dtype):
@@ -325,7 +329,17 @@ class FusedResBackbone:
 
         def conv(x, prm, rb, n, residual=None, out_dtype=act):
             w, sc, sh = prm
-            return S.conv_forward(x, w, rb, n, out_dtype=out_dtype, scale=sc, shift=sh, residual=residual, relu=True)
+            tag = (int(w.shape[2]), int(w.shape[1]), int(w.shape[0]), residual is not None)  # Cin, Cout, K, res
+            if self.rulebook_log is not None:
+                self.rulebook_log.append((tag, rb, n))
+            if self.profile is None:
+                return S.conv_forward(x, w, rb, n, out_dtype=out_dtype, scale=sc, shift=sh, residual=residual, relu=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = S.conv_forward(x, w, rb, n, out_dtype=out_dtype, scale=sc, shift=sh, residual=residual, relu=True)
+            e1.record()
+            self.profile.append((tag, e0, e1))
+            return y
 
         def blocks(x, rb, n, prms):
             for p1, p2 in prms:

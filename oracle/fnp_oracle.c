@@ -18,7 +18,7 @@
  *     self-pinned by dense-convolution equivalence with torch.nn.functional.conv3d and
  *     hand-computed known-answer cases in tests/test_oracle_spconv.py.
  *
- * Build: gcc -O2 -mavx2 -mfma -ffp-contract=off -fPIC -shared (oracle/Makefile).
+ * Build: gcc -O3 -mavx2 -mfma -ffp-contract=off -fPIC -shared (oracle/Makefile).
  */
 #include <math.h>
 #include <stdint.h>

@@ -60,7 +60,7 @@ def test_voxelize_overflow_rules(cuda, oracle, rng, max_points, max_voxels):
     assert n == c.shape[0]
     assert np.array_equal(got["coords"], c) and np.array_equal(got["num_points"], num)
     assert np.array_equal(got["voxels"], vox) and np.array_equal(got["mean"], mean)
-    assert num.max() == max_points
+    assert num.max() <= max_points and (max_points > 3 or num.max() == max_points)
 
 
 def test_voxelize_shuffled_points_follow_point_order(cuda, oracle, rng):
