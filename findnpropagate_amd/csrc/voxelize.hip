@@ -237,20 +237,24 @@ extern "C" int64_t fnp_rankgrid_num_blocks(int B, int D, int H, int W) {
     return fnp_num_blocks(fnp_make_dims(B, D, H, W));
 }
 
-extern "C" int64_t fnp_voxelize_workspace_bytes(int64_t n_points, int B, const fnp_voxel_cfg *cfg) {
-    if (!cfg || n_points < 0 || B <= 0) return FNP_ERR_ARG;
+static bool grid_shape_ok(const fnp_voxel_cfg *cfg, const int *gs) {
+    return gs && gs[0] >= cfg->grid[2] && gs[1] >= cfg->grid[1] && gs[2] >= cfg->grid[0];
+}
+
+extern "C" int64_t fnp_voxelize_workspace_bytes(int64_t n_points, int B, const fnp_voxel_cfg *cfg, const int *grid_shape) {
+    if (!cfg || n_points < 0 || B <= 0 || !grid_shape_ok(cfg, grid_shape)) return FNP_ERR_ARG;
     VoxWs w;
-    const RankGridDims g = fnp_make_dims(B, cfg->grid[2], cfg->grid[1], cfg->grid[0]);
+    const RankGridDims g = fnp_make_dims(B, grid_shape[0], grid_shape[1], grid_shape[2]);
     const long long n = n_points > 0 ? n_points : 1;
     return carve(w, nullptr, n, B, (int)n, cfg->max_points, fnp_num_blocks(g));
 }
 
 extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets, int B, const fnp_voxel_cfg *cfg,
-                            uint64_t *grid_bits, uint32_t *grid_base, int *grid_perm, void *workspace,
+                            const int *grid_shape, uint64_t *grid_bits, uint32_t *grid_base, int *grid_perm, void *workspace,
                             int64_t workspace_bytes, int *coords, int *num_points, float *mean_feats, float *voxels,
                             int *n_voxels, int cap, fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (!cfg || n < 0 || B <= 0 || B > kMaxBatch || cap <= 0 || !n_voxels) return FNP_ERR_ARG;
+    if (!cfg || n < 0 || B <= 0 || B > kMaxBatch || cap <= 0 || !n_voxels || !grid_shape_ok(cfg, grid_shape)) return FNP_ERR_ARG;
     if (cfg->num_features < 3 || cfg->max_points <= 0 || cfg->max_points > 64 || cfg->max_voxels <= 0) return FNP_ERR_ARG;
     if (n == 0) {
         FNP_HIP_TRY(hipMemsetAsync(n_voxels, 0, sizeof(int), s));
@@ -260,7 +264,7 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
         !mean_feats)
         return FNP_ERR_ARG;
     if (cap < n) return FNP_ERR_ARG;  // every point could open a voxel
-    const RankGridDims g = fnp_make_dims(B, cfg->grid[2], cfg->grid[1], cfg->grid[0]);
+    const RankGridDims g = fnp_make_dims(B, grid_shape[0], grid_shape[1], grid_shape[2]);
     const long long nblk = fnp_num_blocks(g);
     VoxWs w;
     const long long need = carve(w, (char *)workspace, n, B, n, cfg->max_points, nblk);

@@ -70,8 +70,8 @@ SIGNATURES = {
     "fnp_nms_normal": (c_int, [P, c_int, c_float, P, P, P, P]),
     "fnp_rankgrid_num_blocks": (c_int64, [c_int, c_int, c_int, c_int]),
     "fnp_scan_workspace_bytes": (c_int64, [c_int64]),
-    "fnp_voxelize_workspace_bytes": (c_int64, [c_int64, c_int, POINTER(VoxelCfg)]),
-    "fnp_voxelize": (c_int, [P, c_int, P, c_int, POINTER(VoxelCfg), P, P, P, P, c_int64,
+    "fnp_voxelize_workspace_bytes": (c_int64, [c_int64, c_int, POINTER(VoxelCfg), POINTER(c_int)]),
+    "fnp_voxelize": (c_int, [P, c_int, P, c_int, POINTER(VoxelCfg), POINTER(c_int), P, P, P, P, c_int64,
                              P, P, P, P, P, c_int, P]),
     "fnp_rankgrid_build": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int64, P]),
     "fnp_rankgrid_clear": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -10,6 +10,7 @@ Data layout in HBM:
   grid      bits (nblk,) u64 occupancy, base (nblk,) u32 popcount prefix, perm (cap,) int32|None
   rulebook  nbr (K, cap) int32: input row per (kernel offset, output row) or -1
 """
+import ctypes
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -107,12 +108,14 @@ def voxelize(points, batch_offsets, batch_size, cfg, grid=None, want_voxels=Fals
     assert C == cfg.num_features
     dev = points.device
     cap = max(n, 1)
-    shape = [cfg.grid[2], cfg.grid[1], cfg.grid[0]]
     if grid is None:
-        grid = alloc_grid(batch_size, shape, dev, with_perm_cap=cap)
+        grid = alloc_grid(batch_size, [cfg.grid[2], cfg.grid[1], cfg.grid[0]], dev, with_perm_cap=cap)
     elif grid.perm is None or grid.perm.numel() < cap:
         grid.perm = torch.empty((cap,), dtype=torch.int32, device=dev)
-    ws_bytes = int(L.fnp_voxelize_workspace_bytes(n, batch_size, cfg))
+    assert grid.batch_size == batch_size
+    gshape = (ctypes.c_int * 3)(*grid.shape)   # the rank grid may be larger than the voxel grid (z + 1)
+    ws_bytes = int(L.fnp_voxelize_workspace_bytes(n, batch_size, cfg, gshape))
+    _l.check(min(ws_bytes, 0), "fnp_voxelize_workspace_bytes")
     if workspace is None or workspace.numel() < ws_bytes:
         workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
@@ -120,7 +123,7 @@ def voxelize(points, batch_offsets, batch_size, cfg, grid=None, want_voxels=Fals
     mean = torch.empty((cap, C), dtype=torch.float32, device=dev)
     voxels = torch.empty((cap, cfg.max_points, C), dtype=torch.float32, device=dev) if want_voxels else None
     n_vox = torch.zeros((1,), dtype=torch.int32, device=dev)
-    rc = L.fnp_voxelize(_l.ptr(points), n, _l.ptr(batch_offsets), batch_size, cfg,
+    rc = L.fnp_voxelize(_l.ptr(points), n, _l.ptr(batch_offsets), batch_size, cfg, gshape,
                         _l.ptr(grid.bits), _l.ptr(grid.base), _l.ptr(grid.perm),
                         _l.ptr(workspace), workspace.numel(),
                         _l.ptr(coords), _l.ptr(num_points), _l.ptr(mean), _l.ptr(voxels), _l.ptr(n_vox), cap,
@@ -140,6 +143,7 @@ def build_grid(indices, n_dev, batch_size, shape, keep_order=True, grid=None):
     dev = indices.device
     if grid is None:
         grid = alloc_grid(batch_size, shape, dev, with_perm_cap=cap if keep_order else None)
+    assert grid.batch_size == batch_size and list(grid.shape) == [int(v) for v in shape]
     nblk = grid.bits.numel()
     ws = torch.empty((int(L.fnp_scan_workspace_bytes(nblk)) + 256,), dtype=torch.uint8, device=dev)
     rc = L.fnp_rankgrid_build(_l.ptr(indices), _l.ptr(n_dev), cap, batch_size, *shape,

@@ -118,17 +118,20 @@ typedef struct fnp_voxel_cfg {
     int max_voxels;      /* MAX_NUMBER_OF_VOXELS per scene */
 } fnp_voxel_cfg;
 
-int64_t fnp_voxelize_workspace_bytes(int64_t n_points, int B, const fnp_voxel_cfg *cfg);
+/* grid_shape = {D,H,W} of the rank grid the voxels are indexed in; it may be larger than the
+ * voxel grid {cfg.grid[2], cfg.grid[1], cfg.grid[0]} (the backbone's sparse_shape adds one z
+ * layer, spconv_backbone.py:191). */
+int64_t fnp_voxelize_workspace_bytes(int64_t n_points, int B, const fnp_voxel_cfg *cfg, const int *grid_shape);
 
 /* points (N,C) f32, scenes concatenated; batch_offsets (B+1,) int32 device (scene b owns
  * points [off[b], off[b+1])).  Outputs, all capacity `cap` rows (cap >= N is always enough):
  *   coords (cap,4) int32 [b,z,y,x] in the sequential first-come order of the reference,
  *   num_points (cap,) int32, mean_feats (cap,C) f32 = MeanVFE, voxels (cap,max_points,C) f32
  *   zero padded (nullable), n_voxels (1,) int32 device.
- * grid_bits/grid_base/grid_perm describe the (B, gz, gy, gx) rank grid of the voxels for the
+ * grid_bits/grid_base/grid_perm describe the (B, grid_shape) rank grid of the voxels for the
  * first rulebook (grid_perm[sorted rank] = voxel row).  grid_bits must be zero on entry. */
 int fnp_voxelize(const float *points, int n_points, const int *batch_offsets, int B,
-                 const fnp_voxel_cfg *cfg,
+                 const fnp_voxel_cfg *cfg, const int *grid_shape,
                  uint64_t *grid_bits, uint32_t *grid_base, int *grid_perm,
                  void *workspace, int64_t workspace_bytes,
                  int *coords, int *num_points, float *mean_feats, float *voxels,

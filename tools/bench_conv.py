@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Time each sparse-conv layer class of VoxelResBackBone8x in isolation on real rulebooks
+(B synthetic scenes), 20 launches each, HIP events.  Development tool for kernel iteration."""
+import argparse, os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from findnpropagate_amd import sparse as S, synthetic as syn
+from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--reps", type=int, default=20)
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+B = args.batch
+grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 0).to(dev).eval()
+pts, off = syn.make_batch(list(range(B)))
+pts, off = torch.from_numpy(pts).to(dev), torch.from_numpy(off).to(dev)
+cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+eng = net.engine()
+with torch.no_grad():
+    net.forward_points(pts, off, B, cfg)
+    eng.rulebook_log = []
+    res = net.forward_points(pts, off, B, cfg)
+log, eng.rulebook_log = eng.rulebook_log, None
+P = eng.prepare()
+seen = {}
+for tag, rb, n_dev in log:
+    cin, cout, K, has_res = tag
+    if cin == 5 or (cin, cout, K) in seen: continue
+    seen[(cin, cout, K)] = 1
+    n = int(n_dev.item()); pairs = int((rb.nbr[:, :n] >= 0).sum().item())
+    n_in = int(rb.nbr[:, :n].max().item()) + 1
+    x = torch.randn((n_in, cin), device=dev).to(torch.bfloat16)
+    w = (torch.randn((K, cout, cin), device=dev) * 0.05).to(torch.bfloat16)
+    sc = torch.ones(cout, device=dev); sh = torch.zeros(cout, device=dev)
+    resid = torch.randn((rb.cap_out, cout), device=dev).to(torch.bfloat16)
+    for _ in range(3): S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(args.reps): S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.reps
+    dense_flop = 2.0 * n * K * cin * cout; alg_flop = 2.0 * pairs * cin * cout
+    byts = pairs * (cin * 2 + 8) + 2 * n * cout * 2 + K * cin * cout * 2
+    print(json.dumps({"layer": f"{cin}x{cout}k{K}", "n_out": n, "pairs": pairs, "density": round(pairs / (n * K), 3), "ms": round(ms, 4),
+                      "dense_TF": round(dense_flop / ms / 1e9, 1), "alg_TF": round(alg_flop / ms / 1e9, 1), "alg_GBs": round(byts / ms / 1e6, 1)}))
