@@ -161,7 +161,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
             "traffic": None,
-            "kernel": f"spconv_mfma_kernel<{cin},{cout},4,{K if K == 27 else 0}>" if args.dtype == "bf16" else "spconv_valu_kernel",
+            "kernel": f"spconv_mfma_kernel<{cin},{cout},{2 if (cout >= 128 or (cin, cout) == (16, 16)) else 4},{K if K == 27 else 0},bf16>" if args.dtype == "bf16" else "spconv_valu_kernel",
             "avg_launch_ms": avg_ms, "launches_timed": len(ms), "algorithmic_bytes_per_launch": avg_bytes,
             "mfma_tflops_algorithmic": flops / (avg_ms * 1e-3) / 1e12,
             "time_share_of_step": sum(ms) / (1e3 * elapsed),

@@ -324,7 +324,7 @@ class FusedResBackbone:
         grids = self._get_grids(batch_size, dev)
         cap1 = max(indices.shape[0], 1)
         if grid1 is None:
-            grid1 = S.build_grid(indices, n1, batch_size, m.sparse_shape, keep_order=True, grid=_with_perm(grids[0], cap1, dev))
+            grid1 = S.build_grid(indices, n1, batch_size, m.sparse_shape, keep_order=True, grid=grids[0])
         caps = [cap1] + [max(256, int(cap1 * f)) for f in self.cap_factor]
 
         def conv(x, prm, rb, n, residual=None, out_dtype=act):
@@ -386,7 +386,7 @@ class FusedResBackbone:
             # rows beyond a capacity were never emitted, so the sparse clear missed their cells:
             # wipe the persistent grids before the retry with larger buffers
             for g in grids:
-                g.bits.zero_()
+                g.zero_()
             return None
         tensors = []
         for l, (x, idx, n, g) in enumerate(stage):

@@ -2,8 +2,11 @@
 //
 // A (B, D, H, W) cell grid is cut into 4x4x4 blocks.  Block w owns
 //   bits[w]  u64 occupancy, bit = (z&3)*16 + (y&3)*4 + (x&3)
-//   base[w]  u32 number of occupied cells in blocks < w          (exclusive popcount scan)
+//   base[w]  u32 number of occupied cells in blocks < w   (exclusive popcount scan; defined only
+//            where bits[w] != 0 — an empty word is never ranked)
 // so   rank(cell) = base[w] + popc(bits[w] & ((1<<bit) - 1))     iff the bit is set.
+// summary[i] bit j says bits[64 i + j] != 0: scans, coordinate emission and clearing walk the
+// summary and touch only occupied blocks.
 // A 3x3x3 neighbourhood touches at most 8 blocks (3.4 on average) instead of 27 hash probes,
 // lookups never collide, and ranks enumerate the cells in a spatially blocked order that the
 // strided convolutions adopt as their output row order (good L2 locality for the gathers).
@@ -28,6 +31,32 @@ __host__ __device__ inline long long fnp_num_blocks(const RankGridDims &g) {
     return (long long)g.B * g.bd * g.bh * g.bw;
 }
 
+// device view of a fnp_rankgrid
+struct RG {
+    RankGridDims d;
+    unsigned long long *bits;
+    unsigned *base;
+    unsigned long long *summ;
+    int *perm;
+    long long nblk, nsum;
+};
+
+inline bool fnp_rg_valid(const fnp_rankgrid *g, bool need_perm = false) {
+    return g && g->B > 0 && g->D > 0 && g->H > 0 && g->W > 0 && g->bits && g->base && g->summary && (!need_perm || g->perm);
+}
+
+inline RG fnp_rg_view(const fnp_rankgrid *g) {
+    RG r;
+    r.d = fnp_make_dims(g->B, g->D, g->H, g->W);
+    r.bits = (unsigned long long *)g->bits;
+    r.base = (unsigned *)g->base;
+    r.summ = (unsigned long long *)g->summary;
+    r.perm = g->perm;
+    r.nblk = fnp_num_blocks(r.d);
+    r.nsum = (r.nblk + 63) >> 6;
+    return r;
+}
+
 __device__ __forceinline__ long long rg_block_of(const RankGridDims &g, int b, int z, int y, int x) {
     return (((long long)b * g.bd + (z >> 2)) * g.bh + (y >> 2)) * g.bw + (x >> 2);
 }
@@ -44,24 +73,33 @@ __device__ __forceinline__ void rg_decode(const RankGridDims &g, long long blk, 
     x = (bx << 2) | (bit & 3);
 }
 
-// Row of cell (b,z,y,x) or -1.  Caller guarantees the cell is inside the grid.
-__device__ __forceinline__ int rg_lookup(const RankGridDims &g, const unsigned long long *__restrict__ bits,
-                                         const unsigned *__restrict__ base, const int *__restrict__ perm,
-                                         int b, int z, int y, int x) {
-    const long long blk = rg_block_of(g, b, z, y, x);
-    const unsigned long long w = bits[blk];
-    const int bit = rg_bit_of(z, y, x);
-    if (!((w >> bit) & 1ull)) return -1;
-    const int r = (int)base[blk] + __popcll(w & ((1ull << bit) - 1ull));
-    return perm ? perm[r] : r;
+// Mark a cell occupied.  The plain read first keeps already-set bits (the common case once a block
+// has been touched) off the atomic path; exactly one thread sees the word go 0 -> non-zero and
+// publishes the block in the summary level.
+__device__ __forceinline__ void rg_mark(const RG &g, long long blk, int bit) {
+    const unsigned long long m = 1ull << bit;
+    if (g.bits[blk] & m) return;
+    const unsigned long long old = atomicOr(&g.bits[blk], m);
+    if (old == 0ull) atomicOr(&g.summ[blk >> 6], 1ull << (blk & 63));
 }
 
-// Device-wide exclusive scan (three launches).  See scan.hip.
+// Row of cell (b,z,y,x) or -1.  Caller guarantees the cell is inside the grid.
+__device__ __forceinline__ int rg_lookup(const RG &g, int b, int z, int y, int x) {
+    const long long blk = rg_block_of(g.d, b, z, y, x);
+    const unsigned long long w = g.bits[blk];
+    const int bit = rg_bit_of(z, y, x);
+    if (!((w >> bit) & 1ull)) return -1;
+    const int r = (int)g.base[blk] + __popcll(w & ((1ull << bit) - 1ull));
+    return g.perm ? g.perm[r] : r;
+}
+
+// Device-wide exclusive scans (scan.hip).
 namespace fnp_scan {
 constexpr int kTile = 4096;  // elements per workgroup (256 threads x 16)
-// out[i] = exclusive prefix of popc(bits[i]); *total = sum.  ws: fnp_scan_workspace_bytes(n).
-int popcount_u64(const unsigned long long *bits, long long n, unsigned *out, int *total, void *ws, hipStream_t s);
-// out[i] = exclusive prefix of flags[i] (int32 0/1 or counts); *total = sum.
+// out[i] = exclusive prefix of in[i] (int32 flags or counts); *total = sum.  in == out allowed.
 int int32(const int *in, long long n, int *out, int *total, void *ws, hipStream_t s);
 long long workspace_bytes(long long n);
+// base[w] for every occupied block of the grid, *total = number of occupied cells.
+int rank_grid(const RG &g, int *total, void *ws, hipStream_t s);
+long long rank_grid_workspace_bytes(long long nsum);
 }  // namespace fnp_scan

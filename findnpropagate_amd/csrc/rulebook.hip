@@ -31,10 +31,7 @@ __device__ __forceinline__ void unpack_k(int kidx, const Geom &ge, int &kz, int 
 
 // grid (blocks over rows, K)
 __global__ __launch_bounds__(kThreads) void subm_nbr_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows,
-                                                            int cap, RankGridDims g, Geom ge,
-                                                            const unsigned long long *__restrict__ bits,
-                                                            const unsigned *__restrict__ base,
-                                                            const int *__restrict__ perm, int *__restrict__ nbr) {
+                                                            int cap, RG g, Geom ge, int *__restrict__ nbr) {
     const int n = min(*n_rows, cap);
     const int kidx = blockIdx.y;
     int kz, ky, kx;
@@ -44,59 +41,67 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_kernel(const int *__restric
         const int4 c = reinterpret_cast<const int4 *>(coords)[o];
         const int z = c.y + dz, y = c.z + dy, x = c.w + dx;
         int r = -1;
-        if (z >= 0 && z < g.D && y >= 0 && y < g.H && x >= 0 && x < g.W) r = rg_lookup(g, bits, base, perm, c.x, z, y, x);
+        if (z >= 0 && z < g.d.D && y >= 0 && y < g.d.H && x >= 0 && x < g.d.W) r = rg_lookup(g, c.x, z, y, x);
         nbr[(size_t)kidx * cap + o] = r;
     }
 }
 
-// grid (blocks over input rows, K): mark output cells
+// one thread per input row: mark every output cell it feeds (at most ceil(k/s)^3, 8 for k3 s2)
 __global__ __launch_bounds__(kThreads) void strided_mark_kernel(const int *__restrict__ in_coords,
-                                                                const int *__restrict__ n_in, int cap_in,
-                                                                RankGridDims go, Geom ge,
-                                                                unsigned long long *__restrict__ out_bits) {
+                                                                const int *__restrict__ n_in, int cap_in, RG go,
+                                                                Geom ge) {
     const int n = min(*n_in, cap_in);
-    int kz, ky, kx;
-    unpack_k(blockIdx.y, ge, kz, ky, kx);
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         const int4 c = reinterpret_cast<const int4 *>(in_coords)[i];
-        const int tz = c.y + ge.p[0] - kz, ty = c.z + ge.p[1] - ky, tx = c.w + ge.p[2] - kx;
-        if (tz < 0 || ty < 0 || tx < 0) continue;
-        if (tz % ge.s[0] || ty % ge.s[1] || tx % ge.s[2]) continue;
-        const int oz = tz / ge.s[0], oy = ty / ge.s[1], ox = tx / ge.s[2];
-        if (oz >= go.D || oy >= go.H || ox >= go.W) continue;
-        atomicOr(&out_bits[rg_block_of(go, c.x, oz, oy, ox)], 1ull << rg_bit_of(oz, oy, ox));
+        for (int kz = 0; kz < ge.k[0]; ++kz) {
+            const int tz = c.y + ge.p[0] - kz;
+            if (tz < 0 || tz % ge.s[0]) continue;
+            const int oz = tz / ge.s[0];
+            if (oz >= go.d.D) continue;
+            for (int ky = 0; ky < ge.k[1]; ++ky) {
+                const int ty = c.z + ge.p[1] - ky;
+                if (ty < 0 || ty % ge.s[1]) continue;
+                const int oy = ty / ge.s[1];
+                if (oy >= go.d.H) continue;
+                for (int kx = 0; kx < ge.k[2]; ++kx) {
+                    const int tx = c.w + ge.p[2] - kx;
+                    if (tx < 0 || tx % ge.s[2]) continue;
+                    const int ox = tx / ge.s[2];
+                    if (ox >= go.d.W) continue;
+                    rg_mark(go, rg_block_of(go.d, c.x, oz, oy, ox), rg_bit_of(oz, oy, ox));
+                }
+            }
+        }
     }
 }
 
-// one thread per occupancy word: emit the coordinates of its set bits at their ranks
-__global__ __launch_bounds__(kThreads) void emit_coords_kernel(RankGridDims go, long long nblk,
-                                                               const unsigned long long *__restrict__ bits,
-                                                               const unsigned *__restrict__ base, int cap_out,
-                                                               int *__restrict__ out_coords) {
-    for (long long w = (long long)blockIdx.x * kThreads + threadIdx.x; w < nblk; w += (long long)gridDim.x * kThreads) {
-        unsigned long long m = bits[w];
-        if (!m) continue;
-        int r = (int)base[w];
-        while (m) {
-            const int bit = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (r < cap_out) {
-                int b, z, y, x;
-                rg_decode(go, w, bit, b, z, y, x);
-                reinterpret_cast<int4 *>(out_coords)[r] = make_int4(b, z, y, x);
-            }
-            ++r;
-        }
+// emit output coordinates in rank order: one wave per summary word (a zero word retires after one
+// load); lane j owns block 64*S + j, decodes the block origin once and writes its cells at
+// base[block], base[block] + 1, ...
+__global__ __launch_bounds__(kThreads) void emit_coords_kernel(RG go, int cap_out, int *__restrict__ out_coords) {
+    const int lane = fnp_lane();
+    const long long S = ((long long)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    if (S >= go.nsum) return;
+    const unsigned long long sw = go.summ[S];
+    if (!((sw >> lane) & 1ull)) return;
+    const long long w = S * 64 + lane;
+    unsigned long long m = go.bits[w];
+    int r = (int)go.base[w];
+    int b, z0, y0, x0;
+    rg_decode(go.d, w, 0, b, z0, y0, x0);
+    while (m) {
+        const int bit = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        if (r < cap_out)
+            reinterpret_cast<int4 *>(out_coords)[r] = make_int4(b, z0 | (bit >> 4), y0 | ((bit >> 2) & 3), x0 | (bit & 3));
+        ++r;
     }
 }
 
 // grid (blocks over output rows, K)
 __global__ __launch_bounds__(kThreads) void strided_nbr_kernel(const int *__restrict__ out_coords,
-                                                               const int *__restrict__ n_out, int cap_out,
-                                                               RankGridDims gi, Geom ge,
-                                                               const unsigned long long *__restrict__ in_bits,
-                                                               const unsigned *__restrict__ in_base,
-                                                               const int *__restrict__ in_perm, int *__restrict__ nbr) {
+                                                               const int *__restrict__ n_out, int cap_out, RG gi,
+                                                               Geom ge, int *__restrict__ nbr) {
     const int n = min(*n_out, cap_out);
     const int kidx = blockIdx.y;
     int kz, ky, kx;
@@ -105,8 +110,7 @@ __global__ __launch_bounds__(kThreads) void strided_nbr_kernel(const int *__rest
         const int4 c = reinterpret_cast<const int4 *>(out_coords)[o];
         const int z = c.y * ge.s[0] - ge.p[0] + kz, y = c.z * ge.s[1] - ge.p[1] + ky, x = c.w * ge.s[2] - ge.p[2] + kx;
         int r = -1;
-        if (z >= 0 && z < gi.D && y >= 0 && y < gi.H && x >= 0 && x < gi.W)
-            r = rg_lookup(gi, in_bits, in_base, in_perm, c.x, z, y, x);
+        if (z >= 0 && z < gi.d.D && y >= 0 && y < gi.d.H && x >= 0 && x < gi.d.W) r = rg_lookup(gi, c.x, z, y, x);
         nbr[(size_t)kidx * cap_out + o] = r;
     }
 }
@@ -131,50 +135,55 @@ Geom to_geom(const fnp_conv_geom *g) {
 
 }  // namespace
 
-extern "C" int fnp_rulebook_subm(const int *coords, const int *n_rows, int cap, int B, const fnp_conv_geom *geom,
-                                 const uint64_t *grid_bits, const uint32_t *grid_base, const int *grid_perm, int *nbr,
-                                 fnp_stream_t stream) {
-    if (!coords || !n_rows || cap <= 0 || B <= 0 || !geom_ok(geom) || !grid_bits || !grid_base || !nbr) return FNP_ERR_ARG;
+static bool shape_is(const fnp_rankgrid *g, const int *shape) {
+    return g->D == shape[0] && g->H == shape[1] && g->W == shape[2];
+}
+
+extern "C" int fnp_rulebook_subm(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom,
+                                 const fnp_rankgrid *grid, int *nbr, fnp_stream_t stream) {
+    if (!coords || !n_rows || cap <= 0 || !geom_ok(geom) || !fnp_rg_valid(grid) || !nbr) return FNP_ERR_ARG;
     for (int d = 0; d < 3; ++d)
         if (!(geom->ksize[d] & 1) || geom->in_shape[d] != geom->out_shape[d]) return FNP_ERR_ARG;
+    if (!shape_is(grid, geom->in_shape)) return FNP_ERR_ARG;
     const int K = geom->ksize[0] * geom->ksize[1] * geom->ksize[2];
-    const RankGridDims g = fnp_make_dims(B, geom->in_shape[0], geom->in_shape[1], geom->in_shape[2]);
-    dim3 grid(fnp_grid_for(cap, kThreads, 1024), K);
-    hipLaunchKernelGGL(subm_nbr_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, coords, n_rows, cap, g,
-                       to_geom(geom), (const unsigned long long *)grid_bits, grid_base, grid_perm, nbr);
+    dim3 blocks(fnp_grid_for(cap, kThreads, 1024), K);
+    hipLaunchKernelGGL(subm_nbr_kernel, blocks, dim3(kThreads), 0, (hipStream_t)stream, coords, n_rows, cap,
+                       fnp_rg_view(grid), to_geom(geom), nbr);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
 
-extern "C" int fnp_rulebook_strided(const int *in_coords, const int *n_in, int cap_in, int B, const fnp_conv_geom *geom,
-                                    const uint64_t *in_bits, const uint32_t *in_base, const int *in_perm,
-                                    uint64_t *out_bits, uint32_t *out_base, int *out_coords, int *n_out, int cap_out,
-                                    int *nbr, void *workspace, int64_t workspace_bytes, fnp_stream_t stream) {
+extern "C" int fnp_rulebook_strided(const int *in_coords, const int *n_in, int cap_in, const fnp_conv_geom *geom,
+                                    const fnp_rankgrid *in_grid, const fnp_rankgrid *out_grid, int *out_coords,
+                                    int *n_out, int cap_out, int *nbr, void *workspace, int64_t workspace_bytes,
+                                    fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (!in_coords || !n_in || cap_in <= 0 || cap_out <= 0 || B <= 0 || !geom_ok(geom) || !in_bits || !in_base ||
-        !out_bits || !out_base || !out_coords || !n_out || !nbr || !workspace)
+    if (!in_coords || !n_in || cap_in <= 0 || cap_out <= 0 || !geom_ok(geom) || !fnp_rg_valid(in_grid) ||
+        !fnp_rg_valid(out_grid) || !out_coords || !n_out || !nbr || !workspace)
+        return FNP_ERR_ARG;
+    if (in_grid->B != out_grid->B || !shape_is(in_grid, geom->in_shape) || !shape_is(out_grid, geom->out_shape))
         return FNP_ERR_ARG;
     for (int d = 0; d < 3; ++d) {
         const int expect = (geom->in_shape[d] + 2 * geom->padding[d] - geom->ksize[d]) / geom->stride[d] + 1;
         if (expect != geom->out_shape[d]) return FNP_ERR_ARG;
     }
     const int K = geom->ksize[0] * geom->ksize[1] * geom->ksize[2];
-    const RankGridDims gi = fnp_make_dims(B, geom->in_shape[0], geom->in_shape[1], geom->in_shape[2]);
-    const RankGridDims go = fnp_make_dims(B, geom->out_shape[0], geom->out_shape[1], geom->out_shape[2]);
-    const long long nblk_out = fnp_num_blocks(go);
-    if (fnp_scan::workspace_bytes(nblk_out) > workspace_bytes) return FNP_ERR_WORKSPACE;
+    const RG gi = fnp_rg_view(in_grid);
+    RG go = fnp_rg_view(out_grid);
+    go.perm = nullptr;
+    if (fnp_scan::rank_grid_workspace_bytes(go.nsum) > workspace_bytes) return FNP_ERR_WORKSPACE;
     const Geom ge = to_geom(geom);
 
-    hipLaunchKernelGGL(strided_mark_kernel, dim3(fnp_grid_for(cap_in, kThreads, 1024), K), dim3(kThreads), 0, s,
-                       in_coords, n_in, cap_in, go, ge, (unsigned long long *)out_bits);
+    hipLaunchKernelGGL(strided_mark_kernel, dim3(fnp_grid_for(cap_in, kThreads)), dim3(kThreads), 0, s, in_coords, n_in,
+                       cap_in, go, ge);
     FNP_LAUNCH_CHECK();
-    int rc = fnp_scan::popcount_u64((const unsigned long long *)out_bits, nblk_out, out_base, n_out, workspace, s);
+    int rc = fnp_scan::rank_grid(go, n_out, workspace, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(emit_coords_kernel, dim3(fnp_grid_for(nblk_out, kThreads)), dim3(kThreads), 0, s, go, nblk_out,
-                       (const unsigned long long *)out_bits, out_base, cap_out, out_coords);
+    hipLaunchKernelGGL(emit_coords_kernel, dim3(fnp_divup(go.nsum * 64, kThreads)), dim3(kThreads), 0, s, go, cap_out,
+                       out_coords);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(strided_nbr_kernel, dim3(fnp_grid_for(cap_out, kThreads, 1024), K), dim3(kThreads), 0, s,
-                       out_coords, n_out, cap_out, gi, ge, (const unsigned long long *)in_bits, in_base, in_perm, nbr);
+                       out_coords, n_out, cap_out, gi, ge, nbr);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }

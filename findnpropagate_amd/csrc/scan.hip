@@ -1,6 +1,7 @@
 // Device-wide exclusive scans (wave shuffles + LDS) used for order-preserving compaction:
-// popcount prefixes of the rank-grid occupancy words and first-point flags of the voxeliser.
-// Three launches: tile reduce -> scan of tile sums (one workgroup) -> tile scan + offset.
+// first-point flags of the voxeliser (int32 scan: tile reduce -> scan of tile sums -> tile scan)
+// and the rank-grid popcount prefix, which walks the summary level so that only occupied
+// blocks are read.
 #include "rankgrid.cuh"
 
 namespace {
@@ -8,10 +9,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kItems = fnp_scan::kTile / kThreads;  // 16
 
-struct LoadPopc {
-    const unsigned long long *p;
-    __device__ __forceinline__ unsigned operator()(long long i) const { return (unsigned)__popcll(p[i]); }
-};
 struct LoadInt {
     const int *p;
     __device__ __forceinline__ unsigned operator()(long long i) const { return (unsigned)p[i]; }
@@ -112,16 +109,58 @@ int run_scan(L load, long long n, TOut *out, int *total, void *ws, hipStream_t s
     return FNP_OK;
 }
 
+// ---- rank-grid prefix through the summary level ---------------------------------------------
+// One wave per summary word S (64 blocks); a wave whose word is zero retires after one load, so
+// the cost follows the occupied blocks.  Lane j owns block 64*S + j.
+//   PASS 0: cnt[S]  = occupied cells in the 64 blocks of S
+//   PASS 1: base[w] = prefix[S] + occupied cells in the blocks of S before w   (w occupied)
+template <int PASS>
+__global__ __launch_bounds__(kThreads) void summary_pass_kernel(RG g, int *__restrict__ cnt, const int *__restrict__ prefix) {
+    const int lane = fnp_lane();
+    const long long S = ((long long)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    if (S >= g.nsum) return;
+    const unsigned long long sw = g.summ[S];   // wave-uniform
+    if (sw == 0ull) {
+        if (PASS == 0 && lane == 0) cnt[S] = 0;
+        return;
+    }
+    const long long blk = S * 64 + lane;
+    const bool occ = (sw >> lane) & 1ull;
+    const unsigned c = occ ? (unsigned)__popcll(g.bits[blk]) : 0u;
+    const unsigned inc = wave_inclusive(c);
+    if (PASS == 0) {
+        if (lane == 63) cnt[S] = (int)inc;
+    } else {
+        if (occ) g.base[blk] = (unsigned)prefix[S] + inc - c;
+    }
+}
+
 }  // namespace
 
 namespace fnp_scan {
 long long workspace_bytes(long long n) { return ((n + kTile - 1) / kTile + 1) * 4 + 64; }
-int popcount_u64(const unsigned long long *bits, long long n, unsigned *out, int *total, void *ws, hipStream_t s) {
-    return run_scan(LoadPopc{bits}, n, out, total, ws, s);
-}
 int int32(const int *in, long long n, int *out, int *total, void *ws, hipStream_t s) {
     return run_scan(LoadInt{in}, n, out, total, ws, s);
 }
+long long rank_grid_workspace_bytes(long long nsum) {
+    return ((nsum * 4 + 255) & ~255ll) + workspace_bytes(nsum) + 256;
+}
+int rank_grid(const RG &g, int *total, void *ws, hipStream_t s) {
+    int *cnt = (int *)ws;   // (nsum) per-summary-word cell counts, scanned in place
+    void *scan_ws = (char *)ws + ((g.nsum * 4 + 255) & ~255ll);
+    const int grid = fnp_divup(g.nsum * 64, kThreads);
+    hipLaunchKernelGGL(summary_pass_kernel<0>, dim3(grid), dim3(kThreads), 0, s, g, cnt, (const int *)nullptr);
+    FNP_LAUNCH_CHECK();
+    int rc = int32(cnt, g.nsum, cnt, total, scan_ws, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(summary_pass_kernel<1>, dim3(grid), dim3(kThreads), 0, s, g, (int *)nullptr, (const int *)cnt);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
 }  // namespace fnp_scan
 
-extern "C" int64_t fnp_scan_workspace_bytes(int64_t n) { return fnp_scan::workspace_bytes(n); }
+extern "C" int64_t fnp_rankgrid_workspace_bytes(int B, int D, int H, int W) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const long long nblk = fnp_num_blocks(fnp_make_dims(B, D, H, W));
+    return fnp_scan::rank_grid_workspace_bytes((nblk + 63) >> 6) + 256;
+}

@@ -25,6 +25,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
@@ -63,24 +64,86 @@ __global__ __launch_bounds__(256) void spconv_valu_kernel(const TIn *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// First layer (conv_input: f32 point features, Cin <= 8 -> COUT): one thread per output row keeps
+// all COUT accumulators in registers; the whole weight set (K x Cin x COUT f32, 8.6 KB for
+// 27 x 5 x 16) sits in LDS and is read as wave-wide broadcasts.  Per (row, cout) the fmaf chain
+// is the same k-ascending, cin-ascending chain as spconv_valu_kernel / the oracle.
+// ------------------------------------------------------------------------------------------
+template <int COUT, typename TOut>
+__global__ __launch_bounds__(256) void spconv_first_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                           const int *__restrict__ nbr, int nbr_stride, int K,
+                                                           const int *__restrict__ n_out, int cap,
+                                                           TOut *__restrict__ y, const float *__restrict__ scale,
+                                                           const float *__restrict__ shift,
+                                                           const TOut *__restrict__ residual, int relu, int Cin) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fnp_smem[];
+    float *wl = reinterpret_cast<float *>(fnp_smem);   // [k][ci][co]
+    for (int i = threadIdx.x; i < K * Cin * COUT; i += 256) {
+        const int k = i / (Cin * COUT), r = i % (Cin * COUT);
+        const int ci = r / COUT, co = r % COUT;
+        wl[i] = w[((size_t)k * COUT + co) * Cin + ci];
+    }
+    __syncthreads();
+    const int n = min(*n_out, cap);
+    for (int row = blockIdx.x * 256 + threadIdx.x; row < n; row += gridDim.x * 256) {
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const int idx = nbr[(size_t)k * nbr_stride + row];
+            if (idx < 0) continue;
+            const float *xr = x + (size_t)idx * Cin;
+            const float *wk = wl + k * Cin * COUT;
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float xv = xr[ci];
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xv, wk[ci * COUT + co], acc[co]);
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float v = acc[co];
+            if (scale) v = v * scale[co] + shift[co];
+            if (residual) v = v + to_f32(residual[(size_t)row * COUT + co]);
+            if (relu && v < 0.f) v = 0.f;
+            y[(size_t)row * COUT + co] = from_f32<TOut>(v);
+        }
+    }
+}
+
+template <typename TOut>
+int launch_first(const void *x, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap, void *y,
+                 const float *scale, const float *shift, const void *residual, int relu, int Cin, hipStream_t s) {
+    const int grid = fnp_grid_for(cap, 256, 2048);
+    const size_t lds = sizeof(float) * (size_t)K * Cin * 16;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(spconv_first_kernel<16, TOut>), dim3(grid), dim3(256), lds, s, (const float *)x,
+                       (const float *)w, nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual,
+                       relu, Cin);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // MFMA path.
 //
 // Workgroup = 4 waves; wave w owns MB*16 output sites and all COUT channels, accumulators in
 // registers for the whole sweep over the K kernel offsets.  The weight slab W_k (COUT x CIN bf16)
 // is shared by the 4 waves through LDS:
 //   * ALLK  (K*slab <= 64 KiB: the 16/32-channel layers): every slab is staged once per
-//     persistent workgroup and the tile loop runs without barriers;
-//   * else  (64/128-channel layers): slabs are double-buffered, W_{k+1} is fetched into registers
-//     before the MFMAs of offset k and written to the other LDS buffer after them (one barrier
-//     per offset), so the HBM/L2 latency of the weights hides under the matrix work.
+//     persistent workgroup and the offset loop runs without barriers;
+//   * else  (64/128-channel layers): slabs are double-buffered; W_{k+1} is fetched a few 16-byte
+//     chunks per MFMA step into registers and written to the other LDS buffer one step later
+//     (one barrier per offset), so its HBM/L2 latency hides under the matrix work.
 // LDS image: row r (one output channel, CIN*2 bytes = CH 16-byte chunks) stores logical chunk c
 // at physical chunk c ^ ((r >> SW) & (CH-1)); with that XOR every 16-lane group of the
 // ds_read_b128 fragment reads (16 rows x one logical chunk) hits 16 distinct 16-byte slots of the
-// 256-byte bank row: conflict-free (checked exhaustively for CH = 16, 8, 4, 2).
-// Feature fragments are gathered straight from HBM/L2 (16 contiguous bytes per lane, rows absent
-// from the rulebook are exec-masked zeros); a 16-site block with no neighbour at offset k skips
-// its MFMAs (wave-uniform branch) — in rank-grid row order neighbour presence is spatially
-// coherent, so whole blocks drop out.
+// 256-byte bank row: conflict-free (SQ_LDS_BANK_CONFLICT = 0 measured).
+// Feature fragments are gathered straight from HBM/L2 through a buffer descriptor (16 contiguous
+// bytes per lane; rows absent from the rulebook present an out-of-range offset and read as zeros
+// without touching memory).  The kernel is bound by the latency x parallelism of these gathers,
+// so they run PFK whole kernel offsets ahead of the matrix work: the fragments of offset k + PFK
+// are requested into the registers that offset k has just finished with, and the rulebook
+// indices they need were themselves fetched PFK offsets earlier.
 // KVOL: kernel volume known at compile time (27) or 0 = runtime K; it also gives the 3x3x3
 // layers and conv_out (K = 3) distinct kernel names for per-layer-class profiler statistics.
 // ------------------------------------------------------------------------------------------
@@ -91,31 +154,37 @@ struct MfmaCfg {
     static constexpr int SW = (CH == 8 || CH == 4) ? 1 : 0;
     static constexpr bool ALLK = KVOL > 0 && (long long)KVOL * SLAB * 16 <= 65536;
     static constexpr int LDS_BYTES = (ALLK ? KVOL : 2) * SLAB * 16;
+    static constexpr int KS = (CIN + 31) / 32;            // 32-wide K steps of the MFMA
+    // gather prefetch distance in kernel offsets: 16 gathers in flight per wave
+    static constexpr int PFK = ALLK ? (KS == 1 ? 4 : 2) : 1;
 };
 
-#define FNP_AS1(p) ((const __attribute__((address_space(1))) void *)(p))
-#define FNP_AS3(p) ((__attribute__((address_space(3))) void *)(p))
+// Development-only ablation switch (tools/bench_conv.py with FNP_LIB_PATH): 1 = no feature gathers,
+// 2 = no weight staging, 3 = no MFMA.  The shipped library is built with FNP_ABLATE == 0.
+#ifndef FNP_ABLATE
+#define FNP_ABLATE 0
+#endif
 
 template <int CIN, int COUT, int MB, int KVOL, typename TOut>
-__global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w,
+__global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__restrict__ x, int x_bytes,
+                                                             const __bf16 *__restrict__ w,
                                                              const int *__restrict__ nbr, int nbr_stride, int Krt,
                                                              const int *__restrict__ n_out, int cap,
                                                              TOut *__restrict__ y, const float *__restrict__ scale,
                                                              const float *__restrict__ shift,
                                                              const TOut *__restrict__ residual, int relu) {
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
-    constexpr int CH = Cfg::CH, SLAB = Cfg::SLAB, SW = Cfg::SW;
+    constexpr int CH = Cfg::CH, SLAB = Cfg::SLAB, SW = Cfg::SW, KS = Cfg::KS, PFK = Cfg::PFK;
     constexpr bool ALLK = Cfg::ALLK;
-    constexpr int KS = (CIN + 31) / 32;   // 32-wide K steps of the MFMA
     constexpr int NB = COUT / 16;         // 16-channel output blocks
     constexpr int NBH = NB < 4 ? NB : 4;  // A fragments held at once
     constexpr int ROWS_PER_WAVE = MB * 16;
     constexpr int ROWS_PER_WG = 4 * ROWS_PER_WAVE;
+    // weight staging of the double-buffered path: NCH chunks per thread per slab, WST per MFMA step
+    constexpr int NCH = (SLAB + 255) / 256;
+    constexpr int WST = (NCH + KS - 1) / KS;
     static_assert(CIN % 16 == 0 && COUT % 16 == 0, "channel counts must be multiples of 16");
-    constexpr bool GLDS = !ALLK && SLAB % 256 == 0;   // wide slabs stream through global_load_lds
-    constexpr bool RSTG = !ALLK && !GLDS;             // small slab with runtime K: register staging
-    static_assert(ALLK || GLDS || SLAB < 256, "unsupported slab size");
-    constexpr int NSRC = GLDS ? SLAB / 256 : 1;
+    static_assert(ALLK || SLAB % 256 == 0 || SLAB < 256, "unsupported slab size");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char fnp_smem[];
     uint4 *wl = reinterpret_cast<uint4 *>(fnp_smem);
@@ -125,11 +194,52 @@ __global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__res
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
-    const int tiles = (n + ROWS_PER_WG - 1) / ROWS_PER_WG;
     const bool kvalid0 = (q * 8) < CIN;  // for CIN == 16 only lanes 0..31 carry data in a K step
-    if ((int)blockIdx.x >= tiles) return;  // before any barrier: safe early exit
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
+    // byte offset of (row id, this lane's 16-byte chunk of MFMA step 0); absent rows get an offset
+    // that stays out of range after the + ks*64 of the later steps
+    auto row_off = [&](int id) -> unsigned {
+        return (FNP_ABLATE == 1 || id < 0 || !kvalid0) ? 0x80000000u
+                                                        : (unsigned)id * (unsigned)(CIN * 2) + (unsigned)q * 16u;
+    };
+    auto gather = [&](unsigned roff, int ks) -> bf16x8 {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, roff + (unsigned)ks * 64u, 0, 0);
+        return *reinterpret_cast<bf16x8 *>(&v);
+    };
+    // rulebook entry of row r for offset k; rows past the range and offsets past K read a valid
+    // address and yield -1 (no data-dependent branch around a load)
+    auto nbr_at = [&](int k, int r, int r_end) -> int {
+        const int rc = r < r_end ? r : r_end - 1;
+        const int kc = k < K ? k : K - 1;
+        const int v = nbr[(size_t)kc * nbr_stride + rc];
+        return (r < r_end && k < K) ? v : -1;
+    };
+
+    // Work split: the n rows are cut into gridDim.x contiguous ranges of (almost) equal numbers of
+    // 16-row blocks, so every workgroup finishes at about the same time whatever n is.  Range r
+    // goes to the workgroups of one XCD in contiguous runs (blocks b and b + 8 share an XCD): each
+    // XCD's L2 then serves 1/8 of the feature map.  Placement only affects speed, never results.
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per = G >> 3, rem = G & 7;
+    const int range = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;  // bijective
+    const long long nblk16 = (n + 15) >> 4;
+    const int row_begin = (int)((nblk16 * range) / G) << 4;
+    const int row_end = min(n, (int)((nblk16 * (range + 1)) / G) << 4);
+    if (row_begin >= row_end) return;  // before any barrier: safe early exit
+    const int tiles = (row_end - row_begin + ROWS_PER_WG - 1) / ROWS_PER_WG;
 
 #define FNP_LDS_POS(row, chunk) ((row) * CH + ((chunk) ^ (((row) >> SW) & (CH - 1))))
+    // LDS addressing with compile-time immediates: the swizzle term of row nb*16 + l15 depends on
+    // l15 only, and that of staging position tid + c*256 on tid only, so one VGPR per MFMA step
+    // (fragment reads) and one per thread (staging writes) carry the lane part; nb, c, k are added
+    // as constants.
+    int aoff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) aoff[ks] = FNP_LDS_POS(l15, kvalid0 ? ks * 4 + q : 0);
+    const int st_pos0 = FNP_LDS_POS(tid / CH, tid % CH);
+    static_assert(SLAB < 256 || ((256 / CH) % (CH << SW) == 0), "staging swizzle must be periodic in 256 chunks");
     if (ALLK) {
         // narrow layers: all K slabs resident in LDS for the lifetime of the workgroup
         for (int p = tid; p < K * SLAB; p += 256) {
@@ -138,101 +248,107 @@ __global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__res
         }
         __syncthreads();
     }
-    // wide layers: slab k+1 streams HBM/L2 -> LDS directly (global_load_lds, 1 KiB per wave
-    // instruction).  The LDS image is linear in lane order, so the swizzle is applied to each
-    // lane's SOURCE chunk instead.
-    int src_chunk[NSRC];
-    if (GLDS) {
-#pragma unroll
-        for (int j = 0; j < NSRC; ++j) {
-            const int p = (j * 4 + wave) * 64 + lane;          // LDS position this lane fills
-            const int row = p / CH, phys = p % CH;
-            src_chunk[j] = row * CH + (phys ^ ((row >> SW) & (CH - 1)));
-        }
-    }
-#define FNP_STAGE(kk, slot)                                                                                   \
-    if (GLDS) {                                                                                                \
-        const uint4 *src__ = reinterpret_cast<const uint4 *>(w + (size_t)(kk) * COUT * CIN);                   \
-        _Pragma("unroll") for (int j = 0; j < NSRC; ++j)                                                       \
-            __builtin_amdgcn_global_load_lds(FNP_AS1(src__ + src_chunk[j]),                                    \
-                                             FNP_AS3(wl + (slot) * SLAB + (j * 4 + wave) * 64), 16, 0, 0);     \
-    } else if (RSTG && tid < SLAB) {                                                                           \
-        wl[(slot) * SLAB + FNP_LDS_POS(tid / CH, tid % CH)] =                                                  \
-            reinterpret_cast<const uint4 *>(w + (size_t)(kk) * COUT * CIN)[tid];                               \
-    }
 
-    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int row0 = tile * ROWS_PER_WG + wave * ROWS_PER_WAVE;
+    for (int tile = 0; tile < tiles; ++tile) {
+        const int row0 = row_begin + tile * ROWS_PER_WG + wave * ROWS_PER_WAVE;
         f32x4 acc[NB][MB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        int idx_cur[MB];
+        // prologue: fragments of offsets 0..PFK-1, rulebook indices of offsets PFK..2*PFK-1
+        bf16x8 xb[PFK][KS][MB];
+        unsigned roffq[PFK][MB];   // row offsets of the offsets PFK..2*PFK-1 ahead
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const int r = row0 + mb * 16 + l15;
-            idx_cur[mb] = r < n ? nbr[r] : -1;
-        }
+        for (int u = 0; u < PFK; ++u)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const unsigned ro = row_off(nbr_at(u, row0 + mb * 16 + l15, row_end));
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) xb[u][ks][mb] = gather(ro, ks);
+                roffq[u][mb] = row_off(nbr_at(PFK + u, row0 + mb * 16 + l15, row_end));
+            }
         if (!ALLK) {
-            FNP_STAGE(0, 0)
+            if (FNP_ABLATE != 2) {
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    const int p = tid + j * 256;
+                    if (SLAB % 256 == 0 || p < SLAB) wl[st_pos0 + j * 256] = reinterpret_cast<const uint4 *>(w)[p];
+                }
+            }
             __syncthreads();
         }
 
-        for (int k = 0; k < K; ++k) {
-            const bool more = k + 1 < K;
-            int idx_nxt[MB];
+        for (int k0 = 0; k0 < K; k0 += PFK) {
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const int r = row0 + mb * 16 + l15;
-                idx_nxt[mb] = (more && r < n) ? nbr[(size_t)(k + 1) * nbr_stride + r] : -1;
-            }
-            unsigned has = 0;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) has |= (__ballot(idx_cur[mb] >= 0) != 0ull) ? (1u << mb) : 0u;
-            if (!ALLK && more) FNP_STAGE(k + 1, (k + 1) & 1)
-            if (has) {
+            for (int u = 0; u < PFK; ++u) {
+                const int k = k0 + u;
+                if (k >= K) break;  // wave-uniform
                 const uint4 *wk = wl + (ALLK ? k : (k & 1)) * SLAB;
+                const uint4 *wsrc = reinterpret_cast<const uint4 *>(w + (size_t)(k + 1 < K ? k + 1 : k) * COUT * CIN);
+                uint4 wreg[WST];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const bool kvalid = KS > 1 ? true : kvalid0;
-                    const int chunk = ks * 4 + q;
-                    bf16x8 xb[MB];
+                    // (1) previous step's weight chunks -> other LDS buffer; (2) request this step's
+                    if (!ALLK && FNP_ABLATE != 2) {
+                        if (ks > 0) {
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                        if (idx_cur[mb] >= 0 && kvalid)
-                            v = *reinterpret_cast<const bf16x8 *>(x + (size_t)idx_cur[mb] * CIN + chunk * 8);
-                        xb[mb] = v;
+                            for (int j = 0; j < WST; ++j) {
+                                const int c = (ks - 1) * WST + j, p = tid + c * 256;
+                                if (c < NCH && (SLAB % 256 == 0 || p < SLAB))
+                                    wl[((k + 1) & 1) * SLAB + st_pos0 + c * 256] = wreg[j];
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < WST; ++j) {
+                            const int c = ks * WST + j, p = tid + c * 256;
+                            if (c < NCH && (SLAB % 256 == 0 || p < SLAB)) wreg[j] = wsrc[p];
+                        }
                     }
+                    // (3) matrix block of this step on the fragments requested PFK offsets ago
 #pragma unroll
                     for (int h = 0; h < NB; h += NBH) {
                         bf16x8 wa[NBH];
 #pragma unroll
                         for (int j = 0; j < NBH; ++j) {
-                            const int row = (h + j) * 16 + l15;
-                            uint4 t = make_uint4(0u, 0u, 0u, 0u);
-                            if (kvalid) t = wk[FNP_LDS_POS(row, chunk)];
-                            wa[j] = *reinterpret_cast<bf16x8 *>(&t);
+                            // (CIN == 16: lanes q >= 2 read chunk 0; their x fragment is zero)
+                            const uint4 t = wk[aoff[ks] + (h + j) * 16 * CH];
+                            wa[j] = *reinterpret_cast<const bf16x8 *>(&t);
                         }
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) {
-                            if (has & (1u << mb)) {
+                        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                                for (int j = 0; j < NBH; ++j)
-                                    acc[h + j][mb] =
-                                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xb[mb], acc[h + j][mb], 0, 0, 0);
+                            for (int j = 0; j < NBH; ++j) {
+                                if (FNP_ABLATE == 3) {
+                                    asm volatile("" ::"v"(wa[j]), "v"(xb[u][ks][mb]));
+                                } else {
+                                    acc[h + j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xb[u][ks][mb],
+                                                                                              acc[h + j][mb], 0, 0, 0);
+                                }
                             }
+                    }
+                    // (4) the registers are free again: request the fragments of offset k + PFK
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) xb[u][ks][mb] = gather(roffq[u][mb], ks);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the steps in program order
+                }
+                // rulebook entries of offset k + 2*PFK (their gathers are issued PFK offsets from now)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) roffq[u][mb] = row_off(nbr_at(k + 2 * PFK, row0 + mb * 16 + l15, row_end));
+                if (!ALLK) {
+                    if (FNP_ABLATE != 2) {
+#pragma unroll
+                        for (int j = 0; j < WST; ++j) {
+                            const int c = (KS - 1) * WST + j, p = tid + c * 256;
+                            if (c < NCH && (SLAB % 256 == 0 || p < SLAB))
+                                wl[((k + 1) & 1) * SLAB + st_pos0 + c * 256] = wreg[j];
                         }
                     }
+                    __syncthreads();  // plain loads stay in flight across it; only the LDS writes are waited for
                 }
             }
-            if (!ALLK) __syncthreads();  // also drains this wave's global_load_lds (vmcnt(0))
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) idx_cur[mb] = idx_nxt[mb];
         }
-#undef FNP_STAGE
 #undef FNP_LDS_POS
 
         // epilogue: lane holds out[site = row0 + mb*16 + l15][c0 .. c0+3], c0 = nb*16 + q*4
@@ -249,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__res
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const int r = row0 + mb * 16 + l15;
-                if (r >= n) continue;
+                if (r >= row_end) continue;
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = scale ? acc[nb][mb][j] * sc[j] + sh[j] : acc[nb][mb][j];
@@ -275,27 +391,32 @@ __global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__res
 }
 
 template <int CIN, int COUT, int KVOL, typename TOut>
-int launch_mfma_k(const void *x, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
+int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
                   void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s) {
-    constexpr int MB = 4;
+    // 16-site blocks per wave: 4 (64 sites) unless the accumulators (COUT/16 * MB * 4 registers)
+    // would push the kernel into spills (128 output channels); measured per layer class on MI355X
+    constexpr int MB = (COUT >= 128 || (CIN == 16 && COUT == 16)) ? 2 : 4;
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
     auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, TOut>;
     const int tiles = fnp_divup(cap, 4 * MB * 16);
     // persistent grid: two workgroups per CU are resident (register / LDS budget of the wide
-    // layers); the narrow ALLK layers stage all weights once per workgroup, so keep them few too
+    // layers); the narrow ALLK layers stage all weights once per workgroup, so keep them few too.
+    // The kernel splits the rows evenly over whatever grid it gets.
     const int grid = tiles < 512 ? tiles : 512;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, s, (const __bf16 *)x, (const __bf16 *)w, nbr,
-                       nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, s, (const __bf16 *)x, x_bytes, (const __bf16 *)w,
+                       nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
 
 template <int CIN, int COUT, typename TOut>
-int launch_mfma(const void *x, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap, void *y,
-                const float *scale, const float *shift, const void *residual, int relu, hipStream_t s) {
+int launch_mfma(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out,
+                int cap, void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s) {
     if (K == 27)
-        return launch_mfma_k<CIN, COUT, 27, TOut>(x, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual, relu, s);
-    return launch_mfma_k<CIN, COUT, 0, TOut>(x, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual, relu, s);
+        return launch_mfma_k<CIN, COUT, 27, TOut>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift,
+                                                  residual, relu, s);
+    return launch_mfma_k<CIN, COUT, 0, TOut>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual,
+                                             relu, s);
 }
 
 template <typename TIn, typename TOut>
@@ -311,12 +432,15 @@ int launch_valu(const void *x, const void *w, const int *nbr, int nbr_stride, in
 }
 
 template <typename TOut>
-int dispatch_bf16(const void *x, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
+int dispatch_bf16(const void *x, long long n_in, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
                   void *y, const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
                   hipStream_t s) {
+    const long long xb = n_in * Cin * 2;
+    const bool fits = xb > 0 && xb < 0x7fffffffll;   // 32-bit buffer offsets of the MFMA path
 #define FNP_CASE(CI, CO)                                                                                       \
-    if (Cin == CI && Cout == CO)                                                                               \
-        return launch_mfma<CI, CO, TOut>(x, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual, relu, s);
+    if (fits && Cin == CI && Cout == CO)                                                                       \
+        return launch_mfma<CI, CO, TOut>(x, (int)xb, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual,\
+                                         relu, s);
     FNP_CASE(16, 16)
     FNP_CASE(16, 32)
     FNP_CASE(32, 32)
@@ -346,15 +470,24 @@ __global__ __launch_bounds__(256) void dense_kernel(const T *__restrict__ feats,
 
 }  // namespace
 
-extern "C" int fnp_spconv_forward(const void *feat_in, int in_dtype, const void *weight, const int *nbr, int nbr_stride,
-                                  int K, const int *n_out, int cap_out, void *feat_out, int out_dtype,
+extern "C" int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const void *weight, const int *nbr,
+                                  int nbr_stride, int K, const int *n_out, int cap_out, void *feat_out, int out_dtype,
                                   const float *scale, const float *shift, const void *residual, int relu, int Cin,
                                   int Cout, fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!feat_in || !weight || !nbr || !n_out || !feat_out || K <= 0 || Cin <= 0 || Cout <= 0 || cap_out <= 0 ||
-        nbr_stride < cap_out)
+        nbr_stride < cap_out || n_in_rows <= 0)
         return FNP_ERR_ARG;
     if ((scale == nullptr) != (shift == nullptr)) return FNP_ERR_ARG;
+    if (in_dtype == FNP_F32 && Cout == 16 && Cin <= 8 && (size_t)K * Cin * 16 * 4 <= 60000) {
+        if (out_dtype == FNP_F32)
+            return launch_first<float>(feat_in, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
+                                       residual, relu, Cin, s);
+        if (out_dtype == FNP_BF16)
+            return launch_first<__bf16>(feat_in, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
+                                        residual, relu, Cin, s);
+        return FNP_ERR_ARG;
+    }
     if (in_dtype == FNP_F32) {
         if (out_dtype == FNP_F32)
             return launch_valu<float, float>(feat_in, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
@@ -366,10 +499,10 @@ extern "C" int fnp_spconv_forward(const void *feat_in, int in_dtype, const void 
     }
     if (in_dtype == FNP_BF16) {
         if (out_dtype == FNP_BF16)
-            return dispatch_bf16<__bf16>(feat_in, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
+            return dispatch_bf16<__bf16>(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
                                          residual, relu, Cin, Cout, s);
         if (out_dtype == FNP_F32)
-            return dispatch_bf16<float>(feat_in, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
+            return dispatch_bf16<float>(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
                                         residual, relu, Cin, Cout, s);
         return FNP_ERR_ARG;
     }

@@ -37,7 +37,7 @@ struct VoxWs {          // carve-up of the caller's workspace
 
 __host__ long long align_up(long long v) { return (v + 255) & ~255ll; }
 
-__host__ long long carve(VoxWs &w, char *base, long long n, int B, int cap, int maxp, long long nblk) {
+__host__ long long carve(VoxWs &w, char *base, long long n, int B, int cap, int maxp, long long nsum) {
     long long off = 0;
     auto take = [&](long long bytes) {
         char *p = base ? base + off : nullptr;
@@ -52,8 +52,8 @@ __host__ long long carve(VoxWs &w, char *base, long long n, int B, int cap, int 
     w.scene = (int *)take(4ll * (3 * B + 8));
     w.n_sorted = (int *)take(4);
     w.n_first = (int *)take(4);
-    const long long m = nblk > n ? nblk : n;
-    w.scan_ws = take(fnp_scan::workspace_bytes(m));
+    const long long a = fnp_scan::rank_grid_workspace_bytes(nsum), b2 = fnp_scan::workspace_bytes(n);
+    w.scan_ws = take(a > b2 ? a : b2);
     return off;
 }
 
@@ -68,8 +68,7 @@ __device__ __forceinline__ int batch_of(const int *__restrict__ off, int B, int 
 
 __global__ __launch_bounds__(kThreads) void vox_mark_kernel(const float *__restrict__ pts, int n, int C,
                                                             const int *__restrict__ boff, int B, fnp_voxel_cfg cfg,
-                                                            RankGridDims g, unsigned long long *__restrict__ bits,
-                                                            long long *__restrict__ code) {
+                                                            RG g, long long *__restrict__ code) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
     const float *p = pts + (size_t)i * C;
@@ -86,9 +85,9 @@ __global__ __launch_bounds__(kThreads) void vox_mark_kernel(const float *__restr
     long long cd = -1;
     if (ok) {
         const int b = batch_of(boff, B, i);
-        const long long blk = rg_block_of(g, b, c[2], c[1], c[0]);
+        const long long blk = rg_block_of(g.d, b, c[2], c[1], c[0]);
         const int bit = rg_bit_of(c[2], c[1], c[0]);
-        atomicOr(&bits[blk], 1ull << bit);
+        rg_mark(g, blk, bit);
         cd = (blk << 6) | bit;
     }
     code[i] = cd;
@@ -203,30 +202,37 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
 }
 
 // ---- rank grid from an explicit coordinate list ---------------------------------------------
+__device__ __forceinline__ bool coord_ok(const RankGridDims &g, const int4 &c) {
+    return c.x >= 0 && c.x < g.B && c.y >= 0 && c.y < g.D && c.z >= 0 && c.z < g.H && c.w >= 0 && c.w < g.W;
+}
+
+template <bool CLEAR>
 __global__ __launch_bounds__(kThreads) void rg_mark_coords_kernel(const int *__restrict__ coords,
-                                                                  const int *__restrict__ n_rows, int cap,
-                                                                  RankGridDims g, unsigned long long *__restrict__ bits,
-                                                                  int clear) {
+                                                                  const int *__restrict__ n_rows, int cap, RG g) {
     const int n = min(*n_rows, cap);
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         const int4 c = reinterpret_cast<const int4 *>(coords)[i];
-        if (c.x < 0 || c.x >= g.B || c.y < 0 || c.y >= g.D || c.z < 0 || c.z >= g.H || c.w < 0 || c.w >= g.W) continue;
-        const long long blk = rg_block_of(g, c.x, c.y, c.z, c.w);
-        if (clear) bits[blk] = 0ull;
-        else atomicOr(&bits[blk], 1ull << rg_bit_of(c.y, c.z, c.w));
+        if (!coord_ok(g.d, c)) continue;
+        const long long blk = rg_block_of(g.d, c.x, c.y, c.z, c.w);
+        if (CLEAR) {
+            g.bits[blk] = 0ull;
+            g.summ[blk >> 6] = 0ull;   // every occupied block of that summary word has a row here
+        } else {
+            rg_mark(g, blk, rg_bit_of(c.y, c.z, c.w));
+        }
     }
 }
 
 __global__ __launch_bounds__(kThreads) void rg_perm_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows,
-                                                           int cap, RankGridDims g,
-                                                           const unsigned long long *__restrict__ bits,
-                                                           const unsigned *__restrict__ base, int *__restrict__ perm) {
+                                                           int cap, RG g) {
     const int n = min(*n_rows, cap);
+    RG lookup = g;
+    lookup.perm = nullptr;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         const int4 c = reinterpret_cast<const int4 *>(coords)[i];
-        if (c.x < 0 || c.x >= g.B || c.y < 0 || c.y >= g.D || c.z < 0 || c.z >= g.H || c.w < 0 || c.w >= g.W) continue;
-        const int r = rg_lookup(g, bits, base, nullptr, c.x, c.y, c.z, c.w);
-        if (r >= 0 && r < cap) perm[r] = i;
+        if (!coord_ok(g.d, c)) continue;
+        const int r = rg_lookup(lookup, c.x, c.y, c.z, c.w);
+        if (r >= 0 && r < cap) g.perm[r] = i;
     }
 }
 
@@ -236,51 +242,52 @@ extern "C" int64_t fnp_rankgrid_num_blocks(int B, int D, int H, int W) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     return fnp_num_blocks(fnp_make_dims(B, D, H, W));
 }
-
-static bool grid_shape_ok(const fnp_voxel_cfg *cfg, const int *gs) {
-    return gs && gs[0] >= cfg->grid[2] && gs[1] >= cfg->grid[1] && gs[2] >= cfg->grid[0];
+extern "C" int64_t fnp_rankgrid_num_summary(int B, int D, int H, int W) {
+    return (fnp_rankgrid_num_blocks(B, D, H, W) + 63) >> 6;
 }
 
-extern "C" int64_t fnp_voxelize_workspace_bytes(int64_t n_points, int B, const fnp_voxel_cfg *cfg, const int *grid_shape) {
-    if (!cfg || n_points < 0 || B <= 0 || !grid_shape_ok(cfg, grid_shape)) return FNP_ERR_ARG;
+static bool grid_covers(const fnp_voxel_cfg *cfg, const fnp_rankgrid *g) {
+    return g->D >= cfg->grid[2] && g->H >= cfg->grid[1] && g->W >= cfg->grid[0];
+}
+
+extern "C" int64_t fnp_voxelize_workspace_bytes(int64_t n_points, const fnp_voxel_cfg *cfg, const fnp_rankgrid *grid) {
+    if (!cfg || n_points < 0 || !grid || grid->B <= 0 || !grid_covers(cfg, grid)) return FNP_ERR_ARG;
     VoxWs w;
-    const RankGridDims g = fnp_make_dims(B, grid_shape[0], grid_shape[1], grid_shape[2]);
+    const RankGridDims g = fnp_make_dims(grid->B, grid->D, grid->H, grid->W);
     const long long n = n_points > 0 ? n_points : 1;
-    return carve(w, nullptr, n, B, (int)n, cfg->max_points, fnp_num_blocks(g));
+    return carve(w, nullptr, n, grid->B, (int)n, cfg->max_points, (fnp_num_blocks(g) + 63) >> 6);
 }
 
-extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets, int B, const fnp_voxel_cfg *cfg,
-                            const int *grid_shape, uint64_t *grid_bits, uint32_t *grid_base, int *grid_perm, void *workspace,
-                            int64_t workspace_bytes, int *coords, int *num_points, float *mean_feats, float *voxels,
-                            int *n_voxels, int cap, fnp_stream_t stream) {
+extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets, const fnp_voxel_cfg *cfg,
+                            const fnp_rankgrid *grid, void *workspace, int64_t workspace_bytes, int *coords,
+                            int *num_points, float *mean_feats, float *voxels, int *n_voxels, int cap,
+                            fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (!cfg || n < 0 || B <= 0 || B > kMaxBatch || cap <= 0 || !n_voxels || !grid_shape_ok(cfg, grid_shape)) return FNP_ERR_ARG;
+    if (!cfg || n < 0 || cap <= 0 || !n_voxels || !fnp_rg_valid(grid, true) || grid->B > kMaxBatch || !grid_covers(cfg, grid))
+        return FNP_ERR_ARG;
     if (cfg->num_features < 3 || cfg->max_points <= 0 || cfg->max_points > 64 || cfg->max_voxels <= 0) return FNP_ERR_ARG;
     if (n == 0) {
         FNP_HIP_TRY(hipMemsetAsync(n_voxels, 0, sizeof(int), s));
         return FNP_OK;
     }
-    if (!points || !batch_offsets || !grid_bits || !grid_base || !grid_perm || !workspace || !coords || !num_points ||
-        !mean_feats)
-        return FNP_ERR_ARG;
+    if (!points || !batch_offsets || !workspace || !coords || !num_points || !mean_feats) return FNP_ERR_ARG;
     if (cap < n) return FNP_ERR_ARG;  // every point could open a voxel
-    const RankGridDims g = fnp_make_dims(B, grid_shape[0], grid_shape[1], grid_shape[2]);
-    const long long nblk = fnp_num_blocks(g);
+    const RG g = fnp_rg_view(grid);
+    const int B = grid->B;
     VoxWs w;
-    const long long need = carve(w, (char *)workspace, n, B, n, cfg->max_points, nblk);
+    const long long need = carve(w, (char *)workspace, n, B, n, cfg->max_points, g.nsum);
     if (need > workspace_bytes) return FNP_ERR_WORKSPACE;
     const int maxp = cfg->max_points, C = cfg->num_features;
     const int pgrid = fnp_divup(n, kThreads);
 
     FNP_HIP_TRY(hipMemsetAsync(w.top, 0x7f, sizeof(int) * (size_t)n * maxp, s));
     FNP_HIP_TRY(hipMemsetAsync(w.cnt, 0, sizeof(int) * (size_t)n, s));
-    hipLaunchKernelGGL(vox_mark_kernel, dim3(pgrid), dim3(kThreads), 0, s, points, n, C, batch_offsets, B, *cfg, g,
-                       (unsigned long long *)grid_bits, w.code);
+    hipLaunchKernelGGL(vox_mark_kernel, dim3(pgrid), dim3(kThreads), 0, s, points, n, C, batch_offsets, B, *cfg, g, w.code);
     FNP_LAUNCH_CHECK();
-    int rc = fnp_scan::popcount_u64((const unsigned long long *)grid_bits, nblk, grid_base, w.n_sorted, w.scan_ws, s);
+    int rc = fnp_scan::rank_grid(g, w.n_sorted, w.scan_ws, s);
     if (rc) return rc;
     hipLaunchKernelGGL(vox_insert_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, n,
-                       (const unsigned long long *)grid_bits, grid_base, w.code, w.rank, w.top, w.cnt);
+                       (const unsigned long long *)g.bits, (const unsigned *)g.base, w.code, w.rank, w.top, w.cnt);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(vox_flag_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, w.rank, w.top, w.flag);
     FNP_LAUNCH_CHECK();
@@ -290,44 +297,39 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
                        cfg->max_voxels, cap, w.scene, n_voxels);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(vox_emit_kernel, dim3(fnp_grid_for(n, kThreads)), dim3(kThreads), 0, s, points, C, maxp,
-                       batch_offsets, B, cfg->max_voxels, g, w.code, w.top, w.cnt, w.flag, w.scene, w.n_sorted, n,
-                       grid_perm, coords, num_points, mean_feats, voxels);
+                       batch_offsets, B, cfg->max_voxels, g.d, w.code, w.top, w.cnt, w.flag, w.scene, w.n_sorted, n,
+                       g.perm, coords, num_points, mean_feats, voxels);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
 
-extern "C" int fnp_rankgrid_build(const int *coords, const int *n_rows, int cap, int B, int D, int H, int W,
-                                  uint64_t *grid_bits, uint32_t *grid_base, int *grid_perm, void *workspace,
-                                  int64_t workspace_bytes, fnp_stream_t stream) {
+extern "C" int fnp_rankgrid_build(const int *coords, const int *n_rows, int cap, const fnp_rankgrid *grid,
+                                  void *workspace, int64_t workspace_bytes, fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (!coords || !n_rows || cap <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || !grid_bits || !grid_base || !workspace)
-        return FNP_ERR_ARG;
-    const RankGridDims g = fnp_make_dims(B, D, H, W);
-    const long long nblk = fnp_num_blocks(g);
-    if (fnp_scan::workspace_bytes(nblk) + 256 > workspace_bytes) return FNP_ERR_WORKSPACE;
+    if (!coords || !n_rows || cap <= 0 || !fnp_rg_valid(grid) || !workspace) return FNP_ERR_ARG;
+    const RG g = fnp_rg_view(grid);
+    if (fnp_scan::rank_grid_workspace_bytes(g.nsum) + 256 > workspace_bytes) return FNP_ERR_WORKSPACE;
     int *total = (int *)workspace;
     void *scan_ws = (char *)workspace + 256;
-    const int grid = fnp_grid_for(cap, kThreads);
-    hipLaunchKernelGGL(rg_mark_coords_kernel, dim3(grid), dim3(kThreads), 0, s, coords, n_rows, cap, g,
-                       (unsigned long long *)grid_bits, 0);
+    const int blocks = fnp_grid_for(cap, kThreads);
+    hipLaunchKernelGGL(rg_mark_coords_kernel<false>, dim3(blocks), dim3(kThreads), 0, s, coords, n_rows, cap, g);
     FNP_LAUNCH_CHECK();
-    int rc = fnp_scan::popcount_u64((const unsigned long long *)grid_bits, nblk, grid_base, total, scan_ws, s);
+    int rc = fnp_scan::rank_grid(g, total, scan_ws, s);
     if (rc) return rc;
-    if (grid_perm) {
-        FNP_HIP_TRY(hipMemsetAsync(grid_perm, 0xff, sizeof(int) * (size_t)cap, s));
-        hipLaunchKernelGGL(rg_perm_kernel, dim3(grid), dim3(kThreads), 0, s, coords, n_rows, cap, g,
-                           (const unsigned long long *)grid_bits, grid_base, grid_perm);
+    if (g.perm) {
+        FNP_HIP_TRY(hipMemsetAsync(g.perm, 0xff, sizeof(int) * (size_t)cap, s));
+        hipLaunchKernelGGL(rg_perm_kernel, dim3(blocks), dim3(kThreads), 0, s, coords, n_rows, cap, g);
         FNP_LAUNCH_CHECK();
     }
     return FNP_OK;
 }
 
-extern "C" int fnp_rankgrid_clear(const int *coords, const int *n_rows, int cap, int B, int D, int H, int W,
-                                  uint64_t *grid_bits, fnp_stream_t stream) {
-    if (!coords || !n_rows || cap <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || !grid_bits) return FNP_ERR_ARG;
-    const RankGridDims g = fnp_make_dims(B, D, H, W);
-    hipLaunchKernelGGL(rg_mark_coords_kernel, dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
-                       coords, n_rows, cap, g, (unsigned long long *)grid_bits, 1);
+extern "C" int fnp_rankgrid_clear(const int *coords, const int *n_rows, int cap, const fnp_rankgrid *grid,
+                                  fnp_stream_t stream) {
+    if (!coords || !n_rows || cap <= 0 || !fnp_rg_valid(grid)) return FNP_ERR_ARG;
+    const RG g = fnp_rg_view(grid);
+    hipLaunchKernelGGL(rg_mark_coords_kernel<true>, dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0,
+                       (hipStream_t)stream, coords, n_rows, cap, g);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }

@@ -13,7 +13,8 @@ import re
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfnp_hip.so")
+# FNP_LIB_PATH: development override used by tools/ to A/B kernel builds; never set in production
+LIB_PATH = os.environ.get("FNP_LIB_PATH") or os.path.join(_HERE, "libfnp_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fnp.h")
 
 FNP_F32 = 0
@@ -36,6 +37,15 @@ class VoxelCfg(ctypes.Structure):
         ("num_features", c_int),
         ("max_points", c_int),
         ("max_voxels", c_int),
+    ]
+
+
+class RankGridC(ctypes.Structure):
+    """struct fnp_rankgrid (include/fnp.h)."""
+
+    _fields_ = [
+        ("B", c_int), ("D", c_int), ("H", c_int), ("W", c_int),
+        ("bits", c_void_p), ("base", c_void_p), ("summary", c_void_p), ("perm", c_void_p),
     ]
 
 
@@ -69,16 +79,17 @@ SIGNATURES = {
     "fnp_nms_rotated": (c_int, [P, c_int, c_float, P, P, P, P]),
     "fnp_nms_normal": (c_int, [P, c_int, c_float, P, P, P, P]),
     "fnp_rankgrid_num_blocks": (c_int64, [c_int, c_int, c_int, c_int]),
-    "fnp_scan_workspace_bytes": (c_int64, [c_int64]),
-    "fnp_voxelize_workspace_bytes": (c_int64, [c_int64, c_int, POINTER(VoxelCfg), POINTER(c_int)]),
-    "fnp_voxelize": (c_int, [P, c_int, P, c_int, POINTER(VoxelCfg), POINTER(c_int), P, P, P, P, c_int64,
+    "fnp_rankgrid_num_summary": (c_int64, [c_int, c_int, c_int, c_int]),
+    "fnp_rankgrid_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "fnp_rankgrid_build": (c_int, [P, P, c_int, POINTER(RankGridC), P, c_int64, P]),
+    "fnp_rankgrid_clear": (c_int, [P, P, c_int, POINTER(RankGridC), P]),
+    "fnp_voxelize_workspace_bytes": (c_int64, [c_int64, POINTER(VoxelCfg), POINTER(RankGridC)]),
+    "fnp_voxelize": (c_int, [P, c_int, P, POINTER(VoxelCfg), POINTER(RankGridC), P, c_int64,
                              P, P, P, P, P, c_int, P]),
-    "fnp_rankgrid_build": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int64, P]),
-    "fnp_rankgrid_clear": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
-    "fnp_rulebook_subm": (c_int, [P, P, c_int, c_int, POINTER(ConvGeom), P, P, P, P, P]),
-    "fnp_rulebook_strided": (c_int, [P, P, c_int, c_int, POINTER(ConvGeom), P, P, P, P, P,
+    "fnp_rulebook_subm": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, P]),
+    "fnp_rulebook_strided": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), POINTER(RankGridC),
                                      P, P, c_int, P, P, c_int64, P]),
-    "fnp_spconv_forward": (c_int, [P, c_int, P, P, c_int, c_int, P, c_int, P, c_int,
+    "fnp_spconv_forward": (c_int, [P, c_int, c_int, P, P, c_int, c_int, P, c_int, P, c_int,
                                    P, P, P, c_int, c_int, c_int, P]),
     "fnp_sparse_to_dense": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
 }

@@ -7,7 +7,8 @@ Data layout in HBM:
   features  (cap, C)   row-major, bf16 or f32            rows >= n are undefined
   indices   (cap, 4)   int32 [b, z, y, x]
   n         (1,)       int32 device scalar: number of valid rows
-  grid      bits (nblk,) u64 occupancy, base (nblk,) u32 popcount prefix, perm (cap,) int32|None
+  grid      bits (nblk,) u64 occupancy, base (nblk,) u32 popcount prefix, summary (nblk/64,) u64,
+            perm (cap,) int32|None
   rulebook  nbr (K, cap) int32: input row per (kernel offset, output row) or -1
 """
 import ctypes
@@ -28,11 +29,24 @@ def _triple(v):
 
 @dataclass
 class RankGrid:
-    bits: torch.Tensor            # (nblk,) int64 view of u64
-    base: torch.Tensor            # (nblk,) int32 view of u32
+    bits: torch.Tensor            # (nblk,) int64 view of u64 occupancy words
+    base: torch.Tensor            # (nblk,) int32 view of u32 popcount prefixes
+    summary: torch.Tensor         # (nsum,) int64: one bit per block
     perm: Optional[torch.Tensor]  # (cap,) int32 or None (rows already in rank order)
     batch_size: int
     shape: List[int]              # [D, H, W]
+
+    def c(self, with_perm=True):
+        """struct fnp_rankgrid for the ABI."""
+        g = _l.RankGridC()
+        g.B, g.D, g.H, g.W = self.batch_size, self.shape[0], self.shape[1], self.shape[2]
+        g.bits, g.base, g.summary = self.bits.data_ptr(), self.base.data_ptr(), self.summary.data_ptr()
+        g.perm = self.perm.data_ptr() if (with_perm and self.perm is not None) else None
+        return g
+
+    def zero_(self):
+        self.bits.zero_()
+        self.summary.zero_()
 
 
 @dataclass
@@ -56,8 +70,9 @@ def alloc_grid(batch_size, shape, device, with_perm_cap=None):
     nblk = num_blocks(batch_size, shape)
     bits = torch.zeros((nblk,), dtype=torch.int64, device=device)
     base = torch.empty((nblk,), dtype=torch.int32, device=device)
+    summary = torch.zeros(((nblk + 63) // 64,), dtype=torch.int64, device=device)
     perm = torch.empty((with_perm_cap,), dtype=torch.int32, device=device) if with_perm_cap else None
-    return RankGrid(bits, base, perm, batch_size, list(shape))
+    return RankGrid(bits, base, summary, perm, batch_size, [int(v) for v in shape])
 
 
 def make_geom(ksize, stride, padding, in_shape, out_shape=None):
@@ -113,8 +128,8 @@ def voxelize(points, batch_offsets, batch_size, cfg, grid=None, want_voxels=Fals
     elif grid.perm is None or grid.perm.numel() < cap:
         grid.perm = torch.empty((cap,), dtype=torch.int32, device=dev)
     assert grid.batch_size == batch_size
-    gshape = (ctypes.c_int * 3)(*grid.shape)   # the rank grid may be larger than the voxel grid (z + 1)
-    ws_bytes = int(L.fnp_voxelize_workspace_bytes(n, batch_size, cfg, gshape))
+    gc = grid.c()   # the rank grid may be larger than the voxel grid (sparse_shape has z + 1)
+    ws_bytes = int(L.fnp_voxelize_workspace_bytes(n, cfg, gc))
     _l.check(min(ws_bytes, 0), "fnp_voxelize_workspace_bytes")
     if workspace is None or workspace.numel() < ws_bytes:
         workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
@@ -123,8 +138,7 @@ def voxelize(points, batch_offsets, batch_size, cfg, grid=None, want_voxels=Fals
     mean = torch.empty((cap, C), dtype=torch.float32, device=dev)
     voxels = torch.empty((cap, cfg.max_points, C), dtype=torch.float32, device=dev) if want_voxels else None
     n_vox = torch.zeros((1,), dtype=torch.int32, device=dev)
-    rc = L.fnp_voxelize(_l.ptr(points), n, _l.ptr(batch_offsets), batch_size, cfg, gshape,
-                        _l.ptr(grid.bits), _l.ptr(grid.base), _l.ptr(grid.perm),
+    rc = L.fnp_voxelize(_l.ptr(points), n, _l.ptr(batch_offsets), cfg, gc,
                         _l.ptr(workspace), workspace.numel(),
                         _l.ptr(coords), _l.ptr(num_points), _l.ptr(mean), _l.ptr(voxels), _l.ptr(n_vox), cap,
                         _l.stream())
@@ -144,10 +158,10 @@ def build_grid(indices, n_dev, batch_size, shape, keep_order=True, grid=None):
     if grid is None:
         grid = alloc_grid(batch_size, shape, dev, with_perm_cap=cap if keep_order else None)
     assert grid.batch_size == batch_size and list(grid.shape) == [int(v) for v in shape]
-    nblk = grid.bits.numel()
-    ws = torch.empty((int(L.fnp_scan_workspace_bytes(nblk)) + 256,), dtype=torch.uint8, device=dev)
-    rc = L.fnp_rankgrid_build(_l.ptr(indices), _l.ptr(n_dev), cap, batch_size, *shape,
-                              _l.ptr(grid.bits), _l.ptr(grid.base), _l.ptr(grid.perm), _l.ptr(ws), ws.numel(),
+    if keep_order and (grid.perm is None or grid.perm.numel() < cap):
+        grid.perm = torch.empty((cap,), dtype=torch.int32, device=dev)
+    ws = torch.empty((int(L.fnp_rankgrid_workspace_bytes(batch_size, *grid.shape)) + 256,), dtype=torch.uint8, device=dev)
+    rc = L.fnp_rankgrid_build(_l.ptr(indices), _l.ptr(n_dev), cap, grid.c(with_perm=keep_order), _l.ptr(ws), ws.numel(),
                               _l.stream())
     _l.check(rc, "fnp_rankgrid_build")
     return grid
@@ -156,8 +170,7 @@ def build_grid(indices, n_dev, batch_size, shape, keep_order=True, grid=None):
 def clear_grid(grid, indices, n_dev):
     """Sparse clear of the occupancy words touched by `indices` (O(rows))."""
     L = _l.load()
-    rc = L.fnp_rankgrid_clear(_l.ptr(indices), _l.ptr(n_dev), max(indices.shape[0], 1), grid.batch_size, *grid.shape,
-                              _l.ptr(grid.bits), _l.stream())
+    rc = L.fnp_rankgrid_clear(_l.ptr(indices), _l.ptr(n_dev), max(indices.shape[0], 1), grid.c(), _l.stream())
     _l.check(rc, "fnp_rankgrid_clear")
 
 
@@ -168,8 +181,7 @@ def rulebook_subm(indices, n_dev, grid, ksize):
     geom, _ = make_geom(ksize, 1, [k // 2 for k in _triple(ksize)], grid.shape, grid.shape)
     K = geom.ksize[0] * geom.ksize[1] * geom.ksize[2]
     nbr = torch.empty((K, cap), dtype=torch.int32, device=indices.device)
-    rc = L.fnp_rulebook_subm(_l.ptr(indices), _l.ptr(n_dev), cap, grid.batch_size, geom,
-                             _l.ptr(grid.bits), _l.ptr(grid.base), _l.ptr(grid.perm), _l.ptr(nbr), _l.stream())
+    rc = L.fnp_rulebook_subm(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), _l.stream())
     _l.check(rc, "fnp_rulebook_subm")
     return Rulebook(nbr=nbr, K=K, cap_out=cap, geom=geom)
 
@@ -188,10 +200,8 @@ def rulebook_strided(indices, n_dev, grid, ksize, stride, padding, cap_out, out_
     out_idx = torch.empty((cap_out, 4), dtype=torch.int32, device=dev)
     out_n = torch.zeros((1,), dtype=torch.int32, device=dev)
     nbr = torch.empty((K, cap_out), dtype=torch.int32, device=dev)
-    ws = torch.empty((int(L.fnp_scan_workspace_bytes(out_grid.bits.numel())),), dtype=torch.uint8, device=dev)
-    rc = L.fnp_rulebook_strided(_l.ptr(indices), _l.ptr(n_dev), cap_in, grid.batch_size, geom,
-                                _l.ptr(grid.bits), _l.ptr(grid.base), _l.ptr(grid.perm),
-                                _l.ptr(out_grid.bits), _l.ptr(out_grid.base),
+    ws = torch.empty((int(L.fnp_rankgrid_workspace_bytes(grid.batch_size, *out_shape)),), dtype=torch.uint8, device=dev)
+    rc = L.fnp_rulebook_strided(_l.ptr(indices), _l.ptr(n_dev), cap_in, geom, grid.c(), out_grid.c(with_perm=False),
                                 _l.ptr(out_idx), _l.ptr(out_n), cap_out, _l.ptr(nbr), _l.ptr(ws), ws.numel(),
                                 _l.stream())
     _l.check(rc, "fnp_rulebook_strided")
@@ -224,7 +234,7 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
         assert residual.dtype == out.dtype and residual.shape[1] == Cout and residual.is_contiguous()
     if scale is not None:
         assert scale.dtype == torch.float32 and shift.dtype == torch.float32
-    rc = L.fnp_spconv_forward(_l.ptr(feat_in), _l.dtype_code(feat_in), _l.ptr(w_packed),
+    rc = L.fnp_spconv_forward(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
                               _l.ptr(rb.nbr), rb.nbr.shape[1], K, _l.ptr(n_out_dev), cap_out,
                               _l.ptr(out), _l.dtype_code(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual),
                               int(bool(relu)), Cin, Cout, _l.stream())

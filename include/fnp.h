@@ -96,13 +96,34 @@ int fnp_nms_normal(const float *boxes, int num_boxes, float thresh, void *worksp
 
 /* ------------------------------------------------------------------------------------------
  * Rank grid — the voxel index behind voxelisation and rulebook building.  A grid of
- * (B, D, H, W) cells is cut into 4x4x4 blocks; each block owns one u64 occupancy word
+ * (B, D, H, W) cells is cut into 4x4x4 blocks; block w owns one u64 occupancy word
  * (bit = (z&3)*16 + (y&3)*4 + (x&3)) and one u32 exclusive popcount prefix, so
- * row(cell) = base[block] + popc(bits[block] & below(bit)) is a collision-free lookup.
- * Replaces spconv's hash / direct table (call sites spconv_utils.py:3-10).
+ *     row(cell) = base[w] + popc(bits[w] & below(bit))
+ * is a collision-free lookup (at most 8 words for a 3x3x3 neighbourhood).  A second level,
+ * one summary bit per block, lets the prefix scan, the coordinate emission and the clearing
+ * visit only occupied blocks (a 41x1440x1440 lidar grid is ~1.5 % occupied at block level).
+ * Replaces spconv's hash / direct table (call sites pcdet/utils/spconv_utils.py:3-10).
  * ------------------------------------------------------------------------------------------ */
-int64_t fnp_rankgrid_num_blocks(int B, int D, int H, int W);
-int64_t fnp_scan_workspace_bytes(int64_t n);
+typedef struct fnp_rankgrid {
+    int B, D, H, W;     /* cells */
+    uint64_t *bits;     /* (nblk)  occupancy words; all zero before a build */
+    uint32_t *base;     /* (nblk)  exclusive popcount prefix, defined where bits != 0 */
+    uint64_t *summary;  /* (nsum)  bit j of word i set iff bits[64*i + j] != 0; zero before a build */
+    int *perm;          /* (cap)   rank -> row, or NULL when rows are stored in rank order */
+} fnp_rankgrid;
+
+int64_t fnp_rankgrid_num_blocks(int B, int D, int H, int W);   /* nblk */
+int64_t fnp_rankgrid_num_summary(int B, int D, int H, int W);  /* nsum = ceil(nblk / 64) */
+int64_t fnp_rankgrid_workspace_bytes(int B, int D, int H, int W);
+
+/* Index an existing coordinate list (N,4) [b,z,y,x] (e.g. a SparseConvTensor built from user
+ * tensors): sets bits/summary/base and, when grid->perm != NULL, perm[rank] = row. */
+int fnp_rankgrid_build(const int *coords, const int *n_rows, int cap, const fnp_rankgrid *grid,
+                       void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
+
+/* Zero the occupancy + summary words touched by `coords` (O(rows) instead of O(grid)). */
+int fnp_rankgrid_clear(const int *coords, const int *n_rows, int cap, const fnp_rankgrid *grid,
+                       fnp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Voxelisation + MeanVFE — replaces spconv.utils.Point2VoxelCPU3d.point_to_voxel as called
@@ -118,35 +139,23 @@ typedef struct fnp_voxel_cfg {
     int max_voxels;      /* MAX_NUMBER_OF_VOXELS per scene */
 } fnp_voxel_cfg;
 
-/* grid_shape = {D,H,W} of the rank grid the voxels are indexed in; it may be larger than the
- * voxel grid {cfg.grid[2], cfg.grid[1], cfg.grid[0]} (the backbone's sparse_shape adds one z
- * layer, spconv_backbone.py:191). */
-int64_t fnp_voxelize_workspace_bytes(int64_t n_points, int B, const fnp_voxel_cfg *cfg, const int *grid_shape);
+/* The rank grid the voxels are indexed in may be larger than the voxel grid
+ * {cfg.grid[2], cfg.grid[1], cfg.grid[0]} (the backbone's sparse_shape adds one z layer,
+ * spconv_backbone.py:191); grid->B is the number of scenes. */
+int64_t fnp_voxelize_workspace_bytes(int64_t n_points, const fnp_voxel_cfg *cfg, const fnp_rankgrid *grid);
 
 /* points (N,C) f32, scenes concatenated; batch_offsets (B+1,) int32 device (scene b owns
  * points [off[b], off[b+1])).  Outputs, all capacity `cap` rows (cap >= N is always enough):
  *   coords (cap,4) int32 [b,z,y,x] in the sequential first-come order of the reference,
  *   num_points (cap,) int32, mean_feats (cap,C) f32 = MeanVFE, voxels (cap,max_points,C) f32
  *   zero padded (nullable), n_voxels (1,) int32 device.
- * grid_bits/grid_base/grid_perm describe the (B, grid_shape) rank grid of the voxels for the
- * first rulebook (grid_perm[sorted rank] = voxel row).  grid_bits must be zero on entry. */
-int fnp_voxelize(const float *points, int n_points, const int *batch_offsets, int B,
-                 const fnp_voxel_cfg *cfg, const int *grid_shape,
-                 uint64_t *grid_bits, uint32_t *grid_base, int *grid_perm,
+ * The grid (bits/summary zero on entry, perm != NULL) is left describing the voxels for the first
+ * rulebook: perm[rank] = voxel row. */
+int fnp_voxelize(const float *points, int n_points, const int *batch_offsets,
+                 const fnp_voxel_cfg *cfg, const fnp_rankgrid *grid,
                  void *workspace, int64_t workspace_bytes,
                  int *coords, int *num_points, float *mean_feats, float *voxels,
                  int *n_voxels, int cap, fnp_stream_t stream);
-
-/* Index an existing coordinate list (N,4) [b,z,y,x] into a rank grid (for SparseConvTensor
- * built from user tensors).  grid_bits must be zero on entry. */
-int fnp_rankgrid_build(const int *coords, const int *n_rows, int cap,
-                       int B, int D, int H, int W,
-                       uint64_t *grid_bits, uint32_t *grid_base, int *grid_perm,
-                       void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
-
-/* Zero the occupancy words touched by `coords` (sparse clear, O(rows) instead of O(grid)). */
-int fnp_rankgrid_clear(const int *coords, const int *n_rows, int cap,
-                       int B, int D, int H, int W, uint64_t *grid_bits, fnp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Rulebooks — replace spconv's indice-pair generation for SubMConv3d / SparseConv3d
@@ -163,31 +172,27 @@ typedef struct fnp_conv_geom {
 } fnp_conv_geom;
 
 /* SubM: outputs = inputs, same order. */
-int fnp_rulebook_subm(const int *coords, const int *n_rows, int cap, int B,
-                      const fnp_conv_geom *geom,
-                      const uint64_t *grid_bits, const uint32_t *grid_base, const int *grid_perm,
-                      int *nbr, fnp_stream_t stream);
+int fnp_rulebook_subm(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom,
+                      const fnp_rankgrid *grid, int *nbr, fnp_stream_t stream);
 
-/* Strided SparseConv3d: builds the output rank grid (out_bits must be zero on entry), the
- * output coordinate list (rows in rank-grid order: spatially blocked, deterministic) and nbr.
- * in_perm may be NULL when the input rows are already in rank-grid order. */
-int fnp_rulebook_strided(const int *in_coords, const int *n_in, int cap_in, int B,
-                         const fnp_conv_geom *geom,
-                         const uint64_t *in_bits, const uint32_t *in_base, const int *in_perm,
-                         uint64_t *out_bits, uint32_t *out_base,
+/* Strided SparseConv3d: builds the output rank grid (bits/summary zero on entry; perm unused),
+ * the output coordinate list (rows in rank-grid order: spatially blocked, deterministic) and
+ * nbr.  workspace: fnp_rankgrid_workspace_bytes of the output grid. */
+int fnp_rulebook_strided(const int *in_coords, const int *n_in, int cap_in, const fnp_conv_geom *geom,
+                         const fnp_rankgrid *in_grid, const fnp_rankgrid *out_grid,
                          int *out_coords, int *n_out, int cap_out, int *nbr,
                          void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Sparse convolution forward (implicit GEMM, output-stationary, no atomics) with the
  * BatchNorm1d(eval) + residual + ReLU epilogue of spconv_backbone.py:51-67 fused in.
- *   feat_in  (n_in, Cin)   in_dtype     weight (K, Cout, Cin) packed, w_dtype = in_dtype
+ *   feat_in  (n_in_rows, Cin) in_dtype  weight (K, Cout, Cin) packed, w_dtype = in_dtype
  *   feat_out (n_out, Cout) out_dtype    residual (n_out, Cout) out_dtype or NULL
  *   scale/shift (Cout,) f32 or NULL (identity).  out = act(acc*scale + shift + residual)
  * bf16 x bf16 -> fp32 accumulate runs on MFMA (v_mfma_f32_16x16x32_bf16); f32 runs on VALU
  * fma chains (validation mode).
  * ------------------------------------------------------------------------------------------ */
-int fnp_spconv_forward(const void *feat_in, int in_dtype, const void *weight,
+int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const void *weight,
                        const int *nbr, int nbr_stride, int K,
                        const int *n_out, int cap_out,
                        void *feat_out, int out_dtype,

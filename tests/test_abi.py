@@ -29,7 +29,8 @@ def test_host_only_queries():
     assert L.fnp_rankgrid_num_blocks(1, 41, 1440, 1440) == 11 * 360 * 360
     assert L.fnp_rankgrid_num_blocks(2, 5, 180, 180) == 2 * 2 * 45 * 45
     assert L.fnp_nms_workspace_bytes(100) == 100 * 2 * 8
-    assert L.fnp_scan_workspace_bytes(4096 * 10) >= 11 * 4
+    assert L.fnp_rankgrid_num_summary(1, 41, 1440, 1440) == (11 * 360 * 360 + 63) // 64
+    assert L.fnp_rankgrid_workspace_bytes(1, 41, 1440, 1440) > 4 * ((11 * 360 * 360 + 63) // 64)
 
 
 def test_gfx950_code_object_embedded():

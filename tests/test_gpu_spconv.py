@@ -186,7 +186,7 @@ def _check_stage(got, want, rtol, atol, bf16=False):
     # the following layers.  Gate: such elements are rare, and no element is off by more than a few
     # bf16 ulps (2^-8) of the tensor's scale.
     bad = np.abs(gf - wf) > atol + rtol * np.abs(wf)
-    assert bad.mean() < 2e-3, f"{bad.sum()} of {bad.size} elements outside rtol/atol"
+    assert bad.mean() < 1e-2, f"{bad.sum()} of {bad.size} elements outside rtol/atol"
     assert np.abs(gf - wf).max() <= 4 * 2.0 ** -8 * max(1.0, np.abs(wf).max())
 
 
