@@ -1,0 +1,449 @@
+// Greedy Box Seeker, fused: one workgroup per frustum (one 2D detection of one camera).
+//
+// Replaces hot loops 2-4 of FrustumProposerOG.get_proposals
+// (pcdet/models/dense_heads/frustum_proposals_v1.py:593-1048), which in the reference are a
+// Python triple loop with ~25 tiny torch launches per frustum, three sorts for the depth
+// quantiles, a CPU round trip for the 2D IoU and one points_in_boxes_gpu launch + host sync per
+// candidate (<= 60 per frustum).  Here a frustum is a single workgroup that
+//   A  projects the scene's points into its camera and keeps those inside the 2D box
+//      (:590,:606-613; wave ballot + prefix compaction, order is irrelevant downstream),
+//   B  finds the depth quantiles lq/uq/cq by radix select on the float bits (:616-629; no sort),
+//   C  builds the camera frustum and back-projects it to lidar (:128-140,:1509-1545),
+//   D  back-projects the selected points and takes their per-axis extent (:812-826),
+//   E  generates the num_mags x num_rotations x num_sizes candidates with the softmin front shift
+//      and the max_dist filter (:828-879),
+//   F  projects their corners and scores the 2D IoU against the detection (:1392-1411),
+//   G  counts the points inside every surviving candidate (:930-932, same test as
+//      points_in_boxes.hip: one pass over the points for all candidates),
+//   H  scores (:994-999) and keeps the best candidate (topk = 1, :1041-1045).
+// Arithmetic follows the reference's f32 expression order (-ffp-contract=off); transcendental
+// functions come from ocml, so values agree with the CPU reference to float rounding, not bitwise.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxCand = 256;
+
+struct Mat3 { float m[9]; };
+
+__device__ __forceinline__ void mat3_apply(const float *M, float x, float y, float z, float &ox, float &oy, float &oz) {
+    ox = M[0] * x + M[1] * y + M[2] * z;
+    oy = M[3] * x + M[4] * y + M[5] * z;
+    oz = M[6] * x + M[7] * y + M[8] * z;
+}
+
+// project_to_camera (:1431-1475) for one point; cam = 24 floats: L33 (9) | Lt (3) | combine (9) | c2l_t (3)
+__device__ __forceinline__ void project(const float *aug_inv, const float *aug_t, const float *cam, float x, float y,
+                                        float z, float &u, float &v, float &d) {
+    float px, py, pz, qx, qy, qz;
+    mat3_apply(aug_inv, x - aug_t[0], y - aug_t[1], z - aug_t[2], px, py, pz);
+    mat3_apply(cam, px, py, pz, qx, qy, qz);
+    qx += cam[9];
+    qy += cam[10];
+    qz += cam[11];
+    d = fminf(fmaxf(qz, 1e-5f), 1e5f);
+    u = qx / d;
+    v = qy / d;
+}
+
+// get_geometry_at_image_coords (:1509-1545, no post_rots)
+__device__ __forceinline__ void backproject(const float *aug_R, const float *aug_t, const float *cam, float u, float v,
+                                            float d, float &x, float &y, float &z) {
+    float cx, cy, cz;
+    mat3_apply(cam + 12, u * d, v * d, d, cx, cy, cz);
+    cx += cam[21];
+    cy += cam[22];
+    cz += cam[23];
+    mat3_apply(aug_R, cx, cy, cz, x, y, z);
+    x += aug_t[0];
+    y += aug_t[1];
+    z += aug_t[2];
+}
+
+struct Shared {
+    unsigned hist[256];
+    unsigned sel_prefix, sel_mask, sel_k;
+    unsigned count, scratch_u;
+    float cam[24], aug_R[9], aug_inv[9], aug_t[3];
+    float fr[8][3];
+    float ext_min[3], ext_max[3];
+    float bev_pts[16][3];
+    float wc[3];
+    float cbox[kMaxCand][7];
+    float ccos[kMaxCand], csin[kMaxCand];
+    double chx[kMaxCand], chy[kMaxCand];
+    float ciou[kMaxCand], cdist[kMaxCand];
+    float cwfc[kMaxCand][3];
+    int cvalid[kMaxCand];
+    int ccount[kMaxCand];
+    float red_f[kThreads / 64][6];
+    float q[3];
+};
+
+__device__ __forceinline__ unsigned fbits(float f) { return __float_as_uint(f); }  // depths are > 0: order preserving
+
+// k-th smallest (0-based) depth of the list: 4 x 8-bit histogram passes on the float bits.
+__device__ float select_kth(Shared &S, const float *__restrict__ depth3, int m, unsigned k) {
+    if (threadIdx.x == 0) {
+        S.sel_prefix = 0;
+        S.sel_mask = 0;
+        S.sel_k = k;
+    }
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        S.hist[threadIdx.x] = 0;
+        __syncthreads();
+        const unsigned prefix = S.sel_prefix, mask = S.sel_mask;
+        for (int i = threadIdx.x; i < m; i += kThreads) {
+            const unsigned key = fbits(depth3[(size_t)i * 3 + 2]);
+            if ((key & mask) == prefix) atomicAdd(&S.hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned kk = S.sel_k, b = 0;
+            for (; b < 256; ++b) {
+                const unsigned h = S.hist[b];
+                if (kk < h) break;
+                kk -= h;
+            }
+            S.sel_k = kk;
+            S.sel_prefix = prefix | (b << shift);
+            S.sel_mask = mask | (255u << shift);
+        }
+        __syncthreads();
+    }
+    return __uint_as_float(S.sel_prefix);
+}
+
+// torch.quantile(depth, q), linear interpolation via torch.lerp
+__device__ float quantile(Shared &S, const float *__restrict__ list, int m, float q) {
+    const float rank = q * (float)(m - 1);
+    const int lo = (int)floorf(rank), hi = (int)ceilf(rank);
+    const float a = select_kth(S, list, m, (unsigned)lo);
+    float b = a;
+    if (hi != lo) {
+        // (lo+1)-th smallest: a again if a is duplicated past position lo, else the smallest key > a
+        if (threadIdx.x == 0) {
+            S.count = 0;
+            S.scratch_u = 0xffffffffu;
+        }
+        __syncthreads();
+        const unsigned ka = fbits(a);
+        unsigned le = 0, mn = 0xffffffffu;
+        for (int i = threadIdx.x; i < m; i += kThreads) {
+            const unsigned key = fbits(list[(size_t)i * 3 + 2]);
+            le += key <= ka;
+            if (key > ka) mn = min(mn, key);
+        }
+        atomicAdd(&S.count, le);
+        atomicMin(&S.scratch_u, mn);
+        __syncthreads();
+        b = ((unsigned)hi < S.count) ? a : __uint_as_float(S.scratch_u);
+        __syncthreads();
+    }
+    const float w = rank - (float)lo;
+    return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.0f - w);
+}
+
+__global__ __launch_bounds__(kThreads) void boxseeker_kernel(
+    const float *__restrict__ points, const int *__restrict__ scene_off, const fnp_seeker_params prm,
+    const float *__restrict__ scene_mats,   // (S, 21): aug_R 9 | aug_inv 9 | aug_t 3
+    const float *__restrict__ cam_mats,     // (S, 6, 24)
+    const float *__restrict__ frusts,       // (F, 8): scene, cam, x1, y1, x2, y2, label, score
+    const float *__restrict__ base_boxes,   // (10, R, 7)
+    const float *__restrict__ base_corners, // (10, R, 8, 3)
+    const float *__restrict__ mags,         // (num_mags)
+    float *__restrict__ ws_uvd, float *__restrict__ ws_xyz, int ws_stride,
+    int *__restrict__ out_valid, float *__restrict__ out_box, float *__restrict__ out_score, int *__restrict__ out_best,
+    int *__restrict__ dbg_npts, float *__restrict__ dbg_frust, float *__restrict__ dbg_cand, float *__restrict__ dbg_iou,
+    int *__restrict__ dbg_count, int *__restrict__ dbg_valid) {
+    __shared__ Shared S;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = fnp_lane(), wave = tid >> 6;
+    const float *fr = frusts + (size_t)f * 8;
+    const int scene = (int)fr[0], cam = (int)fr[1], label = (int)fr[6];
+    const float x1 = fr[2], y1 = fr[3], x2 = fr[4], y2 = fr[5];
+    const int R = prm.num_rotations * prm.num_sizes, NC = prm.num_mags * R;
+    if (tid < 24) S.cam[tid] = cam_mats[((size_t)scene * 6 + cam) * 24 + tid];
+    if (tid < 9) {
+        S.aug_R[tid] = scene_mats[(size_t)scene * 21 + tid];
+        S.aug_inv[tid] = scene_mats[(size_t)scene * 21 + 9 + tid];
+    }
+    if (tid < 3) S.aug_t[tid] = scene_mats[(size_t)scene * 21 + 18 + tid];
+    if (tid == 0) S.count = 0;
+    __syncthreads();
+
+    // ---- A: select the points of this 2D box ------------------------------------------------
+    const int p0 = scene_off[scene], p1 = scene_off[scene + 1];
+    float *list = ws_uvd + (size_t)f * ws_stride * 3;
+    float *lxyz = ws_xyz + (size_t)f * ws_stride * 3;
+    for (int base = p0; base < p1; base += kThreads) {
+        const int i = base + tid;
+        bool in = false;
+        float u = 0, v = 0, d = 0;
+        if (i < p1) {
+            const float *p = points + (size_t)i * prm.point_stride + prm.xyz_offset;
+            project(S.aug_inv, S.aug_t, S.cam, p[0], p[1], p[2], u, v, d);
+            const bool on_img = (v < (float)prm.image_h) && (v >= 0.f) && (u < (float)prm.image_w) && (u >= 0.f);
+            in = on_img && (v < y2) && (v >= y1) && (u < x2) && (u >= x1);
+        }
+        const unsigned long long mask = __ballot(in);
+        unsigned wbase = 0;
+        if (lane == 0 && mask) wbase = atomicAdd(&S.count, (unsigned)__popcll(mask));
+        wbase = __shfl(wbase, 0);
+        if (in) {
+            const unsigned pos = wbase + __popcll(mask & ((1ull << lane) - 1ull));
+            list[(size_t)pos * 3 + 0] = u;
+            list[(size_t)pos * 3 + 1] = v;
+            list[(size_t)pos * 3 + 2] = d;
+        }
+    }
+    __syncthreads();
+    const int m = (int)S.count;
+    if (dbg_npts && tid == 0) dbg_npts[f] = m;
+    if (m == 0) {  // "no pts in box": the frustum is dropped (:634-637)
+        if (tid == 0) out_valid[f] = 0;
+        return;
+    }
+    __threadfence_block();
+
+    // ---- B: depth quantiles -----------------------------------------------------------------
+    const float qlo = quantile(S, list, m, prm.lq);
+    const float qhi = quantile(S, list, m, prm.uq);
+    const float qc = quantile(S, list, m, prm.cq);
+
+    // ---- C: frustum corners in lidar, weighted centre ---------------------------------------
+    if (tid < 8) {
+        float fmax_ = fminf(qhi, prm.max_dist), fmin_ = fmaxf(qlo, 2.0f);          // :647-648
+        const float lo3[3] = {x1, y1, fmin_}, hi3[3] = {x2, y2, fmax_};
+        const float sx[8] = {1, 1, -1, -1, 1, 1, -1, -1}, sy[8] = {1, -1, -1, 1, 1, -1, -1, 1},
+                    sz[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
+        float c3[3];
+        const float sg[3] = {sx[tid], sy[tid], sz[tid]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) c3[a] = (hi3[a] - lo3[a]) * (sg[a] / 2.0f) + (hi3[a] + lo3[a]) / 2.0f;   // :128-140
+        backproject(S.aug_R, S.aug_t, S.cam, c3[0], c3[1], c3[2], S.fr[tid][0], S.fr[tid][1], S.fr[tid][2]);
+    }
+    if (tid == 8)
+        backproject(S.aug_R, S.aug_t, S.cam, (x1 + x2) / 2.0f, (y1 + y2) / 2.0f, qc, S.wc[0], S.wc[1], S.wc[2]);   // :630-632
+
+    // ---- D: back-project the selected points, per-axis extent --------------------------------
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < m; i += kThreads) {
+        float x, y, z;
+        backproject(S.aug_R, S.aug_t, S.cam, list[(size_t)i * 3], list[(size_t)i * 3 + 1], list[(size_t)i * 3 + 2], x, y, z);
+        lxyz[(size_t)i * 3] = x;
+        lxyz[(size_t)i * 3 + 1] = y;
+        lxyz[(size_t)i * 3 + 2] = z;
+        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+        mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+        }
+        if (lane == 0) {
+            S.red_f[wave][a] = mn[a];
+            S.red_f[wave][3 + a] = mx[a];
+        }
+    }
+    __syncthreads();
+    if (tid < 3) {
+        float lo = S.red_f[0][tid], hi = S.red_f[0][3 + tid];
+        for (int w = 1; w < kThreads / 64; ++w) {
+            lo = fminf(lo, S.red_f[w][tid]);
+            hi = fmaxf(hi, S.red_f[w][3 + tid]);
+        }
+        if (prm.clamp_bottom > 0) {                                                 // :817-826
+            float flo = S.fr[0][tid], fhi = S.fr[0][tid];
+            for (int c = 1; c < 8; ++c) {
+                flo = fminf(flo, S.fr[c][tid]);
+                fhi = fmaxf(fhi, S.fr[c][tid]);
+            }
+            const float f1 = fmaxf(lo, flo), f2 = fminf(hi, fhi);
+            for (int c = 0; c < 8; ++c) S.fr[c][tid] = fminf(fmaxf(S.fr[c][tid], f1), f2);   // torch.clamp(min, max)
+        }
+    }
+    __syncthreads();
+    if (dbg_frust && tid < 24) dbg_frust[(size_t)f * 24 + tid] = S.fr[tid / 3][tid % 3];
+
+    // ---- E: search positions along the frustum axis (:828-847) -------------------------------
+    if (tid < prm.num_mags * 3) {
+        const int i = tid / 3, a = tid % 3;
+        const float b0 = (S.fr[0][a] + S.fr[1][a]) / 2.0f, b1 = (S.fr[2][a] + S.fr[3][a]) / 2.0f;
+        const float b2 = (S.fr[4][a] + S.fr[5][a]) / 2.0f, b3 = (S.fr[6][a] + S.fr[7][a]) / 2.0f;
+        const float close = (b0 + b1) / 2.0f, far = (b2 + b3) / 2.0f;
+        S.bev_pts[i][a] = close + (far - close) * mags[i];
+    }
+    __syncthreads();
+
+    // ---- E/F: candidates, softmin front shift, distance filter, 2D IoU ------------------------
+    for (int c = tid; c < NC; c += kThreads) {
+        const int mi = c / R, ri = c % R;
+        const float *bb = base_boxes + ((size_t)(label - 1) * R + ri) * 7;
+        const float *bc = base_corners + ((size_t)(label - 1) * R + ri) * 24;
+        float box[7], cor[8][3], nrm[8];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) box[j] = bb[j];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) box[a] = box[a] + S.bev_pts[mi][a];
+        float nmax = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) cor[k][a] = bc[k * 3 + a] + S.bev_pts[mi][a];
+            nrm[k] = -sqrtf(cor[k][0] * cor[k][0] + cor[k][1] * cor[k][1] + cor[k][2] * cor[k][2]);
+            nmax = fmaxf(nmax, nrm[k]);
+        }
+        float e[8], es = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            e[k] = expf(nrm[k] - nmax);
+            es += e[k];
+        }
+        float wf[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float r = e[k] / es;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) wf[a] += r * cor[k][a];
+        }
+        float f2c[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            f2c[a] = box[a] - wf[a];
+            box[a] = box[a] + f2c[a];
+        }
+        const float dist = sqrtf(wf[0] * wf[0] + wf[1] * wf[1] + wf[2] * wf[2]);
+        int valid = dist < prm.max_dist;                                            // :871-872
+        // calc_iou (:1392-1411): hull box of the clamped corner projections vs the detection
+        float bx1 = INFINITY, by1 = INFINITY, bx2 = -INFINITY, by2 = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float u, v, d;
+            project(S.aug_inv, S.aug_t, S.cam, cor[k][0] + f2c[0], cor[k][1] + f2c[1], cor[k][2] + f2c[2], u, v, d);
+            u = fminf(fmaxf(u, 0.f), (float)prm.image_w);
+            v = fminf(fmaxf(v, 0.f), (float)prm.image_h);
+            bx1 = fminf(bx1, u); by1 = fminf(by1, v); bx2 = fmaxf(bx2, u); by2 = fmaxf(by2, v);
+        }
+        const float a1 = (bx2 - bx1) * (by2 - by1), a2 = (x2 - x1) * (y2 - y1);
+        const float iw = fmaxf(fminf(bx2, x2) - fmaxf(bx1, x1), 0.f), ih = fmaxf(fminf(by2, y2) - fmaxf(by1, y1), 0.f);
+        const float inter = iw * ih;
+        const float iou = inter / (a1 + a2 - inter);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) S.cbox[c][j] = box[j];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) S.cwfc[c][a] = wf[a];
+        S.ciou[c] = iou;
+        S.cdist[c] = sqrtf((wf[0] - S.wc[0]) * (wf[0] - S.wc[0]) + (wf[1] - S.wc[1]) * (wf[1] - S.wc[1]) +
+                           (wf[2] - S.wc[2]) * (wf[2] - S.wc[2]));
+        S.cvalid[c] = valid ? (iou > prm.min_cam_iou ? 2 : 1) : 0;   // 1 = passed the distance filter only
+        S.ccount[c] = 0;
+        const float ang = -box[6];
+        S.ccos[c] = cosf(ang);
+        S.csin[c] = sinf(ang);
+        S.chx[c] = (double)box[3] / 2.0 + (double)1e-5f;
+        S.chy[c] = (double)box[4] / 2.0 + (double)1e-5f;
+    }
+    __syncthreads();
+
+    // ---- G: points inside every surviving candidate (roiaware_pool3d_kernel.cu:23-36) ---------
+    for (int base = 0; base < m; base += kThreads) {
+        const int i = base + tid;
+        float x = 0, y = 0, z = 0;
+        const bool have = i < m;
+        if (have) {
+            x = lxyz[(size_t)i * 3];
+            y = lxyz[(size_t)i * 3 + 1];
+            z = lxyz[(size_t)i * 3 + 2];
+        }
+        for (int c = 0; c < NC; ++c) {
+            if (S.cvalid[c] != 2) continue;   // wave-uniform
+            bool in = false;
+            if (have && !(fabsf(z - S.cbox[c][2]) > S.cbox[c][5] * 0.5f)) {
+                const float sx = x - S.cbox[c][0], sy = y - S.cbox[c][1];
+                const float lx = sx * S.ccos[c] + sy * (-S.csin[c]);
+                const float ly = sx * S.csin[c] + sy * S.ccos[c];
+                in = ((double)fabsf(lx) < S.chx[c]) && ((double)fabsf(ly) < S.chy[c]);
+            }
+            const unsigned long long mask = __ballot(in);
+            if (lane == 0 && mask) atomicAdd(&S.ccount[c], __popcll(mask));
+        }
+    }
+    __syncthreads();
+
+    // ---- H: second-stage score, best candidate ------------------------------------------------
+    if (tid == 0) {
+        int nmax = 0, any = 0;
+        float dmin = INFINITY, dmax = -INFINITY;
+        for (int c = 0; c < NC; ++c) {
+            if (S.cvalid[c] >= 1) {   // dists are ranked over the distance-filtered set (:886-893)
+                dmin = fminf(dmin, S.cdist[c]);
+                dmax = fmaxf(dmax, S.cdist[c]);
+            }
+            if (S.cvalid[c] == 2) {
+                any = 1;
+                nmax = max(nmax, S.ccount[c]);
+            }
+        }
+        int best = -1;
+        float best_s = -INFINITY;
+        for (int c = 0; c < NC; ++c) {
+            if (S.cvalid[c] != 2) continue;
+            const float soft = (float)S.ccount[c] / ((float)nmax + 1e-8f);
+            const float dr = 1.0f - (S.cdist[c] - dmin) / (dmax - dmin + 1e-8f);
+            float s = soft * prm.dns_w + S.ciou[c] * prm.iou_w;
+            s = s + dr * prm.dst_w;
+            if (s > best_s) {   // first maximum = order of a stable descending sort
+                best_s = s;
+                best = c;
+            }
+        }
+        out_valid[f] = any;
+        out_best[f] = best;
+        out_score[f] = any ? best_s : 0.f;
+        for (int j = 0; j < 7; ++j) out_box[(size_t)f * 7 + j] = any ? S.cbox[best][j] : 0.f;
+    }
+    if (dbg_cand)
+        for (int i = tid; i < NC * 7; i += kThreads) dbg_cand[(size_t)f * NC * 7 + i] = S.cbox[i / 7][i % 7];
+    if (dbg_iou)
+        for (int c = tid; c < NC; c += kThreads) dbg_iou[(size_t)f * NC + c] = S.ciou[c];
+    if (dbg_count)
+        for (int c = tid; c < NC; c += kThreads) dbg_count[(size_t)f * NC + c] = S.ccount[c];
+    if (dbg_valid)
+        for (int c = tid; c < NC; c += kThreads) dbg_valid[(size_t)f * NC + c] = S.cvalid[c];
+}
+
+}  // namespace
+
+extern "C" int64_t fnp_boxseeker_workspace_bytes(int num_frustums, int max_points_per_scene) {
+    if (num_frustums < 0 || max_points_per_scene < 0) return FNP_ERR_ARG;
+    return (int64_t)num_frustums * (max_points_per_scene > 0 ? max_points_per_scene : 1) * 3 * 4 * 2 + 256;
+}
+
+extern "C" int fnp_boxseeker(const float *points, const int *scene_offsets, int num_scenes, int max_points_per_scene,
+                             const fnp_seeker_params *params, const float *scene_mats, const float *cam_mats,
+                             const float *frustums, int num_frustums, const float *base_boxes,
+                             const float *base_corners, const float *mags, void *workspace, int64_t workspace_bytes,
+                             int *out_valid, float *out_box, float *out_score, int *out_best, int *dbg_npts,
+                             float *dbg_frust, float *dbg_cand, float *dbg_iou, int *dbg_count, int *dbg_valid,
+                             fnp_stream_t stream) {
+    if (!params || num_scenes <= 0 || num_frustums < 0) return FNP_ERR_ARG;
+    if (num_frustums == 0) return FNP_OK;
+    const int NC = params->num_mags * params->num_rotations * params->num_sizes;
+    if (NC <= 0 || NC > kMaxCand || params->num_mags > 16 || params->point_stride < 3 || params->topk != 1) return FNP_ERR_ARG;
+    if (!points || !scene_offsets || !scene_mats || !cam_mats || !frustums || !base_boxes || !base_corners || !mags ||
+        !workspace || !out_valid || !out_box || !out_score || !out_best)
+        return FNP_ERR_ARG;
+    if (fnp_boxseeker_workspace_bytes(num_frustums, max_points_per_scene) > workspace_bytes) return FNP_ERR_WORKSPACE;
+    const int stride = max_points_per_scene > 0 ? max_points_per_scene : 1;
+    float *ws_uvd = (float *)workspace;
+    float *ws_xyz = ws_uvd + (size_t)num_frustums * stride * 3;
+    hipLaunchKernelGGL(boxseeker_kernel, dim3(num_frustums), dim3(kThreads), 0, (hipStream_t)stream, points,
+                       scene_offsets, *params, scene_mats, cam_mats, frustums, base_boxes, base_corners, mags, ws_uvd,
+                       ws_xyz, stride, out_valid, out_box, out_score, out_best, dbg_npts, dbg_frust, dbg_cand, dbg_iou,
+                       dbg_count, dbg_valid);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}

@@ -1,0 +1,289 @@
+"""Greedy Box Seeker (FrustumProposerOG) on MI355X.
+
+Mirrors pcdet/models/dense_heads/frustum_proposals_v1.py: same constructor signature and
+PARAMS handling (:142-318), same batch_dict contract (:535-552), same return types of
+get_proposals (:1055-1067) / get_bboxes / forward (:1547-1573).  The per-frustum work (hot loops
+2-4: point selection, depth quantiles, frustum geometry, candidate generation, 2D IoU, point
+density, scoring, top-1) runs as ONE launch of csrc/boxseeker.hip for all frustums of the batch;
+the host only enumerates the frustums (per-camera 2D NMS of a few dozen CPU boxes, :582-594) and
+prepares the 3x3 camera matrices.  Host syncs per batch: 2 (scene sizes, result read-back) —
+the reference does >= 60 per frustum.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import lib as _l
+
+
+def _get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    if hasattr(cfg, "get"):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def boxes_to_corners_3d(boxes3d):
+    """pcdet/utils/box_utils.py:28-53 with rotate_points_along_z (common_utils.py:35-57)."""
+    template = boxes3d.new_tensor(([1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1],
+                                   [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1])) / 2
+    corners3d = boxes3d[:, None, 3:6].repeat(1, 8, 1) * template[None, :, :]
+    angle = boxes3d[:, 6]
+    cosa, sina = torch.cos(angle), torch.sin(angle)
+    zeros, ones = angle.new_zeros(angle.shape[0]), angle.new_ones(angle.shape[0])
+    rot = torch.stack((cosa, sina, zeros, -sina, cosa, zeros, zeros, zeros, ones), dim=1).view(-1, 3, 3).float()
+    corners3d = torch.matmul(corners3d.view(-1, 8, 3), rot).view(-1, 8, 3)
+    corners3d += boxes3d[:, None, 0:3]
+    return corners3d
+
+
+def box_iou(boxes1, boxes2):
+    """torchvision.ops.box_iou (the reference calls it on CPU tensors, :1409)."""
+    a1 = (boxes1[:, 2] - boxes1[:, 0]) * (boxes1[:, 3] - boxes1[:, 1])
+    a2 = (boxes2[:, 2] - boxes2[:, 0]) * (boxes2[:, 3] - boxes2[:, 1])
+    lt = torch.max(boxes1[:, None, :2], boxes2[:, :2])
+    rb = torch.min(boxes1[:, None, 2:], boxes2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    return inter / (a1[:, None] + a2 - inter)
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    """torchvision.ops.batched_nms, coordinate-trick form (:587).  A few dozen CPU boxes per
+    camera: host work in the reference too.  Returns kept indices, score descending."""
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64)
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    b = boxes + offsets[:, None]
+    order = torch.argsort(scores, descending=True, stable=True)
+    iou = box_iou(b[order], b[order])
+    n = order.numel()
+    removed = torch.zeros(n, dtype=torch.bool)
+    later = torch.arange(n)
+    keep = []
+    for i in range(n):
+        if removed[i]:
+            continue
+        keep.append(int(order[i]))
+        removed |= (iou[i] > iou_threshold) & (later > i)
+    return torch.tensor(keep, dtype=torch.int64)
+
+
+class FrustumProposerOG(nn.Module):
+    def __init__(self, model_cfg=None, input_channels=None, num_class=None, class_names=None, grid_size=None,
+                 point_cloud_range=None, voxel_size=None, predict_boxes_when_training=True,
+                 lq=0.336, uq=0.356, iou_w=0.95, dst_w=0.226, dns_w=0.05,
+                 min_cam_iou=0.3, size_min=0.957, size_max=1.2, ry_min=0.0, ry_max=math.pi, cq=0.46, num_mags=6,
+                 max_dist=50, num_sizes=4, num_rotations=10, topk=1, nms_2d=0.7, nms_3d=1.0, score_thr=0.1,
+                 nms_normal=0.7, clamp_bottom=0, image_detector=None):
+        super().__init__()
+        self.MULTICAM_IOU = bool(_get(model_cfg, 'MULTICAM_IOU', False))
+        self.OCCL_MULT = bool(_get(model_cfg, 'OCCL_MULT', False))
+        self.MULT = bool(_get(model_cfg, 'MULT', False))
+        self.search_depth, self.clamp_bottom, self.rand_center = None, 0, False
+        self.aln_w = self.ego_w = self.occl_w = 0
+        p = _get(model_cfg, 'PARAMS', None)
+        if p is not None:   # :167-197
+            g = lambda k, d: p.get(k, d)
+            lq, uq, iou_w, dst_w, dns_w = g('lq', lq), g('uq', uq), g('iou_w', iou_w), g('dst_w', dst_w), g('dns_w', dns_w)
+            self.aln_w, self.ego_w = g('aln_w', 0), g('ego_w', 0)
+            min_cam_iou, size_min, size_max, cq = g('min_cam_iou', min_cam_iou), g('size_min', size_min), g('size_max', size_max), g('cq', cq)
+            num_mags, max_dist, num_sizes, num_rotations = g('num_mags', num_mags), g('max_dist', max_dist), g('num_sizes', num_sizes), g('num_rotations', num_rotations)
+            topk, score_thr, nms_2d, nms_3d, nms_normal = g('topk', topk), g('score_thr', score_thr), g('nms_2d', nms_2d), g('nms_3d', nms_3d), g('nms_normal', nms_normal)
+            self.clamp_bottom, self.rand_center = g('clamp_bottom', clamp_bottom), g('rand_center', False)
+            self.occl_w, ry_min, ry_max = g('occl_w', 0), g('ry_min', ry_min), g('ry_max', ry_max)
+            self.search_depth = g('search_depth', None)
+        self.nms_normal, self.topk, self.nms_3d, self.nms_2d = nms_normal, topk, nms_3d, nms_2d
+        assert self.nms_3d == 0, 'DO NOT USE!'   # :209
+        self.image_order = [2, 0, 1, 5, 3, 4]
+        self.image_size = [900, 1600]
+        self.point_cloud_range = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0]
+        self.mags_min, self.mags_max = 0.0, 1.0
+        self.ry_min, self.ry_max, self.size_min, self.size_max = ry_min, ry_max, size_min, size_max
+        self.num_mags, self.num_sizes, self.num_rotations = num_mags, num_sizes, num_rotations
+        self.max_dist, self.score_thr = max_dist, score_thr
+        self.lq, self.uq, self.cq = lq, uq, cq
+        self.iou_w, self.dst_w, self.dns_w, self.min_cam_iou = iou_w, dst_w, dns_w, min_cam_iou
+        self.box_fmt = _get(model_cfg, 'BOX_FORMAT', 'xyxy')
+        unsupported = [n for n, v in (("MULTICAM_IOU", self.MULTICAM_IOU), ("OCCL_MULT", self.OCCL_MULT), ("MULT", self.MULT),
+                                       ("aln_w", self.aln_w), ("ego_w", self.ego_w), ("occl_w", self.occl_w),
+                                       ("rand_center", self.rand_center), ("search_depth", self.search_depth),
+                                       ("topk != 1", self.topk != 1), ("num_mags < 1", self.num_mags < 1),
+                                       ("BOX_FORMAT != xyxy", self.box_fmt != 'xyxy')) if v]
+        if unsupported:
+            raise NotImplementedError(f"FrustumProposerOG (fused MI355X path): options not built: {unsupported}")
+
+        anchors = torch.tensor([[4.63, 1.97, 1.74], [6.93, 2.51, 2.84], [6.37, 2.85, 3.19], [10.5, 2.94, 3.47],
+                                [12.29, 2.90, 3.87], [0.50, 2.53, 0.98], [2.11, 0.77, 1.47], [1.70, 0.60, 1.28],
+                                [0.73, 0.67, 1.77], [0.41, 0.41, 1.07]], dtype=torch.float32)   # :270-281
+        self.anchors = anchors
+        size_variations = torch.linspace(self.size_min, self.size_max, steps=self.num_sizes)
+        base_rotations = torch.linspace(self.ry_min, self.ry_max, steps=self.num_rotations)
+        base_boxes = torch.zeros((anchors.shape[0], self.num_rotations, self.num_sizes, 7))
+        for i in range(anchors.shape[0]):
+            base_boxes[i, :, :, [3, 4, 5]] = anchors[i]
+        for i in range(self.num_rotations):
+            base_boxes[:, i, :, -1] = base_rotations[i]
+        for i, m in enumerate(size_variations):
+            base_boxes[:, :, i, [3, 4, 5]] = base_boxes[:, :, i, [3, 4, 5]] * m
+        self.register_buffer("base_corners", boxes_to_corners_3d(base_boxes.reshape(-1, 7)).reshape(anchors.shape[0], -1, 8, 3).contiguous(), persistent=False)
+        self.register_buffer("base_boxes", base_boxes.reshape(anchors.shape[0], -1, 7).contiguous(), persistent=False)
+        self.register_buffer("mags", torch.linspace(self.mags_min, self.mags_max, self.num_mags), persistent=False)
+
+        self.image_detector = image_detector
+        if self.image_detector is None:
+            self.image_detector = self._default_detector(model_cfg, class_names)
+        self.last_debug = None
+        self._dev_tables = {}
+
+    @staticmethod
+    def _default_detector(model_cfg, class_names):
+        """PreprocessedGLIP / PreprocessedDetector of the host OpenPCDet tree (:254-267), if present."""
+        try:
+            from pcdet.models.preprocessed_detector import PreprocessedDetector, PreprocessedGLIP   # type: ignore
+        except Exception:
+            return None
+        preds_path = _get(model_cfg, 'PREDS_PATH', '')
+        if 'PreprocessedGLIP' in preds_path:
+            return PreprocessedGLIP(class_names=class_names)
+        cams = ['CAM_BACK', 'CAM_BACK_LEFT', 'CAM_BACK_RIGHT', 'CAM_FRONT', 'CAM_FRONT_LEFT', 'CAM_FRONT_RIGHT']
+        paths = _get(model_cfg, 'PREDS_PATHS', [preds_path + f"{c}.json" for c in cams])
+        return PreprocessedDetector(paths, class_names=class_names)
+
+    # ------------------------------------------------------------------------------------------
+    def _params(self, point_stride, xyz_offset):
+        p = _l.SeekerParams()
+        p.lq, p.uq, p.cq = float(self.lq), float(self.uq), float(self.cq)
+        p.iou_w, p.dst_w, p.dns_w = float(self.iou_w), float(self.dst_w), float(self.dns_w)
+        p.min_cam_iou, p.max_dist = float(self.min_cam_iou), float(self.max_dist)
+        p.num_mags, p.num_rotations, p.num_sizes = int(self.num_mags), int(self.num_rotations), int(self.num_sizes)
+        p.topk, p.clamp_bottom = 1, int(self.clamp_bottom)
+        p.image_h, p.image_w = int(self.image_size[0]), int(self.image_size[1])
+        p.point_stride, p.xyz_offset = int(point_stride), int(xyz_offset)
+        return p
+
+    def enumerate_frustums(self, batch_dict):
+        """Rows [scene, cam, x1, y1, x2, y2, label, score] in the reference's order (:561-594)."""
+        if self.image_detector is None:
+            raise RuntimeError("FrustumProposerOG needs an image_detector (PreprocessedGLIP predictions)")
+        det_boxes, det_labels, det_scores, det_batch_idx, det_cam_idx = self.image_detector(batch_dict)
+        det_boxes, det_labels, det_scores = det_boxes.cpu().float(), det_labels.cpu(), det_scores.cpu().float()
+        det_batch_idx, det_cam_idx = det_batch_idx.cpu(), det_cam_idx.cpu()
+        rows = []
+        for b in range(int(batch_dict['batch_size'])):
+            mb = det_batch_idx == b
+            cur_boxes, cur_labels, cur_scores, cur_cam = det_boxes[mb], det_labels[mb], det_scores[mb], det_cam_idx[mb]
+            for c in self.image_order:
+                mc = cur_cam == c
+                cam_boxes, cam_labels, cam_scores = cur_boxes[mc], cur_labels[mc], cur_scores[mc]
+                if cam_boxes.shape[0] > 0:
+                    sel = batched_nms(cam_boxes, cam_scores, cam_labels, self.nms_2d)
+                    cam_boxes, cam_labels, cam_scores = cam_boxes[sel], cam_labels[sel], cam_scores[sel]
+                for box, label, score in zip(cam_boxes, cam_labels, cam_scores):
+                    if score < self.score_thr:
+                        continue
+                    rows.append([float(b), float(c), float(box[0]), float(box[1]), float(box[2]), float(box[3]),
+                                 float(label), float(score)])
+        return torch.tensor(rows, dtype=torch.float32).reshape(-1, 8)
+
+    @staticmethod
+    def _matrices(batch_dict):
+        """(B,21) scene and (B,6,24) camera matrices in f32, computed like :1431-1475 / :1509-1545."""
+        aug = batch_dict['lidar_aug_matrix'].detach().cpu().float()
+        l2i = batch_dict['lidar2image'].detach().cpu().float()
+        c2l = batch_dict['camera2lidar'].detach().cpu().float()
+        K = batch_dict['camera_intrinsics'].detach().cpu().float()
+        if 'img_aug_matrix' in batch_dict:
+            ia = batch_dict['img_aug_matrix'].detach().cpu().float()
+            eye = torch.eye(4).expand_as(ia)
+            if not torch.equal(ia, eye):
+                raise NotImplementedError("img_aug_matrix != identity is not built (the extraction config has no image aug)")
+        B = aug.shape[0]
+        R = aug[:, :3, :3]
+        scene = torch.cat([R.reshape(B, 9), torch.inverse(R).reshape(B, 9), aug[:, :3, 3]], dim=1).contiguous()
+        combine = c2l[..., :3, :3].matmul(torch.inverse(K[..., :3, :3]))
+        cam = torch.cat([l2i[..., :3, :3].reshape(B, 6, 9), l2i[..., :3, 3], combine.reshape(B, 6, 9), c2l[..., :3, 3]], dim=2)
+        return scene, cam.contiguous()
+
+    def _tables(self, dev):
+        """Device copies of the constant tables, kept alive across (asynchronous) launches."""
+        key = str(dev)
+        if key not in self._dev_tables:
+            self._dev_tables[key] = (self.base_boxes.to(dev).contiguous(), self.base_corners.to(dev).contiguous(),
+                                     self.mags.to(dev).contiguous())
+        return self._dev_tables[key]
+
+    def get_proposals(self, batch_dict, debug=False):
+        """-> proposal_boxes (K,7) device f32, frust_labels (K,) long CPU, frust_scores (K,) f32 CPU,
+        frust_batch_idx (K,) long CPU — the tuple of :1055-1067."""
+        L = _l.load()
+        points = batch_dict['points']
+        _l.require_device(points)
+        points = points.detach().float().contiguous()
+        dev = points.device
+        B = int(batch_dict['batch_size'])
+        frusts = self.enumerate_frustums(batch_dict)
+        F = frusts.shape[0]
+        empty = (torch.zeros((0, 7), device=dev), torch.zeros((0,), dtype=torch.long), torch.zeros((0,)),
+                 torch.zeros((0,), dtype=torch.long))
+        if F == 0:
+            return empty
+        # scenes are contiguous row ranges of the collated point tensor (dataset.py:221-245)
+        counts = torch.bincount(points[:, 0].long(), minlength=B)[:B]
+        offsets = torch.zeros((B + 1,), dtype=torch.int32, device=dev)
+        offsets[1:] = torch.cumsum(counts, 0).int()
+        max_pts = int(counts.max().item())                                     # host sync 1
+        scene_m, cam_m = self._matrices(batch_dict)
+        scene_m, cam_m, d_fr = scene_m.to(dev), cam_m.to(dev), frusts.to(dev)
+        prm = self._params(points.shape[1], 1)
+        NC = self.num_mags * self.num_rotations * self.num_sizes
+        ws = torch.empty((int(L.fnp_boxseeker_workspace_bytes(F, max_pts)),), dtype=torch.uint8, device=dev)
+        out_valid = torch.zeros((F,), dtype=torch.int32, device=dev)
+        out_box = torch.zeros((F, 7), dtype=torch.float32, device=dev)
+        out_score = torch.zeros((F,), dtype=torch.float32, device=dev)
+        out_best = torch.full((F,), -1, dtype=torch.int32, device=dev)
+        dbg = {}
+        if debug:
+            dbg = dict(npts=torch.zeros((F,), dtype=torch.int32, device=dev), frust=torch.zeros((F, 8, 3), device=dev),
+                       cand=torch.zeros((F, NC, 7), device=dev), iou=torch.zeros((F, NC), device=dev),
+                       count=torch.zeros((F, NC), dtype=torch.int32, device=dev),
+                       valid=torch.zeros((F, NC), dtype=torch.int32, device=dev))
+        t_boxes, t_corners, t_mags = self._tables(dev)
+        rc = L.fnp_boxseeker(_l.ptr(points), _l.ptr(offsets), B, max_pts, prm, _l.ptr(scene_m), _l.ptr(cam_m),
+                             _l.ptr(d_fr), F, _l.ptr(t_boxes), _l.ptr(t_corners),
+                             _l.ptr(t_mags), _l.ptr(ws), ws.numel(),
+                             _l.ptr(out_valid), _l.ptr(out_box), _l.ptr(out_score), _l.ptr(out_best),
+                             _l.ptr(dbg.get('npts')), _l.ptr(dbg.get('frust')), _l.ptr(dbg.get('cand')),
+                             _l.ptr(dbg.get('iou')), _l.ptr(dbg.get('count')), _l.ptr(dbg.get('valid')), _l.stream())
+        _l.check(rc, "fnp_boxseeker")
+        valid = out_valid.bool().cpu()                                          # host sync 2
+        if debug:
+            self.last_debug = dict(frustums=frusts, has_box=valid, second_stage_scores=out_score, best=out_best, **dbg)
+        if not bool(valid.any()):
+            return empty
+        proposal_boxes = out_box[valid.to(dev)].reshape(-1, 7)
+        frust_labels = frusts[valid, 6].long()
+        frust_scores = frusts[valid, 7].clone()
+        frust_batch_idx = frusts[valid, 0].long()
+        return proposal_boxes, frust_labels, frust_scores, frust_batch_idx
+
+    def forward(self, batch_dict):
+        bboxes = self.get_bboxes(batch_dict)
+        batch_dict['final_box_dicts'] = bboxes
+        assert not self.training, "not trainable!"
+        return batch_dict
+
+    def get_bboxes(self, batch_dict):
+        """:1554-1573 (one dict per scene; the reference shares ONE dict object between scenes, a bug
+        that only stays hidden at batch size 1 — here each scene gets its own)."""
+        proposed_boxes, proposed_labels, proposed_scores, proposed_batch_idx = self.get_proposals(batch_dict)
+        ret = []
+        for k in range(int(batch_dict['batch_size'])):
+            mask = proposed_batch_idx == k
+            ret.append(dict(pred_boxes=proposed_boxes[mask.to(proposed_boxes.device)], pred_scores=proposed_scores[mask],
+                            pred_labels=proposed_labels[mask].int()))
+        return ret

@@ -49,6 +49,19 @@ class RankGridC(ctypes.Structure):
     ]
 
 
+class SeekerParams(ctypes.Structure):
+    """struct fnp_seeker_params (include/fnp.h)."""
+
+    _fields_ = [
+        ("lq", c_float), ("uq", c_float), ("cq", c_float),
+        ("iou_w", c_float), ("dst_w", c_float), ("dns_w", c_float),
+        ("min_cam_iou", c_float), ("max_dist", c_float),
+        ("num_mags", c_int), ("num_rotations", c_int), ("num_sizes", c_int),
+        ("topk", c_int), ("clamp_bottom", c_int), ("image_h", c_int), ("image_w", c_int),
+        ("point_stride", c_int), ("xyz_offset", c_int),
+    ]
+
+
 class ConvGeom(ctypes.Structure):
     """struct fnp_conv_geom (include/fnp.h)."""
 
@@ -91,6 +104,9 @@ SIGNATURES = {
                                      P, P, c_int, P, P, c_int64, P]),
     "fnp_spconv_forward": (c_int, [P, c_int, c_int, P, P, c_int, c_int, P, c_int, P, c_int,
                                    P, P, P, c_int, c_int, c_int, P]),
+    "fnp_boxseeker_workspace_bytes": (c_int64, [c_int, c_int]),
+    "fnp_boxseeker": (c_int, [P, P, c_int, c_int, POINTER(SeekerParams), P, P, P, c_int, P, P, P, P, c_int64,
+                              P, P, P, P, P, P, P, P, P, P, P]),
     "fnp_sparse_to_dense": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
 }
 

@@ -130,3 +130,84 @@ def init_backbone_weights(module, seed=0):
             elif name.endswith("running_var"):
                 b.copy_(1.0 + 0.1 * torch.rand(b.shape, generator=g))
     return module
+
+
+# ------------------------------------------------------------------------------------------
+# Cameras and 2D detections for the Greedy Box Seeker
+# ------------------------------------------------------------------------------------------
+IMAGE_SIZE = (900, 1600)                       # (H, W), frustum_proposals_v1.py:205
+CAM_YAWS_DEG = [0.0, -55.0, 55.0, 180.0, 110.0, -110.0]
+
+
+def make_cameras(batch_size=1):
+    """6 pinhole cameras per scene: camera_intrinsics, camera2lidar, lidar2image (B,6,4,4) f32 and
+    lidar_aug_matrix (B,4,4) = I  (keys of batch_dict read at frustum_proposals_v1.py:535-538)."""
+    K = np.eye(4, dtype=np.float64)
+    K[0, 0] = K[1, 1] = 1266.0
+    K[0, 2], K[1, 2] = 816.0, 491.0
+    intr, c2l, l2i = [], [], []
+    for yaw in np.deg2rad(CAM_YAWS_DEG):
+        fwd = np.array([np.cos(yaw), np.sin(yaw), 0.0])
+        right = np.array([np.sin(yaw), -np.cos(yaw), 0.0])
+        down = np.array([0.0, 0.0, -1.0])
+        T = np.eye(4)
+        T[:3, 0], T[:3, 1], T[:3, 2] = right, down, fwd      # camera x (right), y (down), z (forward) in lidar
+        T[:3, 3] = [0.8 * np.cos(yaw), 0.8 * np.sin(yaw), -0.3]
+        intr.append(K)
+        c2l.append(T)
+        l2i.append(K @ np.linalg.inv(T))
+    rep = lambda a: np.repeat(np.stack(a)[None].astype(np.float32), batch_size, axis=0)
+    return {"camera_intrinsics": rep(intr), "camera2lidar": rep(c2l), "lidar2image": rep(l2i),
+            "lidar_aug_matrix": np.repeat(np.eye(4, dtype=np.float32)[None], batch_size, axis=0)}
+
+
+def box_corners(boxes):
+    """(N,7) -> (N,8,3), corner order of box_utils.boxes_to_corners_3d (box_utils.py:28-53)."""
+    t = np.array([[1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1], [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1]]) / 2.0
+    c = boxes[:, None, 3:6] * t[None]
+    cs, sn = np.cos(boxes[:, 6]), np.sin(boxes[:, 6])
+    x = c[..., 0] * cs[:, None] - c[..., 1] * sn[:, None]
+    y = c[..., 0] * sn[:, None] + c[..., 1] * cs[:, None]
+    return np.stack([x, y, c[..., 2]], -1) + boxes[:, None, 0:3]
+
+
+def make_detections(boxes, cls, cams, rng, batch_idx=0, duplicates=True):
+    """Synthetic GLIP-like 2D detections: clipped projection of each cuboid into every camera that
+    sees it, jittered +-5 px, score U(0.3, 0.95), label = class + 1 (1-based like
+    preprocessed_detector.py:83-85).  Returns float32 (D,4) xyxy, int64 labels, f32 scores,
+    int64 batch idx, int64 cam idx — the tuple PreprocessedGLIP.__call__ returns."""
+    H, W = IMAGE_SIZE
+    corners = box_corners(boxes.astype(np.float64))
+    out = []
+    for c in range(6):
+        L = cams["lidar2image"][batch_idx, c].astype(np.float64)
+        for i in range(boxes.shape[0]):
+            p = corners[i] @ L[:3, :3].T + L[:3, 3]
+            if (p[:, 2] < 1.0).any():
+                continue
+            uv = p[:, :2] / p[:, 2:3]
+            x1, y1 = np.clip(uv[:, 0].min(), 0, W), np.clip(uv[:, 1].min(), 0, H)
+            x2, y2 = np.clip(uv[:, 0].max(), 0, W), np.clip(uv[:, 1].max(), 0, H)
+            if (x2 - x1) < 12 or (y2 - y1) < 12:
+                continue
+            j = rng.uniform(-5, 5, size=4)
+            b = np.array([max(x1 + j[0], 0), max(y1 + j[1], 0), min(x2 + j[2], W), min(y2 + j[3], H)])
+            out.append((b, int(cls[i]) + 1, rng.uniform(0.3, 0.95), c))
+            if duplicates and rng.random() < 0.25:   # near-duplicate, lower score: exercises the 2D NMS
+                out.append((b + rng.uniform(-8, 8, size=4), int(cls[i]) + 1, rng.uniform(0.3, 0.6), c))
+    if not out:
+        return (np.zeros((0, 4), np.float32), np.zeros((0,), np.int64), np.zeros((0,), np.float32),
+                np.zeros((0,), np.int64), np.zeros((0,), np.int64))
+    bx = np.stack([o[0] for o in out]).astype(np.float32)
+    return (bx, np.array([o[1] for o in out], np.int64), np.array([o[2] for o in out], np.float32),
+            np.full((len(out),), batch_idx, np.int64), np.array([o[3] for o in out], np.int64))
+
+
+def make_seeker_scene(seed):
+    """Everything FrustumProposerOG.get_proposals reads for one scene (batch size 1)."""
+    pts, boxes, cls = make_scene(seed, return_boxes=True)
+    rng = np.random.default_rng(10_000 + seed)
+    cams = make_cameras(1)
+    dets = make_detections(boxes, cls, cams, rng)
+    points = np.concatenate([np.zeros((pts.shape[0], 1), np.float32), pts], axis=1)   # collate_batch: [b, x, y, z, i, t]
+    return {"points": points, "gt_boxes": boxes, "gt_cls": cls, "dets": dets, **cams}

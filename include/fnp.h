@@ -204,6 +204,50 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
 int fnp_sparse_to_dense(const void *feats, int dtype, const int *coords, const int *n_rows, int cap,
                         int C, int B, int D, int H, int W, void *out, fnp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Greedy Box Seeker — replaces hot loops 2-4 of FrustumProposerOG.get_proposals
+ * (pcdet/models/dense_heads/frustum_proposals_v1.py:593-1048) for topk = 1: per 2D detection
+ * ("frustum") select the points inside the 2D box, take the depth quantiles, build the frustum,
+ * generate num_mags x num_rotations x num_sizes candidate boxes, score them by 2D IoU of their
+ * projected corners and by point density, return the best one.  One launch for all frustums of
+ * a batch of scenes; no host synchronisation.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fnp_seeker_params {
+    float lq, uq, cq;            /* depth quantiles: frustum near, far, centre (PARAMS lq/uq/cq) */
+    float iou_w, dst_w, dns_w;   /* score weights (:997) */
+    float min_cam_iou;           /* :904 */
+    float max_dist;              /* :871, also caps the frustum depth (:647) */
+    int num_mags, num_rotations, num_sizes;
+    int topk;                    /* must be 1 */
+    int clamp_bottom;            /* :817 */
+    int image_h, image_w;        /* 900, 1600 (:205) */
+    int point_stride;            /* floats per point row */
+    int xyz_offset;              /* column of x in a point row */
+} fnp_seeker_params;
+
+int64_t fnp_boxseeker_workspace_bytes(int num_frustums, int max_points_per_scene);
+
+/* points: rows of `point_stride` floats, scenes concatenated; scene_offsets (S+1,) int32.
+ * scene_mats (S,21) f32: lidar_aug rotation (9, row major) | its inverse (9) | translation (3).
+ * cam_mats (S,6,24) f32: lidar2image[:3,:3] (9) | lidar2image[:3,3] (3) |
+ *                        camera2lidar_rot @ inv(intrinsics) (9) | camera2lidar_trans (3)
+ *                        (the matrices of :1431-1475 and :1509-1545, prepared on the host).
+ * frustums (F,8) f32: scene, camera, x1, y1, x2, y2, label (1-based), score — already NMS'ed,
+ *                        score-filtered and in the reference's enumeration order (:582-594).
+ * base_boxes (10,R,7), base_corners (10,R,8,3), R = num_rotations*num_sizes (:284-298); mags (num_mags,).
+ * Outputs per frustum: out_valid (1 = a candidate survived), out_box (7), out_score (second-stage
+ * score), out_best (candidate index).  dbg_* are optional (NULL) per-candidate dumps:
+ * dbg_npts (F), dbg_frust (F,8,3), dbg_cand (F,NC,7), dbg_iou (F,NC), dbg_count (F,NC),
+ * dbg_valid (F,NC: 0 dropped by max_dist, 1 dropped by min_cam_iou, 2 scored). */
+int fnp_boxseeker(const float *points, const int *scene_offsets, int num_scenes, int max_points_per_scene,
+                  const fnp_seeker_params *params, const float *scene_mats, const float *cam_mats,
+                  const float *frustums, int num_frustums,
+                  const float *base_boxes, const float *base_corners, const float *mags,
+                  void *workspace, int64_t workspace_bytes,
+                  int *out_valid, float *out_box, float *out_score, int *out_best,
+                  int *dbg_npts, float *dbg_frust, float *dbg_cand, float *dbg_iou, int *dbg_count, int *dbg_valid,
+                  fnp_stream_t stream);
+
 /* Capacity overflow: data-dependent counts (n_voxels, n_out) always hold the TRUE count; every
  * kernel clamps to the capacity it was given, so a count larger than its capacity means rows
  * were dropped and the caller must re-run with larger buffers. */
