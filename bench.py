@@ -158,10 +158,22 @@ def main():
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
         cin, cout, K = cls
         flops = 2.0 * float(np.mean([stats[("tags", tag)][0][0] for _, tag in per[cls]])) * cin * cout
+        kname = (f"spconv_mfma_kernel<{cin},{cout},{2 if (cout >= 128 or (cin, cout) == (16, 16)) else 4},{K if K == 27 else 0},bf16>"
+                 if args.dtype == "bf16" else "spconv_valu_kernel")
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+        # WRITE_SIZE in separate runs of this same command, gfx950 FETCH_SIZE x2 correction applied:
+        # profiles/r01_pmc_traffic_b16.json); only quoted when the batch matches, else null
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_b16.json")))
+            if pj.get("batch") == B and kname in pj["kernels"]:
+                traffic = pj["kernels"][kname]["hbm_bytes_corrected"]
+        except Exception:
+            traffic = None
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "traffic": None,
-            "kernel": f"spconv_mfma_kernel<{cin},{cout},{2 if (cout >= 128 or (cin, cout) == (16, 16)) else 4},{K if K == 27 else 0},bf16>" if args.dtype == "bf16" else "spconv_valu_kernel",
+            "traffic": traffic,
+            "kernel": kname,
             "avg_launch_ms": avg_ms, "launches_timed": len(ms), "algorithmic_bytes_per_launch": avg_bytes,
             "mfma_tflops_algorithmic": flops / (avg_ms * 1e-3) / 1e12,
             "time_share_of_step": sum(ms) / (1e3 * elapsed),

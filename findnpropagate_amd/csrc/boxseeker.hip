@@ -417,6 +417,77 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
 
 }  // namespace
 
+// Host side of the frustum enumeration (:561-594): per scene, per camera in image_order, the
+// reference runs torchvision.batched_nms on a few dozen CPU boxes and drops low scores.  Same
+// arithmetic here (coordinate trick: boxes + label * (max_coordinate + 1) in f32, IoU =
+// inter / (a1 + a2 - inter), suppress on IoU > thr, stable score-descending order), as a plain host
+// loop: tens of microseconds per scene instead of ~1 ms of Python/torch small-op overhead.
+extern "C" int fnp_host_enumerate_frustums(const float *boxes, const int64_t *labels, const float *scores,
+                                           const int64_t *batch_idx, const int64_t *cam_idx, int num_dets,
+                                           int num_scenes, const int *image_order, int num_cams, float nms_thr,
+                                           float score_thr, float *rows, int max_rows) {
+    if (num_dets < 0 || num_scenes <= 0 || num_cams <= 0 || !image_order || (num_dets > 0 && (!boxes || !labels || !scores || !batch_idx || !cam_idx)) || !rows)
+        return FNP_ERR_ARG;
+    int n_rows = 0;
+    int *idx = (int *)malloc(sizeof(int) * (size_t)(num_dets > 0 ? num_dets : 1));
+    float *ob = (float *)malloc(sizeof(float) * 4 * (size_t)(num_dets > 0 ? num_dets : 1));
+    unsigned char *removed = (unsigned char *)malloc((size_t)(num_dets > 0 ? num_dets : 1));
+    for (int b = 0; b < num_scenes; ++b) {
+        for (int ci = 0; ci < num_cams; ++ci) {
+            const int c = image_order[ci];
+            int n = 0;
+            float mx = -INFINITY;
+            for (int i = 0; i < num_dets; ++i)
+                if (batch_idx[i] == b && cam_idx[i] == c) {
+                    idx[n++] = i;
+                    for (int k = 0; k < 4; ++k) mx = fmaxf(mx, boxes[(size_t)i * 4 + k]);
+                }
+            if (n == 0) continue;
+            // stable insertion sort by score, descending
+            for (int i = 1; i < n; ++i) {
+                const int v = idx[i];
+                int j = i - 1;
+                while (j >= 0 && scores[idx[j]] < scores[v]) {
+                    idx[j + 1] = idx[j];
+                    --j;
+                }
+                idx[j + 1] = v;
+            }
+            const float shift = mx + 1.0f;
+            for (int i = 0; i < n; ++i) {
+                const float off = (float)labels[idx[i]] * shift;
+                for (int k = 0; k < 4; ++k) ob[i * 4 + k] = boxes[(size_t)idx[i] * 4 + k] + off;
+                removed[i] = 0;
+            }
+            for (int i = 0; i < n; ++i) {
+                if (removed[i]) continue;
+                const float ai = (ob[i * 4 + 2] - ob[i * 4]) * (ob[i * 4 + 3] - ob[i * 4 + 1]);
+                for (int j = i + 1; j < n; ++j) {
+                    if (removed[j]) continue;
+                    const float aj = (ob[j * 4 + 2] - ob[j * 4]) * (ob[j * 4 + 3] - ob[j * 4 + 1]);
+                    const float w = fmaxf(fminf(ob[i * 4 + 2], ob[j * 4 + 2]) - fmaxf(ob[i * 4], ob[j * 4]), 0.f);
+                    const float h = fmaxf(fminf(ob[i * 4 + 3], ob[j * 4 + 3]) - fmaxf(ob[i * 4 + 1], ob[j * 4 + 1]), 0.f);
+                    const float inter = w * h;
+                    if (inter / (ai + aj - inter) > nms_thr) removed[j] = 1;
+                }
+                const int d = idx[i];
+                if (scores[d] < score_thr) continue;   // :594, after the NMS like the reference
+                if (n_rows >= max_rows) {
+                    free(idx); free(ob); free(removed);
+                    return FNP_ERR_WORKSPACE;
+                }
+                float *r = rows + (size_t)n_rows * 8;
+                r[0] = (float)b; r[1] = (float)c;
+                r[2] = boxes[(size_t)d * 4]; r[3] = boxes[(size_t)d * 4 + 1]; r[4] = boxes[(size_t)d * 4 + 2]; r[5] = boxes[(size_t)d * 4 + 3];
+                r[6] = (float)labels[d]; r[7] = scores[d];
+                ++n_rows;
+            }
+        }
+    }
+    free(idx); free(ob); free(removed);
+    return n_rows;
+}
+
 extern "C" int64_t fnp_boxseeker_workspace_bytes(int num_frustums, int max_points_per_scene) {
     if (num_frustums < 0 || max_points_per_scene < 0) return FNP_ERR_ARG;
     return (int64_t)num_frustums * (max_points_per_scene > 0 ? max_points_per_scene : 1) * 3 * 4 * 2 + 256;

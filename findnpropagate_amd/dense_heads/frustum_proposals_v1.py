@@ -9,6 +9,7 @@ the host only enumerates the frustums (per-camera 2D NMS of a few dozen CPU boxe
 prepares the 3x3 camera matrices.  Host syncs per batch: 2 (scene sizes, result read-back) —
 the reference does >= 60 per frustum.
 """
+import ctypes
 import math
 
 import numpy as np
@@ -167,28 +168,28 @@ class FrustumProposerOG(nn.Module):
         return p
 
     def enumerate_frustums(self, batch_dict):
-        """Rows [scene, cam, x1, y1, x2, y2, label, score] in the reference's order (:561-594)."""
+        """Rows [scene, cam, x1, y1, x2, y2, label, score] in the reference's order (:561-594):
+        per scene, per camera in image_order, torchvision.batched_nms (coordinate trick, f32) then the
+        score threshold — host work on a few dozen CPU boxes, done by the native host loop
+        fnp_host_enumerate_frustums (include/fnp.h)."""
         if self.image_detector is None:
             raise RuntimeError("FrustumProposerOG needs an image_detector (PreprocessedGLIP predictions)")
         det_boxes, det_labels, det_scores, det_batch_idx, det_cam_idx = self.image_detector(batch_dict)
-        det_boxes, det_labels, det_scores = det_boxes.cpu().float(), det_labels.cpu(), det_scores.cpu().float()
-        det_batch_idx, det_cam_idx = det_batch_idx.cpu(), det_cam_idx.cpu()
-        rows = []
-        for b in range(int(batch_dict['batch_size'])):
-            mb = det_batch_idx == b
-            cur_boxes, cur_labels, cur_scores, cur_cam = det_boxes[mb], det_labels[mb], det_scores[mb], det_cam_idx[mb]
-            for c in self.image_order:
-                mc = cur_cam == c
-                cam_boxes, cam_labels, cam_scores = cur_boxes[mc], cur_labels[mc], cur_scores[mc]
-                if cam_boxes.shape[0] > 0:
-                    sel = batched_nms(cam_boxes, cam_scores, cam_labels, self.nms_2d)
-                    cam_boxes, cam_labels, cam_scores = cam_boxes[sel], cam_labels[sel], cam_scores[sel]
-                for box, label, score in zip(cam_boxes, cam_labels, cam_scores):
-                    if score < self.score_thr:
-                        continue
-                    rows.append([float(b), float(c), float(box[0]), float(box[1]), float(box[2]), float(box[3]),
-                                 float(label), float(score)])
-        return torch.tensor(rows, dtype=torch.float32).reshape(-1, 8)
+        L = _l.load()
+        boxes = det_boxes.detach().cpu().float().contiguous()
+        labels = det_labels.detach().cpu().long().contiguous()
+        scores = det_scores.detach().cpu().float().contiguous()
+        bidx = det_batch_idx.detach().cpu().long().contiguous()
+        cidx = det_cam_idx.detach().cpu().long().contiguous()
+        D = boxes.shape[0]
+        rows = torch.empty((max(D, 1), 8), dtype=torch.float32)
+        order = (ctypes.c_int * len(self.image_order))(*self.image_order)
+        n = L.fnp_host_enumerate_frustums(_l.ptr(boxes), _l.ptr(labels), _l.ptr(scores), _l.ptr(bidx), _l.ptr(cidx), D,
+                                          int(batch_dict['batch_size']), order, len(self.image_order),
+                                          float(self.nms_2d), float(self.score_thr), _l.ptr(rows), rows.shape[0])
+        if n < 0:
+            _l.check(n, "fnp_host_enumerate_frustums")
+        return rows[:n].clone()
 
     @staticmethod
     def _matrices(batch_dict):

@@ -227,6 +227,17 @@ typedef struct fnp_seeker_params {
 
 int64_t fnp_boxseeker_workspace_bytes(int num_frustums, int max_points_per_scene);
 
+/* HOST function (all pointers are host memory, no GPU work): frustum enumeration of :561-594 —
+ * per scene, per camera in image_order, torchvision.batched_nms (coordinate trick, f32) on the
+ * 2D detections, then the score threshold.  boxes (D,4) xyxy f32, labels/batch_idx/cam_idx (D,)
+ * int64, scores (D,) f32 (the CPU tensors PreprocessedGLIP returns, preprocessed_detector.py:47-101).
+ * rows (max_rows,8) f32 receives [scene, cam, x1, y1, x2, y2, label, score]; returns the number
+ * of rows or a negative error code. */
+int fnp_host_enumerate_frustums(const float *boxes, const int64_t *labels, const float *scores,
+                                const int64_t *batch_idx, const int64_t *cam_idx, int num_dets,
+                                int num_scenes, const int *image_order, int num_cams,
+                                float nms_thr, float score_thr, float *rows, int max_rows);
+
 /* points: rows of `point_stride` floats, scenes concatenated; scene_offsets (S+1,) int32.
  * scene_mats (S,21) f32: lidar_aug rotation (9, row major) | its inverse (9) | translation (3).
  * cam_mats (S,6,24) f32: lidar2image[:3,:3] (9) | lidar2image[:3,3] (3) |

@@ -1,0 +1,102 @@
+"""N > 1 path of the sharded pseudo-label extraction (findnpropagate_amd/extract.py) on CPU:
+world_size 2 over gloo, a deterministic stand-in head (the Box Seeker itself needs a GPU and is
+covered by tests/test_gpu_boxseeker.py).  Checks sharding = pcdet's DistributedSampler, the
+fixed-shape all-gather record, the reference on-disk format, resume, and 1-rank == 2-rank output."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from findnpropagate_amd import extract as E
+
+
+class FakeScenes:
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def frame_id(self, i):
+        return f"n015-2018-{i:04d}.pcd.bin"
+
+    def __getitem__(self, i):
+        return {"frame_id": self.frame_id(i), "index": i, "batch_size": 1}
+
+
+class FakeHead(torch.nn.Module):
+    """K = index % 5 boxes whose values encode the index."""
+
+    def forward(self, bd):
+        i = bd["index"]
+        k = i % 5
+        g = torch.Generator().manual_seed(i)
+        bd["final_box_dicts"] = [dict(pred_boxes=torch.rand((k, 7), generator=g), pred_scores=torch.rand((k,), generator=g),
+                                      pred_labels=torch.randint(1, 11, (k,), generator=g, dtype=torch.int32))]
+        return bd
+
+
+def test_shard_indices_match_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+
+    for n, w in ((10, 2), (7, 2), (13, 4), (3, 8), (1, 2)):
+        got = [E.shard_indices(n, r, w) for r in range(w)]
+        for r in range(w):
+            want = list(DistributedSampler(list(range(n)), num_replicas=w, rank=r, shuffle=False))
+            assert got[r] == want, (n, w, r)
+        assert len({len(g) for g in got}) == 1, "every rank runs the same number of steps"
+    assert E.shard_indices(0, 0, 2) == []
+
+
+def test_record_roundtrip_and_limits():
+    pd = dict(pred_boxes=torch.rand(7, 7), pred_scores=torch.rand(7), pred_labels=torch.randint(1, 11, (7,), dtype=torch.int32))
+    rec, meta = E.pack_record(pd, 42, torch.device("cpu"))
+    assert rec.shape == (E.K_MAX, 9) and meta.tolist() == [7, 42]
+    back, idx = E.unpack_record(rec, meta)
+    assert idx == 42 and torch.equal(back["pred_boxes"], pd["pred_boxes"]) and torch.equal(back["pred_labels"], pd["pred_labels"])
+    assert back["pred_labels"].dtype == torch.int32
+    empty, _ = E.unpack_record(*E.pack_record(dict(pred_boxes=torch.zeros(0, 7), pred_scores=torch.zeros(0), pred_labels=torch.zeros(0, dtype=torch.int32)), 3, torch.device("cpu")))
+    assert empty["pred_boxes"].shape == (0, 7)
+    with pytest.raises(ValueError):
+        E.pack_record(dict(pred_boxes=torch.zeros(E.K_MAX + 1, 7), pred_scores=torch.zeros(E.K_MAX + 1), pred_labels=torch.zeros(E.K_MAX + 1)), 0, torch.device("cpu"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir, n, write):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        E.extract_pseudo_labels(FakeScenes(n), FakeHead(), out_dir, torch.device("cpu"), dist=dist, write=write)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("write", ["rank0", "own"])
+def test_two_ranks_equal_one_rank(write):
+    n = 7   # odd: exercises the wrap-around padding of the last step
+    with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as d2:
+        assert E.extract_pseudo_labels(FakeScenes(n), FakeHead(), d1, torch.device("cpu")) == n
+        mp.spawn(_worker, args=(2, _free_port(), d2, n, write), nprocs=2, join=True)
+        files1, files2 = sorted(os.listdir(d1)), sorted(os.listdir(d2))
+        assert files1 == files2 == sorted(f"n015-2018-{i:04d}_pcd_bin.pth" for i in range(n))
+        for f in files1:
+            a, b = torch.load(os.path.join(d1, f)), torch.load(os.path.join(d2, f))
+            assert isinstance(a, list) and len(a) == 1 and set(a[0]) == {"pred_boxes", "pred_scores", "pred_labels"}
+            for k in a[0]:
+                assert torch.equal(a[0][k], b[0][k]), (f, k)
+        # resume: a second run writes nothing and leaves the files untouched
+        before = {f: os.path.getmtime(os.path.join(d1, f)) for f in files1}
+        assert E.extract_pseudo_labels(FakeScenes(n), FakeHead(), d1, torch.device("cpu")) == 0
+        assert before == {f: os.path.getmtime(os.path.join(d1, f)) for f in files1}
