@@ -165,8 +165,13 @@ struct MfmaCfg {
 #define FNP_ABLATE 0
 #endif
 
+// waves per SIMD the register budget is held to: 3 (<= 168 VGPRs) where it measured faster on
+// MI355X (the channel-doubling strided layers 16->32, 32->64: a third resident workgroup per CU
+// shortens the last, partly filled round of tiles), 2 elsewhere (3 costs spills there)
+template <int CIN, int COUT> struct MfmaOcc { static constexpr int WAVES = (CIN < COUT && COUT <= 64) ? 3 : 2; };
+
 template <int CIN, int COUT, int MB, int KVOL, typename TOut>
-__global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__restrict__ x, int x_bytes,
+__global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const __bf16 *__restrict__ x, int x_bytes,
                                                              const __bf16 *__restrict__ w,
                                                              const int *__restrict__ nbr, int nbr_stride, int Krt,
                                                              const int *__restrict__ n_out, int cap,
@@ -183,6 +188,10 @@ __global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__res
     // weight staging of the double-buffered path: NCH chunks per thread per slab, WST per MFMA step
     constexpr int NCH = (SLAB + 255) / 256;
     constexpr int WST = (NCH + KS - 1) / KS;
+    // small slabs (<= 2 chunks per thread): W_{k+2} is requested at the top of offset k and W_{k+1}
+    // (requested one offset earlier) is written to LDS at its end, so the weights get two offsets of
+    // matrix work to arrive; larger slabs cannot afford the registers and go step by step
+    constexpr bool WDEEP = !ALLK && NCH <= 1;
     static_assert(CIN % 16 == 0 && COUT % 16 == 0, "channel counts must be multiples of 16");
     static_assert(ALLK || SLAB % 256 == 0 || SLAB < 256, "unsupported slab size");
 
@@ -214,6 +223,14 @@ __global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__res
         const int kc = k < K ? k : K - 1;
         const int v = nbr[(size_t)kc * nbr_stride + rc];
         return (r < r_end && k < K) ? v : -1;
+    };
+    // same load, but the value is NOT touched here: the validity select happens where the entry is
+    // consumed (two rounds later).  Any arithmetic on a freshly loaded entry makes the compiler wait
+    // for it — and, VMEM returning in order, for every gather and weight load in flight.
+    auto nbr_raw = [&](int k, int r, int r_end) -> int {
+        const int rc = r < r_end ? r : r_end - 1;
+        const int kc = k < K ? k : K - 1;
+        return nbr[(size_t)kc * nbr_stride + rc];
     };
 
     // Work split: the n rows are cut into gridDim.x contiguous ranges of (almost) equal numbers of
@@ -259,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__res
 
         // prologue: fragments of offsets 0..PFK-1, rulebook indices of offsets PFK..2*PFK-1
         bf16x8 xb[PFK][KS][MB];
-        unsigned roffq[PFK][MB];   // row offsets of the offsets PFK..2*PFK-1 ahead
+        int rawq[PFK][MB];   // raw rulebook entries of the offsets PFK..2*PFK-1 ahead (gathers of this round)
+        int rawr[PFK][MB];   // ... of the offsets 2*PFK..3*PFK-1 ahead (gathers of the next round)
 #pragma unroll
         for (int u = 0; u < PFK; ++u)
 #pragma unroll
@@ -267,7 +285,8 @@ __global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__res
                 const unsigned ro = row_off(nbr_at(u, row0 + mb * 16 + l15, row_end));
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) xb[u][ks][mb] = gather(ro, ks);
-                roffq[u][mb] = row_off(nbr_at(PFK + u, row0 + mb * 16 + l15, row_end));
+                rawq[u][mb] = nbr_raw(PFK + u, row0 + mb * 16 + l15, row_end);
+                rawr[u][mb] = nbr_raw(2 * PFK + u, row0 + mb * 16 + l15, row_end);
             }
         if (!ALLK) {
             if (FNP_ABLATE != 2) {
@@ -279,6 +298,13 @@ __global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__res
             }
             __syncthreads();
         }
+        // (named scalars, not an array: a conditionally written array lands in scratch memory)
+        uint4 wcur0 = make_uint4(0u, 0u, 0u, 0u), wcur1 = make_uint4(0u, 0u, 0u, 0u);
+        if (WDEEP && FNP_ABLATE != 2) {
+            const uint4 *w1 = reinterpret_cast<const uint4 *>(w + (size_t)(K > 1 ? 1 : 0) * COUT * CIN);
+            wcur0 = w1[tid < SLAB ? tid : 0];
+            if (NCH > 1) wcur1 = w1[tid + 256];
+        }
 
         for (int k0 = 0; k0 < K; k0 += PFK) {
 #pragma unroll
@@ -287,11 +313,23 @@ __global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__res
                 if (k >= K) break;  // wave-uniform
                 const uint4 *wk = wl + (ALLK ? k : (k & 1)) * SLAB;
                 const uint4 *wsrc = reinterpret_cast<const uint4 *>(w + (size_t)(k + 1 < K ? k + 1 : k) * COUT * CIN);
+                // rulebook entries for offset k + 3*PFK: requested FIRST in the round, so that they are
+                // older than this round's gathers (VMEM returns in order: a young index load in
+                // front of the next round's first MFMA would stall it)
+                int rawn[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) rawn[mb] = nbr_raw(k + 3 * PFK, row0 + mb * 16 + l15, row_end);
                 uint4 wreg[WST];
+                uint4 wnext0 = make_uint4(0u, 0u, 0u, 0u), wnext1 = make_uint4(0u, 0u, 0u, 0u);
+                if (WDEEP && FNP_ABLATE != 2) {
+                    const uint4 *w2 = reinterpret_cast<const uint4 *>(w + (size_t)(k + 2 < K ? k + 2 : k) * COUT * CIN);
+                    wnext0 = w2[tid < SLAB ? tid : 0];
+                    if (NCH > 1) wnext1 = w2[tid + 256];
+                }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     // (1) previous step's weight chunks -> other LDS buffer; (2) request this step's
-                    if (!ALLK && FNP_ABLATE != 2) {
+                    if (!ALLK && !WDEEP && FNP_ABLATE != 2) {
                         if (ks > 0) {
 #pragma unroll
                             for (int j = 0; j < WST; ++j) {
@@ -328,16 +366,28 @@ __global__ __launch_bounds__(256, 2) void spconv_mfma_kernel(const __bf16 *__res
                                 }
                             }
                     }
-                    // (4) the registers are free again: request the fragments of offset k + PFK
+                    // (4) the registers are free again: request the fragments of offset k + PFK (the
+                    //     rulebook entry was loaded two rounds ago; validity is decided here)
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) xb[u][ks][mb] = gather(roffq[u][mb], ks);
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const bool ok = (k + PFK < K) && (row0 + mb * 16 + l15 < row_end);
+                        xb[u][ks][mb] = gather(row_off(ok ? rawq[u][mb] : -1), ks);
+                    }
                     __builtin_amdgcn_sched_barrier(0);  // keep the steps in program order
                 }
-                // rulebook entries of offset k + 2*PFK (their gathers are issued PFK offsets from now)
+                // rulebook entries run two rounds ahead of their gathers: rotate
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) roffq[u][mb] = row_off(nbr_at(k + 2 * PFK, row0 + mb * 16 + l15, row_end));
+                for (int mb = 0; mb < MB; ++mb) {
+                    rawq[u][mb] = rawr[u][mb];
+                    rawr[u][mb] = rawn[mb];
+                }
                 if (!ALLK) {
-                    if (FNP_ABLATE != 2) {
+                    if (WDEEP && FNP_ABLATE != 2) {
+                        if (SLAB >= 256 || tid < SLAB) wl[((k + 1) & 1) * SLAB + st_pos0] = wcur0;
+                        if (NCH > 1) wl[((k + 1) & 1) * SLAB + st_pos0 + 256] = wcur1;
+                        wcur0 = wnext0;
+                        wcur1 = wnext1;
+                    } else if (FNP_ABLATE != 2) {
 #pragma unroll
                         for (int j = 0; j < WST; ++j) {
                             const int c = (KS - 1) * WST + j, p = tid + c * 256;
@@ -402,7 +452,8 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
     // persistent grid: two workgroups per CU are resident (register / LDS budget of the wide
     // layers); the narrow ALLK layers stage all weights once per workgroup, so keep them few too.
     // The kernel splits the rows evenly over whatever grid it gets.
-    const int grid = tiles < 512 ? tiles : 512;
+    const int resident = 256 * MfmaOcc<CIN, COUT>::WAVES;
+    const int grid = tiles < resident ? tiles : resident;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, s, (const __bf16 *)x, x_bytes, (const __bf16 *)w,
                        nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu);
     FNP_LAUNCH_CHECK();
