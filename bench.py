@@ -39,7 +39,7 @@ def parse():
 
 def algorithmic_bytes(tag, P, n_out, b):
     """P*(Cin*b + 8) + N_out*Cout*b + K*Cin*Cout*b (+ N_out*Cout*b residual read)."""
-    cin, cout, K, res = tag
+    cin, cout, K, res = tag[:4]
     v = P * (cin * b + 8) + n_out * cout * b + K * cin * cout * b
     if res:
         v += n_out * cout * b
@@ -158,7 +158,8 @@ def main():
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
         cin, cout, K = cls
         flops = 2.0 * float(np.mean([stats[("tags", tag)][0][0] for _, tag in per[cls]])) * cin * cout
-        kname = (f"spconv_mfma_kernel<{cin},{cout},{2 if (cout >= 128 or (cin, cout) == (16, 16)) else 4},{K if K == 27 else 0},bf16>"
+        win = "true" if (per[cls][0][1][4] and K == 27 and (cin, cout) == (64, 64)) else "false"
+        kname = (f"spconv_mfma_kernel<{cin},{cout},{2 if (cout >= 128 or (cin, cout) == (16, 16)) else 4},{K if K == 27 else 0},{win},bf16>"
                  if args.dtype == "bf16" else "spconv_valu_kernel")
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
         # WRITE_SIZE in separate runs of this same command, gfx950 FETCH_SIZE x2 correction applied:

@@ -327,24 +327,26 @@ class FusedResBackbone:
             grid1 = S.build_grid(indices, n1, batch_size, m.sparse_shape, keep_order=True, grid=grids[0])
         caps = [cap1] + [max(256, int(cap1 * f)) for f in self.cap_factor]
 
-        def conv(x, prm, rb, n, residual=None, out_dtype=act):
+        def conv(x, prm, rb, n, residual=None, out_dtype=act, ranked=False):
             w, sc, sh = prm
-            tag = (int(w.shape[2]), int(w.shape[1]), int(w.shape[0]), residual is not None)  # Cin, Cout, K, res
+            tag = (int(w.shape[2]), int(w.shape[1]), int(w.shape[0]), residual is not None, ranked)  # Cin, Cout, K, res
             if self.rulebook_log is not None:
                 self.rulebook_log.append((tag, rb, n))
             if self.profile is None:
-                return S.conv_forward(x, w, rb, n, out_dtype=out_dtype, scale=sc, shift=sh, residual=residual, relu=True)
+                return S.conv_forward(x, w, rb, n, out_dtype=out_dtype, scale=sc, shift=sh, residual=residual, relu=True,
+                                      ranked=ranked)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            y = S.conv_forward(x, w, rb, n, out_dtype=out_dtype, scale=sc, shift=sh, residual=residual, relu=True)
+            y = S.conv_forward(x, w, rb, n, out_dtype=out_dtype, scale=sc, shift=sh, residual=residual, relu=True,
+                               ranked=ranked)
             e1.record()
             self.profile.append((tag, e0, e1))
             return y
 
-        def blocks(x, rb, n, prms):
+        def blocks(x, rb, n, prms, ranked=False):
             for p1, p2 in prms:
-                t = conv(x, p1, rb, n)
-                x = conv(t, p2, rb, n, residual=x)
+                t = conv(x, p1, rb, n, ranked=ranked)
+                x = conv(t, p2, rb, n, residual=x, ranked=ranked)
             return x
 
         # stage 1 (conv_input + conv1): one SubM rulebook serves indice_keys 'subm1' and 'res1'
@@ -360,7 +362,8 @@ class FusedResBackbone:
                                      caps[li + 1], out_grid=grids[li + 1])
             x = conv(x_prev, P[down_key], rbs, rbs.out_n)
             rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3)
-            x = blocks(x, rb, rbs.out_n, P[blk_key])
+            # stages 2-4: rows are in rank-grid order on both sides of the SubM convolutions
+            x = blocks(x, rb, rbs.out_n, P[blk_key], ranked=True)
             stage.append((x, rbs.out_indices, rbs.out_n, rbs.out_grid))
             x_prev, idx_prev, n_prev, g_prev = x, rbs.out_indices, rbs.out_n, rbs.out_grid
         oconv = m.conv_out[0]

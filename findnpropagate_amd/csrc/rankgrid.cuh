@@ -1,6 +1,6 @@
 // Rank grid: the collision-free voxel index used by voxelisation and rulebook building.
 //
-// A (B, D, H, W) cell grid is cut into 4x4x4 blocks.  Block w owns
+// A (B, D, H, W) cell grid is cut into 4x4x4 blocks, numbered patch by patch (rg_block_of).  Block w owns
 //   bits[w]  u64 occupancy, bit = (z&3)*16 + (y&3)*4 + (x&3)
 //   base[w]  u32 number of occupied cells in blocks < w   (exclusive popcount scan; defined only
 //            where bits[w] != 0 — an empty word is never ranked)
@@ -18,17 +18,19 @@
 struct RankGridDims {
     int B, D, H, W;       // cells
     int bd, bh, bw;       // blocks per axis
+    int th, tw;           // 8x8-block (32x32-cell) patches per H / W axis (bh, bw rounded up)
 };
 
 __host__ __device__ inline RankGridDims fnp_make_dims(int B, int D, int H, int W) {
     RankGridDims g;
     g.B = B; g.D = D; g.H = H; g.W = W;
     g.bd = (D + 3) >> 2; g.bh = (H + 3) >> 2; g.bw = (W + 3) >> 2;
+    g.th = (g.bh + 7) >> 3; g.tw = (g.bw + 7) >> 3;
     return g;
 }
 
 __host__ __device__ inline long long fnp_num_blocks(const RankGridDims &g) {
-    return (long long)g.B * g.bd * g.bh * g.bw;
+    return (long long)g.B * g.th * g.tw * 64 * g.bd;
 }
 
 // device view of a fnp_rankgrid
@@ -57,17 +59,31 @@ inline RG fnp_rg_view(const fnp_rankgrid *g) {
     return r;
 }
 
+// Block order: scene, then 8x8-block patches of the (H, W) plane row-major, then the 64 block
+// columns of a patch along a Z-order curve, then the blocks of a column bottom to top.  Ranks (and
+// with them the strided convolutions' output rows) therefore run through compact 3-D patches: the
+// rows of one convolution tile share most of their neighbours, which the gathers find in L1/L2.
+__device__ __forceinline__ unsigned rg_morton3(unsigned v) {   // 3 bits abc -> 0a0b0c
+    return (v & 1u) | ((v & 2u) << 1) | ((v & 4u) << 2);
+}
+__device__ __forceinline__ unsigned rg_unmorton3(unsigned m) { // 0a0b0c -> abc
+    return (m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u);
+}
 __device__ __forceinline__ long long rg_block_of(const RankGridDims &g, int b, int z, int y, int x) {
-    return (((long long)b * g.bd + (z >> 2)) * g.bh + (y >> 2)) * g.bw + (x >> 2);
+    const int by = y >> 2, bx = x >> 2;
+    const unsigned col = (rg_morton3(by & 7) << 1) | rg_morton3(bx & 7);
+    return ((((long long)b * g.th + (by >> 3)) * g.tw + (bx >> 3)) * 64 + col) * g.bd + (z >> 2);
 }
 __device__ __forceinline__ int rg_bit_of(int z, int y, int x) { return ((z & 3) << 4) | ((y & 3) << 2) | (x & 3); }
 
 // rank -> (b,z,y,x) decode for a (block, bit) pair
 __device__ __forceinline__ void rg_decode(const RankGridDims &g, long long blk, int bit, int &b, int &z, int &y, int &x) {
-    const int bx = (int)(blk % g.bw); blk /= g.bw;
-    const int by = (int)(blk % g.bh); blk /= g.bh;
     const int bz = (int)(blk % g.bd); blk /= g.bd;
+    const unsigned col = (unsigned)(blk & 63); blk >>= 6;
+    const int tx = (int)(blk % g.tw); blk /= g.tw;
+    const int ty = (int)(blk % g.th); blk /= g.th;
     b = (int)blk;
+    const int by = (ty << 3) | (int)rg_unmorton3(col >> 1), bx = (tx << 3) | (int)rg_unmorton3(col);
     z = (bz << 2) | (bit >> 4);
     y = (by << 2) | ((bit >> 2) & 3);
     x = (bx << 2) | (bit & 3);

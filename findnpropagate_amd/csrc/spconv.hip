@@ -157,10 +157,20 @@ struct MfmaCfg {
     static constexpr int KS = (CIN + 31) / 32;            // 32-wide K steps of the MFMA
     // gather prefetch distance in kernel offsets: 16 gathers in flight per wave
     static constexpr int PFK = ALLK ? (KS == 1 ? 4 : 2) : 1;
+    // feature window (WIN kernels, 32/64-channel layers): rows [tile - WH, tile + rows + WH) of the
+    // input tensor are staged in LDS once per tile; WZERO bytes of zeros follow them
+#ifndef FNP_WH32
+#define FNP_WH32 64
+#endif
+    static constexpr int WH = CH == 4 ? FNP_WH32 : 64;
+    static constexpr int WZERO = 128;
+    static constexpr int XLB = KS == 1 ? 2 : 1;           // window fragments are read XLB offsets ahead
+    static constexpr int win_rows(int mb) { return 4 * mb * 16 + 2 * WH; }
+    static constexpr int lds_bytes(int mb, bool win) { return LDS_BYTES + (win ? win_rows(mb) * CH * 16 + WZERO : 0); }
 };
 
-// Development-only ablation switch (tools/bench_conv.py with FNP_LIB_PATH): 1 = no feature gathers,
-// 2 = no weight staging, 3 = no MFMA.  The shipped library is built with FNP_ABLATE == 0.
+// Development-only ablation bit mask (tools/bench_conv.py with FNP_LIB_PATH): 1 = no feature gathers,
+// 2 = no weight staging, 4 = no MFMA.  The shipped library is built with FNP_ABLATE == 0.
 #ifndef FNP_ABLATE
 #define FNP_ABLATE 0
 #endif
@@ -170,7 +180,7 @@ struct MfmaCfg {
 // shortens the last, partly filled round of tiles), 2 elsewhere (3 costs spills there)
 template <int CIN, int COUT> struct MfmaOcc { static constexpr int WAVES = (CIN < COUT && COUT <= 64) ? 3 : 2; };
 
-template <int CIN, int COUT, int MB, int KVOL, typename TOut>
+template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut>
 __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const __bf16 *__restrict__ x, int x_bytes,
                                                              const __bf16 *__restrict__ w,
                                                              const int *__restrict__ nbr, int nbr_stride, int Krt,
@@ -181,6 +191,8 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
     constexpr int CH = Cfg::CH, SLAB = Cfg::SLAB, SW = Cfg::SW, KS = Cfg::KS, PFK = Cfg::PFK;
     constexpr bool ALLK = Cfg::ALLK;
+    constexpr int XLB = Cfg::XLB, WROWS = Cfg::win_rows(MB), WH = Cfg::WH;
+    static_assert(!WIN || ((CH == 4 || CH == 8) && XLB <= PFK && PFK % XLB == 0), "window path: 32/64 input channels");
     constexpr int NB = COUT / 16;         // 16-channel output blocks
     constexpr int NBH = NB < 4 ? NB : 4;  // A fragments held at once
     constexpr int ROWS_PER_WAVE = MB * 16;
@@ -197,6 +209,12 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
 
     extern __shared__ __attribute__((aligned(16))) unsigned char fnp_smem[];
     uint4 *wl = reinterpret_cast<uint4 *>(fnp_smem);
+    // window image: row d (relative to the window start) stores logical chunk c at physical chunk
+    // c ^ sw(d); sw is chosen so that the four 16-lane groups of a ds_read_b128 B-fragment read
+    // (16 consecutive rows x one logical chunk per quarter wave) are conflict-free
+    unsigned char *const win = fnp_smem + Cfg::LDS_BYTES;
+    constexpr unsigned WIN_ZERO = (unsigned)(Cfg::LDS_BYTES + WROWS * CH * 16);   // byte address of the zeros
+    auto win_sw = [](unsigned d) -> unsigned { return CH == 4 ? ((0u - (d >> 2)) & 3u) : ((d >> 1) & 7u); };
 
     const int K = KVOL > 0 ? KVOL : Krt;
     const int n = min(*n_out, cap);
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
     // byte offset of (row id, this lane's 16-byte chunk of MFMA step 0); absent rows get an offset
     // that stays out of range after the + ks*64 of the later steps
     auto row_off = [&](int id) -> unsigned {
-        return (FNP_ABLATE == 1 || id < 0 || !kvalid0) ? 0x80000000u
+        return ((FNP_ABLATE & 1) || id < 0 || !kvalid0) ? 0x80000000u
                                                         : (unsigned)id * (unsigned)(CIN * 2) + (unsigned)q * 16u;
     };
     auto gather = [&](unsigned roff, int ks) -> bf16x8 {
@@ -232,6 +250,21 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
         const int kc = k < K ? k : K - 1;
         return nbr[(size_t)kc * nbr_stride + rc];
     };
+
+    // window path: LDS byte address of (row id, this lane's chunk of MFMA step 0) when the row is in
+    // the window [wlo, wlo + WROWS), else the zeros; step ks reads at (address ^ ks*64).  The global
+    // gather of the same fragment is then suppressed (out-of-range offset), so every fragment is
+    // the OR of an LDS read and a buffer load of which at most one is non-zero.
+    auto win_off = [&](int id, int wlo) -> unsigned {
+        const unsigned d = (unsigned)(id - wlo);
+        return d < (unsigned)WROWS ? (unsigned)Cfg::LDS_BYTES + ((d * CH + ((unsigned)q ^ win_sw(d))) << 4) : WIN_ZERO;
+    };
+    auto row_off_w = [&](int id, int wlo) -> unsigned {
+        const unsigned d = (unsigned)(id - wlo);
+        return ((FNP_ABLATE & 1) || id < 0 || d < (unsigned)WROWS) ? 0x80000000u
+                                                                    : (unsigned)id * (unsigned)(CIN * 2) + (unsigned)q * 16u;
+    };
+    auto win_read = [&](unsigned off) -> u32x4 { return *reinterpret_cast<const u32x4 *>(fnp_smem + off); };
 
     // Work split: the n rows are cut into gridDim.x contiguous ranges of (almost) equal numbers of
     // 16-row blocks, so every workgroup finishes at about the same time whatever n is.  Range r
@@ -257,6 +290,7 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
     for (int ks = 0; ks < KS; ++ks) aoff[ks] = FNP_LDS_POS(l15, kvalid0 ? ks * 4 + q : 0);
     const int st_pos0 = FNP_LDS_POS(tid / CH, tid % CH);
     static_assert(SLAB < 256 || ((256 / CH) % (CH << SW) == 0), "staging swizzle must be periodic in 256 chunks");
+    if (WIN && tid < Cfg::WZERO / 16) reinterpret_cast<uint4 *>(fnp_smem + WIN_ZERO)[tid] = make_uint4(0u, 0u, 0u, 0u);
     if (ALLK) {
         // narrow layers: all K slabs resident in LDS for the lifetime of the workgroup
         for (int p = tid; p < K * SLAB; p += 256) {
@@ -268,6 +302,27 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
 
     for (int tile = 0; tile < tiles; ++tile) {
         const int row0 = row_begin + tile * ROWS_PER_WG + wave * ROWS_PER_WAVE;
+        // feature window of this tile: WROWS consecutive input rows around the tile's own rows.  With
+        // rows in rank-grid order ~96 % of a tile's neighbours lie in it, each fetched once instead
+        // of once per (site, offset) pair that references it.
+        const int wlo = max(0, row_begin + tile * ROWS_PER_WG - WH);
+        if constexpr (WIN) {
+            constexpr int NST = WROWS * CH / 256;
+            static_assert(WROWS * CH % 256 == 0, "window staging");
+            if (ALLK && tile > 0) __syncthreads();  // every wave is done with the previous window
+            u32x4 st[NST];
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                const unsigned p = (unsigned)tid + j * 256u;   // chunk p of the window, in memory order: coalesced
+                st[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (unsigned)wlo * (unsigned)(CIN * 2) + p * 16u, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                const unsigned p = (unsigned)tid + j * 256u, d = p / CH, c = p % CH;
+                *reinterpret_cast<u32x4 *>(win + ((d * CH + (c ^ win_sw(d))) << 4)) = st[j];
+            }
+            if (ALLK) __syncthreads();  // (double-buffered layers: the slab-0 barrier below)
+        }
         f32x4 acc[NB][MB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -278,18 +333,22 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
         bf16x8 xb[PFK][KS][MB];
         int rawq[PFK][MB];   // raw rulebook entries of the offsets PFK..2*PFK-1 ahead (gathers of this round)
         int rawr[PFK][MB];   // ... of the offsets 2*PFK..3*PFK-1 ahead (gathers of the next round)
+        unsigned loff[WIN ? PFK : 1][WIN ? MB : 1];          // window addresses of the fragments in xb
+        u32x4 xl[WIN ? XLB : 1][WIN ? KS : 1][WIN ? MB : 1];  // window reads, XLB offsets ahead
 #pragma unroll
         for (int u = 0; u < PFK; ++u)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                const unsigned ro = row_off(nbr_at(u, row0 + mb * 16 + l15, row_end));
+                const int id0 = nbr_at(u, row0 + mb * 16 + l15, row_end);
+                const unsigned ro = WIN ? row_off_w(id0, wlo) : row_off(id0);
+                if (WIN) loff[u][mb] = win_off(id0, wlo);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) xb[u][ks][mb] = gather(ro, ks);
                 rawq[u][mb] = nbr_raw(PFK + u, row0 + mb * 16 + l15, row_end);
                 rawr[u][mb] = nbr_raw(2 * PFK + u, row0 + mb * 16 + l15, row_end);
             }
         if (!ALLK) {
-            if (FNP_ABLATE != 2) {
+            if (!(FNP_ABLATE & 2)) {
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
                     const int p = tid + j * 256;
@@ -298,9 +357,17 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
             }
             __syncthreads();
         }
+        if constexpr (WIN) {
+#pragma unroll
+            for (int j = 0; j < XLB; ++j)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) xl[j][ks][mb] = win_read(loff[j][mb] ^ (unsigned)(ks << 6));
+        }
         // (named scalars, not an array: a conditionally written array lands in scratch memory)
         uint4 wcur0 = make_uint4(0u, 0u, 0u, 0u), wcur1 = make_uint4(0u, 0u, 0u, 0u);
-        if (WDEEP && FNP_ABLATE != 2) {
+        if (WDEEP && !(FNP_ABLATE & 2)) {
             const uint4 *w1 = reinterpret_cast<const uint4 *>(w + (size_t)(K > 1 ? 1 : 0) * COUT * CIN);
             wcur0 = w1[tid < SLAB ? tid : 0];
             if (NCH > 1) wcur1 = w1[tid + 256];
@@ -311,6 +378,7 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
             for (int u = 0; u < PFK; ++u) {
                 const int k = k0 + u;
                 if (k >= K) break;  // wave-uniform
+                u32x4 xl_nx[WIN ? KS : 1][WIN ? MB : 1];
                 const uint4 *wk = wl + (ALLK ? k : (k & 1)) * SLAB;
                 const uint4 *wsrc = reinterpret_cast<const uint4 *>(w + (size_t)(k + 1 < K ? k + 1 : k) * COUT * CIN);
                 // rulebook entries for offset k + 3*PFK: requested FIRST in the round, so that they are
@@ -319,9 +387,17 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                 int rawn[MB];
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) rawn[mb] = nbr_raw(k + 3 * PFK, row0 + mb * 16 + l15, row_end);
+                unsigned lnew[WIN ? MB : 1];  // window addresses of offset k + PFK
+                if constexpr (WIN) {
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const bool ok = (k + PFK < K) && (row0 + mb * 16 + l15 < row_end);
+                        lnew[mb] = win_off(ok ? rawq[u][mb] : -1, wlo);
+                    }
+                }
                 uint4 wreg[WST];
                 uint4 wnext0 = make_uint4(0u, 0u, 0u, 0u), wnext1 = make_uint4(0u, 0u, 0u, 0u);
-                if (WDEEP && FNP_ABLATE != 2) {
+                if (WDEEP && !(FNP_ABLATE & 2)) {
                     const uint4 *w2 = reinterpret_cast<const uint4 *>(w + (size_t)(k + 2 < K ? k + 2 : k) * COUT * CIN);
                     wnext0 = w2[tid < SLAB ? tid : 0];
                     if (NCH > 1) wnext1 = w2[tid + 256];
@@ -329,7 +405,7 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     // (1) previous step's weight chunks -> other LDS buffer; (2) request this step's
-                    if (!ALLK && !WDEEP && FNP_ABLATE != 2) {
+                    if (!ALLK && !WDEEP && !(FNP_ABLATE & 2)) {
                         if (ks > 0) {
 #pragma unroll
                             for (int j = 0; j < WST; ++j) {
@@ -344,7 +420,7 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                             if (c < NCH && (SLAB % 256 == 0 || p < SLAB)) wreg[j] = wsrc[p];
                         }
                     }
-                    // (3) matrix block of this step on the fragments requested PFK offsets ago
+                    // (3) matrix blocks of this step on the fragments requested PFK offsets ago
 #pragma unroll
                     for (int h = 0; h < NB; h += NBH) {
                         bf16x8 wa[NBH];
@@ -354,24 +430,43 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                             const uint4 t = wk[aoff[ks] + (h + j) * 16 * CH];
                             wa[j] = *reinterpret_cast<const bf16x8 *>(&t);
                         }
+                        // (3b) window fragments of offset k + XLB into the registers this step frees
+                        if constexpr (WIN) {
+                            if (h + NBH >= NB) {
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                            for (int j = 0; j < NBH; ++j) {
-                                if (FNP_ABLATE == 3) {
-                                    asm volatile("" ::"v"(wa[j]), "v"(xb[u][ks][mb]));
-                                } else {
-                                    acc[h + j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xb[u][ks][mb],
-                                                                                              acc[h + j][mb], 0, 0, 0);
+                                for (int mb = 0; mb < MB; ++mb) {
+                                    const unsigned lo = XLB == PFK ? lnew[mb] : loff[(u + XLB) % PFK][mb];
+                                    xl_nx[ks][mb] = win_read(lo ^ (unsigned)(ks << 6));
                                 }
                             }
+                        }
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) {
+                            bf16x8 xv = xb[u][ks][mb];
+                            if constexpr (WIN) {
+                                const u32x4 t = *reinterpret_cast<const u32x4 *>(&xv) | xl[u % XLB][ks][mb];
+                                xv = *reinterpret_cast<const bf16x8 *>(&t);
+                            }
+#pragma unroll
+                            for (int j = 0; j < NBH; ++j) {
+                                if ((FNP_ABLATE & 4)) {
+                                    asm volatile("" ::"v"(wa[j]), "v"(xv));
+                                } else {
+                                    acc[h + j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xv, acc[h + j][mb], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                    if constexpr (WIN) {
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) xl[u % XLB][ks][mb] = xl_nx[ks][mb];
                     }
                     // (4) the registers are free again: request the fragments of offset k + PFK (the
                     //     rulebook entry was loaded two rounds ago; validity is decided here)
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) {
                         const bool ok = (k + PFK < K) && (row0 + mb * 16 + l15 < row_end);
-                        xb[u][ks][mb] = gather(row_off(ok ? rawq[u][mb] : -1), ks);
+                        xb[u][ks][mb] = gather(WIN ? row_off_w(ok ? rawq[u][mb] : -1, wlo) : row_off(ok ? rawq[u][mb] : -1), ks);
                     }
                     __builtin_amdgcn_sched_barrier(0);  // keep the steps in program order
                 }
@@ -380,14 +475,15 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                 for (int mb = 0; mb < MB; ++mb) {
                     rawq[u][mb] = rawr[u][mb];
                     rawr[u][mb] = rawn[mb];
+                    if (WIN) loff[u][mb] = lnew[mb];
                 }
                 if (!ALLK) {
-                    if (WDEEP && FNP_ABLATE != 2) {
+                    if (WDEEP && !(FNP_ABLATE & 2)) {
                         if (SLAB >= 256 || tid < SLAB) wl[((k + 1) & 1) * SLAB + st_pos0] = wcur0;
                         if (NCH > 1) wl[((k + 1) & 1) * SLAB + st_pos0 + 256] = wcur1;
                         wcur0 = wnext0;
                         wcur1 = wnext1;
-                    } else if (FNP_ABLATE != 2) {
+                    } else if (!(FNP_ABLATE & 2)) {
 #pragma unroll
                         for (int j = 0; j < WST; ++j) {
                             const int c = (KS - 1) * WST + j, p = tid + c * 256;
@@ -440,34 +536,58 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
     }
 }
 
-template <int CIN, int COUT, int KVOL, typename TOut>
+template <int CIN, int COUT, int KVOL, bool WIN, typename TOut>
 int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
                   void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s) {
     // 16-site blocks per wave: 4 (64 sites) unless the accumulators (COUT/16 * MB * 4 registers)
     // would push the kernel into spills (128 output channels); measured per layer class on MI355X
     constexpr int MB = (COUT >= 128 || (CIN == 16 && COUT == 16)) ? 2 : 4;
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
-    auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, TOut>;
+    auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut>;
+    constexpr int lds = Cfg::lds_bytes(MB, WIN);
+    static_assert(lds * MfmaOcc<CIN, COUT>::WAVES <= 160 * 1024, "LDS budget of the resident workgroups");
+    if (lds > 64 * 1024) {
+        static bool raised = false;  // (idempotent; a race only repeats the call)
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                return FNP_ERR_HIP;
+            raised = true;
+        }
+    }
     const int tiles = fnp_divup(cap, 4 * MB * 16);
     // persistent grid: two workgroups per CU are resident (register / LDS budget of the wide
     // layers); the narrow ALLK layers stage all weights once per workgroup, so keep them few too.
     // The kernel splits the rows evenly over whatever grid it gets.
     const int resident = 256 * MfmaOcc<CIN, COUT>::WAVES;
     const int grid = tiles < resident ? tiles : resident;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), Cfg::LDS_BYTES, s, (const __bf16 *)x, x_bytes, (const __bf16 *)w,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const __bf16 *)x, x_bytes, (const __bf16 *)w,
                        nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
 
+// The window variant is used when the caller states that neighbour row ids lie close to the output
+// row ids (FNP_HINT_ROWS_RANKED: both tensors in rank-grid order).  Measured on MI355X (B = 16):
+// 64 -> 64 channels 132 -> 120 us; 32 -> 32 channels 78 -> 115 us (the per-fragment address
+// arithmetic and OR of the dual-source operand outweigh the saved gathers at 8 MFMAs per offset),
+// so only the 64-channel layers take it.
+template <int CIN, int COUT> struct HasWindow { static constexpr bool value = CIN == 64 && COUT == 64; };
+
 template <int CIN, int COUT, typename TOut>
 int launch_mfma(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out,
-                int cap, void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s) {
-    if (K == 27)
-        return launch_mfma_k<CIN, COUT, 27, TOut>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift,
-                                                  residual, relu, s);
-    return launch_mfma_k<CIN, COUT, 0, TOut>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual,
-                                             relu, s);
+                int cap, void *y, const float *scale, const float *shift, const void *residual, int relu, int hints,
+                hipStream_t s) {
+    if (K == 27) {
+        if constexpr (HasWindow<CIN, COUT>::value) {
+            if (hints & FNP_HINT_ROWS_RANKED)
+                return launch_mfma_k<CIN, COUT, 27, true, TOut>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale,
+                                                                shift, residual, relu, s);
+        }
+        return launch_mfma_k<CIN, COUT, 27, false, TOut>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift,
+                                                         residual, relu, s);
+    }
+    return launch_mfma_k<CIN, COUT, 0, false, TOut>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual,
+                                                    relu, s);
 }
 
 template <typename TIn, typename TOut>
@@ -484,14 +604,14 @@ int launch_valu(const void *x, const void *w, const int *nbr, int nbr_stride, in
 
 template <typename TOut>
 int dispatch_bf16(const void *x, long long n_in, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
-                  void *y, const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
-                  hipStream_t s) {
+                  void *y, const float *scale, const float *shift, const void *residual, int relu, int hints, int Cin,
+                  int Cout, hipStream_t s) {
     const long long xb = n_in * Cin * 2;
     const bool fits = xb > 0 && xb < 0x7fffffffll;   // 32-bit buffer offsets of the MFMA path
 #define FNP_CASE(CI, CO)                                                                                       \
     if (fits && Cin == CI && Cout == CO)                                                                       \
         return launch_mfma<CI, CO, TOut>(x, (int)xb, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual,\
-                                         relu, s);
+                                         relu, hints, s);
     FNP_CASE(16, 16)
     FNP_CASE(16, 32)
     FNP_CASE(32, 32)
@@ -523,8 +643,8 @@ __global__ __launch_bounds__(256) void dense_kernel(const T *__restrict__ feats,
 
 extern "C" int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const void *weight, const int *nbr,
                                   int nbr_stride, int K, const int *n_out, int cap_out, void *feat_out, int out_dtype,
-                                  const float *scale, const float *shift, const void *residual, int relu, int Cin,
-                                  int Cout, fnp_stream_t stream) {
+                                  const float *scale, const float *shift, const void *residual, int relu, int hints,
+                                  int Cin, int Cout, fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!feat_in || !weight || !nbr || !n_out || !feat_out || K <= 0 || Cin <= 0 || Cout <= 0 || cap_out <= 0 ||
         nbr_stride < cap_out || n_in_rows <= 0)
@@ -551,10 +671,10 @@ extern "C" int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_ro
     if (in_dtype == FNP_BF16) {
         if (out_dtype == FNP_BF16)
             return dispatch_bf16<__bf16>(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
-                                         residual, relu, Cin, Cout, s);
+                                         residual, relu, hints, Cin, Cout, s);
         if (out_dtype == FNP_F32)
             return dispatch_bf16<float>(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
-                                        residual, relu, Cin, Cout, s);
+                                        residual, relu, hints, Cin, Cout, s);
         return FNP_ERR_ARG;
     }
     return FNP_ERR_ARG;

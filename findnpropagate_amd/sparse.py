@@ -218,9 +218,13 @@ def pack_weight(weight, dtype):
     return weight.detach().reshape(Cout, K, Cin).permute(1, 0, 2).contiguous().to(dtype)
 
 
+HINT_ROWS_RANKED = 1   # fnp.h FNP_HINT_ROWS_RANKED
+
+
 def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, shift=None, residual=None, relu=False,
-                 out=None):
-    """feat_out (cap_out, Cout) = act(conv * scale + shift + residual).  No host sync."""
+                 out=None, ranked=False):
+    """feat_out (cap_out, Cout) = act(conv * scale + shift + residual).  No host sync.
+    ranked: input and output rows are both in rank-grid order (performance hint only)."""
     L = _l.load()
     _l.require_device(feat_in, w_packed, rb.nbr, n_out_dev)
     K, Cout, Cin = w_packed.shape
@@ -237,7 +241,7 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
     rc = L.fnp_spconv_forward(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
                               _l.ptr(rb.nbr), rb.nbr.shape[1], K, _l.ptr(n_out_dev), cap_out,
                               _l.ptr(out), _l.dtype_code(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual),
-                              int(bool(relu)), Cin, Cout, _l.stream())
+                              int(bool(relu)), HINT_ROWS_RANKED if ranked else 0, Cin, Cout, _l.stream())
     _l.check(rc, "fnp_spconv_forward")
     return out
 

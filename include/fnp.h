@@ -191,13 +191,18 @@ int fnp_rulebook_strided(const int *in_coords, const int *n_in, int cap_in, cons
  *   scale/shift (Cout,) f32 or NULL (identity).  out = act(acc*scale + shift + residual)
  * bf16 x bf16 -> fp32 accumulate runs on MFMA (v_mfma_f32_16x16x32_bf16); f32 runs on VALU
  * fma chains (validation mode).
+ * hints: performance only, never changes results.  FNP_HINT_ROWS_RANKED states that neighbour row
+ * ids lie close to the output row ids (input and output rows both in rank-grid order, i.e. a
+ * SubM convolution on the output of fnp_rulebook_strided): the kernel then keeps a window of
+ * input rows in LDS instead of gathering every (site, offset) pair from L2.
  * ------------------------------------------------------------------------------------------ */
+#define FNP_HINT_ROWS_RANKED 1
 int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const void *weight,
                        const int *nbr, int nbr_stride, int K,
                        const int *n_out, int cap_out,
                        void *feat_out, int out_dtype,
                        const float *scale, const float *shift, const void *residual, int relu,
-                       int Cin, int Cout, fnp_stream_t stream);
+                       int hints, int Cin, int Cout, fnp_stream_t stream);
 
 /* SparseConvTensor.dense() as used by HeightCompression (height_compression.py:20-24):
  * feats (n,C) -> out (B,C,D,H,W) of out_dtype, which must be zero on entry. */

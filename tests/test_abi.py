@@ -19,7 +19,7 @@ def test_header_table_and_exports_agree():
 
 def test_library_loads_and_reports_version():
     L = lib.load()
-    assert L.fnp_abi_version() == 1
+    assert L.fnp_abi_version() == 2
     assert b"gfx950" in L.fnp_version()
 
 
@@ -27,7 +27,8 @@ def test_host_only_queries():
     L = lib.load()
     # 41 x 1440 x 1440 cells -> 11 x 360 x 360 blocks of 4x4x4
     assert L.fnp_rankgrid_num_blocks(1, 41, 1440, 1440) == 11 * 360 * 360
-    assert L.fnp_rankgrid_num_blocks(2, 5, 180, 180) == 2 * 2 * 45 * 45
+    # (H, W) blocks are numbered in 8x8-block patches: 45 -> 6 patches of 8 per axis
+    assert L.fnp_rankgrid_num_blocks(2, 5, 180, 180) == 2 * 2 * 48 * 48
     assert L.fnp_nms_workspace_bytes(100) == 100 * 2 * 8
     assert L.fnp_rankgrid_num_summary(1, 41, 1440, 1440) == (11 * 360 * 360 + 63) // 64
     assert L.fnp_rankgrid_workspace_bytes(1, 41, 1440, 1440) > 4 * ((11 * 360 * 360 + 63) // 64)

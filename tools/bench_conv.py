@@ -8,7 +8,7 @@ import numpy as np, torch
 from findnpropagate_amd import sparse as S, synthetic as syn
 from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
 
-ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--reps", type=int, default=20)
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--reps", type=int, default=20); ap.add_argument("--fracs", type=str, default="1.0", help="comma list: time each layer on the first frac*n output rows too (tile staircase)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 B = args.batch
@@ -26,7 +26,7 @@ log, eng.rulebook_log = eng.rulebook_log, None
 P = eng.prepare()
 seen = {}
 for tag, rb, n_dev in log:
-    cin, cout, K, has_res = tag
+    cin, cout, K, has_res, ranked = tag
     if cin == 5 or (cin, cout, K) in seen: continue
     seen[(cin, cout, K)] = 1
     n = int(n_dev.item()); pairs = int((rb.nbr[:, :n] >= 0).sum().item())
@@ -35,13 +35,17 @@ for tag, rb, n_dev in log:
     w = (torch.randn((K, cout, cin), device=dev) * 0.05).to(torch.bfloat16)
     sc = torch.ones(cout, device=dev); sh = torch.zeros(cout, device=dev)
     resid = torch.randn((rb.cap_out, cout), device=dev).to(torch.bfloat16)
-    for _ in range(3): S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); e0.record()
-    for _ in range(args.reps): S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / args.reps
-    dense_flop = 2.0 * n * K * cin * cout; alg_flop = 2.0 * pairs * cin * cout
-    byts = pairs * (cin * 2 + 8) + 2 * n * cout * 2 + K * cin * cout * 2
-    print(json.dumps({"layer": f"{cin}x{cout}k{K}", "n_out": n, "pairs": pairs, "density": round(pairs / (n * K), 3), "ms": round(ms, 4),
-                      "dense_TF": round(dense_flop / ms / 1e9, 1), "alg_TF": round(alg_flop / ms / 1e9, 1), "alg_GBs": round(byts / ms / 1e6, 1)}))
+    n_full = n
+    for frac in [float(f) for f in args.fracs.split(",")]:
+        n = int(n_full * frac); n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+        pairs = int((rb.nbr[:, :n] >= 0).sum().item())
+        for _ in range(3): S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True, ranked=ranked)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(args.reps): S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True, ranked=ranked)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.reps
+        dense_flop = 2.0 * n * K * cin * cout; alg_flop = 2.0 * pairs * cin * cout
+        byts = pairs * (cin * 2 + 8) + 2 * n * cout * 2 + K * cin * cout * 2
+        print(json.dumps({"layer": f"{cin}x{cout}k{K}", "n_out": n, "pairs": pairs, "density": round(pairs / (n * K), 3), "ms": round(ms, 4),
+                          "dense_TF": round(dense_flop / ms / 1e9, 1), "alg_TF": round(alg_flop / ms / 1e9, 1), "alg_GBs": round(byts / ms / 1e6, 1)}))

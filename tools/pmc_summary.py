@@ -8,5 +8,5 @@ for d in sys.argv[1:]:
         acc[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, cs in acc.items():
         if 'spconv_mfma' not in k: continue
-        name = re.sub(r'.*spconv_mfma_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+).*', r'mfma<\1,\2,\3,\4>', k)
+        name = re.sub(r'.*spconv_mfma_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d).*', r'mfma<\1,\2,\3,\4,w\5>', k)
         print(name, {c: round(sum(v) / len(v)) for c, v in cs.items()})
