@@ -159,7 +159,7 @@ def main():
         cin, cout, K = cls
         flops = 2.0 * float(np.mean([stats[("tags", tag)][0][0] for _, tag in per[cls]])) * cin * cout
         win = "true" if (per[cls][0][1][4] and K == 27 and (cin, cout) == (64, 64)) else "false"
-        kname = (f"spconv_mfma_kernel<{cin},{cout},{2 if (cout >= 128 or (cin, cout) == (16, 16)) else 4},{K if K == 27 else 0},{win},bf16>"
+        kname = (f"spconv_mfma_kernel<{cin},{cout},{3 if cout >= 128 else 2 if (cin, cout) == (16, 16) else 4},{K if K == 27 else 0},{win},bf16>"
                  if args.dtype == "bf16" else "spconv_valu_kernel")
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
         # WRITE_SIZE in separate runs of this same command, gfx950 FETCH_SIZE x2 correction applied:

@@ -19,6 +19,7 @@
 //     element, the same chain the CPU oracle evaluates, so it is bit-comparable.
 // No atomics anywhere: every output row is written once, results are run-to-run identical.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -278,7 +279,6 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
     const int row_begin = (int)((nblk16 * range) / G) << 4;
     const int row_end = min(n, (int)((nblk16 * (range + 1)) / G) << 4);
     if (row_begin >= row_end) return;  // before any barrier: safe early exit
-    const int tiles = (row_end - row_begin + ROWS_PER_WG - 1) / ROWS_PER_WG;
 
 #define FNP_LDS_POS(row, chunk) ((row) * CH + ((chunk) ^ (((row) >> SW) & (CH - 1))))
     // LDS addressing with compile-time immediates: the swizzle term of row nb*16 + l15 depends on
@@ -300,16 +300,23 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
         __syncthreads();
     }
 
-    for (int tile = 0; tile < tiles; ++tile) {
-        const int row0 = row_begin + tile * ROWS_PER_WG + wave * ROWS_PER_WAVE;
+    // One tile = MBT 16-site blocks per wave (4 * MBT per workgroup), accumulators in registers for the
+    // sweep over the K offsets.  The body is instantiated for MBT = MBT (full tiles) and for the smaller
+    // block counts of a range's last, partial tile: a workgroup whose range ends with t blocks runs
+    // that tile with ceil(t / 4) blocks per wave instead of MBT, so the matrix work of the tail is
+    // proportional to its rows (every wave of the workgroup still passes the same barriers).
+    bool first_tile = true;
+    auto run_tile = [&](auto mbt_tag, const int tile_base) __attribute__((always_inline)) {
+        constexpr int MBT = decltype(mbt_tag)::value;
+        const int row0 = tile_base + wave * (MBT * 16);
         // feature window of this tile: WROWS consecutive input rows around the tile's own rows.  With
         // rows in rank-grid order ~96 % of a tile's neighbours lie in it, each fetched once instead
         // of once per (site, offset) pair that references it.
-        const int wlo = max(0, row_begin + tile * ROWS_PER_WG - WH);
+        const int wlo = max(0, tile_base - WH);
         if constexpr (WIN) {
             constexpr int NST = WROWS * CH / 256;
             static_assert(WROWS * CH % 256 == 0, "window staging");
-            if (ALLK && tile > 0) __syncthreads();  // every wave is done with the previous window
+            if (ALLK && !first_tile) __syncthreads();  // every wave is done with the previous window
             u32x4 st[NST];
 #pragma unroll
             for (int j = 0; j < NST; ++j) {
@@ -323,22 +330,22 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
             }
             if (ALLK) __syncthreads();  // (double-buffered layers: the slab-0 barrier below)
         }
-        f32x4 acc[NB][MB];
+        f32x4 acc[NB][MBT];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int mb = 0; mb < MBT; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         // prologue: fragments of offsets 0..PFK-1, rulebook indices of offsets PFK..2*PFK-1
-        bf16x8 xb[PFK][KS][MB];
-        int rawq[PFK][MB];   // raw rulebook entries of the offsets PFK..2*PFK-1 ahead (gathers of this round)
-        int rawr[PFK][MB];   // ... of the offsets 2*PFK..3*PFK-1 ahead (gathers of the next round)
-        unsigned loff[WIN ? PFK : 1][WIN ? MB : 1];          // window addresses of the fragments in xb
-        u32x4 xl[WIN ? XLB : 1][WIN ? KS : 1][WIN ? MB : 1];  // window reads, XLB offsets ahead
+        bf16x8 xb[PFK][KS][MBT];
+        int rawq[PFK][MBT];   // raw rulebook entries of the offsets PFK..2*PFK-1 ahead (gathers of this round)
+        int rawr[PFK][MBT];   // ... of the offsets 2*PFK..3*PFK-1 ahead (gathers of the next round)
+        unsigned loff[WIN ? PFK : 1][WIN ? MBT : 1];          // window addresses of the fragments in xb
+        u32x4 xl[WIN ? XLB : 1][WIN ? KS : 1][WIN ? MBT : 1];  // window reads, XLB offsets ahead
 #pragma unroll
         for (int u = 0; u < PFK; ++u)
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
+            for (int mb = 0; mb < MBT; ++mb) {
                 const int id0 = nbr_at(u, row0 + mb * 16 + l15, row_end);
                 const unsigned ro = WIN ? row_off_w(id0, wlo) : row_off(id0);
                 if (WIN) loff[u][mb] = win_off(id0, wlo);
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) xl[j][ks][mb] = win_read(loff[j][mb] ^ (unsigned)(ks << 6));
+                    for (int mb = 0; mb < MBT; ++mb) xl[j][ks][mb] = win_read(loff[j][mb] ^ (unsigned)(ks << 6));
         }
         // (named scalars, not an array: a conditionally written array lands in scratch memory)
         uint4 wcur0 = make_uint4(0u, 0u, 0u, 0u), wcur1 = make_uint4(0u, 0u, 0u, 0u);
@@ -378,24 +385,25 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
             for (int u = 0; u < PFK; ++u) {
                 const int k = k0 + u;
                 if (k >= K) break;  // wave-uniform
-                u32x4 xl_nx[WIN ? KS : 1][WIN ? MB : 1];
+                u32x4 xl_nx[WIN ? KS : 1][WIN ? MBT : 1];
                 const uint4 *wk = wl + (ALLK ? k : (k & 1)) * SLAB;
                 const uint4 *wsrc = reinterpret_cast<const uint4 *>(w + (size_t)(k + 1 < K ? k + 1 : k) * COUT * CIN);
                 // rulebook entries for offset k + 3*PFK: requested FIRST in the round, so that they are
                 // older than this round's gathers (VMEM returns in order: a young index load in
                 // front of the next round's first MFMA would stall it)
-                int rawn[MB];
+                int rawn[MBT];
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) rawn[mb] = nbr_raw(k + 3 * PFK, row0 + mb * 16 + l15, row_end);
-                unsigned lnew[WIN ? MB : 1];  // window addresses of offset k + PFK
+                for (int mb = 0; mb < MBT; ++mb) rawn[mb] = nbr_raw(k + 3 * PFK, row0 + mb * 16 + l15, row_end);
+                unsigned lnew[WIN ? MBT : 1];  // window addresses of offset k + PFK
                 if constexpr (WIN) {
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
+                    for (int mb = 0; mb < MBT; ++mb) {
                         const bool ok = (k + PFK < K) && (row0 + mb * 16 + l15 < row_end);
                         lnew[mb] = win_off(ok ? rawq[u][mb] : -1, wlo);
                     }
                 }
-                uint4 wreg[WST];
+                static_assert(WST <= 2, "weight staging registers");
+                uint4 wreg0 = make_uint4(0u, 0u, 0u, 0u), wreg1 = make_uint4(0u, 0u, 0u, 0u);  // (named: see wcur0)
                 uint4 wnext0 = make_uint4(0u, 0u, 0u, 0u), wnext1 = make_uint4(0u, 0u, 0u, 0u);
                 if (WDEEP && !(FNP_ABLATE & 2)) {
                     const uint4 *w2 = reinterpret_cast<const uint4 *>(w + (size_t)(k + 2 < K ? k + 2 : k) * COUT * CIN);
@@ -411,13 +419,13 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                             for (int j = 0; j < WST; ++j) {
                                 const int c = (ks - 1) * WST + j, p = tid + c * 256;
                                 if (c < NCH && (SLAB % 256 == 0 || p < SLAB))
-                                    wl[((k + 1) & 1) * SLAB + st_pos0 + c * 256] = wreg[j];
+                                    wl[((k + 1) & 1) * SLAB + st_pos0 + c * 256] = (j == 0 ? wreg0 : wreg1);
                             }
                         }
 #pragma unroll
                         for (int j = 0; j < WST; ++j) {
                             const int c = ks * WST + j, p = tid + c * 256;
-                            if (c < NCH && (SLAB % 256 == 0 || p < SLAB)) wreg[j] = wsrc[p];
+                            if (c < NCH && (SLAB % 256 == 0 || p < SLAB)) (j == 0 ? wreg0 : wreg1) = wsrc[p];
                         }
                     }
                     // (3) matrix blocks of this step on the fragments requested PFK offsets ago
@@ -434,14 +442,14 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                         if constexpr (WIN) {
                             if (h + NBH >= NB) {
 #pragma unroll
-                                for (int mb = 0; mb < MB; ++mb) {
+                                for (int mb = 0; mb < MBT; ++mb) {
                                     const unsigned lo = XLB == PFK ? lnew[mb] : loff[(u + XLB) % PFK][mb];
                                     xl_nx[ks][mb] = win_read(lo ^ (unsigned)(ks << 6));
                                 }
                             }
                         }
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) {
+                        for (int mb = 0; mb < MBT; ++mb) {
                             bf16x8 xv = xb[u][ks][mb];
                             if constexpr (WIN) {
                                 const u32x4 t = *reinterpret_cast<const u32x4 *>(&xv) | xl[u % XLB][ks][mb];
@@ -459,12 +467,12 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                     }
                     if constexpr (WIN) {
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) xl[u % XLB][ks][mb] = xl_nx[ks][mb];
+                        for (int mb = 0; mb < MBT; ++mb) xl[u % XLB][ks][mb] = xl_nx[ks][mb];
                     }
                     // (4) the registers are free again: request the fragments of offset k + PFK (the
                     //     rulebook entry was loaded two rounds ago; validity is decided here)
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
+                    for (int mb = 0; mb < MBT; ++mb) {
                         const bool ok = (k + PFK < K) && (row0 + mb * 16 + l15 < row_end);
                         xb[u][ks][mb] = gather(WIN ? row_off_w(ok ? rawq[u][mb] : -1, wlo) : row_off(ok ? rawq[u][mb] : -1), ks);
                     }
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                 }
                 // rulebook entries run two rounds ahead of their gathers: rotate
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
+                for (int mb = 0; mb < MBT; ++mb) {
                     rawq[u][mb] = rawr[u][mb];
                     rawr[u][mb] = rawn[mb];
                     if (WIN) loff[u][mb] = lnew[mb];
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                         for (int j = 0; j < WST; ++j) {
                             const int c = (KS - 1) * WST + j, p = tid + c * 256;
                             if (c < NCH && (SLAB % 256 == 0 || p < SLAB))
-                                wl[((k + 1) & 1) * SLAB + st_pos0 + c * 256] = wreg[j];
+                                wl[((k + 1) & 1) * SLAB + st_pos0 + c * 256] = (j == 0 ? wreg0 : wreg1);
                         }
                     }
                     __syncthreads();  // plain loads stay in flight across it; only the LDS writes are waited for
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                 sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
             }
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
+            for (int mb = 0; mb < MBT; ++mb) {
                 const int r = row0 + mb * 16 + l15;
                 if (r >= row_end) continue;
                 float v[4];
@@ -533,15 +541,29 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                 }
             }
         }
-    }
+        first_tile = false;
+    };
+    const int nblk_wg = (row_end - row_begin + 15) >> 4;
+    const int full = nblk_wg / (4 * MB);
+    for (int t = 0; t < full; ++t) run_tile(std::integral_constant<int, MB>{}, row_begin + t * ROWS_PER_WG);
+    const int tper = (nblk_wg - full * 4 * MB + 3) >> 2;  // blocks per wave in the partial tile (0 = none)
+    const int tail_base = row_begin + full * ROWS_PER_WG;
+    if (tper == MB) run_tile(std::integral_constant<int, MB>{}, tail_base);
+    if constexpr (MB > 1) { if (tper == 1) run_tile(std::integral_constant<int, 1>{}, tail_base); }
+    if constexpr (MB > 2) { if (tper == 2) run_tile(std::integral_constant<int, 2>{}, tail_base); }
+    if constexpr (MB > 3) { if (tper == 3) run_tile(std::integral_constant<int, 3>{}, tail_base); }
 }
 
 template <int CIN, int COUT, int KVOL, bool WIN, typename TOut>
 int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
                   void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s) {
-    // 16-site blocks per wave: 4 (64 sites) unless the accumulators (COUT/16 * MB * 4 registers)
-    // would push the kernel into spills (128 output channels); measured per layer class on MI355X
-    constexpr int MB = (COUT >= 128 || (CIN == 16 && COUT == 16)) ? 2 : 4;
+    // 16-site blocks per wave: 4 (64 sites); 3 for 128 output channels (accumulators = COUT/16 * MB * 4
+    // registers; 4 spills heavily, 3 spills ~16 registers outside the offset loop and measured 13 %
+    // faster than 2 on MI355X: fewer weight-slab sweeps per site); 2 for the 16 -> 16 layers
+#ifndef FNP_MB128
+#define FNP_MB128 3
+#endif
+    constexpr int MB = COUT >= 128 ? FNP_MB128 : (CIN == 16 && COUT == 16) ? 2 : 4;
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
     auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut>;
     constexpr int lds = Cfg::lds_bytes(MB, WIN);
