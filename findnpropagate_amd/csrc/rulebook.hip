@@ -75,6 +75,73 @@ __global__ __launch_bounds__(kThreads) void strided_mark_kernel(const int *__res
     }
 }
 
+// Fast path of the marking step for ceil(k/s) <= 2 on every axis (all convolutions of the backbone):
+// the <= 8 output cells of an input cell are found in closed form (no loop over the kernel volume),
+// and their bits are merged per output block first, so an input costs one atomic per touched block
+// (1.3 on average, and none once the bits are there) instead of one per output cell.
+struct AxisOut {
+    int b0;          // block of the first output
+    unsigned s0, s1; // 4-bit sets of the outputs inside block b0 / block b0 + 1
+    bool any;
+};
+template <int S>
+__device__ __forceinline__ AxisOut axis_outputs(int i, int k, int s_rt, int p, int dout) {
+    const int s = S > 0 ? S : s_rt;
+    const int num = i + p - (k - 1);
+    const int lo = num <= 0 ? 0 : (num + s - 1) / s;
+    const int hi = min((i + p) / s, dout - 1);
+    AxisOut a;
+    a.any = lo <= hi;
+    a.b0 = lo >> 2;
+    a.s0 = 1u << (lo & 3);
+    a.s1 = 0u;
+    if (hi > lo) {   // (hi == lo + 1)
+        if ((hi >> 2) == a.b0) a.s0 |= 1u << (hi & 3);
+        else a.s1 = 1u << (hi & 3);
+    }
+    return a;
+}
+__device__ __forceinline__ unsigned spread4(unsigned s) { return (s & 1u) | ((s & 2u) << 3) | ((s & 4u) << 6) | ((s & 8u) << 9); }
+__device__ __forceinline__ unsigned long long spread16(unsigned s) {
+    return (unsigned long long)(s & 1u) | ((unsigned long long)(s & 2u) << 15) | ((unsigned long long)(s & 4u) << 30) |
+           ((unsigned long long)(s & 8u) << 45);
+}
+__device__ __forceinline__ void rg_mark_mask(const RG &g, long long blk, unsigned long long m) {
+    if ((g.bits[blk] & m) == m) return;
+    const unsigned long long old = atomicOr(&g.bits[blk], m);
+    if (old == 0ull) atomicOr(&g.summ[blk >> 6], 1ull << (blk & 63));
+}
+
+template <int SZ, int SY, int SX>
+__global__ __launch_bounds__(kThreads) void strided_mark2_kernel(const int *__restrict__ in_coords,
+                                                                 const int *__restrict__ n_in, int cap_in, RG go, Geom ge) {
+    const int n = min(*n_in, cap_in);
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const int4 c = reinterpret_cast<const int4 *>(in_coords)[i];
+        const AxisOut az = axis_outputs<SZ>(c.y, ge.k[0], ge.s[0], ge.p[0], go.d.D);
+        const AxisOut ay = axis_outputs<SY>(c.z, ge.k[1], ge.s[1], ge.p[1], go.d.H);
+        const AxisOut ax = axis_outputs<SX>(c.w, ge.k[2], ge.s[2], ge.p[2], go.d.W);
+        if (!(az.any && ay.any && ax.any)) continue;
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz) {
+            const unsigned sz = cz ? az.s1 : az.s0;
+            if (!sz) continue;
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy) {
+                const unsigned sy = cy ? ay.s1 : ay.s0;
+                if (!sy) continue;
+#pragma unroll
+                for (int cx = 0; cx < 2; ++cx) {
+                    const unsigned sx = cx ? ax.s1 : ax.s0;
+                    if (!sx) continue;
+                    const unsigned long long m = (unsigned long long)(sx * spread4(sy)) * spread16(sz);
+                    rg_mark_mask(go, rg_block_of(go.d, c.x, (az.b0 + cz) << 2, (ay.b0 + cy) << 2, (ax.b0 + cx) << 2), m);
+                }
+            }
+        }
+    }
+}
+
 // emit output coordinates in rank order: one wave per summary word (a zero word retires after one
 // load); lane j owns block 64*S + j, decodes the block origin once and writes its cells at
 // base[block], base[block] + 1, ...
@@ -115,6 +182,98 @@ __global__ __launch_bounds__(kThreads) void strided_nbr_kernel(const int *__rest
     }
 }
 
+// One thread per output row for all K = KZ*KY*KX offsets (kernel sizes 1 or 3 per axis): the input
+// cells of a row span at most two blocks per axis, so the thread loads the <= 8 occupancy words and
+// prefixes once (independent loads, all in flight together) and resolves the K cells with bit
+// operations, instead of K threads each re-reading the coordinates and one word.  Stores stay
+// coalesced: for a fixed offset, consecutive threads write consecutive entries of nbr[k][.].
+// lo = first input cell per axis (SubM: c - k/2; strided: c*s - p).
+template <int KZ, int KY, int KX>
+__device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, int lox, int o, int cap, int *__restrict__ nbr) {
+    const int bz0 = loz >> 2, by0 = loy >> 2, bx0 = lox >> 2;   // (arithmetic shift: -1 -> block -1, outside)
+    unsigned long long w[2][2][2];
+    unsigned base[2][2][2];
+#pragma unroll
+    for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+                const int bz = bz0 + cz, by = by0 + cy, bx = bx0 + cx;
+                const bool need = (cz == 0 || ((loz + KZ - 1) >> 2) != bz0) && (cy == 0 || ((loy + KY - 1) >> 2) != by0) &&
+                                  (cx == 0 || ((lox + KX - 1) >> 2) != bx0);
+                const bool in = bz >= 0 && bz < g.d.bd && by >= 0 && by < g.d.bh && bx >= 0 && bx < g.d.bw;
+                unsigned long long ww = 0ull;
+                unsigned bb = 0u;
+                if (need && in) {
+                    const long long blk = rg_block_of(g.d, b, bz << 2, by << 2, bx << 2);
+                    ww = g.bits[blk];
+                    bb = g.base[blk];   // (defined only where ww != 0; unused otherwise)
+                }
+                w[cz][cy][cx] = ww;
+                base[cz][cy][cx] = bb;
+            }
+#pragma unroll
+    for (int jz = 0; jz < KZ; ++jz) {
+        const int z = loz + jz;
+        const bool cz = (z >> 2) != bz0;
+        const bool vz = z >= 0 && z < g.d.D;
+        unsigned long long wz[2][2];
+        unsigned bsz[2][2];
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+                wz[cy][cx] = cz ? w[1][cy][cx] : w[0][cy][cx];
+                bsz[cy][cx] = cz ? base[1][cy][cx] : base[0][cy][cx];
+            }
+#pragma unroll
+        for (int jy = 0; jy < KY; ++jy) {
+            const int y = loy + jy;
+            const bool cy = (y >> 2) != by0;
+            const bool vy = vz && y >= 0 && y < g.d.H;
+            const unsigned long long wy0 = cy ? wz[1][0] : wz[0][0], wy1 = cy ? wz[1][1] : wz[0][1];
+            const unsigned by0v = cy ? bsz[1][0] : bsz[0][0], by1v = cy ? bsz[1][1] : bsz[0][1];
+#pragma unroll
+            for (int jx = 0; jx < KX; ++jx) {
+                const int x = lox + jx;
+                const bool cx = (x >> 2) != bx0;
+                const bool v = vy && x >= 0 && x < g.d.W;
+                const unsigned long long ww = cx ? wy1 : wy0;
+                const unsigned bb = cx ? by1v : by0v;
+                const int bit = rg_bit_of(z, y, x);
+                int r = -1;
+                if (v && ((ww >> bit) & 1ull)) {
+                    r = (int)bb + __popcll(ww & ((1ull << bit) - 1ull));
+                    if (g.perm) r = g.perm[r];
+                }
+                nbr[(size_t)((jz * KY + jy) * KX + jx) * cap + o] = r;
+            }
+        }
+    }
+}
+
+template <int KZ, int KY, int KX>
+__global__ __launch_bounds__(kThreads) void subm_nbr_row_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows,
+                                                                int cap, RG g, int *__restrict__ nbr) {
+    const int n = min(*n_rows, cap);
+    for (int o = blockIdx.x * kThreads + threadIdx.x; o < n; o += gridDim.x * kThreads) {
+        const int4 c = reinterpret_cast<const int4 *>(coords)[o];
+        nbr_row<KZ, KY, KX>(g, c.x, c.y - KZ / 2, c.z - KY / 2, c.w - KX / 2, o, cap, nbr);
+    }
+}
+
+template <int KZ, int KY, int KX>
+__global__ __launch_bounds__(kThreads) void strided_nbr_row_kernel(const int *__restrict__ out_coords,
+                                                                   const int *__restrict__ n_out, int cap_out, RG gi, Geom ge,
+                                                                   int *__restrict__ nbr) {
+    const int n = min(*n_out, cap_out);
+    for (int o = blockIdx.x * kThreads + threadIdx.x; o < n; o += gridDim.x * kThreads) {
+        const int4 c = reinterpret_cast<const int4 *>(out_coords)[o];
+        nbr_row<KZ, KY, KX>(gi, c.x, c.y * ge.s[0] - ge.p[0], c.z * ge.s[1] - ge.p[1], c.w * ge.s[2] - ge.p[2], o, cap_out, nbr);
+    }
+}
+
 bool geom_ok(const fnp_conv_geom *g) {
     if (!g) return false;
     for (int d = 0; d < 3; ++d)
@@ -146,9 +305,14 @@ extern "C" int fnp_rulebook_subm(const int *coords, const int *n_rows, int cap, 
         if (!(geom->ksize[d] & 1) || geom->in_shape[d] != geom->out_shape[d]) return FNP_ERR_ARG;
     if (!shape_is(grid, geom->in_shape)) return FNP_ERR_ARG;
     const int K = geom->ksize[0] * geom->ksize[1] * geom->ksize[2];
-    dim3 blocks(fnp_grid_for(cap, kThreads, 1024), K);
-    hipLaunchKernelGGL(subm_nbr_kernel, blocks, dim3(kThreads), 0, (hipStream_t)stream, coords, n_rows, cap,
-                       fnp_rg_view(grid), to_geom(geom), nbr);
+    if (geom->ksize[0] == 3 && geom->ksize[1] == 3 && geom->ksize[2] == 3) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_kernel<3, 3, 3>), dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0,
+                           (hipStream_t)stream, coords, n_rows, cap, fnp_rg_view(grid), nbr);
+    } else {
+        dim3 blocks(fnp_grid_for(cap, kThreads, 1024), K);
+        hipLaunchKernelGGL(subm_nbr_kernel, blocks, dim3(kThreads), 0, (hipStream_t)stream, coords, n_rows, cap,
+                           fnp_rg_view(grid), to_geom(geom), nbr);
+    }
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
@@ -174,16 +338,33 @@ extern "C" int fnp_rulebook_strided(const int *in_coords, const int *n_in, int c
     if (fnp_scan::rank_grid_workspace_bytes(go.nsum) > workspace_bytes) return FNP_ERR_WORKSPACE;
     const Geom ge = to_geom(geom);
 
-    hipLaunchKernelGGL(strided_mark_kernel, dim3(fnp_grid_for(cap_in, kThreads)), dim3(kThreads), 0, s, in_coords, n_in,
-                       cap_in, go, ge);
+    bool two = true;   // at most two outputs per input cell and axis
+    for (int d = 0; d < 3; ++d) two = two && (ge.k[d] + ge.s[d] - 1) / ge.s[d] <= 2;
+    const dim3 mgrid(fnp_grid_for(cap_in, kThreads));
+    if (two && ge.s[0] == 2 && ge.s[1] == 2 && ge.s[2] == 2)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_mark2_kernel<2, 2, 2>), mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge);
+    else if (two && ge.s[0] == 2 && ge.s[1] == 1 && ge.s[2] == 1)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_mark2_kernel<2, 1, 1>), mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge);
+    else if (two)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_mark2_kernel<0, 0, 0>), mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge);
+    else
+        hipLaunchKernelGGL(strided_mark_kernel, mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge);
     FNP_LAUNCH_CHECK();
     int rc = fnp_scan::rank_grid(go, n_out, workspace, s);
     if (rc) return rc;
     hipLaunchKernelGGL(emit_coords_kernel, dim3(fnp_divup(go.nsum * 64, kThreads)), dim3(kThreads), 0, s, go, cap_out,
                        out_coords);
     FNP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(strided_nbr_kernel, dim3(fnp_grid_for(cap_out, kThreads, 1024), K), dim3(kThreads), 0, s,
-                       out_coords, n_out, cap_out, gi, ge, nbr);
+    const dim3 rgrid(fnp_grid_for(cap_out, kThreads));
+    if (ge.k[0] == 3 && ge.k[1] == 3 && ge.k[2] == 3)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_nbr_row_kernel<3, 3, 3>), rgrid, dim3(kThreads), 0, s, out_coords, n_out,
+                           cap_out, gi, ge, nbr);
+    else if (ge.k[0] == 3 && ge.k[1] == 1 && ge.k[2] == 1)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_nbr_row_kernel<3, 1, 1>), rgrid, dim3(kThreads), 0, s, out_coords, n_out,
+                           cap_out, gi, ge, nbr);
+    else
+        hipLaunchKernelGGL(strided_nbr_kernel, dim3(fnp_grid_for(cap_out, kThreads, 1024), K), dim3(kThreads), 0, s,
+                           out_coords, n_out, cap_out, gi, ge, nbr);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
