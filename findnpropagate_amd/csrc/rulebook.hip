@@ -116,29 +116,54 @@ template <int SZ, int SY, int SX>
 __global__ __launch_bounds__(kThreads) void strided_mark2_kernel(const int *__restrict__ in_coords,
                                                                  const int *__restrict__ n_in, int cap_in, RG go, Geom ge) {
     const int n = min(*n_in, cap_in);
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
-        const int4 c = reinterpret_cast<const int4 *>(in_coords)[i];
-        const AxisOut az = axis_outputs<SZ>(c.y, ge.k[0], ge.s[0], ge.p[0], go.d.D);
-        const AxisOut ay = axis_outputs<SY>(c.z, ge.k[1], ge.s[1], ge.p[1], go.d.H);
-        const AxisOut ax = axis_outputs<SX>(c.w, ge.k[2], ge.s[2], ge.p[2], go.d.W);
-        if (!(az.any && ay.any && ax.any)) continue;
+    const int lane = fnp_lane();
+    const int nround = (n + (int)(gridDim.x * kThreads) - 1) / (int)(gridDim.x * kThreads);
+    for (int it = 0; it < nround; ++it) {   // (whole waves stay in the loop: the shuffles below need them)
+        const int i = (it * gridDim.x + blockIdx.x) * kThreads + threadIdx.x;
+        long long blk0 = -1;          // block of the first outputs (corner 0,0,0) and its bits
+        unsigned long long m0 = 0ull;
+        if (i < n) {
+            const int4 c = reinterpret_cast<const int4 *>(in_coords)[i];
+            const AxisOut az = axis_outputs<SZ>(c.y, ge.k[0], ge.s[0], ge.p[0], go.d.D);
+            const AxisOut ay = axis_outputs<SY>(c.z, ge.k[1], ge.s[1], ge.p[1], go.d.H);
+            const AxisOut ax = axis_outputs<SX>(c.w, ge.k[2], ge.s[2], ge.p[2], go.d.W);
+            if (az.any && ay.any && ax.any) {
 #pragma unroll
-        for (int cz = 0; cz < 2; ++cz) {
-            const unsigned sz = cz ? az.s1 : az.s0;
-            if (!sz) continue;
+                for (int cz = 0; cz < 2; ++cz) {
+                    const unsigned sz = cz ? az.s1 : az.s0;
+                    if (!sz) continue;
 #pragma unroll
-            for (int cy = 0; cy < 2; ++cy) {
-                const unsigned sy = cy ? ay.s1 : ay.s0;
-                if (!sy) continue;
+                    for (int cy = 0; cy < 2; ++cy) {
+                        const unsigned sy = cy ? ay.s1 : ay.s0;
+                        if (!sy) continue;
 #pragma unroll
-                for (int cx = 0; cx < 2; ++cx) {
-                    const unsigned sx = cx ? ax.s1 : ax.s0;
-                    if (!sx) continue;
-                    const unsigned long long m = (unsigned long long)(sx * spread4(sy)) * spread16(sz);
-                    rg_mark_mask(go, rg_block_of(go.d, c.x, (az.b0 + cz) << 2, (ay.b0 + cy) << 2, (ax.b0 + cx) << 2), m);
+                        for (int cx = 0; cx < 2; ++cx) {
+                            const unsigned sx = cx ? ax.s1 : ax.s0;
+                            if (!sx) continue;
+                            const unsigned long long m = (unsigned long long)(sx * spread4(sy)) * spread16(sz);
+                            const long long blk = rg_block_of(go.d, c.x, (az.b0 + cz) << 2, (ay.b0 + cy) << 2, (ax.b0 + cx) << 2);
+                            if (cz + cy + cx == 0) {
+                                blk0 = blk;
+                                m0 = m;
+                            } else {
+                                rg_mark_mask(go, blk, m);   // outputs across a block border: rare
+                            }
+                        }
+                    }
                 }
             }
         }
+        // Inputs in rank-grid order reach one output block from ~30 consecutive rows.  OR the bits of
+        // equal blocks along the wave (a lane may take in any earlier lane's bits of the same block)
+        // and let the last lane of each run issue the one atomic: same-address atomics serialise in L2.
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long nb = __shfl_up(blk0, d);
+            const unsigned long long nm = __shfl_up(m0, d);
+            if (lane >= d && nb == blk0) m0 |= nm;
+        }
+        const long long nxt = __shfl_down(blk0, 1);
+        if (blk0 >= 0 && (lane == 63 || nxt != blk0)) rg_mark_mask(go, blk0, m0);
     }
 }
 

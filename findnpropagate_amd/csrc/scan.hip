@@ -111,14 +111,57 @@ int run_scan(L load, long long n, TOut *out, int *total, void *ws, hipStream_t s
 
 // ---- rank-grid prefix through the summary level ---------------------------------------------
 // One wave per summary word S (64 blocks); a wave whose word is zero retires after one load, so
-// the cost follows the occupied blocks.  Lane j owns block 64*S + j.
-//   PASS 0: cnt[S]  = occupied cells in the 64 blocks of S
-//   PASS 1: base[w] = prefix[S] + occupied cells in the blocks of S before w   (w occupied)
+// the cost follows the occupied blocks.  Lane j owns block 64*S + j.  Three kernels, none of them a
+// scan over the 360 k per-word counts:
+//   PASS 0 : cnt[S]  = occupied cells in the 64 blocks of S
+//   TOTALS : gtot[g] = sum of cnt over group g (64 words), ctot[c] = over chunk c (16 groups);
+//            one workgroup per chunk, coalesced
+//   PASS 1 : base[w] = cells before S + occupied cells in the blocks of S before w   (w occupied),
+//            where "cells before S" = sum(ctot[< c]) + sum(gtot[16c .. g)) + sum(cnt[64g .. S)):
+//            <= 350 + 15 + 63 values, read lane-parallel and reduced once per occupied word
+//            *total = sum(ctot)   (wave of S = 0)
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void rank_totals_kernel(const unsigned *__restrict__ cnt, long long nsum,
+                                                               unsigned *__restrict__ gtot, unsigned *__restrict__ ctot) {
+    __shared__ unsigned part[16];
+    const int wave = threadIdx.x >> 6, lane = fnp_lane();
+    const long long c = blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // wave w sums groups 4w .. 4w+3 of the chunk
+        const long long grp = c * 16 + wave * 4 + i, S = grp * 64 + lane;
+        const unsigned t = wave_sum(S < nsum ? cnt[S] : 0u);
+        if (lane == 0) {
+            part[wave * 4 + i] = t;
+            if (grp * 64 < nsum) gtot[grp] = t;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i];
+        ctot[c] = t;
+    }
+}
+
 template <int PASS>
-__global__ __launch_bounds__(kThreads) void summary_pass_kernel(RG g, int *__restrict__ cnt, const int *__restrict__ prefix) {
+__global__ __launch_bounds__(kThreads) void summary_pass_kernel(RG g, unsigned *__restrict__ cnt, const unsigned *__restrict__ gtot,
+                                                                const unsigned *__restrict__ ctot, int nchunks,
+                                                                int *__restrict__ total) {
     const int lane = fnp_lane();
     const long long S = ((long long)blockIdx.x * kThreads + threadIdx.x) >> 6;
     if (S >= g.nsum) return;
+    if (PASS == 1 && S == 0) {
+        unsigned t = 0;
+        for (int c = lane; c < nchunks; c += 64) t += ctot[c];
+        t = wave_sum(t);
+        if (lane == 0) *total = (int)t;
+    }
     const unsigned long long sw = g.summ[S];   // wave-uniform
     if (sw == 0ull) {
         if (PASS == 0 && lane == 0) cnt[S] = 0;
@@ -129,9 +172,15 @@ __global__ __launch_bounds__(kThreads) void summary_pass_kernel(RG g, int *__res
     const unsigned c = occ ? (unsigned)__popcll(g.bits[blk]) : 0u;
     const unsigned inc = wave_inclusive(c);
     if (PASS == 0) {
-        if (lane == 63) cnt[S] = (int)inc;
+        if (lane == 63) cnt[S] = inc;
     } else {
-        if (occ) g.base[blk] = (unsigned)prefix[S] + inc - c;
+        const long long grp = S >> 6, chunk = S >> 10;
+        unsigned p = 0;
+        for (int i = lane; i < (int)chunk; i += 64) p += ctot[i];
+        if (lane < (int)(grp - chunk * 16)) p += gtot[chunk * 16 + lane];
+        if (lane < (int)(S - grp * 64)) p += cnt[grp * 64 + lane];
+        p = wave_sum(p);
+        if (occ) g.base[blk] = p + inc - c;
     }
 }
 
@@ -143,17 +192,23 @@ int int32(const int *in, long long n, int *out, int *total, void *ws, hipStream_
     return run_scan(LoadInt{in}, n, out, total, ws, s);
 }
 long long rank_grid_workspace_bytes(long long nsum) {
-    return ((nsum * 4 + 255) & ~255ll) + workspace_bytes(nsum) + 256;
+    const long long ngroups = (nsum + 63) >> 6, nchunks = (nsum + 1023) >> 10;
+    return ((nsum * 4 + 255) & ~255ll) + (((ngroups + nchunks) * 4 + 255) & ~255ll) + 256;
 }
 int rank_grid(const RG &g, int *total, void *ws, hipStream_t s) {
-    int *cnt = (int *)ws;   // (nsum) per-summary-word cell counts, scanned in place
-    void *scan_ws = (char *)ws + ((g.nsum * 4 + 255) & ~255ll);
+    const long long ngroups = (g.nsum + 63) >> 6, nchunks = (g.nsum + 1023) >> 10;
+    if (nchunks > 0x7fffffffll) return FNP_ERR_ARG;
+    unsigned *cnt = (unsigned *)ws;   // (nsum) cells per summary word
+    unsigned *gtot = (unsigned *)((char *)ws + ((g.nsum * 4 + 255) & ~255ll));
+    unsigned *ctot = gtot + ngroups;
     const int grid = fnp_divup(g.nsum * 64, kThreads);
-    hipLaunchKernelGGL(summary_pass_kernel<0>, dim3(grid), dim3(kThreads), 0, s, g, cnt, (const int *)nullptr);
+    hipLaunchKernelGGL(summary_pass_kernel<0>, dim3(grid), dim3(kThreads), 0, s, g, cnt, (const unsigned *)nullptr,
+                       (const unsigned *)nullptr, (int)nchunks, total);
     FNP_LAUNCH_CHECK();
-    int rc = int32(cnt, g.nsum, cnt, total, scan_ws, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(summary_pass_kernel<1>, dim3(grid), dim3(kThreads), 0, s, g, (int *)nullptr, (const int *)cnt);
+    hipLaunchKernelGGL(rank_totals_kernel, dim3((unsigned)nchunks), dim3(kThreads), 0, s, (const unsigned *)cnt, g.nsum, gtot, ctot);
+    FNP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(summary_pass_kernel<1>, dim3(grid), dim3(kThreads), 0, s, g, cnt, (const unsigned *)gtot,
+                       (const unsigned *)ctot, (int)nchunks, total);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
