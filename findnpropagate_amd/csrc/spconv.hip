@@ -90,15 +90,31 @@ __global__ __launch_bounds__(256) void spconv_first_kernel(const float *__restri
         float acc[COUT];
 #pragma unroll
         for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-        for (int k = 0; k < K; ++k) {
-            const int idx = nbr[(size_t)k * nbr_stride + row];
-            if (idx < 0) continue;
-            const float *xr = x + (size_t)idx * Cin;
-            const float *wk = wl + k * Cin * COUT;
-            for (int ci = 0; ci < Cin; ++ci) {
-                const float xv = xr[ci];
+        // Branch-free sweep in groups of 9 offsets: the rulebook entries of a group are loaded
+        // together, the feature rows unconditionally (row 0 stands in for an absent neighbour and is
+        // multiplied by 0: fmaf(0, w, acc) == acc, the chain of the present neighbours is unchanged),
+        // so the loads of a group are all in flight before its first fma instead of one dependent
+        // load per offset.
+        for (int k0 = 0; k0 < K; k0 += 9) {
+            int idx[9];
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xv, wk[ci * COUT + co], acc[co]);
+            for (int j = 0; j < 9; ++j) idx[j] = k0 + j < K ? nbr[(size_t)(k0 + j) * nbr_stride + row] : -1;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                if (k0 + j >= K) break;   // uniform
+                const bool ok = idx[j] >= 0;
+                const float *xr = x + (size_t)(ok ? idx[j] : 0) * Cin;
+                const float *wk = wl + (k0 + j) * Cin * COUT;
+                float xv[8];   // (Cin <= 8 by dispatch)
+#pragma unroll
+                for (int ci = 0; ci < 8; ++ci) xv[ci] = ci < Cin ? xr[ci] : 0.f;
+#pragma unroll
+                for (int ci = 0; ci < 8; ++ci) {
+                    if (ci >= Cin) break;   // uniform
+                    const float xc = ok ? xv[ci] : 0.f;
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xc, wk[ci * COUT + co], acc[co]);
+                }
             }
         }
 #pragma unroll

@@ -28,7 +28,6 @@ struct VoxWs {          // carve-up of the caller's workspace
     int *rank;          // (N)   sorted rank of the point's cell, or -1
     int *flag;          // (N)   first-point flag, then exclusive scan (first-come rank)
     int *top;           // (cap, max_points) smallest point indices per cell, ascending
-    int *cnt;           // (cap) points per cell
     int *scene;         // (3*B + 4): fc_start[B+1], out_base[B+1], misc
     int *n_sorted;      // (1)
     int *n_first;       // (1)
@@ -48,7 +47,6 @@ __host__ long long carve(VoxWs &w, char *base, long long n, int B, int cap, int 
     w.rank = (int *)take(4 * n);
     w.flag = (int *)take(4 * n);
     w.top = (int *)take(4ll * cap * maxp);
-    w.cnt = (int *)take(4ll * cap);
     w.scene = (int *)take(4ll * (3 * B + 8));
     w.n_sorted = (int *)take(4);
     w.n_first = (int *)take(4);
@@ -97,8 +95,7 @@ __global__ __launch_bounds__(kThreads) void vox_insert_kernel(int n, int maxp, i
                                                               const unsigned long long *__restrict__ bits,
                                                               const unsigned *__restrict__ base,
                                                               const long long *__restrict__ code,
-                                                              int *__restrict__ rank, int *__restrict__ top,
-                                                              int *__restrict__ cnt) {
+                                                              int *__restrict__ rank, int *__restrict__ top) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
     const long long cd = code[i];
@@ -111,7 +108,6 @@ __global__ __launch_bounds__(kThreads) void vox_insert_kernel(int n, int maxp, i
     }
     rank[i] = r;
     if (r < 0) return;
-    atomicAdd(&cnt[r], 1);
     // bubble insert: slot j ends up holding the (j+1)-th smallest index whatever the interleaving
     int carry = i;
     int *slots = top + (size_t)r * maxp;
@@ -130,33 +126,45 @@ __global__ __launch_bounds__(kThreads) void vox_flag_kernel(int n, int maxp, con
     flag[i] = (r >= 0 && top[(size_t)r * maxp] == i) ? 1 : 0;
 }
 
-// one workgroup: per-scene first-come starts and output bases after the max_voxels cut.
-__global__ void vox_scene_kernel(const int *__restrict__ boff, int B, int n, const int *__restrict__ fc,
-                                 const int *__restrict__ n_first, int max_voxels, int cap,
-                                 int *__restrict__ scene, int *__restrict__ n_voxels) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one wave: per-scene first-come starts and output bases after the max_voxels cut (B <= kMaxBatch;
+// lane-strided over the scenes, running prefix carried across the 64-scene rounds).
+__global__ __launch_bounds__(64) void vox_scene_kernel(const int *__restrict__ boff, int B, int n, const int *__restrict__ fc,
+                                                       const int *__restrict__ n_first, int max_voxels, int cap,
+                                                       int *__restrict__ scene, int *__restrict__ n_voxels) {
     int *fc_start = scene;           // (B+1)
     int *out_base = scene + (B + 1); // (B+1)
+    const int lane = threadIdx.x;
     const int total = *n_first;
-    for (int b = 0; b <= B; ++b) {
-        const int o = boff[b];
-        fc_start[b] = (o < n) ? fc[o] : total;
-    }
     int acc = 0;
-    for (int b = 0; b < B; ++b) {
-        out_base[b] = acc;
-        int c = fc_start[b + 1] - fc_start[b];
-        if (c > max_voxels) c = max_voxels;
-        acc += c;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + lane;
+        int c = 0;
+        if (b < B) {
+            const int o0 = boff[b], o1 = boff[b + 1];
+            const int f0 = (o0 < n) ? fc[o0] : total, f1 = (o1 < n) ? fc[o1] : total;
+            fc_start[b] = f0;
+            if (b == B - 1) fc_start[B] = f1;
+            c = min(f1 - f0, max_voxels);
+        }
+        int inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
+        }
+        if (b < B) out_base[b] = acc + inc - c;
+        acc += __shfl(inc, 63);
     }
-    out_base[B] = acc;
-    *n_voxels = acc;  // true count; consumers clamp to their capacity
+    if (lane == 0) {
+        out_base[B] = acc;
+        *n_voxels = acc;  // true count; consumers clamp to their capacity
+    }
 }
 
 __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restrict__ pts, int C, int maxp,
                                                             const int *__restrict__ boff, int B, int max_voxels,
                                                             RankGridDims g, const long long *__restrict__ code,
-                                                            const int *__restrict__ top, const int *__restrict__ cnt,
+                                                            const int *__restrict__ top,
                                                             const int *__restrict__ fc, const int *__restrict__ scene,
                                                             const int *__restrict__ n_sorted, int cap,
                                                             int *__restrict__ perm, int *__restrict__ coords,
@@ -168,24 +176,25 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
     for (int r = blockIdx.x * kThreads + threadIdx.x; r < ns; r += gridDim.x * kThreads) {
         const int *slots = top + (size_t)r * maxp;
         const int p0 = slots[0];
-        const int b = batch_of(boff, B, p0);
-        const int srank = fc[p0] - fc_start[b];
+        // the scene of the cell is in its block number: no search in the batch offsets
+        const long long cd = code[p0];
+        int bb, z, y, x;
+        rg_decode(g, cd >> 6, (int)(cd & 63), bb, z, y, x);
+        const int srank = fc[p0] - fc_start[bb];
+        // points kept = filled slots (the list holds the max_points smallest indices of the cell)
+        int np = 0;
+        for (int j = 0; j < maxp; ++j) np += slots[j] != kSentinel ? 1 : 0;
         if (srank >= max_voxels) {
             perm[r] = -1;
             continue;
         }
-        const int id = out_base[b] + srank;
+        const int id = out_base[bb] + srank;
         if (id >= cap) {
             perm[r] = -1;
             continue;
         }
         perm[r] = id;
-        const long long cd = code[p0];
-        int bb, z, y, x;
-        rg_decode(g, cd >> 6, (int)(cd & 63), bb, z, y, x);
         reinterpret_cast<int4 *>(coords)[id] = make_int4(bb, z, y, x);
-        int np = cnt[r];
-        if (np > maxp) np = maxp;
         num_points[id] = np;
         const float norm = (float)(np < 1 ? 1 : np);
         for (int c = 0; c < C; ++c) {
@@ -281,13 +290,12 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
     const int pgrid = fnp_divup(n, kThreads);
 
     FNP_HIP_TRY(hipMemsetAsync(w.top, 0x7f, sizeof(int) * (size_t)n * maxp, s));
-    FNP_HIP_TRY(hipMemsetAsync(w.cnt, 0, sizeof(int) * (size_t)n, s));
     hipLaunchKernelGGL(vox_mark_kernel, dim3(pgrid), dim3(kThreads), 0, s, points, n, C, batch_offsets, B, *cfg, g, w.code);
     FNP_LAUNCH_CHECK();
     int rc = fnp_scan::rank_grid(g, w.n_sorted, w.scan_ws, s);
     if (rc) return rc;
     hipLaunchKernelGGL(vox_insert_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, n,
-                       (const unsigned long long *)g.bits, (const unsigned *)g.base, w.code, w.rank, w.top, w.cnt);
+                       (const unsigned long long *)g.bits, (const unsigned *)g.base, w.code, w.rank, w.top);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(vox_flag_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, w.rank, w.top, w.flag);
     FNP_LAUNCH_CHECK();
@@ -297,7 +305,7 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
                        cfg->max_voxels, cap, w.scene, n_voxels);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(vox_emit_kernel, dim3(fnp_grid_for(n, kThreads)), dim3(kThreads), 0, s, points, C, maxp,
-                       batch_offsets, B, cfg->max_voxels, g.d, w.code, w.top, w.cnt, w.flag, w.scene, w.n_sorted, n,
+                       batch_offsets, B, cfg->max_voxels, g.d, w.code, w.top, w.flag, w.scene, w.n_sorted, n,
                        g.perm, coords, num_points, mean_feats, voxels);
     FNP_LAUNCH_CHECK();
     return FNP_OK;

@@ -137,7 +137,7 @@ def voxelize(points, batch_offsets, batch_size, cfg, grid=None, want_voxels=Fals
     num_points = torch.empty((cap,), dtype=torch.int32, device=dev)
     mean = torch.empty((cap, C), dtype=torch.float32, device=dev)
     voxels = torch.empty((cap, cfg.max_points, C), dtype=torch.float32, device=dev) if want_voxels else None
-    n_vox = torch.zeros((1,), dtype=torch.int32, device=dev)
+    n_vox = torch.empty((1,), dtype=torch.int32, device=dev)    # always written by fnp_voxelize
     rc = L.fnp_voxelize(_l.ptr(points), n, _l.ptr(batch_offsets), cfg, gc,
                         _l.ptr(workspace), workspace.numel(),
                         _l.ptr(coords), _l.ptr(num_points), _l.ptr(mean), _l.ptr(voxels), _l.ptr(n_vox), cap,
@@ -198,7 +198,7 @@ def rulebook_strided(indices, n_dev, grid, ksize, stride, padding, cap_out, out_
         out_grid = alloc_grid(grid.batch_size, out_shape, dev)
     cap_out = max(int(cap_out), 1)
     out_idx = torch.empty((cap_out, 4), dtype=torch.int32, device=dev)
-    out_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+    out_n = torch.empty((1,), dtype=torch.int32, device=dev)    # always written by fnp_rulebook_strided
     nbr = torch.empty((K, cap_out), dtype=torch.int32, device=dev)
     ws = torch.empty((int(L.fnp_rankgrid_workspace_bytes(grid.batch_size, *out_shape)),), dtype=torch.uint8, device=dev)
     rc = L.fnp_rulebook_strided(_l.ptr(indices), _l.ptr(n_dev), cap_in, geom, grid.c(), out_grid.c(with_perm=False),
