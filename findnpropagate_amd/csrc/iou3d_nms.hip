@@ -16,6 +16,8 @@
 //     one wave on the device (diagonal tile resolved in registers, later column words updated
 //     64 at a time), so the whole op is asynchronous on the caller's stream.
 #include "common.h"
+#include <cmath>
+#include <vector>
 
 namespace {
 
@@ -30,11 +32,11 @@ struct RBox {           // one rotated rectangle, prepared once
     float hx, hy;       // dx/2 + 1e-2f, dy/2 + 1e-2f (f32, :61)
 };
 
-__device__ __forceinline__ float cross3(const P2 &p1, const P2 &p2, const P2 &p0) {
+__host__ __device__ __forceinline__ float cross3(const P2 &p1, const P2 &p2, const P2 &p0) {
     return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
 }
 
-__device__ __forceinline__ void prep_box(const float *b, RBox &r) {
+__host__ __device__ __forceinline__ void prep_box(const float *b, RBox &r) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) r.raw[i] = b[i];
     const float hx = b[3] / 2, hy = b[4] / 2;
@@ -54,13 +56,13 @@ __device__ __forceinline__ void prep_box(const float *b, RBox &r) {
     r.hy = b[4] / 2 + 1e-2f;
 }
 
-__device__ __forceinline__ bool corner_inside(const RBox &box, const P2 &p) {
+__host__ __device__ __forceinline__ bool corner_inside(const RBox &box, const P2 &p) {
     const float rx = (p.x - box.raw[0]) * box.ncos + (p.y - box.raw[1]) * (-box.nsin);
     const float ry = (p.x - box.raw[0]) * box.nsin + (p.y - box.raw[1]) * box.ncos;
     return fabsf(rx) < box.hx && fabsf(ry) < box.hy;
 }
 
-__device__ __forceinline__ bool seg_cross(const P2 &p1, const P2 &p0, const P2 &q1, const P2 &q0, P2 &ans) {
+__host__ __device__ __forceinline__ bool seg_cross(const P2 &p1, const P2 &p0, const P2 &q1, const P2 &q0, P2 &ans) {
     const bool bb = fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
                     fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y);
     if (!bb) return false;
@@ -83,7 +85,7 @@ __device__ __forceinline__ bool seg_cross(const P2 &p1, const P2 &p0, const P2 &
     return true;
 }
 
-__device__ float overlap_area(const RBox &A, const RBox &B) {
+__host__ __device__ float overlap_area(const RBox &A, const RBox &B) {
     P2 poly[24];
     float key[24];
     int cnt = 0;
@@ -133,7 +135,7 @@ __device__ float overlap_area(const RBox &A, const RBox &B) {
     return fabsf(area) * 0.5f;  // == (float)(fabs(area) / 2.0)
 }
 
-__device__ __forceinline__ float iou_from_overlap(const float *a, const float *b, float ov) {
+__host__ __device__ __forceinline__ float iou_from_overlap(const float *a, const float *b, float ov) {
     const float sa = a[3] * a[4], sb = b[3] * b[4];
     return ov / fmaxf(sa + sb - ov, 1e-8f);
 }
@@ -343,4 +345,32 @@ extern "C" int fnp_nms_rotated(const float *boxes, int n, float thresh, void *ws
 extern "C" int fnp_nms_normal(const float *boxes, int n, float thresh, void *ws, int64_t *keep, int *num_keep,
                               fnp_stream_t s) {
     return launch_nms<false>(boxes, n, thresh, ws, keep, num_keep, s);
+}
+
+// ---- host entry points (iou3d_cpu.cpp:232-272: boxes_iou_bev_cpu / boxes_aligned_iou_bev_cpu) ----
+// Plain host loops over the same prepared-box / overlap functions as the kernels above (compiled for
+// the host; libm's cosf/sinf/atan2f instead of the device library's).  Used by the pseudo-label
+// mixing in dataloader workers (pseudo_loader.py:29-55): no stream, no device memory.
+extern "C" int fnp_host_boxes_iou_bev(const float *a, int na, const float *b, int nb, float *out) {
+    if (na < 0 || nb < 0 || ((na > 0 && nb > 0) && (!a || !b || !out))) return FNP_ERR_ARG;
+    std::vector<RBox> pb((size_t)nb);
+    for (int j = 0; j < nb; ++j) prep_box(b + (size_t)j * 7, pb[j]);
+    for (int i = 0; i < na; ++i) {
+        RBox A;
+        prep_box(a + (size_t)i * 7, A);
+        for (int j = 0; j < nb; ++j)
+            out[(size_t)i * nb + j] = iou_from_overlap(a + (size_t)i * 7, b + (size_t)j * 7, overlap_area(A, pb[j]));
+    }
+    return FNP_OK;
+}
+
+extern "C" int fnp_host_boxes_aligned_iou_bev(const float *a, const float *b, int n, float *out) {
+    if (n < 0 || (n > 0 && (!a || !b || !out))) return FNP_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        RBox A, B;
+        prep_box(a + (size_t)i * 7, A);
+        prep_box(b + (size_t)i * 7, B);
+        out[i] = iou_from_overlap(a + (size_t)i * 7, b + (size_t)i * 7, overlap_area(A, B));
+    }
+    return FNP_OK;
 }

@@ -83,11 +83,29 @@ def nms_normal_gpu(boxes, keep, nms_overlap_thresh):
     return n
 
 
+def _check_host(*ts):
+    for t in ts:
+        if t.is_cuda or t.dtype != torch.float32:
+            raise _l.FnpError("must be a float32 host tensor")
+        if not t.is_contiguous():
+            raise _l.FnpError("must be contiguous tensor")
+
+
 def boxes_iou_bev_cpu(boxes_a, boxes_b, ans_iou):
-    """iou3d_cpu.cpp:232-252 takes HOST tensors (pseudo-label mixing in dataloader workers).  The
-    host-side rotated IoU is a 'next' row and is not built in this round."""
-    raise NotImplementedError("boxes_iou_bev_cpu: host-side rotated IoU is not built yet; use boxes_iou_bev_gpu")
+    """iou3d_cpu.cpp:232-252: HOST tensors (N,7),(M,7) -> ans_iou (N,M), rotated BEV IoU (pseudo-label
+    mixing in dataloader workers).  Runs the library's host entry point; no GPU is touched."""
+    _check_host(boxes_a, boxes_b, ans_iou)
+    assert ans_iou.shape[0] == boxes_a.shape[0] and ans_iou.shape[1] == boxes_b.shape[0]
+    rc = _l.load().fnp_host_boxes_iou_bev(_l.ptr(boxes_a), boxes_a.shape[0], _l.ptr(boxes_b), boxes_b.shape[0],
+                                          _l.ptr(ans_iou))
+    _l.check(rc, "fnp_host_boxes_iou_bev")
+    return 1
 
 
 def boxes_aligned_iou_bev_cpu(boxes_a, boxes_b, ans_iou):
-    raise NotImplementedError("boxes_aligned_iou_bev_cpu: host-side rotated IoU is not built yet")
+    """iou3d_cpu.cpp:254-272: HOST tensors (N,7),(N,7) -> ans_iou (N,1)."""
+    _check_host(boxes_a, boxes_b, ans_iou)
+    assert boxes_a.shape[0] == boxes_b.shape[0] and ans_iou.numel() == boxes_a.shape[0]
+    rc = _l.load().fnp_host_boxes_aligned_iou_bev(_l.ptr(boxes_a), _l.ptr(boxes_b), boxes_a.shape[0], _l.ptr(ans_iou))
+    _l.check(rc, "fnp_host_boxes_aligned_iou_bev")
+    return 1

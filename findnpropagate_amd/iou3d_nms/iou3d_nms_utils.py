@@ -62,5 +62,16 @@ def nms_normal_gpu(boxes, scores, thresh, **kwargs):
 
 
 def boxes_bev_iou_cpu(boxes_a, boxes_b):
-    """iou3d_nms_utils.py:12-28 (host tensors; pseudo-label mixing).  Not built in this round."""
-    raise NotImplementedError("boxes_bev_iou_cpu: host-side rotated IoU is a 'next' row (SURVEY.md §8f rank 2)")
+    """iou3d_nms_utils.py:12-28: (N,7),(M,7) host tensors or numpy arrays -> (N,M) rotated BEV IoU of
+    the same kind (numpy in -> numpy out).  Device tensors are refused like in the reference."""
+    import numpy as np
+    is_numpy = isinstance(boxes_a, np.ndarray)
+    if isinstance(boxes_a, np.ndarray):
+        boxes_a = torch.from_numpy(boxes_a).float()
+    if isinstance(boxes_b, np.ndarray):
+        boxes_b = torch.from_numpy(boxes_b).float()
+    assert not (boxes_a.is_cuda or boxes_b.is_cuda), 'Only support CPU tensors'
+    assert boxes_a.shape[1] == 7 and boxes_b.shape[1] == 7
+    ans_iou = boxes_a.new_zeros(torch.Size((boxes_a.shape[0], boxes_b.shape[0])))
+    iou3d_nms_cuda.boxes_iou_bev_cpu(boxes_a.contiguous(), boxes_b.contiguous(), ans_iou)
+    return ans_iou.numpy() if is_numpy else ans_iou

@@ -83,6 +83,12 @@ int fnp_boxes_aligned_overlap_bev(const float *boxes_a, const float *boxes_b, in
 int fnp_boxes_iou3d(const float *boxes_a, int num_a, const float *boxes_b, int num_b,
                     float *ans_iou, fnp_stream_t stream);
 
+/* Host-side rotated BEV IoU (no device, no stream): replaces boxes_iou_bev_cpu (N x M) and
+ * boxes_aligned_iou_bev_cpu (N pairs) of pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp:232-272, called by the
+ * pseudo-label mixing in dataloader workers (pseudo_loader.py:29-55).  Host pointers, (n,7) boxes. */
+int fnp_host_boxes_iou_bev(const float *boxes_a, int na, const float *boxes_b, int nb, float *iou_out);
+int fnp_host_boxes_aligned_iou_bev(const float *boxes_a, const float *boxes_b, int n, float *iou_out);
+
 /* Bytes of the u64 suppression-mask workspace for N boxes. */
 int64_t fnp_nms_workspace_bytes(int num_boxes);
 /* nms_gpu / nms_normal_gpu (iou3d_nms.cpp:113-209): boxes (N,7) pre-sorted by score desc.
