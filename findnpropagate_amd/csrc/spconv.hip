@@ -661,22 +661,6 @@ int dispatch_bf16(const void *x, long long n_in, const void *w, const int *nbr, 
     return launch_valu<__bf16, TOut>(x, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual, relu, Cin, Cout, s);
 }
 
-// SparseConvTensor.dense(): thread per (row, channel).
-template <typename T>
-__global__ __launch_bounds__(256) void dense_kernel(const T *__restrict__ feats, const int *__restrict__ coords,
-                                                    const int *__restrict__ n_rows, int cap, int C, int D, int H, int W,
-                                                    T *__restrict__ out) {
-    const int n = min(*n_rows, cap);
-    const long long total = (long long)n * C;
-    const long long vol = (long long)D * H * W;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
-        const int row = (int)(t / C), c = (int)(t % C);
-        const int4 cd = reinterpret_cast<const int4 *>(coords)[row];
-        const long long sp = ((long long)cd.y * H + cd.z) * W + cd.w;
-        out[((long long)cd.x * C + c) * vol + sp] = feats[t];
-    }
-}
-
 }  // namespace
 
 extern "C" int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const void *weight, const int *nbr,
@@ -716,21 +700,4 @@ extern "C" int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_ro
         return FNP_ERR_ARG;
     }
     return FNP_ERR_ARG;
-}
-
-extern "C" int fnp_sparse_to_dense(const void *feats, int dtype, const int *coords, const int *n_rows, int cap, int C,
-                                   int B, int D, int H, int W, void *out, fnp_stream_t stream) {
-    if (!feats || !coords || !n_rows || !out || cap <= 0 || C <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0)
-        return FNP_ERR_ARG;
-    const int grid = fnp_grid_for((long long)cap * C, 256, 256 * 16);
-    if (dtype == FNP_F32)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(dense_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                           (const float *)feats, coords, n_rows, cap, C, D, H, W, (float *)out);
-    else if (dtype == FNP_BF16)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(dense_kernel<__bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                           (const __bf16 *)feats, coords, n_rows, cap, C, D, H, W, (__bf16 *)out);
-    else
-        return FNP_ERR_ARG;
-    FNP_LAUNCH_CHECK();
-    return FNP_OK;
 }

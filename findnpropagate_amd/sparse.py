@@ -246,12 +246,19 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
     return out
 
 
-def to_dense(features, indices, n_dev, batch_size, shape):
-    """SparseConvTensor.dense(): (B, C, D, H, W) zeros + scatter."""
+def to_dense(features, indices, n_dev, batch_size, shape, workspace=None, out=None):
+    """SparseConvTensor.dense(): (B, C, D, H, W), written once (zeros included) through a cell -> row map.
+    workspace / out: optional persistent buffers of a caller that densifies every step."""
     L = _l.load()
     C = features.shape[1]
-    out = torch.zeros((batch_size, C, *shape), dtype=features.dtype, device=features.device)
+    need = int(L.fnp_sparse_to_dense_workspace_bytes(batch_size, *shape))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=features.device)
+    if out is None:
+        out = torch.empty((batch_size, C, *shape), dtype=features.dtype, device=features.device)
+    assert out.is_contiguous() and out.dtype == features.dtype and tuple(out.shape) == (batch_size, C, *shape)
     rc = L.fnp_sparse_to_dense(_l.ptr(features), _l.dtype_code(features), _l.ptr(indices), _l.ptr(n_dev),
-                               max(indices.shape[0], 1), C, batch_size, *shape, _l.ptr(out), _l.stream())
+                               max(indices.shape[0], 1), C, batch_size, *shape, _l.ptr(out), _l.ptr(workspace),
+                               workspace.numel(), _l.stream())
     _l.check(rc, "fnp_sparse_to_dense")
     return out

@@ -211,9 +211,14 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
                        int hints, int Cin, int Cout, fnp_stream_t stream);
 
 /* SparseConvTensor.dense() as used by HeightCompression (height_compression.py:20-24):
- * feats (n,C) -> out (B,C,D,H,W) of out_dtype, which must be zero on entry. */
+ * feats (n,C) -> out (B,C,D,H,W) of the same dtype (viewed as (B, C*D, H, W) by the caller).
+ * With a workspace of fnp_sparse_to_dense_workspace_bytes() (a cell -> row map) every element of
+ * `out` is written exactly once, zeros included, in 128-byte segments: `out` need not be zeroed.
+ * With workspace == NULL a row-driven scatter runs and `out` must be zero on entry. */
+int64_t fnp_sparse_to_dense_workspace_bytes(int B, int D, int H, int W);
 int fnp_sparse_to_dense(const void *feats, int dtype, const int *coords, const int *n_rows, int cap,
-                        int C, int B, int D, int H, int W, void *out, fnp_stream_t stream);
+                        int C, int B, int D, int H, int W, void *out,
+                        void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Greedy Box Seeker — replaces hot loops 2-4 of FrustumProposerOG.get_proposals

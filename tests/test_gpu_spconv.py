@@ -286,3 +286,39 @@ def test_forward_points_full_size_properties(cuda, oracle):
     want = oracle.backbone_forward(sd, res["voxel_features"].cpu().numpy(), coords, 3, [41, 1440, 1440], bf16=True)
     for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out"):
         _check_stage(res[name], want[name], 3e-2, 3e-2, bf16=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape,C,B,n", [((2, 180, 180), 128, 3, 9000), ((2, 11, 12), 128, 2, 150), ((3, 7, 5), 6, 1, 40),
+                                          ((1, 9, 70), 33, 2, 300), ((2, 16, 16), 16, 2, 0)])
+def test_dense_writes_every_element_once(cuda, rng, dtype, shape, C, B, n):
+    """fnp_sparse_to_dense with a workspace (height_compression.py:20-24): exact copy of the rows, zeros
+    elsewhere, on a DIRTY output buffer; odd row sizes fall back to memset + scatter; and the
+    HeightCompression module view."""
+    from findnpropagate_amd import sparse as S
+    from findnpropagate_amd import spconv
+    from findnpropagate_amd.backbones_2d import HeightCompression
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    feats, idx = _random_sparse(rng, B, shape, max(n, 1), C)
+    feats, idx = feats[:n], idx[:n]
+    f = torch.from_numpy(feats).to(cuda).to(td)
+    cap = max(n, 1) + 7                                   # rows beyond n are garbage and must be ignored
+    fpad = torch.full((cap, C), 7.0, device=cuda, dtype=td)
+    ipad = torch.full((cap, 4), 0, device=cuda, dtype=torch.int32)
+    fpad[:n] = f
+    ipad[:n] = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    out = torch.full((B, C, *shape), 3.0, device=cuda, dtype=td)          # dirty
+    got = S.to_dense(fpad, ipad, n_dev, B, list(shape), out=out)
+    want = torch.zeros((B, C, *shape), dtype=td)
+    if n:
+        ii = torch.from_numpy(idx).long()
+        want[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]] = f.cpu()
+    assert torch.equal(got.cpu(), want)
+    if n:
+        t = spconv.SparseConvTensor(f, torch.from_numpy(idx).to(cuda), list(shape), B)
+        hc = HeightCompression({"NUM_BEV_FEATURES": C * shape[0]})
+        bd = hc({"encoded_spconv_tensor": t, "encoded_spconv_tensor_stride": 8})
+        assert bd["spatial_features_stride"] == 8 and hc.num_bev_features == C * shape[0]
+        assert torch.equal(bd["spatial_features"].cpu(), want.view(B, C * shape[0], shape[1], shape[2]))
