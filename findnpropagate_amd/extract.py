@@ -88,12 +88,22 @@ def save_frame(out_dir, frame_id, pred_dict):
     return path
 
 
-def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank0", resume=True, progress=None):
+RECALL_THRESH = (0.3, 0.5, 0.7)   # extract_pseudo_labels.py:108
+
+
+def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank0", resume=True, progress=None,
+                          recall=None, recall_fn=None):
     """Run `head` (a FrustumProposerOG-like module: forward(batch_dict) -> batch_dict with
     'final_box_dicts') over `dataset` sharded across the process group.
 
     dataset: len(), __getitem__(i) -> batch_dict for ONE scene (batch_size 1; tensors on `device` or
              CPU) with 'frame_id' (str) — the collated form extract_pseudo_labels.py:115 iterates.
+    recall:  optional dict; when given and the scenes carry 'gt_boxes', the running recall of
+             extract_pseudo_labels.py:108-131 is kept (Detector3DTemplate.generate_recall_record per
+             frame, thresholds 0.3/0.5/0.7) and, at the end, summed over the ranks with one all-reduce
+             of the counter vector (wrap-around duplicates are counted once); `recall` then holds the
+             totals plus 'recall_<thr>' = rcnn_<thr> / gt.  recall_fn: the record function
+             (default Detector3DTemplate.generate_recall_record; the CPU tests inject a counter).
     Returns the number of frames this rank wrote.
     """
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
@@ -102,6 +112,7 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
     n = len(dataset)
     mine = shard_indices(n, rank, world)
     written = 0
+    rec_local = {}
     head.eval()
     with torch.no_grad():
         for step, index in enumerate(mine):
@@ -114,6 +125,12 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
             else:
                 pred = head.forward(data)["final_box_dicts"][0]
                 index_tag = index
+                duplicate = step * world + rank >= n      # wrap-around padding of the sampler
+                if recall is not None and "gt_boxes" in data and not duplicate:
+                    if recall_fn is None:
+                        from .detectors import Detector3DTemplate
+                        recall_fn = Detector3DTemplate.generate_recall_record
+                    rec_local = recall_fn(pred["pred_boxes"], rec_local, 0, data, thresh_list=list(RECALL_THRESH))
             rec, meta = pack_record(pred, index_tag, device)
             recs, metas = all_gather_records(rec, meta, dist)
             for r in range(recs.shape[0]):
@@ -131,6 +148,18 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
                 written += 1
             if progress is not None:
                 progress(step, len(mine))
+    if recall is not None:
+        keys = ["gt", "num_3known", "num_6known", "num_4unknown", "num_7unknown"]
+        for t in RECALL_THRESH:
+            keys += [stem % str(t) for stem in ("roi_%s", "rcnn_%s", "rcnn_3known_%s", "rcnn_6known_%s", "rcnn_4unknown_%s",
+                                                "rcnn_7unknown_%s")]
+        vec = torch.tensor([float(rec_local.get(k, 0)) for k in keys], dtype=torch.float64, device=device)
+        if dist is not None and dist.is_initialized() and world > 1:
+            dist.all_reduce(vec)
+        recall.clear()
+        recall.update({k: int(v) for k, v in zip(keys, vec.cpu().tolist())})
+        for t in RECALL_THRESH:
+            recall["recall_%s" % str(t)] = recall["rcnn_%s" % str(t)] / max(recall["gt"], 1)
     if dist is not None and dist.is_initialized():
         dist.barrier()
     return written

@@ -316,3 +316,61 @@ def backbone_forward(params, voxel_features, voxel_coords, batch_size, sparse_sh
     o = sparse_conv(x_conv4, W("conv_out.0.weight"), (2, 1, 1), last_pad)   # :228-234, kernel (3,1,1)
     out = post(o, o.features, "conv_out.1")
     return {"x_conv1": x_conv1, "x_conv2": x_conv2, "x_conv3": x_conv3, "x_conv4": x_conv4, "out": out}
+
+
+# ---- recall bookkeeping and class NMS (host logic around the IoU / NMS operators) ----------------
+ALL_CLASS_NAMES = ['car', 'truck', 'construction_vehicle', 'bus', 'trailer', 'barrier', 'motorcycle', 'bicycle',
+                   'pedestrian', 'traffic_cone']                                   # detector3d_template.py:15-16
+KNOWN3 = [ALL_CLASS_NAMES.index(x) + 1 for x in ('car', 'bicycle', 'pedestrian')]   # :17,21
+KNOWN6 = [ALL_CLASS_NAMES.index(x) + 1 for x in ('car', 'construction_vehicle', 'trailer', 'barrier', 'bicycle',
+                                                  'pedestrian')]                   # :18-19,22
+
+
+def generate_recall_record(box_preds, recall_dict, gt_boxes, rois, thresh_list):
+    """detector3d_template.py:314-399, statement by statement, in numpy (gt_boxes (G, 7+..+1) with the
+    class label last and all-zero padding rows at the end; rois (R,7+) or None)."""
+    if len(recall_dict) == 0:
+        recall_dict = {'gt': 0, 'num_3known': 0, 'num_6known': 0, 'num_4unknown': 0, 'num_7unknown': 0}
+        for t in thresh_list:
+            for stem in ('roi_%s', 'rcnn_%s', 'rcnn_3known_%s', 'rcnn_6known_%s', 'rcnn_4unknown_%s', 'rcnn_7unknown_%s'):
+                recall_dict[stem % str(t)] = 0
+    cur_gt = np.asarray(gt_boxes, np.float32)
+    k = len(cur_gt) - 1
+    while k >= 0 and cur_gt[k].sum() == 0:
+        k -= 1
+    cur_gt = cur_gt[:k + 1]
+    if cur_gt.shape[0] > 0:
+        labels = cur_gt[:, -1].astype(np.int64)
+        k3 = np.array([l in KNOWN3 for l in labels]); k6 = np.array([l in KNOWN6 for l in labels])
+        recall_dict['num_3known'] += int(k3.sum()); recall_dict['num_6known'] += int(k6.sum())
+        recall_dict['num_7unknown'] += int((~k3).sum()); recall_dict['num_4unknown'] += int((~k6).sum())
+        iou_rcnn = boxes_iou3d(box_preds[:, :7], cur_gt[:, :7]) if box_preds.shape[0] > 0 else np.zeros((0, cur_gt.shape[0]), np.float32)
+        iou_roi = boxes_iou3d(rois[:, :7], cur_gt[:, :7]) if rois is not None else None
+        for t in thresh_list:
+            if iou_rcnn.shape[0] > 0:
+                hit = iou_rcnn.max(axis=0) > np.float32(t)
+                recall_dict['rcnn_%s' % str(t)] += int(hit.sum())
+                recall_dict['rcnn_3known_%s' % str(t)] += int((hit & k3).sum())
+                recall_dict['rcnn_6known_%s' % str(t)] += int((hit & k6).sum())
+                recall_dict['rcnn_7unknown_%s' % str(t)] += int((hit & ~k3).sum())
+                recall_dict['rcnn_4unknown_%s' % str(t)] += int((hit & ~k6).sum())
+            if iou_roi is not None:
+                recall_dict['roi_%s' % str(t)] += int((iou_roi.max(axis=0) > np.float32(t)).sum())
+        recall_dict['gt'] += cur_gt.shape[0]
+    return recall_dict
+
+
+def class_agnostic_nms(box_scores, box_preds, nms_type, thresh, pre_max, post_max, score_thresh=None):
+    """model_nms_utils.py:6-27 in numpy (stable top-k; ties are the caller's concern)."""
+    src = np.asarray(box_scores, np.float32)
+    idx0 = np.arange(src.shape[0])
+    if score_thresh is not None:
+        m = src >= np.float32(score_thresh)
+        idx0 = idx0[m]
+    sc, bx = src[idx0], np.asarray(box_preds, np.float32)[idx0]
+    if sc.shape[0] == 0:
+        return np.zeros((0,), np.int64), np.zeros((0,), np.float32)
+    order = np.argsort(-sc, kind="stable")[:min(pre_max, sc.shape[0])]
+    keep = nms_gpu(bx[order][:, :7], sc[order], thresh, rotated=(nms_type == "nms_gpu"))
+    sel = idx0[order[keep[:post_max]]]
+    return sel, src[sel]

@@ -24,7 +24,8 @@ class FakeScenes:
         return f"n015-2018-{i:04d}.pcd.bin"
 
     def __getitem__(self, i):
-        return {"frame_id": self.frame_id(i), "index": i, "batch_size": 1}
+        # (i + 2) ground-truth rows: the recall counters below depend on the scene index
+        return {"frame_id": self.frame_id(i), "index": i, "batch_size": 1, "gt_boxes": torch.ones((1, i + 2, 10))}
 
 
 class FakeHead(torch.nn.Module):
@@ -72,13 +73,39 @@ def _free_port():
     return p
 
 
+def _count_recall(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):
+    """stand-in for generate_recall_record (which needs the GPU IoU): gt rows and predictions per frame"""
+    if not recall_dict:
+        recall_dict = {"gt": 0}
+        for t in thresh_list:
+            recall_dict["rcnn_%s" % str(t)] = 0
+    recall_dict["gt"] += int(data_dict["gt_boxes"][batch_index].shape[0])
+    for j, t in enumerate(thresh_list):
+        recall_dict["rcnn_%s" % str(t)] += int(box_preds.shape[0]) + j
+    return recall_dict
+
+
+def _expected_recall(n):
+    gt = sum(i + 2 for i in range(n))
+    out = {"gt": gt}
+    for j, t in enumerate(E.RECALL_THRESH):
+        out["rcnn_%s" % str(t)] = sum(i % 5 + j for i in range(n))
+        out["recall_%s" % str(t)] = out["rcnn_%s" % str(t)] / gt
+    return out
+
+
 def _worker(rank, world, port, out_dir, n, write):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        E.extract_pseudo_labels(FakeScenes(n), FakeHead(), out_dir, torch.device("cpu"), dist=dist, write=write)
+        rec = {}
+        E.extract_pseudo_labels(FakeScenes(n), FakeHead(), out_dir, torch.device("cpu"), dist=dist, write=write,
+                                recall=rec, recall_fn=_count_recall)
+        # every rank ends with the totals over ALL scenes, wrap-around duplicates counted once
+        want = _expected_recall(n)
+        assert {k: rec[k] for k in want} == want, (rank, rec, want)
     finally:
         dist.destroy_process_group()
 
@@ -87,7 +114,10 @@ def _worker(rank, world, port, out_dir, n, write):
 def test_two_ranks_equal_one_rank(write):
     n = 7   # odd: exercises the wrap-around padding of the last step
     with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as d2:
-        assert E.extract_pseudo_labels(FakeScenes(n), FakeHead(), d1, torch.device("cpu")) == n
+        rec1 = {}
+        assert E.extract_pseudo_labels(FakeScenes(n), FakeHead(), d1, torch.device("cpu"), recall=rec1, recall_fn=_count_recall) == n
+        want = _expected_recall(n)
+        assert {k: rec1[k] for k in want} == want
         mp.spawn(_worker, args=(2, _free_port(), d2, n, write), nprocs=2, join=True)
         files1, files2 = sorted(os.listdir(d1)), sorted(os.listdir(d2))
         assert files1 == files2 == sorted(f"n015-2018-{i:04d}_pcd_bin.pth" for i in range(n))

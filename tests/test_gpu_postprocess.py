@@ -1,0 +1,67 @@
+"""Host logic around the IoU/NMS operators on the extraction path: generate_recall_record
+(detector3d_template.py:314-399, called by tools/extract_pseudo_labels.py:124) and the class NMS helpers
+(model_nms_utils.py:6-66), against the oracle's statement-by-statement numpy restatements."""
+import numpy as np
+import pytest
+import torch
+
+from findnpropagate_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+THRESH = [0.3, 0.5, 0.7]
+
+
+def _gt(rng, n, pad):
+    g = np.zeros((n + pad, 10), np.float32)
+    g[:n, :7] = syn.random_boxes(rng, n, centre_range=15.0)
+    g[:n, 7:9] = rng.normal(size=(n, 2))
+    g[:n, 9] = rng.integers(1, 11, size=n)
+    return g
+
+
+@pytest.mark.parametrize("n_gt,pad,n_pred,with_rois", [(12, 3, 30, False), (20, 0, 25, True), (5, 4, 0, True), (0, 6, 9, False)])
+def test_generate_recall_record(cuda, oracle, rng, n_gt, pad, n_pred, with_rois):
+    from findnpropagate_amd.detectors import Detector3DTemplate
+    gt = _gt(rng, n_gt, pad)
+    preds = syn.random_boxes(rng, n_pred, centre_range=15.0) if n_pred else np.zeros((0, 7), np.float32)
+    # make a good share of the predictions sit on ground-truth boxes with a perturbation
+    for i in range(min(n_pred, n_gt)):
+        preds[i] = gt[i, :7] + rng.normal(scale=[0.2, 0.2, 0.1, 0.2, 0.2, 0.1, 0.1]).astype(np.float32)
+    rois = preds[: max(n_pred // 2, 1)] + np.float32(0.05) if with_rois and n_pred else (syn.random_boxes(rng, 4) if with_rois else None)
+    data = {"gt_boxes": torch.from_numpy(gt)[None].to(cuda)}
+    if rois is not None:
+        data["rois"] = torch.from_numpy(rois)[None].to(cuda)
+    want, got = {}, {}
+    for rep in range(2):   # accumulation over two calls
+        got = Detector3DTemplate.generate_recall_record(torch.from_numpy(preds).to(cuda), got, 0, data, thresh_list=THRESH)
+        want = oracle.generate_recall_record(preds, want, gt, rois, THRESH)
+    assert got == want
+    if n_gt and n_pred:
+        assert got["rcnn_0.3"] > 0 and got["gt"] == 2 * n_gt
+    assert Detector3DTemplate.generate_recall_record(torch.from_numpy(preds).to(cuda), {}, 0, {}, thresh_list=THRESH) == {}
+
+
+@pytest.mark.parametrize("nms_type", ["nms_gpu", "nms_normal_gpu"])
+@pytest.mark.parametrize("score_thresh", [None, 0.35])
+def test_class_agnostic_and_multi_class_nms(cuda, oracle, rng, nms_type, score_thresh):
+    from findnpropagate_amd.model_utils import model_nms_utils as M
+    n = 300
+    boxes = syn.random_boxes(rng, n, centre_range=12.0)
+    boxes9 = np.concatenate([boxes, rng.normal(size=(n, 2)).astype(np.float32)], 1)
+    scores = rng.permutation(n).astype(np.float32) / n          # distinct scores: no tie ambiguity
+    cfg = {"NMS_TYPE": nms_type, "NMS_THRESH": 0.2, "NMS_PRE_MAXSIZE": 200, "NMS_POST_MAXSIZE": 50}
+    sel, sc = M.class_agnostic_nms(torch.from_numpy(scores).to(cuda), torch.from_numpy(boxes9).to(cuda), cfg, score_thresh)
+    w_sel, w_sc = oracle.class_agnostic_nms(scores, boxes9, nms_type, 0.2, 200, 50, score_thresh)
+    assert np.array_equal(sel.cpu().numpy(), w_sel) and np.array_equal(sc.cpu().numpy(), w_sc)
+    assert 0 < len(w_sel) <= 50
+
+    class Cfg:   # attribute-style config (EasyDict in the reference)
+        NMS_TYPE, NMS_THRESH, NMS_PRE_MAXSIZE, NMS_POST_MAXSIZE = nms_type, 0.2, 100, 20
+    cls = np.stack([scores, rng.permutation(n).astype(np.float32) / n, np.zeros(n, np.float32)], 1)
+    ps, pl, pb = M.multi_classes_nms(torch.from_numpy(cls).to(cuda), torch.from_numpy(boxes9).to(cuda), Cfg, score_thresh)
+    ws, wl, wb = [], [], []
+    for k in range(3):
+        s_k, _ = oracle.class_agnostic_nms(cls[:, k], boxes9, nms_type, 0.2, 100, 20, score_thresh)
+        ws.append(cls[s_k, k]); wl.append(np.full(len(s_k), k, np.int64)); wb.append(boxes9[s_k])
+    assert np.array_equal(ps.cpu().numpy(), np.concatenate(ws)) and np.array_equal(pl.cpu().numpy(), np.concatenate(wl))
+    assert np.array_equal(pb.cpu().numpy(), np.concatenate(wb))
