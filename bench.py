@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="scenes per step per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="scenes per step per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes timed through the CPU oracle (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket conv launches with events")
@@ -163,10 +163,10 @@ def main():
                  if args.dtype == "bf16" else "spconv_valu_kernel")
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
         # WRITE_SIZE in separate runs of this same command, gfx950 FETCH_SIZE x2 correction applied:
-        # profiles/r01_pmc_traffic_b16.json); only quoted when the batch matches, else null
+        # profiles/r01_pmc_traffic_b<B>.json); only quoted when a profile of this batch size is committed, else null
         traffic = None
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_b16.json")))
+            pj = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{B}.json")))
             if pj.get("batch") == B and kname in pj["kernels"]:
                 traffic = pj["kernels"][kname]["hbm_bytes_corrected"]
         except Exception:
