@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="scenes per step per GPU")
+    ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph (small batches "
+                                                          "are launch-bound); per-kernel events are not recorded")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes timed through the CPU oracle (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket conv launches with events")
@@ -81,6 +83,8 @@ def main():
 
     def step():
         with torch.no_grad():
+            if args.graph and eng.rulebook_log is None and eng.profile is None:
+                return net.forward_points_graphed(pts, off, B, cfg)
             return net.forward_points(pts, off, B, cfg)  # ends with the one host sync that sizes the outputs
 
     def barrier():
@@ -105,7 +109,7 @@ def main():
         stats.setdefault(("tags", tag), []).append((stats[key], n))
     torch.cuda.synchronize()
 
-    if not args.no_events:
+    if not args.no_events and not args.graph:
         eng.profile = []
     barrier()
     t0 = time.perf_counter()
@@ -138,7 +142,8 @@ def main():
                    "scenes_per_step_per_gpu": B, "points_per_scene": int(pts_np.shape[0] // B),
                    "voxels_per_scene": int(counts[0] // B), "sparse_shape": [41, 1440, 1440],
                    "site_counts": [int(c) for c in counts], "weights": "seeded random init",
-                   "parallelism": f"scenes sharded {world}x, no data-path collective"},
+                   "parallelism": f"scenes sharded {world}x, no data-path collective",
+                   "launch": "hipGraph replay" if args.graph else "stream launches"},
     }
 
     if rank == 0 and prof:

@@ -232,6 +232,40 @@ class VoxelResBackBone8x(_BackboneBase):
         'voxel_features'."""
         return self.engine().run_points(points, batch_offsets, batch_size, voxel_cfg, sync=sync)
 
+    def forward_points_graphed(self, points, batch_offsets, batch_size, voxel_cfg, capacity=None):
+        """forward_points replayed from a captured hipGraph (one graph launch instead of ~100 kernel
+        launches: small batches are launch-bound).  Same results; the returned tensors are views of the
+        graph's static buffers and are overwritten by the next call with the same (batch_size, capacity).
+        capacity: point capacity of the graph (default: N rounded up to 64 Ki)."""
+        return self.engine().run_points_graphed(points, batch_offsets, batch_size, voxel_cfg, capacity)
+
+
+class _PointsGraph:
+    """Static inputs + captured forward of one (batch_size, point capacity) configuration."""
+    FAR = 1.0e9   # padding points: outside every range, dropped by the voxeliser
+
+    def __init__(self, engine, capacity, n_feat, batch_size, voxel_cfg, device):
+        self.engine, self.capacity, self.batch_size = engine, capacity, batch_size
+        self.pts = torch.full((capacity, n_feat), self.FAR, dtype=torch.float32, device=device)
+        self.off = torch.zeros((batch_size + 1,), dtype=torch.int32, device=device)
+        self.n_prev = 0
+        self.cap_factor = list(engine.cap_factor)
+        self.prep_key = engine._prep_key
+        # warm-up on a side stream (allocations of persistent grids/workspaces, lazy kernel attributes), then capture
+        self._body(voxel_cfg)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.vox, self.res = self._body(voxel_cfg)
+
+    def _body(self, voxel_cfg):
+        e = self.engine
+        grids = e._get_grids(self.batch_size, self.pts.device)
+        vox = S.voxelize(self.pts, self.off, self.batch_size, voxel_cfg, grid=grids[0], workspace=e._vox_ws)
+        e._vox_ws = vox['workspace']
+        res = e._run_once(vox['mean'], vox['coords'], vox['n'], self.batch_size, grids[0], sync=False)
+        return vox, res
+
 
 class FusedResBackbone:
     """Sync-free executor of VoxelResBackBone8x in eval mode (see module docstring)."""
@@ -245,6 +279,7 @@ class FusedResBackbone:
         # capacity of stage l (l = 2..5) as a multiple of the stage-1 capacity; grown on overflow
         self.cap_factor = [3.0, 2.0, 1.0, 1.0]
         self._vox_ws = None
+        self._graphs = {}
         # measurement hooks (bench.py): when `profile` is a list every conv launch is bracketed by
         # stream events, (tag, start, end) appended; `rulebook_log` receives (tag, Rulebook, n_dev)
         self.profile = None
@@ -308,6 +343,43 @@ class FusedResBackbone:
             res['voxel_num_points'] = vox['num_points'][:n1]
             res['voxel_features'] = vox['mean'][:n1]
         return res
+
+    def run_points_graphed(self, points, batch_offsets, batch_size, voxel_cfg, capacity=None):
+        assert self.profile is None and self.rulebook_log is None, "measurement hooks are not capturable"
+        n, C = points.shape
+        capacity = int(capacity) if capacity else max(65536, (n + 65535) // 65536 * 65536)
+        assert n <= capacity
+        self.prepare()
+        key = (batch_size, capacity, C, str(points.device))
+        while True:
+            g = self._graphs.get(key)
+            if g is None or g.cap_factor != self.cap_factor or g.prep_key != self._prep_key:
+                g = _PointsGraph(self, capacity, C, batch_size, voxel_cfg, points.device)
+                self._graphs[key] = g
+            g.pts[:n].copy_(points)
+            if g.n_prev > n:
+                g.pts[n:g.n_prev].fill_(_PointsGraph.FAR)
+            g.n_prev = n
+            g.off.copy_(batch_offsets)
+            g.graph.replay()
+            stage, caps, shapes = g.res['stages'], g.res['caps'], g.res['shapes']
+            counts = torch.cat([s[2] for s in stage]).cpu().tolist()   # the one host sync
+            overflow = False
+            for l in range(1, 5):
+                if counts[l] > caps[l]:
+                    self.cap_factor[l - 1] = max(self.cap_factor[l - 1] * 2.0, counts[l] * 1.25 / caps[0])
+                    overflow = True
+            if not overflow:
+                break
+            for gr in self._get_grids(batch_size, points.device):   # see _run_once: the sparse clear missed cells
+                gr.zero_()
+            del self._graphs[key]                                  # recapture with the larger buffers
+        tensors = [spconv.SparseConvTensor(x[:counts[l]], idx[:counts[l]], shapes[l], batch_size, n_dev=nd)
+                   for l, (x, idx, nd, _) in enumerate(stage)]
+        n1 = counts[0]
+        return {'x_conv1': tensors[0], 'x_conv2': tensors[1], 'x_conv3': tensors[2], 'x_conv4': tensors[3],
+                'out': tensors[4], 'counts': counts, 'voxel_coords': g.vox['coords'][:n1],
+                'voxel_num_points': g.vox['num_points'][:n1], 'voxel_features': g.vox['mean'][:n1]}
 
     def run(self, feats, indices, n1, batch_size, grid1=None, sync=True):
         """feats (cap1,Cin) f32, indices (cap1,4) i32, n1 (1,) i32 device."""

@@ -187,7 +187,7 @@ struct MfmaCfg {
 };
 
 // Development-only ablation bit mask (tools/bench_conv.py with FNP_LIB_PATH): 1 = no feature gathers,
-// 2 = no weight staging, 4 = no MFMA.  The shipped library is built with FNP_ABLATE == 0.
+// 2 = no weight staging, 4 = no MFMA, 8 = window kernels issue no global gathers, 16 = no window reads.  The shipped library is built with FNP_ABLATE == 0.
 #ifndef FNP_ABLATE
 #define FNP_ABLATE 0
 #endif
@@ -248,7 +248,8 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                                                         : (unsigned)id * (unsigned)(CIN * 2) + (unsigned)q * 16u;
     };
     auto gather = [&](unsigned roff, int ks) -> bf16x8 {
-        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, roff + (unsigned)ks * 64u, 0, 0);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (!(WIN && (FNP_ABLATE & 8))) v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, roff + (unsigned)ks * 64u, 0, 0);
         return *reinterpret_cast<bf16x8 *>(&v);
     };
     // rulebook entry of row r for offset k; rows past the range and offsets past K read a valid
@@ -281,7 +282,10 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
         return ((FNP_ABLATE & 1) || id < 0 || d < (unsigned)WROWS) ? 0x80000000u
                                                                     : (unsigned)id * (unsigned)(CIN * 2) + (unsigned)q * 16u;
     };
-    auto win_read = [&](unsigned off) -> u32x4 { return *reinterpret_cast<const u32x4 *>(fnp_smem + off); };
+    auto win_read = [&](unsigned off) -> u32x4 {
+        if (FNP_ABLATE & 16) return u32x4{off, 0u, 0u, 0u};
+        return *reinterpret_cast<const u32x4 *>(fnp_smem + off);
+    };
 
     // Work split: the n rows are cut into gridDim.x contiguous ranges of (almost) equal numbers of
     // 16-row blocks, so every workgroup finishes at about the same time whatever n is.  Range r
@@ -609,7 +613,10 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
 // 64 -> 64 channels 132 -> 120 us; 32 -> 32 channels 78 -> 115 us (the per-fragment address
 // arithmetic and OR of the dual-source operand outweigh the saved gathers at 8 MFMAs per offset),
 // so only the 64-channel layers take it.
-template <int CIN, int COUT> struct HasWindow { static constexpr bool value = CIN == 64 && COUT == 64; };
+#ifndef FNP_WIN32
+#define FNP_WIN32 0
+#endif
+template <int CIN, int COUT> struct HasWindow { static constexpr bool value = (CIN == 64 && COUT == 64) || (FNP_WIN32 && CIN == 32 && COUT == 32); };
 
 template <int CIN, int COUT, typename TOut>
 int launch_mfma(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out,

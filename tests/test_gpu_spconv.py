@@ -322,3 +322,31 @@ def test_dense_writes_every_element_once(cuda, rng, dtype, shape, C, B, n):
         bd = hc({"encoded_spconv_tensor": t, "encoded_spconv_tensor_stride": 8})
         assert bd["spatial_features_stride"] == 8 and hc.num_bev_features == C * shape[0]
         assert torch.equal(bd["spatial_features"].cpu(), want.view(B, C * shape[0], shape[1], shape[2]))
+
+
+@pytest.mark.gpu
+def test_graphed_forward_equals_eager(cuda):
+    """forward_points_graphed (hipGraph replay, padded static inputs) returns exactly what forward_points
+    returns, for inputs of different sizes replayed on the same captured graph."""
+    from findnpropagate_amd import sparse as S, synthetic as syn
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 0).to(cuda).eval()
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+    n_graphs = []
+    for seeds in ([0, 1], [2, 3], [4, 5]):
+        pts, off = syn.make_batch(seeds)
+        if seeds == [4, 5]:
+            pts, off = pts[: off[2] - 5000], off.copy()    # fewer points than the call before: stale padding must go
+            off[2] = pts.shape[0]
+        pts, off = torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda)
+        with torch.no_grad():
+            want = net.forward_points(pts, off, 2, cfg)
+            want = {k: (v.features.clone(), v.indices.clone()) if hasattr(v, "features") else v for k, v in want.items()}
+            got = net.forward_points_graphed(pts, off, 2, cfg, capacity=80000)
+        assert got["counts"] == want["counts"]
+        for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out"):
+            assert torch.equal(got[k].features, want[k][0]) and torch.equal(got[k].indices, want[k][1]), k
+        assert torch.equal(got["voxel_coords"], want["voxel_coords"]) and torch.equal(got["voxel_features"], want["voxel_features"])
+        n_graphs.append(len(net.engine()._graphs))
+    assert n_graphs == [1, 1, 1], "one capture serves every call of that (batch, capacity)"
