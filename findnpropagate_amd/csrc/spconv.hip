@@ -664,6 +664,10 @@ int dispatch_bf16(const void *x, long long n_in, const void *w, const int *nbr, 
     FNP_CASE(64, 64)
     FNP_CASE(64, 128)
     FNP_CASE(128, 128)
+    // transposed channel pairs: the data gradients of the three channel-doubling convolutions
+    FNP_CASE(32, 16)
+    FNP_CASE(64, 32)
+    FNP_CASE(128, 64)
 #undef FNP_CASE
     return launch_valu<__bf16, TOut>(x, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual, relu, Cin, Cout, s);
 }

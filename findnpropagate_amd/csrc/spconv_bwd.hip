@@ -1,0 +1,164 @@
+// Backward of the sparse convolution (spconv's autograd behind SubMConv3d /
+// SparseConv3d in the self-training step, tools/train_st.py; call sites spconv_backbone.py:12-17,39-46).
+//
+//   forward   out[o] = sum_k W_k^T x[nbr[k][o]]                        W_k: (Cout, Cin)
+//   dgrad     dx[i]  = sum_k W_k  dy[nbrT[k][i]]    nbrT[k][i] = o  <=>  nbr[k][o] = i
+//             = the forward kernel on the TRANSPOSED rulebook with the (Cin, Cout) transposed slabs, so
+//               it runs on the same MFMA / VALU implicit-GEMM kernels (fnp_spconv_forward); only the
+//               transposition of the rulebook is new (one scatter, each (k, i) has at most one o)
+//   wgrad     dW_k   = sum_o dy[o] (x) x[nbr[k][o]]                     (Cout, Cin) per offset
+//             two stages, no atomics: every (row chunk, offset) workgroup accumulates its Cout x Cin
+//             block in registers from LDS-staged row tiles (f32), writes a partial, and a second kernel
+//             adds the partials in chunk order -> bit-reproducible gradients.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__global__ __launch_bounds__(kThreads) void transpose_rulebook_kernel(const int *__restrict__ nbr, int nbr_stride, int K,
+                                                                      const int *__restrict__ n_out, int cap_out,
+                                                                      int *__restrict__ nbr_t, int cap_in) {
+    const int n = min(*n_out, cap_out);
+    const int k = blockIdx.y;
+    for (int o = blockIdx.x * kThreads + threadIdx.x; o < n; o += gridDim.x * kThreads) {
+        const int i = nbr[(size_t)k * nbr_stride + o];
+        if (i >= 0 && i < cap_in) nbr_t[(size_t)k * cap_in + i] = o;
+    }
+}
+
+__device__ __forceinline__ float ld_f32(const float *p) { return *p; }
+__device__ __forceinline__ float ld_f32(const __bf16 *p) { return (float)*p; }
+
+// grid (chunks, K).  TR rows per tile; LDS: dy tile (TR x Cout) + x tile (TR x Cin), f32.
+// Thread t owns the pairs p = t + 256 j (co = p / Cin, ci = p % Cin), at most PMAX of them.
+template <typename TX, typename TY, int PMAX>
+__global__ __launch_bounds__(kThreads) void wgrad_partial_kernel(const TX *__restrict__ x, const TY *__restrict__ dy,
+                                                                 const int *__restrict__ nbr, int nbr_stride,
+                                                                 const int *__restrict__ n_out, int cap_out, int rows_per_chunk,
+                                                                 int Cin, int Cout, float *__restrict__ partial) {
+    constexpr int TR = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fnp_wg_smem[];
+    float *sy = reinterpret_cast<float *>(fnp_wg_smem);   // [TR][Cout]
+    float *sx = sy + TR * Cout;                           // [TR][Cin]
+    __shared__ int sidx[TR];
+    const int n = min(*n_out, cap_out);
+    const int k = blockIdx.y, chunk = blockIdx.x, K = gridDim.y;
+    const int r0 = chunk * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    const int pairs = Cin * Cout;
+    float acc[PMAX];
+#pragma unroll
+    for (int j = 0; j < PMAX; ++j) acc[j] = 0.f;
+    for (int t0 = r0; t0 < r1; t0 += TR) {
+        __syncthreads();
+        if (threadIdx.x < TR) {
+            const int r = t0 + threadIdx.x;
+            sidx[threadIdx.x] = r < r1 ? nbr[(size_t)k * nbr_stride + r] : -1;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < TR * Cout; e += kThreads) {
+            const int rr = e / Cout, c = e % Cout, r = t0 + rr;
+            sy[e] = (r < r1 && sidx[rr] >= 0) ? ld_f32(dy + (size_t)r * Cout + c) : 0.f;
+        }
+        for (int e = threadIdx.x; e < TR * Cin; e += kThreads) {
+            const int rr = e / Cin, c = e % Cin, id = sidx[rr];
+            sx[e] = id >= 0 ? ld_f32(x + (size_t)id * Cin + c) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PMAX; ++j) {
+            const int p = threadIdx.x + j * kThreads;
+            if (p < pairs) {
+                const int co = p / Cin, ci = p % Cin;
+                float a = acc[j];
+#pragma unroll
+                for (int rr = 0; rr < TR; ++rr) a = fmaf(sy[rr * Cout + co], sx[rr * Cin + ci], a);
+                acc[j] = a;
+            }
+        }
+    }
+    float *out = partial + ((size_t)chunk * K + k) * pairs;
+#pragma unroll
+    for (int j = 0; j < PMAX; ++j) {
+        const int p = threadIdx.x + j * kThreads;
+        if (p < pairs) out[p] = acc[j];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float *__restrict__ partial, int chunks, long long total,
+                                                                float *__restrict__ dw) {
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kThreads) {
+        float s = 0.f;
+        for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * total + e];   // fixed order
+        dw[e] = s;
+    }
+}
+
+constexpr int kMaxChunks = 32;
+
+template <typename TX, typename TY>
+int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, float *dw,
+              int Cin, int Cout, void *ws, int64_t ws_bytes, hipStream_t s) {
+    const long long pairs = (long long)Cin * Cout, total = pairs * K;
+    if (pairs > 64 * kThreads) return FNP_ERR_ARG;   // <= 128 x 128
+    int chunks = fnp_divup(cap_out, 2048);
+    if (chunks > kMaxChunks) chunks = kMaxChunks;
+    if (chunks < 1) chunks = 1;
+    const int rows_per_chunk = fnp_divup(fnp_divup(cap_out, chunks), 16) * 16;
+    if ((long long)chunks * total * 4 > ws_bytes) return FNP_ERR_WORKSPACE;
+    const size_t lds = (size_t)16 * (Cin + Cout) * 4;
+    const dim3 grid(chunks, K);
+    float *partial = (float *)ws;
+#define FNP_WG(P)                                                                                                          \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_partial_kernel<TX, TY, P>), grid, dim3(kThreads), lds, s, (const TX *)x,         \
+                       (const TY *)dy, nbr, nbr_stride, n_out, cap_out, rows_per_chunk, Cin, Cout, partial)
+    if (pairs <= 4 * kThreads) FNP_WG(4);
+    else if (pairs <= 16 * kThreads) FNP_WG(16);
+    else FNP_WG(64);
+#undef FNP_WG
+    FNP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fnp_grid_for(total, kThreads)), dim3(kThreads), 0, s, (const float *)partial, chunks,
+                       total, dw);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+}  // namespace
+
+extern "C" int fnp_rulebook_transpose(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int *nbr_t,
+                                      int cap_in, fnp_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!nbr || !n_out || !nbr_t || K <= 0 || cap_out <= 0 || cap_in <= 0 || nbr_stride < cap_out) return FNP_ERR_ARG;
+    FNP_HIP_TRY(hipMemsetAsync(nbr_t, 0xff, sizeof(int) * (size_t)K * cap_in, s));
+    hipLaunchKernelGGL(transpose_rulebook_kernel, dim3(fnp_grid_for(cap_out, kThreads, 1024), K), dim3(kThreads), 0, s, nbr,
+                       nbr_stride, K, n_out, cap_out, nbr_t, cap_in);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+extern "C" int64_t fnp_spconv_wgrad_workspace_bytes(int K, int Cin, int Cout) {
+    if (K <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    return (int64_t)kMaxChunks * K * Cin * Cout * 4;
+}
+
+extern "C" int fnp_spconv_wgrad(const void *feat_in, int in_dtype, const void *grad_out, int grad_dtype, const int *nbr,
+                                int nbr_stride, int K, const int *n_out, int cap_out, float *grad_weight, int Cin, int Cout,
+                                void *workspace, int64_t workspace_bytes, fnp_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!feat_in || !grad_out || !nbr || !n_out || !grad_weight || !workspace || K <= 0 || Cin <= 0 || Cout <= 0 ||
+        cap_out <= 0 || nbr_stride < cap_out)
+        return FNP_ERR_ARG;
+    if (in_dtype == FNP_F32 && grad_dtype == FNP_F32)
+        return run_wgrad<float, float>(feat_in, grad_out, nbr, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
+                                       workspace_bytes, s);
+    if (in_dtype == FNP_BF16 && grad_dtype == FNP_BF16)
+        return run_wgrad<__bf16, __bf16>(feat_in, grad_out, nbr, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
+                                         workspace_bytes, s);
+    if (in_dtype == FNP_F32 && grad_dtype == FNP_BF16)
+        return run_wgrad<float, __bf16>(feat_in, grad_out, nbr, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
+                                        workspace_bytes, s);
+    if (in_dtype == FNP_BF16 && grad_dtype == FNP_F32)
+        return run_wgrad<__bf16, float>(feat_in, grad_out, nbr, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
+                                        workspace_bytes, s);
+    return FNP_ERR_ARG;
+}

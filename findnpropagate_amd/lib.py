@@ -110,6 +110,9 @@ SIGNATURES = {
     "fnp_host_enumerate_frustums": (c_int, [P, P, P, P, P, c_int, c_int, POINTER(c_int), c_int, c_float, c_float, P, c_int]),
     "fnp_boxseeker": (c_int, [P, P, c_int, c_int, POINTER(SeekerParams), P, P, P, c_int, P, P, P, P, c_int64,
                               P, P, P, P, P, P, P, P, P, P, P]),
+    "fnp_rulebook_transpose": (c_int, [P, c_int, c_int, P, c_int, P, c_int, P]),
+    "fnp_spconv_wgrad_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "fnp_spconv_wgrad": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, c_int, P, c_int, c_int, P, c_int64, P]),
     "fnp_sparse_to_dense_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "fnp_sparse_to_dense": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64, P]),
 }

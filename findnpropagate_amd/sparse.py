@@ -246,6 +246,47 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
     return out
 
 
+# --------------------------------------------------------------------------------- backward
+def rulebook_transpose(rb, n_out_dev, cap_in):
+    """nbr (K, cap_out) over output rows -> (K, cap_in) over input rows (for the data gradient)."""
+    L = _l.load()
+    nbr_t = torch.empty((rb.K, cap_in), dtype=torch.int32, device=rb.nbr.device)
+    rc = L.fnp_rulebook_transpose(_l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, _l.ptr(n_out_dev), rb.cap_out, _l.ptr(nbr_t), cap_in,
+                                  _l.stream())
+    _l.check(rc, "fnp_rulebook_transpose")
+    return nbr_t
+
+
+def conv_dgrad(grad_out, w_packed, nbr_t, n_in_dev, cap_in):
+    """dx (cap_in, Cin) = sum_k W_k dy[nbr_t[k]]: the forward kernel on the transposed rulebook and slabs.
+    w_packed (K, Cout, Cin) in grad_out's dtype."""
+    L = _l.load()
+    K, Cout, Cin = w_packed.shape
+    w_t = w_packed.transpose(1, 2).contiguous()            # (K, Cin, Cout): "Cout" = Cin, "Cin" = Cout
+    assert grad_out.is_contiguous() and grad_out.dtype == w_t.dtype and grad_out.shape[1] == Cout
+    dx = torch.empty((cap_in, Cin), dtype=grad_out.dtype, device=grad_out.device)
+    rc = L.fnp_spconv_forward(_l.ptr(grad_out), _l.dtype_code(grad_out), grad_out.shape[0], _l.ptr(w_t),
+                              _l.ptr(nbr_t), nbr_t.shape[1], K, _l.ptr(n_in_dev), cap_in,
+                              _l.ptr(dx), _l.dtype_code(dx), None, None, None, 0, 0, Cout, Cin, _l.stream())
+    _l.check(rc, "fnp_spconv_forward (dgrad)")
+    return dx
+
+
+def conv_wgrad(feat_in, grad_out, rb, n_out_dev, Cin, Cout):
+    """dW (K, Cout, Cin) f32 = sum_o dy[o] (x) x[nbr[k][o]] (deterministic two-stage reduction)."""
+    L = _l.load()
+    assert feat_in.is_contiguous() and grad_out.is_contiguous()
+    assert feat_in.shape[1] == Cin and grad_out.shape[1] == Cout
+    dw = torch.empty((rb.K, Cout, Cin), dtype=torch.float32, device=feat_in.device)
+    ws = torch.empty((int(L.fnp_spconv_wgrad_workspace_bytes(rb.K, Cin, Cout)),), dtype=torch.uint8, device=feat_in.device)
+    cap = min(rb.cap_out, grad_out.shape[0])
+    rc = L.fnp_spconv_wgrad(_l.ptr(feat_in), _l.dtype_code(feat_in), _l.ptr(grad_out), _l.dtype_code(grad_out),
+                            _l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, _l.ptr(n_out_dev), cap, _l.ptr(dw), Cin, Cout,
+                            _l.ptr(ws), ws.numel(), _l.stream())
+    _l.check(rc, "fnp_spconv_wgrad")
+    return dw
+
+
 def to_dense(features, indices, n_dev, batch_size, shape, workspace=None, out=None):
     """SparseConvTensor.dense(): (B, C, D, H, W), written once (zeros included) through a cell -> row map.
     workspace / out: optional persistent buffers of a caller that densifies every step."""

@@ -2,8 +2,9 @@
 
 Parameters keep spconv 2.x names and layout so the released checkpoint loads through the
 reference's own loader (detector3d_template.py:401-433): `weight` (Cout,kD,kH,kW,Cin), `bias`.
-Forward only: the backward of the sparse convolution is not built yet and a
-training-mode call with grad enabled raises instead of silently returning a graph-less tensor.
+With grad enabled the convolution runs through `SparseConvFunction`: data gradient
+= the forward kernel on the transposed rulebook, weight gradient = deterministic two-stage reduction
+(`csrc/spconv_bwd.hip`); BatchNorm / ReLU / residual adds stay ordinary torch ops on `.features`.
 """
 import math
 
@@ -17,6 +18,36 @@ from .modules import SparseModule
 
 def _triple(v):
     return [int(x) for x in v] if isinstance(v, (list, tuple)) else [int(v)] * 3
+
+
+class SparseConvFunction(torch.autograd.Function):
+    """out (cap_out, Cout) = sum_k W_k^T x[nbr[k]]  with autograd (features and weight).
+
+    weight is the module parameter (Cout, kD, kH, kW, Cin); computation dtype = features dtype (f32 or
+    bf16), weight gradient accumulated in f32 and returned in the parameter's dtype."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, rb, n_out_dev, n_in_dev):
+        w = S.pack_weight(weight, feats.dtype)
+        out = S.conv_forward(feats, w, rb, n_out_dev)
+        ctx.save_for_backward(feats, weight)
+        ctx.rb, ctx.n_out_dev, ctx.n_in_dev = rb, n_out_dev, n_in_dev
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feats, weight = ctx.saved_tensors
+        rb, n_out_dev, n_in_dev = ctx.rb, ctx.n_out_dev, ctx.n_in_dev
+        grad_out = grad_out.contiguous().to(feats.dtype)
+        K, Cout, Cin = rb.K, weight.shape[0], weight.shape[-1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            nbr_t = S.rulebook_transpose(rb, n_out_dev, feats.shape[0])
+            dx = S.conv_dgrad(grad_out, S.pack_weight(weight, feats.dtype), nbr_t, n_in_dev, feats.shape[0])
+        if ctx.needs_input_grad[1]:
+            dwp = S.conv_wgrad(feats, grad_out, rb, n_out_dev, Cin, Cout)               # (K, Cout, Cin) f32
+            dw = dwp.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
+        return dx, dw, None, None, None
 
 
 class SparseConvolution(SparseModule):
@@ -66,23 +97,26 @@ class SparseConvolution(SparseModule):
 
     def forward(self, input: SparseConvTensor):
         assert isinstance(input, SparseConvTensor)
-        if torch.is_grad_enabled() and self.training and self.weight.requires_grad:
-            raise NotImplementedError(
-                "findnpropagate_amd.spconv: sparse-conv backward is not built yet (forward/inference only); "
-                "call under torch.no_grad() / model.eval()")
-        feats = input.features.detach()
+        with_grad = torch.is_grad_enabled() and (self.weight.requires_grad or input.features.requires_grad)
+        feats = input.features if with_grad else input.features.detach()
         if feats.dtype not in (torch.float32, torch.bfloat16):
             feats = feats.to(torch.bfloat16)
         feats = feats.contiguous()
-        w = self.packed_weight(feats.dtype)
+        w = None if with_grad else self.packed_weight(feats.dtype)
         n_dev = input.n_dev()
+
+        def run(rb, n_out_dev):
+            if with_grad:
+                return SparseConvFunction.apply(feats, self.weight, rb, n_out_dev, n_dev)
+            return S.conv_forward(feats, w, rb, n_out_dev)
+
         if self.subm:
             rb = input.find_indice_pair(self.indice_key)
-            if rb is None or rb.K != w.shape[0]:
+            if rb is None or rb.K != self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]:
                 rb = S.rulebook_subm(input.indices, n_dev, input.rank_grid(), self.kernel_size)
                 if self.indice_key is not None:
                     input.indice_dict[self.indice_key] = rb
-            out_feats = S.conv_forward(feats, w, rb, n_dev)
+            out_feats = run(rb, n_dev)
             if out_feats.shape[0] != feats.shape[0]:
                 out_feats = out_feats[: feats.shape[0]]
             if self.bias is not None:
@@ -99,7 +133,7 @@ class SparseConvolution(SparseModule):
         cap_out = max(1, min(n_in * kvol, cells))
         rb = S.rulebook_strided(input.indices, n_dev, input.rank_grid(), self.kernel_size, self.stride, self.padding,
                                 cap_out)
-        out_feats = S.conv_forward(feats, w, rb, rb.out_n)
+        out_feats = run(rb, rb.out_n)
         n_out = int(rb.out_n.item())
         assert n_out <= cap_out
         out_feats = out_feats[:n_out]

@@ -210,6 +210,24 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
                        const float *scale, const float *shift, const void *residual, int relu,
                        int hints, int Cin, int Cout, fnp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Backward of the sparse convolution (spconv's autograd behind SubMConv3d / SparseConv3d in the
+ * self-training step, tools/train_st.py; modules at spconv_backbone.py:12-17,39-46).
+ *   dgrad: dx[i] = sum_k W_k dy[nbrT[k][i]] = fnp_spconv_forward on the transposed rulebook with the
+ *          transposed slabs (weight (K, Cin, Cout) passed as (K, "Cout"=Cin, "Cin"=Cout)).
+ *   fnp_rulebook_transpose: nbr (K, nbr_stride) over output rows -> nbr_t (K, cap_in) over input rows
+ *          (nbr_t[k][i] = o iff nbr[k][o] = i, else -1).
+ *   fnp_spconv_wgrad: grad_weight (K, Cout, Cin) f32 = sum_o grad_out[o] (x) feat_in[nbr[k][o]];
+ *          deterministic (per-chunk partials in `workspace`, added in chunk order).
+ * ------------------------------------------------------------------------------------------ */
+int fnp_rulebook_transpose(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out,
+                           int *nbr_t, int cap_in, fnp_stream_t stream);
+int64_t fnp_spconv_wgrad_workspace_bytes(int K, int Cin, int Cout);
+int fnp_spconv_wgrad(const void *feat_in, int in_dtype, const void *grad_out, int grad_dtype,
+                     const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out,
+                     float *grad_weight, int Cin, int Cout,
+                     void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
+
 /* SparseConvTensor.dense() as used by HeightCompression (height_compression.py:20-24):
  * feats (n,C) -> out (B,C,D,H,W) of the same dtype (viewed as (B, C*D, H, W) by the caller).
  * With a workspace of fnp_sparse_to_dense_workspace_bytes() (a cell -> row map) every element of

@@ -215,6 +215,27 @@ def conv_apply(features, weight, pin, pout, pn, n_out):
     return out
 
 
+def conv_backward(features, weight, pin, pout, pn, grad_out):
+    """Backward of conv_apply (spconv's autograd), f64 accumulation:
+    dx[i] += W_k dy[o],  dW[co, k, ci] += dy[o, co] x[i, ci]  over the rulebook pairs (k, i, o).
+    Returns (dx (n_in, Cin), dW in the weight's (Cout, kD, kH, kW, Cin) layout), both f32."""
+    features, weight, grad_out = _f32(features), _f32(weight), _f32(grad_out)
+    Cout, Cin = weight.shape[0], weight.shape[-1]
+    K = int(np.prod(weight.shape[1:4]))
+    w = weight.reshape(Cout, K, Cin).astype(np.float64)
+    dx = np.zeros((features.shape[0], Cin), np.float64)
+    dw = np.zeros((Cout, K, Cin), np.float64)
+    for k in range(K):
+        m = int(pn[k])
+        if m == 0:
+            continue
+        i, o = pin[k, :m], pout[k, :m]
+        dy = grad_out[o].astype(np.float64)
+        np.add.at(dx, i, dy @ w[:, k, :])                       # (m, Cout) @ (Cout, Cin)
+        dw[:, k, :] += dy.T @ features[i].astype(np.float64)     # (Cout, m) @ (m, Cin)
+    return dx.astype(np.float32), dw.reshape(weight.shape).astype(np.float32)
+
+
 def subm_conv(x, weight, indice_key=None):
     """spconv.SubMConv3d forward (spconv_backbone.py:39-46): rulebook cached per indice_key."""
     ksize = weight.shape[1:4]

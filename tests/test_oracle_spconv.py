@@ -215,3 +215,36 @@ def test_backbone_graph_shapes_and_dense_equivalence(oracle, rng):
     mo = (F.conv3d(m4, torch.ones((1, 1, 3, 1, 1)), stride=(2, 1, 1)) > 0).float()
     x = torch.relu(bn(F.conv3d(x, _w_torch(sd["conv_out.0.weight"]), stride=(2, 1, 1)), "conv_out.1")) * mo
     np.testing.assert_allclose(res["out"].dense(), x.numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("mode,k,s,p", [("subm", 3, 1, 1), ("subm", (3, 1, 1), 1, (1, 0, 0)), ("strided", 3, 2, 1),
+                                        ("strided", 3, 2, (0, 1, 1)), ("strided", (3, 1, 1), (2, 1, 1), 0)])
+def test_conv_backward_equals_dense_conv_autograd(oracle, rng, mode, k, s, p):
+    """oracle.conv_backward against torch autograd through the dense conv3d the forward
+    is pinned to: the gradient of a random linear functional of the sparse output w.r.t. the input rows
+    and the weight."""
+    B, shape, n, Cin, Cout = 2, [7, 10, 9], 160, 4, 6
+    feats, idx = _random_sparse(rng, B, shape, n, Cin)
+    kk = [k] * 3 if np.isscalar(k) else list(k)
+    ss = [s] * 3 if np.isscalar(s) else list(s)
+    pp = [p] * 3 if np.isscalar(p) else list(p)
+    w = rng.standard_normal((Cout, *kk, Cin)).astype(np.float32)
+    if mode == "subm":
+        pin, pout, pnum = oracle.rulebook_subm(idx, shape, kk)
+        oi = idx
+    else:
+        oi, _, pin, pout, pnum = oracle.rulebook_strided(idx, shape, kk, ss, pp)
+    dy = rng.standard_normal((oi.shape[0], Cout)).astype(np.float32)
+    dx, dw = oracle.conv_backward(feats, w, pin, pout, pnum, dy)
+
+    xt = torch.from_numpy(feats).requires_grad_(True)
+    wt = torch.from_numpy(w).requires_grad_(True)
+    ii = [torch.from_numpy(idx[:, j]).long() for j in range(4)]
+    dense_in = torch.zeros((B, *shape, Cin)).index_put((ii[0], ii[1], ii[2], ii[3]), xt).permute(0, 4, 1, 2, 3)
+    dense = F.conv3d(dense_in, wt.permute(0, 4, 1, 2, 3), stride=ss if mode == "strided" else 1,
+                     padding=pp if mode == "strided" else [q // 2 for q in kk])
+    out = dense[oi[:, 0], :, oi[:, 1], oi[:, 2], oi[:, 3]]
+    (out * torch.from_numpy(dy)).sum().backward()   # out: (n_out, Cout) rows at the output sites
+    np.testing.assert_allclose(dx, xt.grad.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dw, wt.grad.numpy(), rtol=1e-5, atol=2e-5)
+    assert np.abs(dx).max() > 0 and np.abs(dw).max() > 0
