@@ -35,7 +35,7 @@ __device__ __forceinline__ float ld_f32(const __bf16 *p) { return (float)*p; }
 template <typename TX, typename TY, int PMAX>
 __global__ __launch_bounds__(kThreads) void wgrad_partial_kernel(const TX *__restrict__ x, const TY *__restrict__ dy,
                                                                  const int *__restrict__ nbr, int nbr_stride,
-                                                                 const int *__restrict__ n_out, int cap_out, int rows_per_chunk,
+                                                                 const int *__restrict__ n_out, int cap_out, int /*unused*/,
                                                                  int Cin, int Cout, float *__restrict__ partial) {
     constexpr int TR = 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char fnp_wg_smem[];
@@ -44,7 +44,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_partial_kernel(const TX *__res
     __shared__ int sidx[TR];
     const int n = min(*n_out, cap_out);
     const int k = blockIdx.y, chunk = blockIdx.x, K = gridDim.y;
-    const int r0 = chunk * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    // the row count is only known on the device: cut the n rows (not the capacity) into gridDim.x chunks
+    const int rows_per_chunk = ((n + (int)gridDim.x - 1) / (int)gridDim.x + 127) / 128 * 128;
+    const int r0 = min(n, chunk * rows_per_chunk), r1 = min(n, r0 + rows_per_chunk);
     const int pairs = Cin * Cout;
     float acc[PMAX];
 #pragma unroll
@@ -94,6 +96,166 @@ __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float *__r
     }
 }
 
+// ---- MFMA weight gradient (bf16 x bf16 -> f32) ---------------------------------------------------
+// dW_k (COUT x CIN) = dY^T (COUT x rows) . X_k (rows x CIN): rows are the GEMM's K dimension, so both
+// MFMA operands are "k-major" fragments of row-major tensors.  A 32-row tile of dy and of the gathered x
+// rows is therefore staged TRANSPOSED in LDS ([channel][32 rows] bf16, 64-byte rows): a fragment is then
+// one ds_read_b128 per lane (16 channels x 64 B = 1 KiB contiguous per wave: conflict-free).  The staging
+// threads load 16 contiguous bytes of a row from global memory and scatter its 8 channels to LDS.
+// Workgroup = 4 waves = WB waves across the COUT/16 row blocks of dW x WK = 4/WB row slices of the tile
+// (k-split); tiles are double-buffered, one barrier per tile; the WK partial sums meet in LDS at the end.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy,
+                                                              const int *__restrict__ nbr, int nbr_stride,
+                                                              const int *__restrict__ n_out, int cap_out, int /*unused*/,
+                                                              float *__restrict__ partial) {
+    constexpr int NBO = COUT / 16, NBI = CIN / 16;
+    constexpr int WB = NBO >= 4 ? 4 : NBO;          // waves across output-channel blocks
+    constexpr int WK = 4 / WB;                      // row slices (k-split)
+    constexpr int OB = NBO / WB;                    // output-channel blocks per wave
+    constexpr int TR = 32;                          // rows per slice and tile
+    constexpr int GT = WB * 64;                     // threads of one k-split group
+    constexpr int XCH = CIN / 8, YCH = COUT / 8;    // 16-byte chunks per row
+    constexpr int SLICE = (COUT + CIN) * TR;        // bf16 elements of one slice image: dyT then xT
+    static_assert(NBO % WB == 0 && CIN % 16 == 0 && COUT % 16 == 0, "channel counts");
+    extern __shared__ __attribute__((aligned(16))) unsigned char fnp_wg_smem[];
+    __bf16 *lds = reinterpret_cast<__bf16 *>(fnp_wg_smem);     // [2 buffers][WK slices][SLICE]
+
+    const int n = min(*n_out, cap_out);
+    const int k = blockIdx.y, chunk = blockIdx.x, K = gridDim.y;
+    const int rows_per_chunk = ((n + (int)gridDim.x - 1) / (int)gridDim.x + 127) / 128 * 128;   // from n, not the capacity
+    const int r0 = min(n, chunk * rows_per_chunk), r1 = min(n, r0 + rows_per_chunk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ks = wave / WB, wb = wave % WB;       // this wave's row slice and block column
+    const int gtid = tid - ks * GT;                 // thread index inside the k-split group
+    const int l15 = lane & 15, kq = lane >> 4;
+
+    f32x4_t acc[OB][NBI];
+#pragma unroll
+    for (int a = 0; a < OB; ++a)
+#pragma unroll
+        for (int b = 0; b < NBI; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int YL = (TR * YCH + GT - 1) / GT, XL = (TR * XCH + GT - 1) / GT;   // 16-byte loads per thread and tile
+    uint4 ry[YL], rx[XL];
+    // tile t of this slice covers rows r0 + (t*WK + ks)*TR .. + TR
+    auto fetch = [&](int t) {
+        const int base = r0 + (t * WK + ks) * TR;
+#pragma unroll
+        for (int j = 0; j < YL; ++j) {
+            const int e = gtid + j * GT, rr = e / YCH, c = e % YCH, r = base + rr;
+            ry[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (e < TR * YCH && r < r1) ry[j] = *reinterpret_cast<const uint4 *>(dy + (size_t)r * COUT + c * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            const int e = gtid + j * GT, rr = e / XCH, c = e % XCH, r = base + rr;
+            rx[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (e < TR * XCH && r < r1) {
+                const int id = nbr[(size_t)k * nbr_stride + r];
+                if (id >= 0) rx[j] = *reinterpret_cast<const uint4 *>(x + (size_t)id * CIN + c * 8);
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+        __bf16 *img = lds + (size_t)(buf * WK + ks) * SLICE;
+#pragma unroll
+        for (int j = 0; j < YL; ++j) {
+            const int e = gtid + j * GT, rr = e / YCH, c = e % YCH;
+            if (e < TR * YCH) {
+                const __bf16 *v = reinterpret_cast<const __bf16 *>(&ry[j]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) img[(c * 8 + q) * TR + rr] = v[q];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            const int e = gtid + j * GT, rr = e / XCH, c = e % XCH;
+            if (e < TR * XCH) {
+                const __bf16 *v = reinterpret_cast<const __bf16 *>(&rx[j]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) img[COUT * TR + (c * 8 + q) * TR + rr] = v[q];
+            }
+        }
+    };
+
+    const int tiles = (r1 - r0 + WK * TR - 1) / (WK * TR);   // (workgroup-uniform)
+    if (tiles > 0) {
+        fetch(0);
+        stage(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < tiles; ++t) {
+        if (t + 1 < tiles) fetch(t + 1);   // global loads of the next tile fly under this tile's MFMAs
+        const __bf16 *img = lds + (size_t)((t & 1) * WK + ks) * SLICE;
+        bf16x8_t bfr[NBI];
+#pragma unroll
+        for (int b = 0; b < NBI; ++b)
+            bfr[b] = *reinterpret_cast<const bf16x8_t *>(img + COUT * TR + (b * 16 + l15) * TR + kq * 8);
+#pragma unroll
+        for (int a = 0; a < OB; ++a) {
+            const bf16x8_t afr = *reinterpret_cast<const bf16x8_t *>(img + ((wb * OB + a) * 16 + l15) * TR + kq * 8);
+#pragma unroll
+            for (int b = 0; b < NBI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[b], acc[a][b], 0, 0, 0);
+        }
+        if (t + 1 < tiles) stage((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // lane holds dW[co = blk*16 + kq*4 + r][ci = b*16 + l15]; the WK slices are added through LDS (slice 0 writes)
+    float *red = reinterpret_cast<float *>(fnp_wg_smem);
+    float *out = partial + ((size_t)chunk * K + k) * (COUT * CIN);
+    for (int pass = 1; pass < WK; ++pass) {   // (WK is 1, 2 or 4)
+        __syncthreads();
+        if (ks == pass) {
+#pragma unroll
+            for (int a = 0; a < OB; ++a)
+#pragma unroll
+                for (int b = 0; b < NBI; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        red[((wb * OB + a) * 16 + kq * 4 + r) * CIN + b * 16 + l15] = acc[a][b][r];
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int a = 0; a < OB; ++a)
+#pragma unroll
+                for (int b = 0; b < NBI; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[a][b][r] += red[((wb * OB + a) * 16 + kq * 4 + r) * CIN + b * 16 + l15];
+        }
+    }
+    if (ks == 0) {
+#pragma unroll
+        for (int a = 0; a < OB; ++a)
+#pragma unroll
+            for (int b = 0; b < NBI; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    out[((wb * OB + a) * 16 + kq * 4 + r) * CIN + b * 16 + l15] = acc[a][b][r];
+    }
+}
+
+template <int CIN, int COUT>
+constexpr size_t wgrad_mfma_lds() {
+    constexpr int NBO = COUT / 16, WB = NBO >= 4 ? 4 : NBO, WK = 4 / WB;
+    const size_t tiles = (size_t)2 * WK * (COUT + CIN) * 32 * 2, red = (size_t)COUT * CIN * 4;
+    return tiles > red ? tiles : red;
+}
+
+template <int CIN, int COUT>
+void launch_wgrad_mfma(dim3 grid, hipStream_t s, const __bf16 *x, const __bf16 *dy, const int *nbr, int nbr_stride,
+                       const int *n_out, int cap_out, int rows_per_chunk, float *partial) {
+    auto kern = wgrad_mfma_kernel<CIN, COUT>;
+    const size_t lds = wgrad_mfma_lds<CIN, COUT>();
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, x, dy, nbr, nbr_stride, n_out, cap_out, rows_per_chunk, partial);
+}
+
 constexpr int kMaxChunks = 32;
 
 template <typename TX, typename TY>
@@ -104,11 +266,34 @@ int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int
     int chunks = fnp_divup(cap_out, 2048);
     if (chunks > kMaxChunks) chunks = kMaxChunks;
     if (chunks < 1) chunks = 1;
-    const int rows_per_chunk = fnp_divup(fnp_divup(cap_out, chunks), 16) * 16;
+    const int rows_per_chunk = fnp_divup(fnp_divup(cap_out, chunks), 128) * 128;   // multiple of every tile height
     if ((long long)chunks * total * 4 > ws_bytes) return FNP_ERR_WORKSPACE;
     const size_t lds = (size_t)16 * (Cin + Cout) * 4;
     const dim3 grid(chunks, K);
     float *partial = (float *)ws;
+    if constexpr (sizeof(TX) == 2 && sizeof(TY) == 2) {
+        bool done = true;
+#define FNP_WM(CI, CO)                                                                                         \
+    else if (Cin == CI && Cout == CO) launch_wgrad_mfma<CI, CO>(grid, s, (const __bf16 *)x, (const __bf16 *)dy, nbr,     \
+                                                                nbr_stride, n_out, cap_out, rows_per_chunk, partial)
+        if (false) {}
+        FNP_WM(16, 16);
+        FNP_WM(16, 32);
+        FNP_WM(32, 32);
+        FNP_WM(32, 64);
+        FNP_WM(64, 64);
+        FNP_WM(64, 128);
+        FNP_WM(128, 128);
+        else done = false;
+#undef FNP_WM
+        if (done) {
+            FNP_LAUNCH_CHECK();
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fnp_grid_for(total, kThreads)), dim3(kThreads), 0, s,
+                               (const float *)partial, chunks, total, dw);
+            FNP_LAUNCH_CHECK();
+            return FNP_OK;
+        }
+    }
 #define FNP_WG(P)                                                                                                          \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_partial_kernel<TX, TY, P>), grid, dim3(kThreads), lds, s, (const TX *)x,         \
                        (const TY *)dy, nbr, nbr_stride, n_out, cap_out, rows_per_chunk, Cin, Cout, partial)

@@ -90,7 +90,7 @@ def test_backbone_training_step_runs_and_matches_torch_reference_ops(cuda, rng):
         out = net(bd())
         loss = sum((t.features.float() ** 2).mean() for t in list(out["multi_scale_3d_features"].values()) + [out["encoded_spconv_tensor"]])
         loss.backward()
-        return float(loss), {k: v.grad.clone() for k, v in net.named_parameters()}
+        return float(loss.detach()), {k: v.grad.clone() for k, v in net.named_parameters()}
 
     loss_a, grads_a = run()
 

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Forward + backward of VoxelResBackBone8x in train mode (BASELINE.json configs[4]: the backbone part of the
+self-training step) on B synthetic scenes; HIP events.  Development tool."""
+import argparse, os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from findnpropagate_amd import sparse as S, synthetic as syn
+from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4); ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--dtype", default="bf16")
+args = ap.parse_args()
+dev = torch.device("cuda", 0); B = args.batch
+grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False, "FNP_DTYPE": args.dtype}, 5, grid), 0).to(dev)
+pts, off = syn.make_batch(list(range(B)))
+cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+vox = S.voxelize(torch.from_numpy(pts).to(dev), torch.from_numpy(off).to(dev), B, cfg)
+n = int(vox["n"].item())
+bd = lambda: {"voxel_features": vox["mean"][:n], "voxel_coords": vox["coords"][:n].float(), "batch_size": B}
+opt = torch.optim.SGD(net.parameters(), lr=1e-4)
+
+def fwd():
+    out = net(bd())
+    return sum((t.features.float() ** 2).mean() for t in list(out["multi_scale_3d_features"].values()) + [out["encoded_spconv_tensor"]])
+
+def timed(fn, reps):
+    for _ in range(2): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    loss = fwd(); loss.backward(); opt.step()
+
+net.train()
+ms_step = timed(step, args.reps)
+with torch.no_grad():
+    ms_fwd_train = timed(fwd, args.reps)          # module path, BN batch statistics, no graph
+net.eval()
+with torch.no_grad():
+    ms_fwd_eval = timed(lambda: net(bd()), args.reps)   # fused inference path
+print(json.dumps({"batch": B, "voxels": n, "dtype": args.dtype, "train_step_ms": round(ms_step, 2), "module_forward_ms": round(ms_fwd_train, 2),
+                  "fused_eval_forward_ms": round(ms_fwd_eval, 2), "scenes_per_s_train": round(B / ms_step * 1e3, 1)}))
