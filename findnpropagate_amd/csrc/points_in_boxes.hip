@@ -163,3 +163,34 @@ extern "C" int fnp_points_in_boxes_dense(const float *boxes, const float *pts, i
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
+
+// ---- host entry point: PseudoSampler.points_in_boxes (pcdet/datasets/augmentor/pseudo_loader.py:270-316) ----
+// Dense (T, N) membership of N points in T boxes for the copy-paste / pseudo-label mixing in dataloader
+// workers, with the box-frame points (T, N, C) the reference returns alongside (centre subtracted, rotated
+// by -heading: x' = x cos(-h) - y sin(-h), y' = x sin(-h) + y cos(-h); common_utils.py:35-57), faces
+// INCLUSIVE (>= lower, <= upper: unlike the CUDA operator's strict test).  Plain host loops, no device.
+#include <cmath>
+extern "C" int fnp_host_points_in_boxes_frame(const float *points, int n, int C, const float *boxes, int t,
+                                              unsigned char *in_box, float *points_out) {
+    if (n < 0 || t < 0 || C < 3 || ((n > 0 && t > 0) && (!points || !boxes || !in_box))) return FNP_ERR_ARG;
+    for (int b = 0; b < t; ++b) {
+        const float *bx = boxes + (size_t)b * 7;
+        const float ca = cosf(-bx[6]), sa = sinf(-bx[6]);
+        // corner template +-1/2 of the extents: min/max per axis (pseudo_loader.py:275-290)
+        const float hx = bx[3] * 0.5f, hy = bx[4] * 0.5f, hz = bx[5] * 0.5f;
+        const float x1 = fminf(hx, -hx), x2 = fmaxf(hx, -hx), y1 = fminf(hy, -hy), y2 = fmaxf(hy, -hy);
+        const float z1 = fminf(hz, -hz), z2 = fmaxf(hz, -hz);
+        for (int i = 0; i < n; ++i) {
+            const float *p = points + (size_t)i * C;
+            const float px = p[0] - bx[0], py = p[1] - bx[1], pz = p[2] - bx[2];
+            const float rx = px * ca + py * (-sa), ry = px * sa + py * ca;
+            in_box[(size_t)b * n + i] = (rx >= x1 && rx <= x2 && ry >= y1 && ry <= y2 && pz >= z1 && pz <= z2) ? 1 : 0;
+            if (points_out) {
+                float *o = points_out + ((size_t)b * n + i) * C;
+                o[0] = rx; o[1] = ry; o[2] = pz;
+                for (int c = 3; c < C; ++c) o[c] = p[c];
+            }
+        }
+    }
+    return FNP_OK;
+}

@@ -88,6 +88,7 @@ SIGNATURES = {
     "fnp_boxes_iou_bev": (c_int, [P, c_int, P, c_int, P, P]),
     "fnp_boxes_aligned_overlap_bev": (c_int, [P, P, c_int, P, P]),
     "fnp_boxes_iou3d": (c_int, [P, c_int, P, c_int, P, P]),
+    "fnp_host_points_in_boxes_frame": (c_int, [P, c_int, c_int, P, c_int, P, P]),
     "fnp_host_boxes_iou_bev": (c_int, [P, c_int, P, c_int, P]),
     "fnp_host_boxes_aligned_iou_bev": (c_int, [P, P, c_int, P]),
     "fnp_nms_workspace_bytes": (c_int64, [c_int]),

@@ -83,6 +83,12 @@ int fnp_boxes_aligned_overlap_bev(const float *boxes_a, const float *boxes_b, in
 int fnp_boxes_iou3d(const float *boxes_a, int num_a, const float *boxes_b, int num_b,
                     float *ans_iou, fnp_stream_t stream);
 
+/* Host-side dense point-in-box test of the pseudo-label mixing (PseudoSampler.points_in_boxes,
+ * pcdet/datasets/augmentor/pseudo_loader.py:270-316): points (N,C>=3), boxes (T,7) -> in_box (T,N) u8 with
+ * INCLUSIVE faces, and optionally the points in each box frame (T,N,C) (points_out may be NULL). */
+int fnp_host_points_in_boxes_frame(const float *points, int n, int C, const float *boxes, int t,
+                                   unsigned char *in_box, float *points_out);
+
 /* Host-side rotated BEV IoU (no device, no stream): replaces boxes_iou_bev_cpu (N x M) and
  * boxes_aligned_iou_bev_cpu (N pairs) of pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp:232-272, called by the
  * pseudo-label mixing in dataloader workers (pseudo_loader.py:29-55).  Host pointers, (n,7) boxes. */

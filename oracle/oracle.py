@@ -395,3 +395,41 @@ def class_agnostic_nms(box_scores, box_preds, nms_type, thresh, pre_max, post_ma
     keep = nms_gpu(bx[order][:, :7], sc[order], thresh, rotated=(nms_type == "nms_gpu"))
     sel = idx0[order[keep[:post_max]]]
     return sel, src[sel]
+
+
+# ---- pseudo-label mixing host operators (pcdet/datasets/augmentor/pseudo_loader.py) ----------------
+def bev_nms_cpu(boxes, scores, thresh=0.5):
+    """pseudo_loader.py:29-55 statement by statement (the double Python loop), on the oracle's IoU."""
+    boxes, scores = np.asarray(boxes, np.float32), np.asarray(scores, np.float32)
+    N = boxes.shape[0]
+    keep = np.ones((N,), bool)
+    order = np.argsort(-scores, kind="stable")
+    ious = boxes_iou_bev(boxes, boxes) if N else np.zeros((0, 0), np.float32)
+    for i in range(N):
+        if keep[i]:
+            curr = order[i]
+            for j in range(i + 1, N):
+                if ious[curr, order[j]] > thresh:
+                    keep[j] = False
+    return order[keep]
+
+
+def pseudo_points_in_boxes(points, boxes3d):
+    """PseudoSampler.points_in_boxes (pseudo_loader.py:270-316) in numpy f32: corner-template extents,
+    points centred and rotated by -heading (common_utils.rotate_points_along_z :35-57), inclusive faces."""
+    points, boxes3d = np.asarray(points, np.float32), np.asarray(boxes3d, np.float32)
+    N = boxes3d.shape[0]
+    template = (np.array([[1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1], [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1]]) / 2).astype(np.float32)
+    corners = boxes3d[:, None, 3:6].repeat(8, axis=1) * template[None]
+    p = points[:, None, :].repeat(N, axis=1)
+    p[..., :3] = p[..., :3] - boxes3d[None, :, 0:3]
+    p = p.transpose((1, 0, 2)).copy()
+    a = -boxes3d[:, 6]
+    ca, sa = np.cos(a).astype(np.float32), np.sin(a).astype(np.float32)
+    x = p[..., 0] * ca[:, None] + p[..., 1] * (-sa[:, None])
+    y = p[..., 0] * sa[:, None] + p[..., 1] * ca[:, None]
+    p[..., 0], p[..., 1] = x, y
+    lo, hi = corners.min(axis=1, keepdims=True), corners.max(axis=1, keepdims=True)
+    in_box = ((p[..., 0] >= lo[..., 0]) & (p[..., 0] <= hi[..., 0]) & (p[..., 1] >= lo[..., 1]) & (p[..., 1] <= hi[..., 1]) &
+              (p[..., 2] >= lo[..., 2]) & (p[..., 2] <= hi[..., 2]))
+    return in_box, p
