@@ -19,6 +19,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fnp.h")
 
 FNP_F32 = 0
 FNP_BF16 = 1
+FNP_F16 = 2
 
 _ERRORS = {-1: "FNP_ERR_ARG", -2: "FNP_ERR_LAUNCH", -3: "FNP_ERR_HIP", -4: "FNP_ERR_WORKSPACE"}
 
@@ -114,6 +115,8 @@ SIGNATURES = {
     "fnp_rulebook_transpose": (c_int, [P, c_int, c_int, P, c_int, P, c_int, P]),
     "fnp_spconv_wgrad_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "fnp_spconv_wgrad": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, c_int, P, c_int, c_int, P, c_int64, P]),
+    "fnp_clipcrop_plan": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, P, P, P]),
+    "fnp_clipcrop_sample": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, P, P]),
     "fnp_sparse_to_dense_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "fnp_sparse_to_dense": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64, P]),
 }
@@ -184,6 +187,8 @@ def dtype_code(t):
         return FNP_F32
     if t.dtype == torch.bfloat16:
         return FNP_BF16
+    if t.dtype == torch.float16:
+        return FNP_F16
     raise FnpError(f"unsupported feature dtype {t.dtype}")
 
 

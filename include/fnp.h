@@ -35,7 +35,7 @@ enum {
     FNP_ERR_WORKSPACE = -4 /* workspace too small */
 };
 
-enum { FNP_F32 = 0, FNP_BF16 = 1 };
+enum { FNP_F32 = 0, FNP_BF16 = 1, FNP_F16 = 2 };
 
 /* Library / build identification: returns a static string "fnp-hip gfx950 <abi version>". */
 const char *fnp_version(void);
@@ -233,6 +233,26 @@ int fnp_spconv_wgrad(const void *feat_in, int in_dtype, const void *grad_out, in
                      const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out,
                      float *grad_weight, int Cin, int Cout,
                      void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CLIP-crop scoring, geometry half (CLIPBoxClassification.forward,
+ * pcdet/models/dense_heads/clip_box_classification.py:230-379): which camera sees which box and the
+ * square image crop CLIP looks at.
+ *   fnp_clipcrop_plan: boxes (N,7) device; lidar_aug_rot_inv (9) and lidar_aug_trans (3) HOST floats
+ *       (torch.inverse of the augmentation rotation is the caller's, like the reference :205-207);
+ *       lidar2image, img_aug (6,4,4) device -> rect (N,6,4) f32 [x1, y1, side, has_crop] and
+ *       cam_mask (N,6) u8 (box visible in the camera, set even when the crop is < min_crop px).
+ *   fnp_clipcrop_sample: images (6, C, H, W) f32/f16 device, pairs (M,2) i32 [box, cam] in the caller's
+ *       order, unit_grid (out_size) f32 = the [0,1] sampling positions (F.affine_grid normalised as in
+ *       :318-319) -> crops (M, C, out_size, out_size), F.grid_sample arithmetic (bilinear,
+ *       align_corners = False, zeros padding).
+ * ------------------------------------------------------------------------------------------ */
+int fnp_clipcrop_plan(const float *boxes, int n, const float *lidar_aug_rot_inv, const float *lidar_aug_trans,
+                      const float *lidar2image, const float *img_aug, int image_h, int image_w, int min_crop,
+                      float *rect, unsigned char *cam_mask, fnp_stream_t stream);
+int fnp_clipcrop_sample(const void *images, int dtype, int channels, int image_h, int image_w,
+                        const float *rect, const int *pairs, int num_pairs, const float *unit_grid,
+                        int out_size, void *crops, fnp_stream_t stream);
 
 /* SparseConvTensor.dense() as used by HeightCompression (height_compression.py:20-24):
  * feats (n,C) -> out (B,C,D,H,W) of the same dtype (viewed as (B, C*D, H, W) by the caller).
