@@ -81,6 +81,8 @@ def test_crop_equals_grid_sample(cuda, rng):
             x1, y1, side, _ = rect[b, c].tolist()
             gx, gy = unit[None, :].expand(224, 224) * side + x1, unit[:, None].expand(224, 224) * side + y1
             grid = torch.stack([(gx / 200) * 2 - 1, (gy / 120) * 2 - 1], -1)[None]
-            want = F.grid_sample(images[[c]].to(dt), grid.to(dt), align_corners=False)
-            tol = 1e-4 if dt == torch.float32 else 4e-3   # 1e-4: the fp32 bar of BASELINE.json (white-noise image, rounding of the sampling positions)
+            # (torch's f16 grid_sample also rounds the sampling positions to f16; the kernel keeps them in f32,
+            #  so both dtypes are held against the f32 result)
+            want = F.grid_sample(images[[c]], grid, align_corners=False)
+            tol = 1e-4 if dt == torch.float32 else 2e-3   # 1e-4: the fp32 bar of BASELINE.json (white-noise image, rounding of the sampling positions)
             assert (got[m].float() - want[0].float()).abs().max() <= tol

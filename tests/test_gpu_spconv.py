@@ -159,10 +159,11 @@ def test_module_api_matches_oracle_and_dense(cuda, oracle, rng):
     assert np.array_equal(got_i, want_i)
     np.testing.assert_allclose(got_f, want_f, rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(dense, o2.dense(), rtol=1e-6, atol=1e-6)
-    # training-mode call with autograd must fail loudly, not return a graph-less tensor
+    # a call with autograd enabled returns a tensor that carries the graph (tests/test_gpu_backward.py checks the values)
     m1.train()
-    with pytest.raises(NotImplementedError):
-        m1(x)
+    yt = m1(x)
+    assert yt.features.requires_grad and yt.features.grad_fn is not None
+    assert torch.equal(yt.features.detach(), y1.features)
 
 
 def _small_net(cuda, dtype):
