@@ -187,7 +187,9 @@ struct MfmaCfg {
 };
 
 // Development-only ablation bit mask (tools/bench_conv.py with FNP_LIB_PATH): 1 = no feature gathers,
-// 2 = no weight staging, 4 = no MFMA, 8 = window kernels issue no global gathers, 16 = no window reads.  The shipped library is built with FNP_ABLATE == 0.
+// 2 = no weight staging, 4 = no MFMA, 8 = window kernels issue no global gathers, 16 = no window reads,
+// 32 = rulebook entries read from a 64 KiB (cache-resident) slice of the table, 64 = window address taken
+// from the entry without arithmetic (timing probe for pre-computed addresses).  The shipped library is built with FNP_ABLATE == 0.
 #ifndef FNP_ABLATE
 #define FNP_ABLATE 0
 #endif
@@ -197,8 +199,18 @@ struct MfmaCfg {
 // shortens the last, partly filled round of tiles), 2 elsewhere (3 costs spills there)
 template <int CIN, int COUT> struct MfmaOcc { static constexpr int WAVES = (CIN < COUT && COUT <= 64) ? 3 : 2; };
 
+// waves per workgroup: 8 for the 128-channel layers (one 32 KiB weight slab per offset then serves 384 sites
+// instead of 192: the slab stream through L2 is the largest term of those layers), 4 elsewhere
+#ifndef FNP_NW128
+#define FNP_NW128 8
+#endif
+#ifndef FNP_NW_MINCIN
+#define FNP_NW_MINCIN 128
+#endif
+template <int CIN, int COUT> struct MfmaWg { static constexpr int NW = (COUT == 128 && CIN >= FNP_NW_MINCIN) ? FNP_NW128 : 4; };
+
 template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut>
-__global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const __bf16 *__restrict__ x, int x_bytes,
+__global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const __bf16 *__restrict__ x, int x_bytes,
                                                              const __bf16 *__restrict__ w,
                                                              const int *__restrict__ nbr, int nbr_stride, int Krt,
                                                              const int *__restrict__ n_out, int cap,
@@ -213,16 +225,17 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
     constexpr int NB = COUT / 16;         // 16-channel output blocks
     constexpr int NBH = NB < 4 ? NB : 4;  // A fragments held at once
     constexpr int ROWS_PER_WAVE = MB * 16;
-    constexpr int ROWS_PER_WG = 4 * ROWS_PER_WAVE;
+    constexpr int NW = MfmaWg<CIN, COUT>::NW, NT = NW * 64;   // waves / threads per workgroup
+    constexpr int ROWS_PER_WG = NW * ROWS_PER_WAVE;
     // weight staging of the double-buffered path: NCH chunks per thread per slab, WST per MFMA step
-    constexpr int NCH = (SLAB + 255) / 256;
+    constexpr int NCH = (SLAB + NT - 1) / NT;
     constexpr int WST = (NCH + KS - 1) / KS;
     // small slabs (<= 2 chunks per thread): W_{k+2} is requested at the top of offset k and W_{k+1}
     // (requested one offset earlier) is written to LDS at its end, so the weights get two offsets of
     // matrix work to arrive; larger slabs cannot afford the registers and go step by step
     constexpr bool WDEEP = !ALLK && NCH <= 1;
     static_assert(CIN % 16 == 0 && COUT % 16 == 0, "channel counts must be multiples of 16");
-    static_assert(ALLK || SLAB % 256 == 0 || SLAB < 256, "unsupported slab size");
+    static_assert(ALLK || SLAB % NT == 0 || SLAB < NT, "unsupported slab size");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char fnp_smem[];
     uint4 *wl = reinterpret_cast<uint4 *>(fnp_smem);
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
     auto nbr_at = [&](int k, int r, int r_end) -> int {
         const int rc = r < r_end ? r : r_end - 1;
         const int kc = k < K ? k : K - 1;
-        const int v = nbr[(size_t)kc * nbr_stride + rc];
+        const int v = nbr[(FNP_ABLATE & 32) ? (size_t)((kc * 64 + rc) & 0x3fff) : (size_t)kc * nbr_stride + rc];
         return (r < r_end && k < K) ? v : -1;
     };
     // same load, but the value is NOT touched here: the validity select happens where the entry is
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
     auto nbr_raw = [&](int k, int r, int r_end) -> int {
         const int rc = r < r_end ? r : r_end - 1;
         const int kc = k < K ? k : K - 1;
-        return nbr[(size_t)kc * nbr_stride + rc];
+        return nbr[(FNP_ABLATE & 32) ? (size_t)((kc * 64 + rc) & 0x3fff) : (size_t)kc * nbr_stride + rc];
     };
 
     // window path: LDS byte address of (row id, this lane's chunk of MFMA step 0) when the row is in
@@ -274,6 +287,8 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
     // gather of the same fragment is then suppressed (out-of-range offset), so every fragment is
     // the OR of an LDS read and a buffer load of which at most one is non-zero.
     auto win_off = [&](int id, int wlo) -> unsigned {
+        if (FNP_ABLATE & 64)   // timing probe: the entry is taken as a pre-computed LDS address
+            return (unsigned)Cfg::LDS_BYTES + ((((unsigned)id << 6) & 0x3fc0u) ^ ((unsigned)q << 4));
         const unsigned d = (unsigned)(id - wlo);
         return d < (unsigned)WROWS ? (unsigned)Cfg::LDS_BYTES + ((d * CH + ((unsigned)q ^ win_sw(d))) << 4) : WIN_ZERO;
     };
@@ -309,11 +324,11 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) aoff[ks] = FNP_LDS_POS(l15, kvalid0 ? ks * 4 + q : 0);
     const int st_pos0 = FNP_LDS_POS(tid / CH, tid % CH);
-    static_assert(SLAB < 256 || ((256 / CH) % (CH << SW) == 0), "staging swizzle must be periodic in 256 chunks");
+    static_assert(SLAB < NT || ((NT / CH) % (CH << SW) == 0), "staging swizzle must be periodic in NT chunks");
     if (WIN && tid < Cfg::WZERO / 16) reinterpret_cast<uint4 *>(fnp_smem + WIN_ZERO)[tid] = make_uint4(0u, 0u, 0u, 0u);
     if (ALLK) {
         // narrow layers: all K slabs resident in LDS for the lifetime of the workgroup
-        for (int p = tid; p < K * SLAB; p += 256) {
+        for (int p = tid; p < K * SLAB; p += NT) {
             const int kk = p / SLAB, r = p % SLAB;
             wl[kk * SLAB + FNP_LDS_POS(r / CH, r % CH)] = reinterpret_cast<const uint4 *>(w)[p];
         }
@@ -334,18 +349,18 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
         // of once per (site, offset) pair that references it.
         const int wlo = max(0, tile_base - WH);
         if constexpr (WIN) {
-            constexpr int NST = WROWS * CH / 256;
-            static_assert(WROWS * CH % 256 == 0, "window staging");
+            constexpr int NST = WROWS * CH / NT;
+            static_assert(WROWS * CH % NT == 0, "window staging");
             if (ALLK && !first_tile) __syncthreads();  // every wave is done with the previous window
             u32x4 st[NST];
 #pragma unroll
             for (int j = 0; j < NST; ++j) {
-                const unsigned p = (unsigned)tid + j * 256u;   // chunk p of the window, in memory order: coalesced
+                const unsigned p = (unsigned)tid + j * (unsigned)NT;   // chunk p of the window, in memory order: coalesced
                 st[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (unsigned)wlo * (unsigned)(CIN * 2) + p * 16u, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < NST; ++j) {
-                const unsigned p = (unsigned)tid + j * 256u, d = p / CH, c = p % CH;
+                const unsigned p = (unsigned)tid + j * (unsigned)NT, d = p / CH, c = p % CH;
                 *reinterpret_cast<u32x4 *>(win + ((d * CH + (c ^ win_sw(d))) << 4)) = st[j];
             }
             if (ALLK) __syncthreads();  // (double-buffered layers: the slab-0 barrier below)
@@ -378,8 +393,8 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
             if (!(FNP_ABLATE & 2)) {
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
-                    const int p = tid + j * 256;
-                    if (SLAB % 256 == 0 || p < SLAB) wl[st_pos0 + j * 256] = reinterpret_cast<const uint4 *>(w)[p];
+                    const int p = tid + j * NT;
+                    if (SLAB % NT == 0 || p < SLAB) wl[st_pos0 + j * NT] = reinterpret_cast<const uint4 *>(w)[p];
                 }
             }
             __syncthreads();
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
         if (WDEEP && !(FNP_ABLATE & 2)) {
             const uint4 *w1 = reinterpret_cast<const uint4 *>(w + (size_t)(K > 1 ? 1 : 0) * COUT * CIN);
             wcur0 = w1[tid < SLAB ? tid : 0];
-            if (NCH > 1) wcur1 = w1[tid + 256];
+            if (NCH > 1) wcur1 = w1[tid + NT];
         }
 
         for (int k0 = 0; k0 < K; k0 += PFK) {
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                 if (WDEEP && !(FNP_ABLATE & 2)) {
                     const uint4 *w2 = reinterpret_cast<const uint4 *>(w + (size_t)(k + 2 < K ? k + 2 : k) * COUT * CIN);
                     wnext0 = w2[tid < SLAB ? tid : 0];
-                    if (NCH > 1) wnext1 = w2[tid + 256];
+                    if (NCH > 1) wnext1 = w2[tid + NT];
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
@@ -437,15 +452,15 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                         if (ks > 0) {
 #pragma unroll
                             for (int j = 0; j < WST; ++j) {
-                                const int c = (ks - 1) * WST + j, p = tid + c * 256;
-                                if (c < NCH && (SLAB % 256 == 0 || p < SLAB))
-                                    wl[((k + 1) & 1) * SLAB + st_pos0 + c * 256] = (j == 0 ? wreg0 : wreg1);
+                                const int c = (ks - 1) * WST + j, p = tid + c * NT;
+                                if (c < NCH && (SLAB % NT == 0 || p < SLAB))
+                                    wl[((k + 1) & 1) * SLAB + st_pos0 + c * NT] = (j == 0 ? wreg0 : wreg1);
                             }
                         }
 #pragma unroll
                         for (int j = 0; j < WST; ++j) {
-                            const int c = ks * WST + j, p = tid + c * 256;
-                            if (c < NCH && (SLAB % 256 == 0 || p < SLAB)) (j == 0 ? wreg0 : wreg1) = wsrc[p];
+                            const int c = ks * WST + j, p = tid + c * NT;
+                            if (c < NCH && (SLAB % NT == 0 || p < SLAB)) (j == 0 ? wreg0 : wreg1) = wsrc[p];
                         }
                     }
                     // (3) matrix blocks of this step on the fragments requested PFK offsets ago
@@ -507,16 +522,16 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
                 }
                 if (!ALLK) {
                     if (WDEEP && !(FNP_ABLATE & 2)) {
-                        if (SLAB >= 256 || tid < SLAB) wl[((k + 1) & 1) * SLAB + st_pos0] = wcur0;
-                        if (NCH > 1) wl[((k + 1) & 1) * SLAB + st_pos0 + 256] = wcur1;
+                        if (SLAB >= NT || tid < SLAB) wl[((k + 1) & 1) * SLAB + st_pos0] = wcur0;
+                        if (NCH > 1) wl[((k + 1) & 1) * SLAB + st_pos0 + NT] = wcur1;
                         wcur0 = wnext0;
                         wcur1 = wnext1;
                     } else if (!(FNP_ABLATE & 2)) {
 #pragma unroll
                         for (int j = 0; j < WST; ++j) {
-                            const int c = (KS - 1) * WST + j, p = tid + c * 256;
-                            if (c < NCH && (SLAB % 256 == 0 || p < SLAB))
-                                wl[((k + 1) & 1) * SLAB + st_pos0 + c * 256] = (j == 0 ? wreg0 : wreg1);
+                            const int c = (KS - 1) * WST + j, p = tid + c * NT;
+                            if (c < NCH && (SLAB % NT == 0 || p < SLAB))
+                                wl[((k + 1) & 1) * SLAB + st_pos0 + c * NT] = (j == 0 ? wreg0 : wreg1);
                         }
                     }
                     __syncthreads();  // plain loads stay in flight across it; only the LDS writes are waited for
@@ -564,9 +579,9 @@ __global__ __launch_bounds__(256, (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_
         first_tile = false;
     };
     const int nblk_wg = (row_end - row_begin + 15) >> 4;
-    const int full = nblk_wg / (4 * MB);
+    const int full = nblk_wg / (NW * MB);
     for (int t = 0; t < full; ++t) run_tile(std::integral_constant<int, MB>{}, row_begin + t * ROWS_PER_WG);
-    const int tper = (nblk_wg - full * 4 * MB + 3) >> 2;  // blocks per wave in the partial tile (0 = none)
+    const int tper = (nblk_wg - full * NW * MB + NW - 1) / NW;  // blocks per wave in the partial tile (0 = none)
     const int tail_base = row_begin + full * ROWS_PER_WG;
     if (tper == MB) run_tile(std::integral_constant<int, MB>{}, tail_base);
     if constexpr (MB > 1) { if (tper == 1) run_tile(std::integral_constant<int, 1>{}, tail_base); }
@@ -587,7 +602,7 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
     auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut>;
     constexpr int lds = Cfg::lds_bytes(MB, WIN);
-    static_assert(lds * MfmaOcc<CIN, COUT>::WAVES <= 160 * 1024, "LDS budget of the resident workgroups");
+    static_assert(lds * MfmaOcc<CIN, COUT>::WAVES * 4 / MfmaWg<CIN, COUT>::NW <= 160 * 1024, "LDS budget of the resident workgroups");
     if (lds > 64 * 1024) {
         static bool raised = false;  // (idempotent; a race only repeats the call)
         if (!raised) {
@@ -596,13 +611,13 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
             raised = true;
         }
     }
-    const int tiles = fnp_divup(cap, 4 * MB * 16);
+    const int tiles = fnp_divup(cap, MfmaWg<CIN, COUT>::NW * MB * 16);
     // persistent grid: two workgroups per CU are resident (register / LDS budget of the wide
     // layers); the narrow ALLK layers stage all weights once per workgroup, so keep them few too.
     // The kernel splits the rows evenly over whatever grid it gets.
-    const int resident = 256 * MfmaOcc<CIN, COUT>::WAVES;
+    const int resident = 256 * MfmaOcc<CIN, COUT>::WAVES * 4 / MfmaWg<CIN, COUT>::NW;
     const int grid = tiles < resident ? tiles : resident;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const __bf16 *)x, x_bytes, (const __bf16 *)w,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MfmaWg<CIN, COUT>::NW * 64), lds, s, (const __bf16 *)x, x_bytes, (const __bf16 *)w,
                        nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu);
     FNP_LAUNCH_CHECK();
     return FNP_OK;

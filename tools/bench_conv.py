@@ -8,7 +8,7 @@ import numpy as np, torch
 from findnpropagate_amd import sparse as S, synthetic as syn
 from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
 
-ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--reps", type=int, default=20); ap.add_argument("--fracs", type=str, default="1.0", help="comma list: time each layer on the first frac*n output rows too (tile staircase)")
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--reps", type=int, default=20); ap.add_argument("--identity", action="store_true", help="replace every valid rulebook entry by the output row itself (perfect gather locality, same instruction stream)"); ap.add_argument("--fracs", type=str, default="1.0", help="comma list: time each layer on the first frac*n output rows too (tile staircase)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 B = args.batch
@@ -36,6 +36,10 @@ for tag, rb, n_dev in log:
     sc = torch.ones(cout, device=dev); sh = torch.zeros(cout, device=dev)
     resid = torch.randn((rb.cap_out, cout), device=dev).to(torch.bfloat16)
     n_full = n
+    if args.identity and n_in >= n:
+        import copy
+        rb = copy.copy(rb); ar = torch.arange(rb.nbr.shape[1], device=dev, dtype=torch.int32)[None].expand_as(rb.nbr)
+        rb.nbr = torch.where(rb.nbr >= 0, ar, rb.nbr).contiguous()
     for frac in [float(f) for f in args.fracs.split(",")]:
         n = int(n_full * frac); n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
         pairs = int((rb.nbr[:, :n] >= 0).sum().item())
