@@ -197,7 +197,7 @@ struct MfmaCfg {
 // waves per SIMD the register budget is held to: 3 (<= 168 VGPRs) where it measured faster on
 // MI355X (the channel-doubling strided layers 16->32, 32->64: a third resident workgroup per CU
 // shortens the last, partly filled round of tiles), 2 elsewhere (3 costs spills there)
-template <int CIN, int COUT> struct MfmaOcc { static constexpr int WAVES = (CIN < COUT && COUT <= 64) ? 3 : 2; };
+template <int CIN, int COUT> struct MfmaOcc;
 
 // waves per workgroup: 8 for the 128-channel layers (one 32 KiB weight slab per offset then serves 384 sites
 // instead of 192: the slab stream through L2 is the largest term of those layers), 4 elsewhere
@@ -207,7 +207,12 @@ template <int CIN, int COUT> struct MfmaOcc { static constexpr int WAVES = (CIN 
 #ifndef FNP_NW_MINCIN
 #define FNP_NW_MINCIN 128
 #endif
-template <int CIN, int COUT> struct MfmaWg { static constexpr int NW = (COUT == 128 && CIN >= FNP_NW_MINCIN) ? FNP_NW128 : 4; };
+#ifndef FNP_NW32
+#define FNP_NW32 4
+#endif
+template <int CIN, int COUT> struct MfmaWg { static constexpr int NW = (COUT == 128 && CIN >= FNP_NW_MINCIN) ? FNP_NW128 : (CIN == 32 && COUT == 32) ? FNP_NW32 : 4; };
+
+template <int CIN, int COUT> struct MfmaOcc { static constexpr int WAVES = ((CIN < COUT && COUT <= 64) || MfmaWg<CIN, COUT>::NW == 6) ? 3 : 2; };
 
 template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut>
 __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const __bf16 *__restrict__ x, int x_bytes,
