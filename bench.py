@@ -186,7 +186,7 @@ def main():
             "all_conv_classes_ms_per_step": {f"{k[0]}x{k[1]}k{k[2]}": sum(x[0] for x in v) / args.steps for k, v in per.items()},
         }
 
-    if rank == 0 and args.cpu_scenes > 0:
+    if rank == 0 and world == 1 and args.cpu_scenes > 0:   # (baseline leg: N = 1 only)
         from oracle import oracle as O
 
         sd = {k: t.detach().cpu().numpy() for k, t in net.state_dict().items()}
