@@ -351,3 +351,28 @@ def test_graphed_forward_equals_eager(cuda):
         assert torch.equal(got["voxel_coords"], want["voxel_coords"]) and torch.equal(got["voxel_features"], want["voxel_features"])
         n_graphs.append(len(net.engine()._graphs))
     assert n_graphs == [1, 1, 1], "one capture serves every call of that (batch, capacity)"
+
+
+@pytest.mark.gpu
+def test_capacity_overflow_regrows_eager_and_graphed(cuda):
+    """Stage capacities that are too small are detected after the step (true counts live on the device),
+    grown, the persistent grids wiped, and the step repeated — eager and hipGraph paths, same results."""
+    from findnpropagate_amd import sparse as S, synthetic as syn
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 0).to(cuda).eval()
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+    pts, off = syn.make_batch([3])
+    pts, off = torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda)
+    with torch.no_grad():
+        want = net.forward_points(pts, off, 1, cfg)
+        want = {k: (want[k].features.clone(), want[k].indices.clone()) for k in ("x_conv2", "x_conv4", "out")}
+        for graphed in (False, True):
+            net.engine().cap_factor = [0.5, 0.2, 0.1, 0.05]          # far too small for stages 2-5
+            net.engine()._graphs.clear()
+            got = (net.forward_points_graphed(pts, off, 1, cfg) if graphed else net.forward_points(pts, off, 1, cfg))
+            assert net.engine().cap_factor[0] > 0.5 and net.engine().cap_factor[3] > 0.05
+            for k in want:
+                assert torch.equal(got[k].features, want[k][0]) and torch.equal(got[k].indices, want[k][1]), (graphed, k)
+            again = net.forward_points(pts, off, 1, cfg)              # the grids were left clean
+            assert torch.equal(again["out"].features, want["out"][0])
