@@ -113,17 +113,23 @@ __device__ __forceinline__ void rg_mark_mask(const RG &g, long long blk, unsigne
 }
 
 template <int SZ, int SY, int SX>
+// order: optional rank -> row map of the input grid (stage 1, whose rows are in the voxeliser's first-come
+// order): the inputs are then visited in rank order, which is what makes the wave-level merging below bite.
 __global__ __launch_bounds__(kThreads) void strided_mark2_kernel(const int *__restrict__ in_coords,
-                                                                 const int *__restrict__ n_in, int cap_in, RG go, Geom ge) {
+                                                                 const int *__restrict__ n_in, int cap_in, RG go, Geom ge,
+                                                                 const int *__restrict__ order) {
     const int n = min(*n_in, cap_in);
     const int lane = fnp_lane();
-    const int nround = (n + (int)(gridDim.x * kThreads) - 1) / (int)(gridDim.x * kThreads);
+    const int span = order ? cap_in : n;   // ranks of dropped / absent cells map to -1
+    const int nround = (span + (int)(gridDim.x * kThreads) - 1) / (int)(gridDim.x * kThreads);
     for (int it = 0; it < nround; ++it) {   // (whole waves stay in the loop: the shuffles below need them)
         const int i = (it * gridDim.x + blockIdx.x) * kThreads + threadIdx.x;
         long long blk0 = -1;          // block of the first outputs (corner 0,0,0) and its bits
         unsigned long long m0 = 0ull;
-        if (i < n) {
-            const int4 c = reinterpret_cast<const int4 *>(in_coords)[i];
+        int row = i < span ? i : -1;
+        if (order && row >= 0) row = order[row];
+        if (row >= 0 && row < n) {
+            const int4 c = reinterpret_cast<const int4 *>(in_coords)[row];
             const AxisOut az = axis_outputs<SZ>(c.y, ge.k[0], ge.s[0], ge.p[0], go.d.D);
             const AxisOut ay = axis_outputs<SY>(c.z, ge.k[1], ge.s[1], ge.p[1], go.d.H);
             const AxisOut ax = axis_outputs<SX>(c.w, ge.k[2], ge.s[2], ge.p[2], go.d.W);
@@ -367,11 +373,11 @@ extern "C" int fnp_rulebook_strided(const int *in_coords, const int *n_in, int c
     for (int d = 0; d < 3; ++d) two = two && (ge.k[d] + ge.s[d] - 1) / ge.s[d] <= 2;
     const dim3 mgrid(fnp_grid_for(cap_in, kThreads));
     if (two && ge.s[0] == 2 && ge.s[1] == 2 && ge.s[2] == 2)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_mark2_kernel<2, 2, 2>), mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_mark2_kernel<2, 2, 2>), mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge, (const int *)gi.perm);
     else if (two && ge.s[0] == 2 && ge.s[1] == 1 && ge.s[2] == 1)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_mark2_kernel<2, 1, 1>), mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_mark2_kernel<2, 1, 1>), mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge, (const int *)gi.perm);
     else if (two)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_mark2_kernel<0, 0, 0>), mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_mark2_kernel<0, 0, 0>), mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge, (const int *)gi.perm);
     else
         hipLaunchKernelGGL(strided_mark_kernel, mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge);
     FNP_LAUNCH_CHECK();

@@ -173,6 +173,8 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
     const int ns = min(*n_sorted, cap);
     const int *fc_start = scene;
     const int *out_base = scene + (B + 1);
+    // ranks beyond the occupied cells map to no row (consumers walk perm[0 .. cap))
+    for (int r = ns + blockIdx.x * kThreads + threadIdx.x; r < cap; r += gridDim.x * kThreads) perm[r] = -1;
     for (int r = blockIdx.x * kThreads + threadIdx.x; r < ns; r += gridDim.x * kThreads) {
         const int *slots = top + (size_t)r * maxp;
         const int p0 = slots[0];
