@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Secondary measurement (BASELINE.json configs[3]): pseudo-label extraction end to end — Greedy Box Seeker per
+scene (batch size 1, like tools/extract_pseudo_labels.py), fixed-shape all-gather of the boxes (when launched
+under torch.distributed.run), running recall, `.pth` files in the reference's format.  One JSON line from rank 0.
+
+    python tools/bench_extract.py --scenes 64
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+        tools/bench_extract.py --scenes 512
+"""
+import argparse, json, os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from findnpropagate_amd import extract as E, synthetic as syn
+from findnpropagate_amd.dense_heads import FrustumProposerOG
+
+ap = argparse.ArgumentParser(); ap.add_argument("--scenes", type=int, default=64); ap.add_argument("--distinct", type=int, default=8)
+args = ap.parse_args()
+rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+torch.cuda.set_device(local); dev = torch.device("cuda", local)
+dist = None
+if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("nccl", device_id=dev)
+PARAMS = {'lq': 0.0, 'uq': 0.25, 'cq': 1.0, 'iou_w': 1.0, 'nms_normal': 1.0, 'dst_w': 0.0, 'dns_w': 1.0,
+          'min_cam_iou': 0.3, 'score_thr': 0.45, 'nms_2d': 0.4, 'nms_3d': 0.0, 'clamp_bottom': 1, 'num_sizes': 1}
+
+
+class Scenes:
+    """`distinct` synthetic scenes resident on the device, cycled to `n` frames (frame ids differ)."""
+    def __init__(self, n, distinct):
+        self.n, self.base = n, []
+        for s in range(distinct):
+            sc = syn.make_seeker_scene(s)
+            d = {"points": torch.from_numpy(sc["points"]).to(dev), "batch_size": 1, "dets": tuple(torch.from_numpy(a) for a in sc["dets"])}
+            for k in ("camera_intrinsics", "camera2lidar", "lidar2image", "lidar_aug_matrix"):
+                d[k] = torch.from_numpy(sc[k]).to(dev)
+            g = np.zeros((1, sc["gt_boxes"].shape[0], 10), np.float32)
+            g[0, :, :7] = sc["gt_boxes"]; g[0, :, 9] = sc["gt_cls"] + 1
+            d["gt_boxes"] = torch.from_numpy(g).to(dev)
+            self.base.append(d)
+    def __len__(self): return self.n
+    def frame_id(self, i): return f"synthetic-{i:06d}.pcd.bin"
+    def __getitem__(self, i):
+        d = dict(self.base[i % len(self.base)]); d["frame_id"] = self.frame_id(i)
+        return d
+
+
+data = Scenes(args.scenes, args.distinct)
+cur = {}
+head = FrustumProposerOG(model_cfg={"PARAMS": PARAMS, "PREDS_PATH": "PreprocessedGLIP", "BOX_FORMAT": "xyxy"},
+                         image_detector=lambda bd: bd["dets"]).eval()
+with tempfile.TemporaryDirectory() as warm:
+    E.extract_pseudo_labels(Scenes(2 * world, args.distinct), head, warm, dev, dist=dist, write="own")
+out_dir = tempfile.mkdtemp(prefix="fnp_extract_")
+rec = {}
+torch.cuda.synchronize(); t0 = time.perf_counter()
+written = E.extract_pseudo_labels(data, head, out_dir, dev, dist=dist, write="own", recall=rec)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+if dist is not None:
+    t = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+if rank == 0:
+    print(json.dumps({"workload": "pseudo-label extraction: Box Seeker per scene + all-gather + recall + .pth", "n_gpus": world,
+                      "scenes": args.scenes, "seconds": round(dt, 3), "scenes_per_s": round(args.scenes / dt, 1),
+                      "ms_per_scene_per_gpu": round(1e3 * dt * world / args.scenes, 3),
+                      "recall": {k: round(v, 3) for k, v in rec.items() if k.startswith("recall_")}, "gt": rec.get("gt")}))
+import shutil; shutil.rmtree(out_dir, ignore_errors=True)
