@@ -143,9 +143,9 @@ int launch_first(const void *x, const void *w, const int *nbr, int nbr_stride, i
 // ------------------------------------------------------------------------------------------
 // MFMA path.
 //
-// Workgroup = 4 waves; wave w owns MB*16 output sites and all COUT channels, accumulators in
-// registers for the whole sweep over the K kernel offsets.  The weight slab W_k (COUT x CIN bf16)
-// is shared by the 4 waves through LDS:
+// Workgroup = NW waves (4; 8 for 128 -> 128 channels); wave w owns MB*16 output sites and all COUT
+// channels, accumulators in registers for the whole sweep over the K kernel offsets.  The weight slab
+// W_k (COUT x CIN bf16) is shared by the waves through LDS:
 //   * ALLK  (K*slab <= 64 KiB: the 16/32-channel layers): every slab is staged once per
 //     persistent workgroup and the offset loop runs without barriers;
 //   * else  (64/128-channel layers): slabs are double-buffered; W_{k+1} is fetched a few 16-byte
@@ -157,7 +157,7 @@ int launch_first(const void *x, const void *w, const int *nbr, int nbr_stride, i
 // 256-byte bank row: conflict-free (SQ_LDS_BANK_CONFLICT = 0 measured).
 // Feature fragments are gathered straight from HBM/L2 through a buffer descriptor (16 contiguous
 // bytes per lane; rows absent from the rulebook present an out-of-range offset and read as zeros
-// without touching memory).  The kernel is bound by the latency x parallelism of these gathers,
+// without touching memory).  The kernel is bound by the per-CU rate of these gathers,
 // so they run PFK whole kernel offsets ahead of the matrix work: the fragments of offset k + PFK
 // are requested into the registers that offset k has just finished with, and the rulebook
 // indices they need were themselves fetched PFK offsets earlier.
