@@ -243,10 +243,14 @@ class FrustumProposerOG(nn.Module):
         if F == 0:
             return empty
         # scenes are contiguous row ranges of the collated point tensor (dataset.py:221-245)
-        counts = torch.bincount(points[:, 0].long(), minlength=B)[:B]
-        offsets = torch.zeros((B + 1,), dtype=torch.int32, device=dev)
-        offsets[1:] = torch.cumsum(counts, 0).int()
-        max_pts = int(counts.max().item())                                     # host sync 1
+        if B == 1:      # the extraction script's batch size (:36,54): the scene is the whole tensor, no sync needed
+            offsets = torch.tensor([0, points.shape[0]], dtype=torch.int32, device=dev)
+            max_pts = int(points.shape[0])
+        else:
+            counts = torch.bincount(points[:, 0].long(), minlength=B)[:B]
+            offsets = torch.zeros((B + 1,), dtype=torch.int32, device=dev)
+            offsets[1:] = torch.cumsum(counts, 0).int()
+            max_pts = int(counts.max().item())                                 # host sync 1
         scene_m, cam_m = self._matrices(batch_dict)
         scene_m, cam_m, d_fr = scene_m.to(dev), cam_m.to(dev), frusts.to(dev)
         prm = self._params(points.shape[1], 1)
