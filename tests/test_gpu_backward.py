@@ -120,3 +120,34 @@ def test_backbone_training_step_runs_and_matches_torch_reference_ops(cuda, rng):
         ga, gb = grads_a[name].float().cpu().numpy(), grads_b[name].float().cpu().numpy()
         assert np.isfinite(ga).all(), name
         assert np.abs(ga - gb).max() <= 2e-3 * max(np.abs(gb).max(), 1e-6), (name, np.abs(ga - gb).max(), np.abs(gb).max())
+
+
+def test_ddp_wraps_the_backbone(cuda, rng):
+    """cfg 5 runs the detector under DistributedDataParallel (tools/train_st.py:245): the backbone's parameters are
+    ordinary nn.Parameters behind a custom autograd Function, so DDP (RCCL all-reduce of the bucketed gradients;
+    world size 1 here) must wrap it unchanged and give the same gradients."""
+    import socket
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    from findnpropagate_amd import synthetic as syn
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=cuda)
+    try:
+        grid = np.array([96, 88, 40])
+        net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False, "FNP_DTYPE": "bf16"}, 5, grid), 0).to(cuda).train()
+        feats, idx = _random_sparse(rng, 2, net.sparse_shape, 4000, 5)
+        bd = lambda: {"voxel_features": torch.from_numpy(feats).to(cuda), "voxel_coords": torch.from_numpy(idx).to(cuda).float(), "batch_size": 2}
+        loss_of = lambda out: sum((t.features.float() ** 2).mean() for t in out["multi_scale_3d_features"].values())
+        net.zero_grad()
+        loss_of(net(bd())).backward()
+        want = {k: v.grad.clone() for k, v in net.named_parameters() if v.grad is not None}
+        ddp = DDP(net, device_ids=[cuda.index])
+        net.zero_grad()
+        loss_of(ddp(bd())).backward()
+        got = {k: v.grad for k, v in net.named_parameters() if v.grad is not None}
+        assert set(got) == set(want) and len(got) > 50
+        for k in want:
+            assert torch.equal(got[k], want[k]), k          # deterministic kernels + world size 1: identical
+    finally:
+        dist.destroy_process_group()
