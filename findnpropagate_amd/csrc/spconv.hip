@@ -327,7 +327,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     // as constants.
     int aoff[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) aoff[ks] = FNP_LDS_POS(l15, kvalid0 ? ks * 4 + q : 0);
+    for (int ks = 0; ks < KS; ++ks) aoff[ks] = FNP_LDS_POS(l15, kvalid0 ? ks * 4 + q : (q & (CH - 1)));   // (idle lanes mirror the conflict-free pattern)
     const int st_pos0 = FNP_LDS_POS(tid / CH, tid % CH);
     static_assert(SLAB < NT || ((NT / CH) % (CH << SW) == 0), "staging swizzle must be periodic in NT chunks");
     if (WIN && tid < Cfg::WZERO / 16) reinterpret_cast<uint4 *>(fnp_smem + WIN_ZERO)[tid] = make_uint4(0u, 0u, 0u, 0u);
