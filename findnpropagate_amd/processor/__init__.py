@@ -1,1 +1,1 @@
-from .data_processor import VoxelGeneratorWrapper  # noqa: F401
+from .data_processor import DataProcessor, VoxelGeneratorWrapper, mask_points_by_range  # noqa: F401
