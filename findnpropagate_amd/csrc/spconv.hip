@@ -239,6 +239,13 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     // (requested one offset earlier) is written to LDS at its end, so the weights get two offsets of
     // matrix work to arrive; larger slabs cannot afford the registers and go step by step
     constexpr bool WDEEP = !ALLK && NCH <= 1;
+    // 8-wave workgroups (128 -> 128): one chunk per thread and MFMA step, each held in a register for a whole
+    // offset: chunk ks of W_{k+2} is requested at step ks of offset k and written to LDS at step ks of offset
+    // k + 1, so the slab stream never waits for its own L2 latency (a step is ~0.15 us, the latency ~0.5-1 us)
+#ifndef FNP_WD4
+#define FNP_WD4 1
+#endif
+    constexpr bool WD4 = FNP_WD4 && !ALLK && NW == 8 && NCH == KS && NCH == 4;
     static_assert(CIN % 16 == 0 && COUT % 16 == 0, "channel counts must be multiples of 16");
     static_assert(ALLK || SLAB % NT == 0 || SLAB < NT, "unsupported slab size");
 
@@ -420,6 +427,11 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
             if (NCH > 1) wcur1 = w1[tid + NT];
         }
 
+        uint4 wd0 = make_uint4(0u, 0u, 0u, 0u), wd1 = wd0, wd2 = wd0, wd3 = wd0;   // (named: see wcur0)
+        if (WD4 && !(FNP_ABLATE & 2)) {
+            const uint4 *w1 = reinterpret_cast<const uint4 *>(w + (size_t)(K > 1 ? 1 : 0) * COUT * CIN);
+            wd0 = w1[tid]; wd1 = w1[tid + NT]; wd2 = w1[tid + 2 * NT]; wd3 = w1[tid + 3 * NT];
+        }
         for (int k0 = 0; k0 < K; k0 += PFK) {
 #pragma unroll
             for (int u = 0; u < PFK; ++u) {
@@ -452,8 +464,14 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
+                    if (WD4 && !(FNP_ABLATE & 2)) {
+                        uint4 &wd = ks == 0 ? wd0 : ks == 1 ? wd1 : ks == 2 ? wd2 : wd3;
+                        wl[((k + 1) & 1) * SLAB + st_pos0 + ks * NT] = wd;                    // chunk ks of W_{k+1}
+                        const uint4 *w2 = reinterpret_cast<const uint4 *>(w + (size_t)(k + 2 < K ? k + 2 : k) * COUT * CIN);
+                        wd = w2[tid + ks * NT];                                               // chunk ks of W_{k+2}
+                    }
                     // (1) previous step's weight chunks -> other LDS buffer; (2) request this step's
-                    if (!ALLK && !WDEEP && !(FNP_ABLATE & 2)) {
+                    if (!ALLK && !WDEEP && !WD4 && !(FNP_ABLATE & 2)) {
                         if (ks > 0) {
 #pragma unroll
                             for (int j = 0; j < WST; ++j) {
@@ -531,7 +549,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                         if (NCH > 1) wl[((k + 1) & 1) * SLAB + st_pos0 + NT] = wcur1;
                         wcur0 = wnext0;
                         wcur1 = wnext1;
-                    } else if (!(FNP_ABLATE & 2)) {
+                    } else if (!WD4 && !(FNP_ABLATE & 2)) {
 #pragma unroll
                         for (int j = 0; j < WST; ++j) {
                             const int c = (KS - 1) * WST + j, p = tid + c * NT;
