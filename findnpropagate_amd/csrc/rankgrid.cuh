@@ -115,7 +115,8 @@ constexpr int kTile = 4096;  // elements per workgroup (256 threads x 16)
 // out[i] = exclusive prefix of in[i] (int32 flags or counts); *total = sum.  in == out allowed.
 int int32(const int *in, long long n, int *out, int *total, void *ws, hipStream_t s);
 long long workspace_bytes(long long n);
-// base[w] for every occupied block of the grid, *total = number of occupied cells.
-int rank_grid(const RG &g, int *total, void *ws, hipStream_t s);
+// base[w] for every occupied block of the grid, *total = number of occupied cells.  With out_coords the
+// (b, z, y, x) of every occupied cell is written at its rank (rows >= cap_out dropped) in the same sweep.
+int rank_grid(const RG &g, int *total, void *ws, hipStream_t s, int *out_coords = nullptr, int cap_out = 0);
 long long rank_grid_workspace_bytes(long long nsum);
 }  // namespace fnp_scan

@@ -173,29 +173,6 @@ __global__ __launch_bounds__(kThreads) void strided_mark2_kernel(const int *__re
     }
 }
 
-// emit output coordinates in rank order: one wave per summary word (a zero word retires after one
-// load); lane j owns block 64*S + j, decodes the block origin once and writes its cells at
-// base[block], base[block] + 1, ...
-__global__ __launch_bounds__(kThreads) void emit_coords_kernel(RG go, int cap_out, int *__restrict__ out_coords) {
-    const int lane = fnp_lane();
-    const long long S = ((long long)blockIdx.x * kThreads + threadIdx.x) >> 6;
-    if (S >= go.nsum) return;
-    const unsigned long long sw = go.summ[S];
-    if (!((sw >> lane) & 1ull)) return;
-    const long long w = S * 64 + lane;
-    unsigned long long m = go.bits[w];
-    int r = (int)go.base[w];
-    int b, z0, y0, x0;
-    rg_decode(go.d, w, 0, b, z0, y0, x0);
-    while (m) {
-        const int bit = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        if (r < cap_out)
-            reinterpret_cast<int4 *>(out_coords)[r] = make_int4(b, z0 | (bit >> 4), y0 | ((bit >> 2) & 3), x0 | (bit & 3));
-        ++r;
-    }
-}
-
 // grid (blocks over output rows, K)
 __global__ __launch_bounds__(kThreads) void strided_nbr_kernel(const int *__restrict__ out_coords,
                                                                const int *__restrict__ n_out, int cap_out, RG gi,
@@ -381,11 +358,8 @@ extern "C" int fnp_rulebook_strided(const int *in_coords, const int *n_in, int c
     else
         hipLaunchKernelGGL(strided_mark_kernel, mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge);
     FNP_LAUNCH_CHECK();
-    int rc = fnp_scan::rank_grid(go, n_out, workspace, s);
+    int rc = fnp_scan::rank_grid(go, n_out, workspace, s, out_coords, cap_out);   // ranks + coordinates in rank order
     if (rc) return rc;
-    hipLaunchKernelGGL(emit_coords_kernel, dim3(fnp_divup(go.nsum * 64, kThreads)), dim3(kThreads), 0, s, go, cap_out,
-                       out_coords);
-    FNP_LAUNCH_CHECK();
     const dim3 rgrid(fnp_grid_for(cap_out, kThreads));
     if (ge.k[0] == 3 && ge.k[1] == 3 && ge.k[2] == 3)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_nbr_row_kernel<3, 3, 3>), rgrid, dim3(kThreads), 0, s, out_coords, n_out,

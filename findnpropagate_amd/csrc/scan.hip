@@ -110,34 +110,44 @@ int run_scan(L load, long long n, TOut *out, int *total, void *ws, hipStream_t s
 }
 
 // ---- rank-grid prefix through the summary level ---------------------------------------------
-// One wave per summary word S (64 blocks); a wave whose word is zero retires after one load, so
-// the cost follows the occupied blocks.  Lane j owns block 64*S + j.  Three kernels, none of them a
-// scan over the 360 k per-word counts:
-//   PASS 0 : cnt[S]  = occupied cells in the 64 blocks of S
-//   TOTALS : gtot[g] = sum of cnt over group g (64 words), ctot[c] = over chunk c (16 groups);
+// One wave per UNIT of WPW consecutive summary words (64 WPW blocks): lane j < WPW loads word j of the
+// unit (one coalesced read), a ballot names the non-zero words, and only those are visited — four at a
+// time, so that the occupancy-word loads of a round are in flight together.  WPW = 64 for the large,
+// ~98 % empty grids (the 41 x 1440 x 1440 lidar grid of a 32-scene batch has 713 k summary words: a wave
+// per word spent 85 us launching waves that retire after one load); WPW = 1 for the small dense grids of
+// the later stages, where a wave per word is the parallel form.  Three kernels, none of them a scan over
+// the per-unit counts:
+//   PASS 0 : cnt[U]  = occupied cells in the blocks of unit U             (no scan: a per-lane sum)
+//   TOTALS : gtot[g] = sum of cnt over group g (64 units), ctot[c] = over chunk c (16 groups);
 //            one workgroup per chunk, coalesced
-//   PASS 1 : base[w] = cells before S + occupied cells in the blocks of S before w   (w occupied),
-//            where "cells before S" = sum(ctot[< c]) + sum(gtot[16c .. g)) + sum(cnt[64g .. S)):
-//            <= 350 + 15 + 63 values, read lane-parallel and reduced once per occupied word
-//            *total = sum(ctot)   (wave of S = 0)
+//   PASS 1 : base[w] = cells before U + cells in the earlier words of U + cells in the blocks of w's word
+//            before w, where "cells before U" = sum(ctot[< c]) + sum(gtot[16c .. g)) + sum(cnt[64g .. U))
+//            (lane-parallel reads, reduced once per wave) and the words of U are walked in order with a
+//            running sum;  *total = sum(ctot)  (wave of U = 0).
+//            With out_coords the coordinates of the occupied cells are written at their ranks in the
+//            same sweep (lane = block: decode the block origin once, one int4 per set bit).
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     return v;
 }
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
 
-__global__ __launch_bounds__(kThreads) void rank_totals_kernel(const unsigned *__restrict__ cnt, long long nsum,
+__global__ __launch_bounds__(kThreads) void rank_totals_kernel(const unsigned *__restrict__ cnt, long long nunits,
                                                                unsigned *__restrict__ gtot, unsigned *__restrict__ ctot) {
     __shared__ unsigned part[16];
     const int wave = threadIdx.x >> 6, lane = fnp_lane();
     const long long c = blockIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {   // wave w sums groups 4w .. 4w+3 of the chunk
-        const long long grp = c * 16 + wave * 4 + i, S = grp * 64 + lane;
-        const unsigned t = wave_sum(S < nsum ? cnt[S] : 0u);
+        const long long grp = c * 16 + wave * 4 + i, U = grp * 64 + lane;
+        const unsigned t = wave_sum(U < nunits ? cnt[U] : 0u);
         if (lane == 0) {
             part[wave * 4 + i] = t;
-            if (grp * 64 < nsum) gtot[grp] = t;
+            if (grp * 64 < nunits) gtot[grp] = t;
         }
     }
     __syncthreads();
@@ -149,38 +159,89 @@ __global__ __launch_bounds__(kThreads) void rank_totals_kernel(const unsigned *_
     }
 }
 
-template <int PASS>
-__global__ __launch_bounds__(kThreads) void summary_pass_kernel(RG g, unsigned *__restrict__ cnt, const unsigned *__restrict__ gtot,
+template <int PASS, int WPW>
+__global__ __launch_bounds__(kThreads) void summary_pass_kernel(RG g, long long nunits, unsigned *__restrict__ cnt,
+                                                                const unsigned *__restrict__ gtot,
                                                                 const unsigned *__restrict__ ctot, int nchunks,
-                                                                int *__restrict__ total) {
+                                                                int *__restrict__ total, int cap_out,
+                                                                int *__restrict__ out_coords) {
+    constexpr int ROUND = WPW < 4 ? WPW : 4;   // non-zero summary words visited per round
     const int lane = fnp_lane();
-    const long long S = ((long long)blockIdx.x * kThreads + threadIdx.x) >> 6;
-    if (S >= g.nsum) return;
-    if (PASS == 1 && S == 0) {
+    const long long U = ((long long)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    if (U >= nunits) return;
+    if (PASS == 1 && U == 0) {
         unsigned t = 0;
         for (int c = lane; c < nchunks; c += 64) t += ctot[c];
         t = wave_sum(t);
         if (lane == 0) *total = (int)t;
     }
-    const unsigned long long sw = g.summ[S];   // wave-uniform
-    if (sw == 0ull) {
-        if (PASS == 0 && lane == 0) cnt[S] = 0;
+    const long long S0 = U * WPW;
+    unsigned long long swl, todo;
+    if (WPW == 1) {
+        swl = g.summ[S0];          // wave-uniform
+        todo = swl != 0ull ? 1ull : 0ull;
+    } else {
+        swl = (lane < WPW && S0 + lane < g.nsum) ? g.summ[S0 + lane] : 0ull;
+        todo = __ballot(swl != 0ull);
+    }
+    if (todo == 0ull) {
+        if (PASS == 0 && lane == 0) cnt[U] = 0u;
         return;
     }
-    const long long blk = S * 64 + lane;
-    const bool occ = (sw >> lane) & 1ull;
-    const unsigned c = occ ? (unsigned)__popcll(g.bits[blk]) : 0u;
-    const unsigned inc = wave_inclusive(c);
-    if (PASS == 0) {
-        if (lane == 63) cnt[S] = inc;
-    } else {
-        const long long grp = S >> 6, chunk = S >> 10;
+    unsigned run = 0;   // PASS 0: per-lane sum; PASS 1: cells before the current word (same in every lane)
+    if (PASS == 1) {
+        const long long grp = U >> 6, chunk = U >> 10;
         unsigned p = 0;
         for (int i = lane; i < (int)chunk; i += 64) p += ctot[i];
         if (lane < (int)(grp - chunk * 16)) p += gtot[chunk * 16 + lane];
-        if (lane < (int)(S - grp * 64)) p += cnt[grp * 64 + lane];
-        p = wave_sum(p);
-        if (occ) g.base[blk] = p + inc - c;
+        if (lane < (int)(U - grp * 64)) p += cnt[grp * 64 + lane];
+        run = wave_sum(p);
+    }
+    while (todo) {
+        int j[ROUND];
+        bool v[ROUND];
+        unsigned long long bits[ROUND];
+#pragma unroll
+        for (int u = 0; u < ROUND; ++u) {
+            v[u] = todo != 0ull;
+            j[u] = v[u] ? __builtin_ctzll(todo) : 0;
+            if (v[u]) todo &= todo - 1ull;
+            const unsigned long long sw = WPW == 1 ? swl : readlane64(swl, j[u]);
+            const bool occ = v[u] && ((sw >> lane) & 1ull);
+            bits[u] = occ ? g.bits[(S0 + j[u]) * 64 + lane] : 0ull;   // (the loads of a round are issued together)
+        }
+#pragma unroll
+        for (int u = 0; u < ROUND; ++u) {
+            const unsigned c = (unsigned)__popcll(bits[u]);
+            if (PASS == 0) {
+                run += c;
+            } else {
+                if (!v[u]) break;   // uniform
+                const unsigned inc = wave_inclusive(c);
+                const long long blk = (S0 + j[u]) * 64 + lane;
+                int r = (int)(run + inc - c);
+                if (bits[u]) {
+                    g.base[blk] = (unsigned)r;
+                    if (out_coords) {
+                        int b, z0, y0, x0;
+                        rg_decode(g.d, blk, 0, b, z0, y0, x0);
+                        unsigned long long m = bits[u];
+                        while (m) {
+                            const int bit = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            if (r < cap_out)
+                                reinterpret_cast<int4 *>(out_coords)[r] = make_int4(b, z0 | (bit >> 4), y0 | ((bit >> 2) & 3), x0 | (bit & 3));
+                            ++r;
+                        }
+                    }
+                }
+                if (WPW > 1) run += (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
+            }
+        }
+    }
+    if (PASS == 0) {
+        run = wave_sum(run);
+        if (lane == 0) cnt[U] = run;
     }
 }
 
@@ -191,26 +252,35 @@ long long workspace_bytes(long long n) { return ((n + kTile - 1) / kTile + 1) * 
 int int32(const int *in, long long n, int *out, int *total, void *ws, hipStream_t s) {
     return run_scan(LoadInt{in}, n, out, total, ws, s);
 }
+// (sized for one unit per summary word, the finest split)
 long long rank_grid_workspace_bytes(long long nsum) {
     const long long ngroups = (nsum + 63) >> 6, nchunks = (nsum + 1023) >> 10;
     return ((nsum * 4 + 255) & ~255ll) + (((ngroups + nchunks) * 4 + 255) & ~255ll) + 256;
 }
-int rank_grid(const RG &g, int *total, void *ws, hipStream_t s) {
-    const long long ngroups = (g.nsum + 63) >> 6, nchunks = (g.nsum + 1023) >> 10;
+template <int WPW>
+static int rank_grid_w(const RG &g, int *total, void *ws, hipStream_t s, int *out_coords, int cap_out) {
+    const long long nunits = (g.nsum + WPW - 1) / WPW;
+    const long long ngroups = (nunits + 63) >> 6, nchunks = (nunits + 1023) >> 10;
     if (nchunks > 0x7fffffffll) return FNP_ERR_ARG;
-    unsigned *cnt = (unsigned *)ws;   // (nsum) cells per summary word
-    unsigned *gtot = (unsigned *)((char *)ws + ((g.nsum * 4 + 255) & ~255ll));
+    unsigned *cnt = (unsigned *)ws;   // (nunits) cells per unit
+    unsigned *gtot = (unsigned *)((char *)ws + ((nunits * 4 + 255) & ~255ll));
     unsigned *ctot = gtot + ngroups;
-    const int grid = fnp_divup(g.nsum * 64, kThreads);
-    hipLaunchKernelGGL(summary_pass_kernel<0>, dim3(grid), dim3(kThreads), 0, s, g, cnt, (const unsigned *)nullptr,
-                       (const unsigned *)nullptr, (int)nchunks, total);
+    const int grid = fnp_divup(nunits * 64, kThreads);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(summary_pass_kernel<0, WPW>), dim3(grid), dim3(kThreads), 0, s, g, nunits, cnt,
+                       (const unsigned *)nullptr, (const unsigned *)nullptr, (int)nchunks, total, 0, (int *)nullptr);
     FNP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rank_totals_kernel, dim3((unsigned)nchunks), dim3(kThreads), 0, s, (const unsigned *)cnt, g.nsum, gtot, ctot);
+    hipLaunchKernelGGL(rank_totals_kernel, dim3((unsigned)nchunks), dim3(kThreads), 0, s, (const unsigned *)cnt, nunits, gtot, ctot);
     FNP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(summary_pass_kernel<1>, dim3(grid), dim3(kThreads), 0, s, g, cnt, (const unsigned *)gtot,
-                       (const unsigned *)ctot, (int)nchunks, total);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(summary_pass_kernel<1, WPW>), dim3(grid), dim3(kThreads), 0, s, g, nunits, cnt,
+                       (const unsigned *)gtot, (const unsigned *)ctot, (int)nchunks, total, cap_out, out_coords);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
+}
+int rank_grid(const RG &g, int *total, void *ws, hipStream_t s, int *out_coords, int cap_out) {
+    // the split only changes who computes what, never the ranks
+    if (g.nsum >= (1ll << 18)) return rank_grid_w<64>(g, total, ws, s, out_coords, cap_out);
+    if (g.nsum >= (1ll << 15)) return rank_grid_w<8>(g, total, ws, s, out_coords, cap_out);
+    return rank_grid_w<1>(g, total, ws, s, out_coords, cap_out);
 }
 }  // namespace fnp_scan
 

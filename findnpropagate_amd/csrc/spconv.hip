@@ -193,6 +193,10 @@ struct MfmaCfg {
 #ifndef FNP_ABLATE
 #define FNP_ABLATE 0
 #endif
+// L2 line-touch prefetch of the rows above a tile (bit 0) — see run_tile
+#ifndef FNP_PF
+#define FNP_PF 0
+#endif
 
 // waves per SIMD the register budget is held to: 3 (<= 168 VGPRs) where it measured faster on
 // MI355X (the channel-doubling strided layers 16->32, 32->64: a third resident workgroup per CU
@@ -221,7 +225,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                                                              const int *__restrict__ n_out, int cap,
                                                              TOut *__restrict__ y, const float *__restrict__ scale,
                                                              const float *__restrict__ shift,
-                                                             const TOut *__restrict__ residual, int relu) {
+                                                             const TOut *__restrict__ residual, int relu, int hints) {
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
     constexpr int CH = Cfg::CH, SLAB = Cfg::SLAB, SW = Cfg::SW, KS = Cfg::KS, PFK = Cfg::PFK;
     constexpr bool ALLK = Cfg::ALLK;
@@ -401,6 +405,19 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                 rawq[u][mb] = nbr_raw(PFK + u, row0 + mb * 16 + l15, row_end);
                 rawr[u][mb] = nbr_raw(2 * PFK + u, row0 + mb * 16 + l15, row_end);
             }
+        // L2 line touch (ranked rows): the input rows just above this tile — the next tile's own rows, first
+        // reached by the upper-neighbour offsets of this one — are requested one dword per 128-byte line now,
+        // so the gathers that reach them later in the sweep hit L2 instead of each paying a fabric round trip
+        // (VMEM returns in order: one late row holds back every younger gather of the wave, and the
+        // per-offset barrier passes that wait on to the whole workgroup).  The values are never used.
+        constexpr int NPF = (FNP_PF & 1) && !WIN && CIN == COUT ? (ROWS_PER_WG * CIN * 2 / 128 + NT - 1) / NT : 0;
+        unsigned pfv[NPF > 0 ? NPF : 1];
+        if constexpr (NPF > 0) {
+            const unsigned pbase = ((hints & FNP_HINT_ROWS_RANKED) ? (unsigned)(tile_base + NW * MBT * 16) * (unsigned)(CIN * 2) : 0x80000000u);
+#pragma unroll
+            for (int j = 0; j < NPF; ++j)
+                pfv[j] = __builtin_amdgcn_raw_buffer_load_b32(xrsrc, pbase + ((unsigned)tid + j * (unsigned)NT) * 128u, 0, 0);
+        }
         if (!ALLK) {
             if (!(FNP_ABLATE & 2)) {
 #pragma unroll
@@ -562,6 +579,10 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
             }
         }
 #undef FNP_LDS_POS
+        if constexpr (NPF > 0) {
+#pragma unroll
+            for (int j = 0; j < NPF; ++j) asm volatile("" ::"v"(pfv[j]));
+        }
 
         // epilogue: lane holds out[site = row0 + mb*16 + l15][c0 .. c0+3], c0 = nb*16 + q*4
 #pragma unroll
@@ -614,7 +635,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
 
 template <int CIN, int COUT, int KVOL, bool WIN, typename TOut>
 int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
-                  void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s) {
+                  void *y, const float *scale, const float *shift, const void *residual, int relu, int hints, hipStream_t s) {
     // 16-site blocks per wave: 4 (64 sites); 3 for 128 output channels (accumulators = COUT/16 * MB * 4
     // registers; 4 spills heavily, 3 spills ~16 registers outside the offset loop and measured 13 %
     // faster than 2 on MI355X: fewer weight-slab sweeps per site); 2 for the 16 -> 16 layers
@@ -641,7 +662,7 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
     const int resident = 256 * MfmaOcc<CIN, COUT>::WAVES * 4 / MfmaWg<CIN, COUT>::NW;
     const int grid = tiles < resident ? tiles : resident;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MfmaWg<CIN, COUT>::NW * 64), lds, s, (const __bf16 *)x, x_bytes, (const __bf16 *)w,
-                       nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu);
+                       nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu, hints);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
@@ -664,13 +685,13 @@ int launch_mfma(const void *x, int x_bytes, const void *w, const int *nbr, int n
         if constexpr (HasWindow<CIN, COUT>::value) {
             if (hints & FNP_HINT_ROWS_RANKED)
                 return launch_mfma_k<CIN, COUT, 27, true, TOut>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale,
-                                                                shift, residual, relu, s);
+                                                                shift, residual, relu, hints, s);
         }
         return launch_mfma_k<CIN, COUT, 27, false, TOut>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift,
-                                                         residual, relu, s);
+                                                         residual, relu, hints, s);
     }
     return launch_mfma_k<CIN, COUT, 0, false, TOut>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual,
-                                                    relu, s);
+                                                    relu, hints, s);
 }
 
 template <typename TIn, typename TOut>
