@@ -89,15 +89,17 @@ __device__ __forceinline__ void rg_decode(const RankGridDims &g, long long blk, 
     x = (bx << 2) | (bit & 3);
 }
 
-// Mark a cell occupied.  The plain read first keeps already-set bits (the common case once a block
-// has been touched) off the atomic path; exactly one thread sees the word go 0 -> non-zero and
-// publishes the block in the summary level.
-__device__ __forceinline__ void rg_mark(const RG &g, long long blk, int bit) {
-    const unsigned long long m = 1ull << bit;
-    if (g.bits[blk] & m) return;
+// Mark the cells `m` of block `blk` occupied.  The plain read first keeps already-set bits (the common
+// case once a block has been touched) off the atomic path; exactly one thread sees the word go
+// 0 -> non-zero and publishes the block in the summary level.  (Measured: publishing from every thread
+// that reads the summary bit as unset — two independent no-return atomics instead of a dependent pair —
+// is 2.5x slower; same-address atomics serialise in L2.)
+__device__ __forceinline__ void rg_mark_mask(const RG &g, long long blk, unsigned long long m) {
+    if ((g.bits[blk] & m) == m) return;
     const unsigned long long old = atomicOr(&g.bits[blk], m);
     if (old == 0ull) atomicOr(&g.summ[blk >> 6], 1ull << (blk & 63));
 }
+__device__ __forceinline__ void rg_mark(const RG &g, long long blk, int bit) { rg_mark_mask(g, blk, 1ull << bit); }
 
 // Row of cell (b,z,y,x) or -1.  Caller guarantees the cell is inside the grid.
 __device__ __forceinline__ int rg_lookup(const RG &g, int b, int z, int y, int x) {

@@ -106,12 +106,6 @@ __device__ __forceinline__ unsigned long long spread16(unsigned s) {
     return (unsigned long long)(s & 1u) | ((unsigned long long)(s & 2u) << 15) | ((unsigned long long)(s & 4u) << 30) |
            ((unsigned long long)(s & 8u) << 45);
 }
-__device__ __forceinline__ void rg_mark_mask(const RG &g, long long blk, unsigned long long m) {
-    if ((g.bits[blk] & m) == m) return;
-    const unsigned long long old = atomicOr(&g.bits[blk], m);
-    if (old == 0ull) atomicOr(&g.summ[blk >> 6], 1ull << (blk & 63));
-}
-
 template <int SZ, int SY, int SX>
 // order: optional rank -> row map of the input grid (stage 1, whose rows are in the voxeliser's first-come
 // order): the inputs are then visited in rank order, which is what makes the wave-level merging below bite.

@@ -67,28 +67,47 @@ __device__ __forceinline__ int batch_of(const int *__restrict__ off, int B, int 
 __global__ __launch_bounds__(kThreads) void vox_mark_kernel(const float *__restrict__ pts, int n, int C,
                                                             const int *__restrict__ boff, int B, fnp_voxel_cfg cfg,
                                                             RG g, long long *__restrict__ code) {
-    const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n) return;
-    const float *p = pts + (size_t)i * C;
-    int c[3];
-    bool ok = true;
+    const int i = blockIdx.x * kThreads + threadIdx.x;   // (whole waves stay: the shuffles below need them)
+    const int lane = fnp_lane();
+    long long blk = -1;
+    unsigned long long m = 0ull;
+    if (i < n) {
+        const float *p = pts + (size_t)i * C;
+        int c[3];
+        bool ok = true;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        // f32 subtract, f32 divide (IEEE, correctly rounded), floor -> int: same as the reference loop
-        const float q = (p[j] - cfg.range_min[j]) / cfg.voxel_size[j];
-        const float f = floorf(q);
-        ok = ok && (f >= 0.f) && (f < (float)cfg.grid[j]);
-        c[j] = (int)f;
+        for (int j = 0; j < 3; ++j) {
+            // f32 subtract, f32 divide (IEEE, correctly rounded), floor -> int: same as the reference loop
+            const float q = (p[j] - cfg.range_min[j]) / cfg.voxel_size[j];
+            const float f = floorf(q);
+            ok = ok && (f >= 0.f) && (f < (float)cfg.grid[j]);
+            c[j] = (int)f;
+        }
+        long long cd = -1;
+        if (ok) {
+            // scene of the point: searched once per wave for its first point (uniform: scalar loads, not queued
+            // behind the point loads); a wave that crosses a scene border searches per lane
+            const int i0 = __builtin_amdgcn_readfirstlane(i);
+            int b = batch_of(boff, B, i0);
+            if (b + 1 < B && i >= boff[b + 1]) b = batch_of(boff, B, i);
+            blk = rg_block_of(g.d, b, c[2], c[1], c[0]);
+            const int bit = rg_bit_of(c[2], c[1], c[0]);
+            m = 1ull << bit;
+            cd = (blk << 6) | bit;
+        }
+        code[i] = cd;
     }
-    long long cd = -1;
-    if (ok) {
-        const int b = batch_of(boff, B, i);
-        const long long blk = rg_block_of(g.d, b, c[2], c[1], c[0]);
-        const int bit = rg_bit_of(c[2], c[1], c[0]);
-        rg_mark(g, blk, bit);
-        cd = (blk << 6) | bit;
+    // A lidar sweep visits a 4x4x4 block with runs of consecutive points: OR the bits of equal blocks along
+    // the wave (a lane may take in any earlier lane's bits of the same block) and let the last lane of each
+    // run issue the one atomic — same-address atomics serialise in L2.  Any point order gives the same grid.
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long nb = __shfl_up(blk, d);
+        const unsigned long long nm = __shfl_up(m, d);
+        if (lane >= d && nb == blk) m |= nm;
     }
-    code[i] = cd;
+    const long long nxt = __shfl_down(blk, 1);
+    if (blk >= 0 && (lane == 63 || nxt != blk)) rg_mark_mask(g, blk, m);
 }
 
 __global__ __launch_bounds__(kThreads) void vox_insert_kernel(int n, int maxp, int cap,
@@ -199,10 +218,29 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
         reinterpret_cast<int4 *>(coords)[id] = make_int4(bb, z, y, x);
         num_points[id] = np;
         const float norm = (float)(np < 1 ? 1 : np);
-        for (int c = 0; c < C; ++c) {
-            float s = 0.f;
-            for (int j = 0; j < np; ++j) s += pts[(size_t)slots[j] * C + c];  // slot order, like sum(dim=1)
-            mean[(size_t)id * C + c] = s / norm;
+        // per channel the sum runs in slot order, like sum(dim=1); the C loads of a point (and the next
+        // point's) are independent and in flight together: the chain is np adds long, not np * C loads
+        if (C <= 8) {
+            float s8[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s8[c] = 0.f;
+            for (int j = 0; j < np; ++j) {
+                const float *pr = pts + (size_t)slots[j] * C;
+                float v8[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v8[c] = c < C ? pr[c] : 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) s8[c] += v8[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < C) mean[(size_t)id * C + c] = s8[c] / norm;
+        } else {
+            for (int c = 0; c < C; ++c) {
+                float s = 0.f;
+                for (int j = 0; j < np; ++j) s += pts[(size_t)slots[j] * C + c];
+                mean[(size_t)id * C + c] = s / norm;
+            }
         }
         if (voxels) {
             float *v = voxels + (size_t)id * maxp * C;
