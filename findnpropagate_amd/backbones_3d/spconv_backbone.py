@@ -263,7 +263,7 @@ class _PointsGraph:
         grids = e._get_grids(self.batch_size, self.pts.device)
         vox = S.voxelize(self.pts, self.off, self.batch_size, voxel_cfg, grid=grids[0], workspace=e._vox_ws)
         e._vox_ws = vox['workspace']
-        res = e._run_once(vox['mean'], vox['coords'], vox['n'], self.batch_size, grids[0], sync=False)
+        res = e._run_once(vox['mean'], vox['coords'], vox['n'], self.batch_size, grids[0], sync=False, n_cells=vox['n_cells'])
         return vox, res
 
 
@@ -335,7 +335,7 @@ class FusedResBackbone:
         grids = self._get_grids(batch_size, points.device)
         vox = S.voxelize(points, batch_offsets, batch_size, voxel_cfg, grid=grids[0], workspace=self._vox_ws)
         self._vox_ws = vox['workspace']
-        res = self.run(vox['mean'], vox['coords'], vox['n'], batch_size, grid1=grids[0], sync=sync)
+        res = self.run(vox['mean'], vox['coords'], vox['n'], batch_size, grid1=grids[0], sync=sync, n_cells=vox['n_cells'])
         res['voxel_coords'], res['voxel_num_points'], res['voxel_features'] = vox['coords'], vox['num_points'], vox['mean']
         if sync:
             n1 = res['counts'][0]
@@ -381,16 +381,17 @@ class FusedResBackbone:
                 'out': tensors[4], 'counts': counts, 'voxel_coords': g.vox['coords'][:n1],
                 'voxel_num_points': g.vox['num_points'][:n1], 'voxel_features': g.vox['mean'][:n1]}
 
-    def run(self, feats, indices, n1, batch_size, grid1=None, sync=True):
-        """feats (cap1,Cin) f32, indices (cap1,4) i32, n1 (1,) i32 device."""
+    def run(self, feats, indices, n1, batch_size, grid1=None, sync=True, n_cells=None):
+        """feats (cap1,Cin) f32, indices (cap1,4) i32, n1 (1,) i32 device.
+        n_cells: rows [n1, n_cells) of indices list further cells set in grid1 (voxels the voxeliser dropped)."""
         while True:
-            res = self._run_once(feats, indices, n1, batch_size, grid1, sync)
+            res = self._run_once(feats, indices, n1, batch_size, grid1, sync, n_cells)
             if res is not None:
                 return res
             # overflow: capacities were grown and grids cleared; rebuild grid1 from the indices
             grid1 = None
 
-    def _run_once(self, feats, indices, n1, batch_size, grid1, sync):
+    def _run_once(self, feats, indices, n1, batch_size, grid1, sync, n_cells=None):
         m, P, act = self.m, self.prepare(), self.act
         dev = feats.device
         grids = self._get_grids(batch_size, dev)
@@ -445,8 +446,8 @@ class FusedResBackbone:
         stage.append((xo, rbo.out_indices, rbo.out_n, rbo.out_grid))
 
         # leave every persistent grid zeroed for the next call (O(rows) sparse clear)
-        for (_, idx, n, g) in stage:
-            S.clear_grid(g, idx, n)
+        for l, (_, idx, n, g) in enumerate(stage):
+            S.clear_grid(g, idx, n_cells if (l == 0 and n_cells is not None) else n)
 
         shapes = self._stage_shapes()
         if not sync:

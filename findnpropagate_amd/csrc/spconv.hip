@@ -199,8 +199,8 @@ struct MfmaCfg {
 #endif
 
 // waves per SIMD the register budget is held to: 3 (<= 168 VGPRs) where it measured faster on
-// MI355X (the channel-doubling strided layers 16->32, 32->64: a third resident workgroup per CU
-// shortens the last, partly filled round of tiles), 2 elsewhere (3 costs spills there)
+// MI355X (the channel-doubling strided layer 32->64: a third resident workgroup per CU
+// shortens the last, partly filled round of tiles), 4 for 16->32, 2 elsewhere (3 costs spills there)
 template <int CIN, int COUT> struct MfmaOcc;
 
 // waves per workgroup: 8 for the 128-channel layers (one 32 KiB weight slab per offset then serves 384 sites
@@ -216,7 +216,7 @@ template <int CIN, int COUT> struct MfmaOcc;
 #endif
 template <int CIN, int COUT> struct MfmaWg { static constexpr int NW = (COUT == 128 && CIN >= FNP_NW_MINCIN) ? FNP_NW128 : (CIN == 32 && COUT == 32) ? FNP_NW32 : 4; };
 
-template <int CIN, int COUT> struct MfmaOcc { static constexpr int WAVES = ((CIN < COUT && COUT <= 64) || MfmaWg<CIN, COUT>::NW == 6) ? 3 : 2; };
+template <int CIN, int COUT> struct MfmaOcc { static constexpr int WAVES = (CIN == 16 && COUT == 32) ? 4 : ((CIN < COUT && COUT <= 64) || MfmaWg<CIN, COUT>::NW == 6) ? 3 : 2; };
 
 template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut>
 __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const __bf16 *__restrict__ x, int x_bytes,
@@ -642,7 +642,8 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
 #ifndef FNP_MB128
 #define FNP_MB128 3
 #endif
-    constexpr int MB = COUT >= 128 ? FNP_MB128 : (CIN == 16 && COUT == 16) ? 2 : 4;
+    // (16 -> 32, 8 % of the pairs present: 2 blocks at 4 waves/SIMD measured 9 % faster than 4 blocks at 3)
+    constexpr int MB = COUT >= 128 ? FNP_MB128 : (CIN == 16 && COUT <= 32) ? 2 : 4;
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
     auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut>;
     constexpr int lds = Cfg::lds_bytes(MB, WIN);

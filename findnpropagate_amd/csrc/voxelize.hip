@@ -176,6 +176,7 @@ __global__ __launch_bounds__(64) void vox_scene_kernel(const int *__restrict__ b
     }
     if (lane == 0) {
         out_base[B] = acc;
+        scene[2 * (B + 1)] = 0;   // dropped-cell counter of the emit pass
         *n_voxels = acc;  // true count; consumers clamp to their capacity
     }
 }
@@ -188,10 +189,12 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
                                                             const int *__restrict__ n_sorted, int cap,
                                                             int *__restrict__ perm, int *__restrict__ coords,
                                                             int *__restrict__ num_points, float *__restrict__ mean,
-                                                            float *__restrict__ voxels) {
+                                                            float *__restrict__ voxels, int *__restrict__ n_cells,
+                                                            int *__restrict__ n_dropped) {
     const int ns = min(*n_sorted, cap);
     const int *fc_start = scene;
     const int *out_base = scene + (B + 1);
+    if (n_cells && blockIdx.x == 0 && threadIdx.x == 0) *n_cells = ns;
     // ranks beyond the occupied cells map to no row (consumers walk perm[0 .. cap))
     for (int r = ns + blockIdx.x * kThreads + threadIdx.x; r < cap; r += gridDim.x * kThreads) perm[r] = -1;
     for (int r = blockIdx.x * kThreads + threadIdx.x; r < ns; r += gridDim.x * kThreads) {
@@ -205,13 +208,15 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
         // points kept = filled slots (the list holds the max_points smallest indices of the cell)
         int np = 0;
         for (int j = 0; j < maxp; ++j) np += slots[j] != kSentinel ? 1 : 0;
-        if (srank >= max_voxels) {
-            perm[r] = -1;
-            continue;
-        }
         const int id = out_base[bb] + srank;
-        if (id >= cap) {
+        if (srank >= max_voxels || id >= cap) {
+            // dropped by the per-scene cut: no voxel row; its cell goes behind the voxels in the coordinate
+            // list (any order) so that the sparse clear of a persistent grid reaches it
             perm[r] = -1;
+            if (n_cells) {
+                const int t = out_base[B] + atomicAdd(n_dropped, 1);
+                if (t < cap) reinterpret_cast<int4 *>(coords)[t] = make_int4(bb, z, y, x);
+            }
             continue;
         }
         perm[r] = id;
@@ -309,7 +314,7 @@ extern "C" int64_t fnp_voxelize_workspace_bytes(int64_t n_points, const fnp_voxe
 
 extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets, const fnp_voxel_cfg *cfg,
                             const fnp_rankgrid *grid, void *workspace, int64_t workspace_bytes, int *coords,
-                            int *num_points, float *mean_feats, float *voxels, int *n_voxels, int cap,
+                            int *num_points, float *mean_feats, float *voxels, int *n_voxels, int *n_cells, int cap,
                             fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!cfg || n < 0 || cap <= 0 || !n_voxels || !fnp_rg_valid(grid, true) || grid->B > kMaxBatch || !grid_covers(cfg, grid))
@@ -317,6 +322,7 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
     if (cfg->num_features < 3 || cfg->max_points <= 0 || cfg->max_points > 64 || cfg->max_voxels <= 0) return FNP_ERR_ARG;
     if (n == 0) {
         FNP_HIP_TRY(hipMemsetAsync(n_voxels, 0, sizeof(int), s));
+        if (n_cells) FNP_HIP_TRY(hipMemsetAsync(n_cells, 0, sizeof(int), s));
         return FNP_OK;
     }
     if (!points || !batch_offsets || !workspace || !coords || !num_points || !mean_feats) return FNP_ERR_ARG;
@@ -346,7 +352,7 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(vox_emit_kernel, dim3(fnp_grid_for(n, kThreads)), dim3(kThreads), 0, s, points, C, maxp,
                        batch_offsets, B, cfg->max_voxels, g.d, w.code, w.top, w.flag, w.scene, w.n_sorted, n,
-                       g.perm, coords, num_points, mean_feats, voxels);
+                       g.perm, coords, num_points, mean_feats, voxels, n_cells, w.scene + 2 * (B + 1));
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }

@@ -113,7 +113,8 @@ def voxelize(points, batch_offsets, batch_size, cfg, grid=None, want_voxels=Fals
     """points (N,C) f32 device, batch_offsets (B+1,) int32 device.
 
     Returns dict(coords (N,4) i32, num_points (N,), mean (N,C) f32, voxels|None, n (1,) i32 device,
-    grid RankGrid with perm).  Rows >= n are undefined.  No host sync.
+    grid RankGrid with perm, n_cells (1,) i32 device).  Rows >= n are undefined, except that coords rows
+    [n, n_cells) list the cells of voxels dropped by max_voxels (for clear_grid).  No host sync.
     """
     L = _l.load()
     _l.require_device(points, batch_offsets)
@@ -137,14 +138,14 @@ def voxelize(points, batch_offsets, batch_size, cfg, grid=None, want_voxels=Fals
     num_points = torch.empty((cap,), dtype=torch.int32, device=dev)
     mean = torch.empty((cap, C), dtype=torch.float32, device=dev)
     voxels = torch.empty((cap, cfg.max_points, C), dtype=torch.float32, device=dev) if want_voxels else None
-    n_vox = torch.empty((1,), dtype=torch.int32, device=dev)    # always written by fnp_voxelize
+    n_vox = torch.empty((2,), dtype=torch.int32, device=dev)    # always written by fnp_voxelize: voxels, cells
     rc = L.fnp_voxelize(_l.ptr(points), n, _l.ptr(batch_offsets), cfg, gc,
                         _l.ptr(workspace), workspace.numel(),
-                        _l.ptr(coords), _l.ptr(num_points), _l.ptr(mean), _l.ptr(voxels), _l.ptr(n_vox), cap,
-                        _l.stream())
+                        _l.ptr(coords), _l.ptr(num_points), _l.ptr(mean), _l.ptr(voxels), _l.ptr(n_vox),
+                        n_vox.data_ptr() + 4, cap, _l.stream())
     _l.check(rc, "fnp_voxelize")
-    return dict(coords=coords, num_points=num_points, mean=mean, voxels=voxels, n=n_vox, grid=grid,
-                workspace=workspace, cap=cap)
+    return dict(coords=coords, num_points=num_points, mean=mean, voxels=voxels, n=n_vox[:1], n_cells=n_vox[1:],
+                grid=grid, workspace=workspace, cap=cap)
 
 
 # --------------------------------------------------------------------------------- grids

@@ -162,12 +162,15 @@ int64_t fnp_voxelize_workspace_bytes(int64_t n_points, const fnp_voxel_cfg *cfg,
  *   num_points (cap,) int32, mean_feats (cap,C) f32 = MeanVFE, voxels (cap,max_points,C) f32
  *   zero padded (nullable), n_voxels (1,) int32 device.
  * The grid (bits/summary zero on entry, perm != NULL) is left describing the voxels for the first
- * rulebook: perm[rank] = voxel row. */
+ * rulebook: perm[rank] = voxel row, -1 for a cell whose voxel fell to the max_voxels cut.
+ * n_cells (1,) int32 device, nullable: number of occupied cells (>= n_voxels); rows
+ * [n_voxels, n_cells) of coords then list the cells of the dropped voxels in no particular order, so
+ * that fnp_rankgrid_clear(coords, n_cells, ...) wipes every word the voxeliser set in a persistent grid. */
 int fnp_voxelize(const float *points, int n_points, const int *batch_offsets,
                  const fnp_voxel_cfg *cfg, const fnp_rankgrid *grid,
                  void *workspace, int64_t workspace_bytes,
                  int *coords, int *num_points, float *mean_feats, float *voxels,
-                 int *n_voxels, int cap, fnp_stream_t stream);
+                 int *n_voxels, int *n_cells, int cap, fnp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Rulebooks — replace spconv's indice-pair generation for SubMConv3d / SparseConv3d

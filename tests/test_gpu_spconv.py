@@ -376,3 +376,38 @@ def test_capacity_overflow_regrows_eager_and_graphed(cuda):
                 assert torch.equal(got[k].features, want[k][0]) and torch.equal(got[k].indices, want[k][1]), (graphed, k)
             again = net.forward_points(pts, off, 1, cfg)              # the grids were left clean
             assert torch.equal(again["out"].features, want["out"][0])
+
+
+@pytest.mark.gpu
+def test_dropped_voxels_leave_persistent_grids_clean(cuda):
+    """max_voxels cuts voxels: their cells were marked in the persistent stage-1 grid but have no row.  The
+    voxeliser lists them behind the voxels (n_cells) so the sparse clear reaches them: a second call on the
+    same engine (other scene, then the same scene) equals a fresh engine's result."""
+    from findnpropagate_amd import sparse as S, synthetic as syn
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 6000)     # ~19k voxels per scene: 2/3 dropped
+    batches = []
+    for seeds in ([0, 1], [2, 3]):
+        pts, off = syn.make_batch(seeds)
+        batches.append((torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda)))
+
+    def fresh(b):
+        net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 0).to(cuda).eval()
+        with torch.no_grad():
+            r = net.forward_points(*batches[b], 2, cfg)
+        return net, r
+
+    net, r0 = fresh(0)
+    _, r1 = fresh(1)
+    assert r0["counts"][0] == 12000 and int(S.voxelize(*batches[0], 2, cfg)["n_cells"].item()) > 30000
+    with torch.no_grad():
+        a1 = net.forward_points(*batches[1], 2, cfg)     # same engine, grids left by batch 0
+        a0 = net.forward_points(*batches[0], 2, cfg)
+    for got, want in ((a1, r1), (a0, r0)):
+        assert got["counts"] == want["counts"]
+        assert torch.equal(got["voxel_coords"], want["voxel_coords"])
+        for k in ("x_conv1", "x_conv3", "out"):
+            assert torch.equal(got[k].indices, want[k].indices) and torch.equal(got[k].features, want[k].features), k
+    for g in net.engine()._get_grids(2, cuda):
+        assert int(g.bits.count_nonzero()) == 0 and int(g.summary.count_nonzero()) == 0
