@@ -182,8 +182,8 @@ struct MfmaCfg {
     static constexpr int WH = CH == 4 ? FNP_WH32 : 64;
     static constexpr int WZERO = 128;
     static constexpr int XLB = KS == 1 ? 2 : 1;           // window fragments are read XLB offsets ahead
-    static constexpr int win_rows(int mb) { return 4 * mb * 16 + 2 * WH; }
-    static constexpr int lds_bytes(int mb, bool win) { return LDS_BYTES + (win ? win_rows(mb) * CH * 16 + WZERO : 0); }
+    static constexpr int win_rows(int nw, int mb) { return nw * mb * 16 + 2 * WH; }
+    static constexpr int lds_bytes(int nw, int mb, bool win) { return LDS_BYTES + (win ? win_rows(nw, mb) * CH * 16 + WZERO : 0); }
 };
 
 // Development-only ablation bit mask (tools/bench_conv.py with FNP_LIB_PATH): 1 = no feature gathers,
@@ -212,11 +212,26 @@ template <int CIN, int COUT> struct MfmaOcc;
 #define FNP_NW_MINCIN 128
 #endif
 #ifndef FNP_NW32
-#define FNP_NW32 4
+#define FNP_NW32 8
 #endif
-template <int CIN, int COUT> struct MfmaWg { static constexpr int NW = (COUT == 128 && CIN >= FNP_NW_MINCIN) ? FNP_NW128 : (CIN == 32 && COUT == 32) ? FNP_NW32 : 4; };
+#ifndef FNP_NW64
+#define FNP_NW64 8
+#endif
+template <int CIN, int COUT> struct MfmaWg { static constexpr int NW = (COUT == 128 && CIN >= FNP_NW_MINCIN) ? FNP_NW128 : (CIN == 32 && COUT == 32) ? FNP_NW32 : (CIN == 64 && COUT == 64) ? FNP_NW64 : 4; };
 
-template <int CIN, int COUT> struct MfmaOcc { static constexpr int WAVES = (CIN == 16 && COUT == 32) ? 4 : ((CIN < COUT && COUT <= 64) || MfmaWg<CIN, COUT>::NW == 6) ? 3 : 2; };
+#ifndef FNP_OCC1616
+#define FNP_OCC1616 2
+#endif
+#ifndef FNP_OCC3232
+#define FNP_OCC3232 4
+#endif
+#ifndef FNP_OCC6464
+#define FNP_OCC6464 4
+#endif
+#ifndef FNP_OCC128
+#define FNP_OCC128 2
+#endif
+template <int CIN, int COUT> struct MfmaOcc { static constexpr int WAVES = (CIN == 128 && COUT == 128) ? FNP_OCC128 : (CIN == 16 && COUT == 16) ? FNP_OCC1616 : (CIN == 32 && COUT == 32) ? FNP_OCC3232 : (CIN == 64 && COUT == 64) ? FNP_OCC6464 : (CIN == 16 && COUT == 32) ? 4 : ((CIN < COUT && COUT <= 64) || MfmaWg<CIN, COUT>::NW == 6) ? 3 : 2; };
 
 template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut>
 __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const __bf16 *__restrict__ x, int x_bytes,
@@ -229,7 +244,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
     constexpr int CH = Cfg::CH, SLAB = Cfg::SLAB, SW = Cfg::SW, KS = Cfg::KS, PFK = Cfg::PFK;
     constexpr bool ALLK = Cfg::ALLK;
-    constexpr int XLB = Cfg::XLB, WROWS = Cfg::win_rows(MB), WH = Cfg::WH;
+    constexpr int XLB = Cfg::XLB, WROWS = Cfg::win_rows(MfmaWg<CIN, COUT>::NW, MB), WH = Cfg::WH;
     static_assert(!WIN || ((CH == 4 || CH == 8) && XLB <= PFK && PFK % XLB == 0), "window path: 32/64 input channels");
     constexpr int NB = COUT / 16;         // 16-channel output blocks
     constexpr int NBH = NB < 4 ? NB : 4;  // A fragments held at once
@@ -262,7 +277,11 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     constexpr unsigned WIN_ZERO = (unsigned)(Cfg::LDS_BYTES + WROWS * CH * 16);   // byte address of the zeros
     auto win_sw = [](unsigned d) -> unsigned { return CH == 4 ? ((0u - (d >> 2)) & 3u) : ((d >> 1) & 7u); };
 
+#ifdef FNP_KLIM   // timing probe only (results are wrong): sweep the first FNP_KLIM offsets
+    const int K = KVOL > 0 ? (KVOL < FNP_KLIM ? KVOL : FNP_KLIM) : Krt;
+#else
     const int K = KVOL > 0 ? KVOL : Krt;
+#endif
     const int n = min(*n_out, cap);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -643,10 +662,16 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
 #define FNP_MB128 3
 #endif
     // (16 -> 32, 8 % of the pairs present: 2 blocks at 4 waves/SIMD measured 9 % faster than 4 blocks at 3)
-    constexpr int MB = COUT >= 128 ? FNP_MB128 : (CIN == 16 && COUT <= 32) ? 2 : 4;
+#ifndef FNP_MB3232
+#define FNP_MB3232 2
+#endif
+#ifndef FNP_MB6464
+#define FNP_MB6464 2
+#endif
+    constexpr int MB = COUT >= 128 ? FNP_MB128 : (CIN == 16 && COUT <= 32) ? 2 : (CIN == 32 && COUT == 32) ? FNP_MB3232 : (CIN == 64 && COUT == 64) ? FNP_MB6464 : 4;
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
     auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut>;
-    constexpr int lds = Cfg::lds_bytes(MB, WIN);
+    constexpr int lds = Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN);
     static_assert(lds * MfmaOcc<CIN, COUT>::WAVES * 4 / MfmaWg<CIN, COUT>::NW <= 160 * 1024, "LDS budget of the resident workgroups");
     if (lds > 64 * 1024) {
         static bool raised = false;  // (idempotent; a race only repeats the call)
@@ -676,7 +701,10 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
 #ifndef FNP_WIN32
 #define FNP_WIN32 0
 #endif
-template <int CIN, int COUT> struct HasWindow { static constexpr bool value = (CIN == 64 && COUT == 64) || (FNP_WIN32 && CIN == 32 && COUT == 32); };
+#ifndef FNP_WIN64
+#define FNP_WIN64 1
+#endif
+template <int CIN, int COUT> struct HasWindow { static constexpr bool value = (FNP_WIN64 && CIN == 64 && COUT == 64) || (FNP_WIN32 && CIN == 32 && COUT == 32); };
 
 template <int CIN, int COUT, typename TOut>
 int launch_mfma(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out,
