@@ -283,6 +283,7 @@ class FusedResBackbone:
         # measurement hooks (bench.py): when `profile` is a list every conv launch is bracketed by
         # stream events, (tag, start, end) appended; `rulebook_log` receives (tag, Rulebook, n_dev)
         self.profile = None
+        self.profile_only = None      # optional set of (Cin, Cout, K): bracket only these layer classes
         self.rulebook_log = None
 
     # ---- weights --------------------------------------------------------------------------
@@ -405,7 +406,7 @@ class FusedResBackbone:
             tag = (int(w.shape[2]), int(w.shape[1]), int(w.shape[0]), residual is not None, ranked)  # Cin, Cout, K, res
             if self.rulebook_log is not None:
                 self.rulebook_log.append((tag, rb, n))
-            if self.profile is None:
+            if self.profile is None or (self.profile_only is not None and tag[:3] not in self.profile_only):
                 return S.conv_forward(x, w, rb, n, out_dtype=out_dtype, scale=sc, shift=sh, residual=residual, relu=True,
                                       ranked=ranked)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
