@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph (small batches "
                                                           "are launch-bound); per-kernel events are not recorded")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--cpu-scenes", type=int, default=4, help="scenes timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-scenes", type=int, default=12, help="scenes timed through the CPU oracle (0 = skip)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket conv launches with events")
     return ap.parse_args()
 
