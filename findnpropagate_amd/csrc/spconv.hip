@@ -183,13 +183,24 @@ struct MfmaCfg {
     static constexpr int WZERO = 128;
     static constexpr int XLB = KS == 1 ? 2 : 1;           // window fragments are read XLB offsets ahead
     static constexpr int win_rows(int nw, int mb) { return nw * mb * 16 + 2 * WH; }
+    // wide epilogue (bf16 outputs, >= 32 channels): one 16-site block of the wave's tile is transposed through a
+    // wave-private LDS strip so that residual reads and output stores move 16 bytes per lane over whole rows
+    // (128-byte cache lines) instead of 8 bytes per lane over 32-byte row pieces.  Window kernels lay the strips
+    // over the window (free once the last offset's barrier has passed) and close the tile with a barrier.
+#ifndef FNP_WIDE_EPI
+#define FNP_WIDE_EPI 1
+#endif
+    static constexpr bool WIDE = FNP_WIDE_EPI && COUT >= 32;
+    static constexpr int ESTRIDE = COUT * 2 + 16;   // bytes per staged row
+    static constexpr int epi_bytes(int nw, bool win, bool out16) { return (WIDE && out16 && !win) ? nw * 16 * ESTRIDE : 0; }
     static constexpr int lds_bytes(int nw, int mb, bool win) { return LDS_BYTES + (win ? win_rows(nw, mb) * CH * 16 + WZERO : 0); }
 };
 
 // Development-only ablation bit mask (tools/bench_conv.py with FNP_LIB_PATH): 1 = no feature gathers,
 // 2 = no weight staging, 4 = no MFMA, 8 = window kernels issue no global gathers, 16 = no window reads,
 // 32 = rulebook entries read from a 64 KiB (cache-resident) slice of the table, 64 = window address taken
-// from the entry without arithmetic (timing probe for pre-computed addresses).  The shipped library is built with FNP_ABLATE == 0.
+// from the entry without arithmetic (timing probe for pre-computed addresses), 128 = no output stores,
+// 256 = no residual loads.  The shipped library is built with FNP_ABLATE == 0.
 #ifndef FNP_ABLATE
 #define FNP_ABLATE 0
 #endif
@@ -604,6 +615,63 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
         }
 
         // epilogue: lane holds out[site = row0 + mb*16 + l15][c0 .. c0+3], c0 = nb*16 + q*4
+        constexpr bool WIDE = Cfg::WIDE && sizeof(TOut) == 2;
+        if constexpr (WIDE) {
+            constexpr int LPR = COUT / 8;        // 16-byte chunks (lanes) per row
+            constexpr int SPI = 64 / LPR;        // sites per wave-wide 16-byte access
+            constexpr int NRD = 16 / SPI;        // accesses per 16-site block
+            constexpr int ES = Cfg::ESTRIDE;
+            static_assert(LPR <= 16 && 16 % SPI == 0, "wide epilogue shape");
+            static_assert(!WIN || NW * 16 * ES <= WROWS * CH * 16, "epilogue strips must fit in the window");
+            unsigned char *const eb = fnp_smem + (WIN ? Cfg::LDS_BYTES : Cfg::lds_bytes(NW, MB, WIN)) + wave * (16 * ES);
+            const int wsite = lane / LPR, wchunk = lane % LPR;
+#pragma unroll
+            for (int mb = 0; mb < MBT; ++mb) {
+                const int rb = row0 + mb * 16;
+                if (residual && !(FNP_ABLATE & 256)) {
+                    u32x4 rs[NRD];
+#pragma unroll
+                    for (int i = 0; i < NRD; ++i) {
+                        const int r = rb + i * SPI + wsite;
+                        rs[i] = u32x4{0u, 0u, 0u, 0u};
+                        if (r < row_end) rs[i] = *reinterpret_cast<const u32x4 *>(residual + (size_t)r * COUT + wchunk * 8);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NRD; ++i)
+                        *reinterpret_cast<u32x4 *>(eb + (i * SPI + wsite) * ES + wchunk * 16) = rs[i];
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int c0 = nb * 16 + q * 4;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[nb][mb][j];
+                    if (scale) {
+                        const float4 s4 = *reinterpret_cast<const float4 *>(scale + c0);
+                        const float4 h4 = *reinterpret_cast<const float4 *>(shift + c0);
+                        v[0] = v[0] * s4.x + h4.x; v[1] = v[1] * s4.y + h4.y; v[2] = v[2] * s4.z + h4.z; v[3] = v[3] * s4.w + h4.w;
+                    }
+                    bf16x4 *slot = reinterpret_cast<bf16x4 *>(eb + l15 * ES + c0 * 2);
+                    if (residual && !(FNP_ABLATE & 256)) {
+                        const bf16x4 t = *slot;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] + (float)t[j];
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.f ? 0.f : v[j];
+                    }
+                    *slot = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < NRD; ++i) {
+                    const int r = rb + i * SPI + wsite;
+                    const u32x4 t = *reinterpret_cast<const u32x4 *>(eb + (i * SPI + wsite) * ES + wchunk * 16);
+                    if (r < row_end && !(FNP_ABLATE & 128)) *reinterpret_cast<u32x4 *>(y + (size_t)r * COUT + wchunk * 8) = t;
+                }
+            }
+            if (WIN) __syncthreads();   // the strips lie over the window the next tile restages
+        } else {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int c0 = nb * 16 + q * 4;
@@ -621,7 +689,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = scale ? acc[nb][mb][j] * sc[j] + sh[j] : acc[nb][mb][j];
-                if (residual) {
+                if (residual && !(FNP_ABLATE & 256)) {
                     const TOut *rp = residual + (size_t)r * COUT + c0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = v[j] + to_f32(rp[j]);
@@ -631,6 +699,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                     for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.f ? 0.f : v[j];
                 }
                 TOut *yp = y + (size_t)r * COUT + c0;
+                if (FNP_ABLATE & 128) { if (v[0] == 12345.678f) yp[0] = from_f32<TOut>(v[1] + v[2] + v[3]); continue; }   // (probe: no stores)
                 if constexpr (sizeof(TOut) == 2) {
                     bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                     *reinterpret_cast<bf16x4 *>(yp) = o;
@@ -638,6 +707,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                     *reinterpret_cast<float4 *>(yp) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
+        }
         }
         first_tile = false;
     };
@@ -671,7 +741,7 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
     constexpr int MB = COUT >= 128 ? FNP_MB128 : (CIN == 16 && COUT <= 32) ? 2 : (CIN == 32 && COUT == 32) ? FNP_MB3232 : (CIN == 64 && COUT == 64) ? FNP_MB6464 : 4;
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
     auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut>;
-    constexpr int lds = Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN);
+    constexpr int lds = Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN) + Cfg::epi_bytes(MfmaWg<CIN, COUT>::NW, WIN, sizeof(TOut) == 2);
     static_assert(lds * MfmaOcc<CIN, COUT>::WAVES * 4 / MfmaWg<CIN, COUT>::NW <= 160 * 1024, "LDS budget of the resident workgroups");
     if (lds > 64 * 1024) {
         static bool raised = false;  // (idempotent; a race only repeats the call)
