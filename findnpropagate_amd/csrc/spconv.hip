@@ -185,14 +185,14 @@ struct MfmaCfg {
     static constexpr int win_rows(int nw, int mb) { return nw * mb * 16 + 2 * WH; }
     // wide epilogue (bf16 outputs, >= 32 channels): one 16-site block of the wave's tile is transposed through a
     // wave-private LDS strip so that residual reads and output stores move 16 bytes per lane over whole rows
-    // (128-byte cache lines) instead of 8 bytes per lane over 32-byte row pieces.  Window kernels lay the strips
-    // over the window (free once the last offset's barrier has passed) and close the tile with a barrier.
+    // (128-byte cache lines) instead of 8 bytes per lane over 32-byte row pieces.
 #ifndef FNP_WIDE_EPI
 #define FNP_WIDE_EPI 1
 #endif
     static constexpr bool WIDE = FNP_WIDE_EPI && COUT >= 32;
     static constexpr int ESTRIDE = COUT * 2 + 16;   // bytes per staged row
-    static constexpr int epi_bytes(int nw, bool win, bool out16) { return (WIDE && out16 && !win) ? nw * 16 * ESTRIDE : 0; }
+    static constexpr int epi_sites(bool win) { return win ? 8 : 16; }   // sites per strip pass (window kernels: LDS is tight)
+    static constexpr int epi_bytes(int nw, bool win, bool out16) { return (WIDE && out16 && !win) ? nw * epi_sites(win) * ESTRIDE : 0; }
     static constexpr int lds_bytes(int nw, int mb, bool win) { return LDS_BYTES + (win ? win_rows(nw, mb) * CH * 16 + WZERO : 0); }
 };
 
@@ -615,62 +615,68 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
         }
 
         // epilogue: lane holds out[site = row0 + mb*16 + l15][c0 .. c0+3], c0 = nb*16 + q*4
-        constexpr bool WIDE = Cfg::WIDE && sizeof(TOut) == 2;
+        // (window kernel: measured slower with either strip placement — 194 -> 200 / 214 us — and keeps the narrow form)
+        constexpr bool WIDE = Cfg::WIDE && sizeof(TOut) == 2 && !WIN;
         if constexpr (WIDE) {
+            constexpr int EH = Cfg::epi_sites(WIN);   // sites per strip pass
             constexpr int LPR = COUT / 8;        // 16-byte chunks (lanes) per row
             constexpr int SPI = 64 / LPR;        // sites per wave-wide 16-byte access
-            constexpr int NRD = 16 / SPI;        // accesses per 16-site block
+            constexpr int NRD = EH / SPI;        // accesses per pass
             constexpr int ES = Cfg::ESTRIDE;
-            static_assert(LPR <= 16 && 16 % SPI == 0, "wide epilogue shape");
-            static_assert(!WIN || NW * 16 * ES <= WROWS * CH * 16, "epilogue strips must fit in the window");
-            unsigned char *const eb = fnp_smem + (WIN ? Cfg::LDS_BYTES : Cfg::lds_bytes(NW, MB, WIN)) + wave * (16 * ES);
+            static_assert(LPR <= 16 && EH % SPI == 0 && NRD >= 1, "wide epilogue shape");
+            unsigned char *const eb = fnp_smem + Cfg::lds_bytes(NW, MB, WIN) + wave * (EH * ES);
             const int wsite = lane / LPR, wchunk = lane % LPR;
 #pragma unroll
             for (int mb = 0; mb < MBT; ++mb) {
-                const int rb = row0 + mb * 16;
-                if (residual && !(FNP_ABLATE & 256)) {
-                    u32x4 rs[NRD];
+#pragma unroll
+                for (int h = 0; h < 16 / EH; ++h) {
+                    const int rb = row0 + mb * 16 + h * EH;
+                    const bool mine = EH == 16 || (l15 / EH) == h;   // this lane's site is in the pass
+                    if (residual && !(FNP_ABLATE & 256)) {
+                        u32x4 rs[NRD];
+#pragma unroll
+                        for (int i = 0; i < NRD; ++i) {
+                            const int r = rb + i * SPI + wsite;
+                            rs[i] = u32x4{0u, 0u, 0u, 0u};
+                            if (r < row_end) rs[i] = *reinterpret_cast<const u32x4 *>(residual + (size_t)r * COUT + wchunk * 8);
+                        }
+#pragma unroll
+                        for (int i = 0; i < NRD; ++i)
+                            *reinterpret_cast<u32x4 *>(eb + (i * SPI + wsite) * ES + wchunk * 16) = rs[i];
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int c0 = nb * 16 + q * 4;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = acc[nb][mb][j];
+                        if (scale) {
+                            const float4 s4 = *reinterpret_cast<const float4 *>(scale + c0);
+                            const float4 h4 = *reinterpret_cast<const float4 *>(shift + c0);
+                            v[0] = v[0] * s4.x + h4.x; v[1] = v[1] * s4.y + h4.y; v[2] = v[2] * s4.z + h4.z; v[3] = v[3] * s4.w + h4.w;
+                        }
+                        if (mine) {
+                            bf16x4 *slot = reinterpret_cast<bf16x4 *>(eb + (l15 % EH) * ES + c0 * 2);
+                            if (residual && !(FNP_ABLATE & 256)) {
+                                const bf16x4 t = *slot;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = v[j] + (float)t[j];
+                            }
+                            if (relu) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.f ? 0.f : v[j];
+                            }
+                            *slot = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < NRD; ++i) {
                         const int r = rb + i * SPI + wsite;
-                        rs[i] = u32x4{0u, 0u, 0u, 0u};
-                        if (r < row_end) rs[i] = *reinterpret_cast<const u32x4 *>(residual + (size_t)r * COUT + wchunk * 8);
+                        const u32x4 t = *reinterpret_cast<const u32x4 *>(eb + (i * SPI + wsite) * ES + wchunk * 16);
+                        if (r < row_end && !(FNP_ABLATE & 128)) *reinterpret_cast<u32x4 *>(y + (size_t)r * COUT + wchunk * 8) = t;
                     }
-#pragma unroll
-                    for (int i = 0; i < NRD; ++i)
-                        *reinterpret_cast<u32x4 *>(eb + (i * SPI + wsite) * ES + wchunk * 16) = rs[i];
-                }
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int c0 = nb * 16 + q * 4;
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[nb][mb][j];
-                    if (scale) {
-                        const float4 s4 = *reinterpret_cast<const float4 *>(scale + c0);
-                        const float4 h4 = *reinterpret_cast<const float4 *>(shift + c0);
-                        v[0] = v[0] * s4.x + h4.x; v[1] = v[1] * s4.y + h4.y; v[2] = v[2] * s4.z + h4.z; v[3] = v[3] * s4.w + h4.w;
-                    }
-                    bf16x4 *slot = reinterpret_cast<bf16x4 *>(eb + l15 * ES + c0 * 2);
-                    if (residual && !(FNP_ABLATE & 256)) {
-                        const bf16x4 t = *slot;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = v[j] + (float)t[j];
-                    }
-                    if (relu) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.f ? 0.f : v[j];
-                    }
-                    *slot = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                }
-#pragma unroll
-                for (int i = 0; i < NRD; ++i) {
-                    const int r = rb + i * SPI + wsite;
-                    const u32x4 t = *reinterpret_cast<const u32x4 *>(eb + (i * SPI + wsite) * ES + wchunk * 16);
-                    if (r < row_end && !(FNP_ABLATE & 128)) *reinterpret_cast<u32x4 *>(y + (size_t)r * COUT + wchunk * 8) = t;
                 }
             }
-            if (WIN) __syncthreads();   // the strips lie over the window the next tile restages
         } else {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
