@@ -208,6 +208,10 @@ struct MfmaCfg {
 #ifndef FNP_PF
 #define FNP_PF 0
 #endif
+// window kernel epilogue: 16-byte accesses through lane-row swaps (see the epilogue)
+#ifndef FNP_SWAP_EPI
+#define FNP_SWAP_EPI 1
+#endif
 
 // waves per SIMD the register budget is held to: 3 (<= 168 VGPRs) where it measured faster on
 // MI355X (the channel-doubling strided layer 32->64: a third resident workgroup per CU
@@ -675,6 +679,60 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                         const u32x4 t = *reinterpret_cast<const u32x4 *>(eb + (i * SPI + wsite) * ES + wchunk * 16);
                         if (r < row_end && !(FNP_ABLATE & 128)) *reinterpret_cast<u32x4 *>(y + (size_t)r * COUT + wchunk * 8) = t;
                     }
+                }
+            }
+        } else if constexpr (FNP_SWAP_EPI && WIN && sizeof(TOut) == 2 && NB % 2 == 0) {
+            // window kernel (its LDS is busy with the other resident workgroup's window reads: the strip form
+            // measured slower): the 8-byte pieces of channel blocks k and k + 1 are exchanged between the lane
+            // rows q, q ^ 1 of a site (v_permlane16_swap: odd rows of the first register <-> even rows of the
+            // second), after which a lane holds 16 contiguous bytes — half the residual-load and store
+            // instructions, 64 instead of 32 contiguous bytes per site.  Same arithmetic, same single rounding.
+            const int poff = (q & 1) * 32 + (q >> 1) * 16;   // byte offset of this lane's 16 bytes inside a 64-byte pair
+#pragma unroll
+            for (int mb = 0; mb < MBT; ++mb) {
+                const int r = row0 + mb * 16 + l15;
+                const bool live = r < row_end;
+#pragma unroll
+                for (int kp = 0; kp < NB / 2; ++kp) {
+                    uint2 ra = make_uint2(0u, 0u), rb = make_uint2(0u, 0u);
+                    if (residual && !(FNP_ABLATE & 256)) {
+                        uint4 rv = make_uint4(0u, 0u, 0u, 0u);
+                        if (live) rv = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(residual) + (size_t)r * (COUT * 2) + kp * 64 + poff);
+                        auto t0 = __builtin_amdgcn_permlane16_swap(rv.x, rv.z, false, false);
+                        auto t1 = __builtin_amdgcn_permlane16_swap(rv.y, rv.w, false, false);
+                        ra = make_uint2(t0[0], t1[0]);   // block 2 kp,     channels q*4 .. q*4+3
+                        rb = make_uint2(t0[1], t1[1]);   // block 2 kp + 1
+                    }
+                    uint2 o[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int nb = 2 * kp + h, c0 = nb * 16 + q * 4;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = acc[nb][mb][j];
+                        if (scale) {
+                            const float4 s4 = *reinterpret_cast<const float4 *>(scale + c0);
+                            const float4 h4 = *reinterpret_cast<const float4 *>(shift + c0);
+                            v[0] = v[0] * s4.x + h4.x; v[1] = v[1] * s4.y + h4.y; v[2] = v[2] * s4.z + h4.z; v[3] = v[3] * s4.w + h4.w;
+                        }
+                        if (residual && !(FNP_ABLATE & 256)) {
+                            const uint2 rr = h ? rb : ra;
+                            const bf16x4 t = *reinterpret_cast<const bf16x4 *>(&rr);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = v[j] + (float)t[j];
+                        }
+                        if (relu) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.f ? 0.f : v[j];
+                        }
+                        const bf16x4 ob = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        o[h] = *reinterpret_cast<const uint2 *>(&ob);
+                    }
+                    auto t0 = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
+                    auto t1 = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);
+                    if (live && !(FNP_ABLATE & 128))
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(y) + (size_t)r * (COUT * 2) + kp * 64 + poff) =
+                            make_uint4(t0[0], t1[0], t0[1], t1[1]);
                 }
             }
         } else {
