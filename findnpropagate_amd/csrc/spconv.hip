@@ -166,11 +166,21 @@ int launch_first(const void *x, const void *w, const int *nbr, int nbr_stride, i
 // ------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int KVOL>
 struct MfmaCfg {
-    static constexpr int CH = CIN / 8;                    // 16-byte chunks per weight row
+    // PAIR (16 input channels, 3x3x3): two kernel offsets share one MFMA step.  A 16-channel row fills only
+    // half of the 32-wide K step and of a gather instruction's lanes, and these layers are bound by the NUMBER
+    // of gather instructions (15.6 clk per 64-lane b128 instruction per CU, whether or not its lanes are in
+    // range): lanes q < 2 take offset 2p, lanes q >= 2 offset 2p + 1, the weight image holds [W_2p | W_2p+1]
+    // per output channel, and the sweep has 14 steps instead of 27.
+#ifndef FNP_PAIR16
+#define FNP_PAIR16 1
+#endif
+    static constexpr bool PAIR = FNP_PAIR16 && CIN == 16 && KVOL == 27;
+    static constexpr int KEFF = PAIR ? (KVOL + 1) / 2 : KVOL;   // steps of the offset sweep
+    static constexpr int CH = PAIR ? 4 : CIN / 8;         // 16-byte chunks per weight row (image row)
     static constexpr int SLAB = COUT * CH;                // chunks per slab
     static constexpr int SW = (CH == 8 || CH == 4) ? 1 : 0;
-    static constexpr bool ALLK = KVOL > 0 && (long long)KVOL * SLAB * 16 <= 65536;
-    static constexpr int LDS_BYTES = (ALLK ? KVOL : 2) * SLAB * 16;
+    static constexpr bool ALLK = KVOL > 0 && (long long)KEFF * SLAB * 16 <= 65536;
+    static constexpr int LDS_BYTES = (ALLK ? KEFF : 2) * SLAB * 16;
     static constexpr int KS = (CIN + 31) / 32;            // 32-wide K steps of the MFMA
     // gather prefetch distance in kernel offsets: 16 gathers in flight per wave
     static constexpr int PFK = ALLK ? (KS == 1 ? 4 : 2) : 1;
@@ -292,23 +302,25 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     constexpr unsigned WIN_ZERO = (unsigned)(Cfg::LDS_BYTES + WROWS * CH * 16);   // byte address of the zeros
     auto win_sw = [](unsigned d) -> unsigned { return CH == 4 ? ((0u - (d >> 2)) & 3u) : ((d >> 1) & 7u); };
 
+    constexpr bool PAIR = Cfg::PAIR;
 #ifdef FNP_KLIM   // timing probe only (results are wrong): sweep the first FNP_KLIM offsets
-    const int K = KVOL > 0 ? (KVOL < FNP_KLIM ? KVOL : FNP_KLIM) : Krt;
+    const int K = KVOL > 0 ? (Cfg::KEFF < FNP_KLIM ? Cfg::KEFF : FNP_KLIM) : Krt;
 #else
-    const int K = KVOL > 0 ? KVOL : Krt;
+    const int K = KVOL > 0 ? Cfg::KEFF : Krt;   // (PAIR: offset pairs)
 #endif
     const int n = min(*n_out, cap);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
-    const bool kvalid0 = (q * 8) < CIN;  // for CIN == 16 only lanes 0..31 carry data in a K step
+    const bool kvalid0 = PAIR || (q * 8) < CIN;  // for CIN == 16 without pairing only lanes 0..31 carry data in a K step
+    const int qk = PAIR ? (q >> 1) : 0;          // PAIR: which offset of the pair this lane works on
 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
     // byte offset of (row id, this lane's 16-byte chunk of MFMA step 0); absent rows get an offset
     // that stays out of range after the + ks*64 of the later steps
     auto row_off = [&](int id) -> unsigned {
         return ((FNP_ABLATE & 1) || id < 0 || !kvalid0) ? 0x80000000u
-                                                        : (unsigned)id * (unsigned)(CIN * 2) + (unsigned)q * 16u;
+                                                        : (unsigned)id * (unsigned)(CIN * 2) + (unsigned)(PAIR ? (q & 1) : q) * 16u;
     };
     auto gather = [&](unsigned roff, int ks) -> bf16x8 {
         u32x4 v = {0u, 0u, 0u, 0u};
@@ -317,20 +329,25 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     };
     // rulebook entry of row r for offset k; rows past the range and offsets past K read a valid
     // address and yield -1 (no data-dependent branch around a load)
+    // (PAIR: step k stands for the offsets 2k and 2k + 1; the lane's own one is 2k + qk, absent past KVOL - 1)
     auto nbr_at = [&](int k, int r, int r_end) -> int {
         const int rc = r < r_end ? r : r_end - 1;
-        const int kc = k < K ? k : K - 1;
+        const int kr = PAIR ? 2 * k + qk : k, KR = PAIR ? KVOL : K;
+        const int kc = kr < KR ? kr : KR - 1;
         const int v = nbr[(FNP_ABLATE & 32) ? (size_t)((kc * 64 + rc) & 0x3fff) : (size_t)kc * nbr_stride + rc];
-        return (r < r_end && k < K) ? v : -1;
+        return (r < r_end && kr < KR) ? v : -1;
     };
     // same load, but the value is NOT touched here: the validity select happens where the entry is
     // consumed (two rounds later).  Any arithmetic on a freshly loaded entry makes the compiler wait
     // for it — and, VMEM returning in order, for every gather and weight load in flight.
     auto nbr_raw = [&](int k, int r, int r_end) -> int {
         const int rc = r < r_end ? r : r_end - 1;
-        const int kc = k < K ? k : K - 1;
+        const int kr = PAIR ? 2 * k + qk : k, KR = PAIR ? KVOL : K;
+        const int kc = kr < KR ? kr : KR - 1;
         return nbr[(FNP_ABLATE & 32) ? (size_t)((kc * 64 + rc) & 0x3fff) : (size_t)kc * nbr_stride + rc];
     };
+    // is the lane's offset of step k a real one (raw entries are validated where they are consumed)
+    auto k_live = [&](int k) -> bool { return PAIR ? (2 * k + qk < KVOL) : (k < K); };
 
     // window path: LDS byte address of (row id, this lane's chunk of MFMA step 0) when the row is in
     // the window [wlo, wlo + WROWS), else the zeros; step ks reads at (address ^ ks*64).  The global
@@ -380,7 +397,15 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
         // narrow layers: all K slabs resident in LDS for the lifetime of the workgroup
         for (int p = tid; p < K * SLAB; p += NT) {
             const int kk = p / SLAB, r = p % SLAB;
-            wl[kk * SLAB + FNP_LDS_POS(r / CH, r % CH)] = reinterpret_cast<const uint4 *>(w)[p];
+            if constexpr (PAIR) {
+                // image row of output channel co: [W_2kk (2 chunks) | W_2kk+1 (2 chunks)], zeros past the last offset
+                const int co = r / CH, c = r % CH, kr = 2 * kk + (c >> 1);
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (kr < KVOL) v = reinterpret_cast<const uint4 *>(w)[((size_t)kr * COUT + co) * 2 + (c & 1)];
+                wl[kk * SLAB + FNP_LDS_POS(co, c)] = v;
+            } else {
+                wl[kk * SLAB + FNP_LDS_POS(r / CH, r % CH)] = reinterpret_cast<const uint4 *>(w)[p];
+            }
         }
         __syncthreads();
     }
@@ -501,7 +526,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                 if constexpr (WIN) {
 #pragma unroll
                     for (int mb = 0; mb < MBT; ++mb) {
-                        const bool ok = (k + PFK < K) && (row0 + mb * 16 + l15 < row_end);
+                        const bool ok = k_live(k + PFK) && (row0 + mb * 16 + l15 < row_end);
                         lnew[mb] = win_off(ok ? rawq[u][mb] : -1, wlo);
                     }
                 }
@@ -582,7 +607,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                     //     rulebook entry was loaded two rounds ago; validity is decided here)
 #pragma unroll
                     for (int mb = 0; mb < MBT; ++mb) {
-                        const bool ok = (k + PFK < K) && (row0 + mb * 16 + l15 < row_end);
+                        const bool ok = k_live(k + PFK) && (row0 + mb * 16 + l15 < row_end);
                         xb[u][ks][mb] = gather(WIN ? row_off_w(ok ? rawq[u][mb] : -1, wlo) : row_off(ok ? rawq[u][mb] : -1), ks);
                     }
                     __builtin_amdgcn_sched_barrier(0);  // keep the steps in program order
