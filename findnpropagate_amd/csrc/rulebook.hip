@@ -190,8 +190,11 @@ __global__ __launch_bounds__(kThreads) void strided_nbr_kernel(const int *__rest
 // operations, instead of K threads each re-reading the coordinates and one word.  Stores stay
 // coalesced: for a fixed offset, consecutive threads write consecutive entries of nbr[k][.].
 // lo = first input cell per axis (SubM: c - k/2; strided: c*s - p).
+// The K entries of a row go to a wave-private LDS strip ([k][lane]); nbr_flush then writes the strip out 16 bytes
+// per lane, four offsets (4 x 256 contiguous bytes) per wave instruction instead of one: the 4-byte form was
+// bound by the number of store instructions, not by bytes.
 template <int KZ, int KY, int KX>
-__device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, int lox, int o, int cap, int *__restrict__ nbr) {
+__device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, int lox, int *__restrict__ strip) {
     const int bz0 = loz >> 2, by0 = loy >> 2, bx0 = lox >> 2;   // (arithmetic shift: -1 -> block -1, outside)
     unsigned long long w[2][2][2];
     unsigned base[2][2][2];
@@ -249,19 +252,52 @@ __device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, in
                     r = (int)bb + __popcll(ww & ((1ull << bit) - 1ull));
                     if (g.perm) r = g.perm[r];
                 }
-                nbr[(size_t)((jz * KY + jy) * KX + jx) * cap + o] = r;
+                strip[((jz * KY + jy) * KX + jx) * 64] = r;
             }
         }
+    }
+}
+
+// strip -> nbr[k][o0 .. o0 + 63] for the K offsets (table stride `cap`); rows >= n are never written
+template <int K>
+__device__ __forceinline__ void nbr_flush(const int *__restrict__ strip_wave, int o0, int n, int cap, int *__restrict__ nbr) {
+    const int lane = fnp_lane();
+    if ((cap & 3) == 0) {   // 16-byte aligned rows of the table (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < (K * 16 + 63) / 64; ++j) {
+            const int e = j * 64 + lane, k = e >> 4, c = e & 15;
+            if (k < K) {
+                const int4 v = *reinterpret_cast<const int4 *>(strip_wave + k * 64 + c * 4);
+                const int o = o0 + c * 4;
+                if (o + 3 < n) *reinterpret_cast<int4 *>(nbr + (size_t)k * cap + o) = v;
+                else {
+                    if (o < n) nbr[(size_t)k * cap + o] = v.x;
+                    if (o + 1 < n) nbr[(size_t)k * cap + o + 1] = v.y;
+                    if (o + 2 < n) nbr[(size_t)k * cap + o + 2] = v.z;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (o0 + lane < n) nbr[(size_t)k * cap + o0 + lane] = strip_wave[k * 64 + lane];
     }
 }
 
 template <int KZ, int KY, int KX>
 __global__ __launch_bounds__(kThreads) void subm_nbr_row_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows,
                                                                 int cap, RG g, int *__restrict__ nbr) {
+    constexpr int K = KZ * KY * KX;
+    __shared__ __attribute__((aligned(16))) int strips[kThreads / 64][K * 64];
+    int *strip_wave = strips[threadIdx.x >> 6];
     const int n = min(*n_rows, cap);
-    for (int o = blockIdx.x * kThreads + threadIdx.x; o < n; o += gridDim.x * kThreads) {
-        const int4 c = reinterpret_cast<const int4 *>(coords)[o];
-        nbr_row<KZ, KY, KX>(g, c.x, c.y - KZ / 2, c.z - KY / 2, c.w - KX / 2, o, cap, nbr);
+    for (int base = blockIdx.x * kThreads; base < n; base += gridDim.x * kThreads) {   // (whole waves stay in the loop)
+        const int o = base + threadIdx.x;
+        if (o < n) {
+            const int4 c = reinterpret_cast<const int4 *>(coords)[o];
+            nbr_row<KZ, KY, KX>(g, c.x, c.y - KZ / 2, c.z - KY / 2, c.w - KX / 2, strip_wave + fnp_lane());
+        }
+        nbr_flush<K>(strip_wave, base + (threadIdx.x & ~63), n, cap, nbr);
     }
 }
 
@@ -269,10 +305,17 @@ template <int KZ, int KY, int KX>
 __global__ __launch_bounds__(kThreads) void strided_nbr_row_kernel(const int *__restrict__ out_coords,
                                                                    const int *__restrict__ n_out, int cap_out, RG gi, Geom ge,
                                                                    int *__restrict__ nbr) {
+    constexpr int K = KZ * KY * KX;
+    __shared__ __attribute__((aligned(16))) int strips[kThreads / 64][K * 64];
+    int *strip_wave = strips[threadIdx.x >> 6];
     const int n = min(*n_out, cap_out);
-    for (int o = blockIdx.x * kThreads + threadIdx.x; o < n; o += gridDim.x * kThreads) {
-        const int4 c = reinterpret_cast<const int4 *>(out_coords)[o];
-        nbr_row<KZ, KY, KX>(gi, c.x, c.y * ge.s[0] - ge.p[0], c.z * ge.s[1] - ge.p[1], c.w * ge.s[2] - ge.p[2], o, cap_out, nbr);
+    for (int base = blockIdx.x * kThreads; base < n; base += gridDim.x * kThreads) {
+        const int o = base + threadIdx.x;
+        if (o < n) {
+            const int4 c = reinterpret_cast<const int4 *>(out_coords)[o];
+            nbr_row<KZ, KY, KX>(gi, c.x, c.y * ge.s[0] - ge.p[0], c.z * ge.s[1] - ge.p[1], c.w * ge.s[2] - ge.p[2], strip_wave + fnp_lane());
+        }
+        nbr_flush<K>(strip_wave, base + (threadIdx.x & ~63), n, cap_out, nbr);
     }
 }
 
