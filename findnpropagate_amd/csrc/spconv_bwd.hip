@@ -263,7 +263,9 @@ void launch_wgrad_mfma(dim3 grid, hipStream_t s, const __bf16 *x, const __bf16 *
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, x, dy, nbr, nbr_stride, n_out, cap_out, rows_per_chunk, partial);
 }
 
-constexpr int kMaxChunks = 32;
+// row chunks per offset: the narrow layers do little matrix work per 32-row tile and are bound by the latency of a
+// tile (barrier + loads), so they get more, shorter chunks (the partials stay small: chunks x K x Cin x Cout floats)
+static inline int max_chunks(int Cin, int Cout) { return (long long)Cin * Cout <= 4096 ? 128 : (long long)Cin * Cout <= 8192 ? 64 : 32; }
 
 template <typename TX, typename TY>
 int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, float *dw,
@@ -271,7 +273,7 @@ int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int
     const long long pairs = (long long)Cin * Cout, total = pairs * K;
     if (pairs > 64 * kThreads) return FNP_ERR_ARG;   // <= 128 x 128
     int chunks = fnp_divup(cap_out, 2048);
-    if (chunks > kMaxChunks) chunks = kMaxChunks;
+    if (chunks > max_chunks(Cin, Cout)) chunks = max_chunks(Cin, Cout);
     if (chunks < 1) chunks = 1;
     const int rows_per_chunk = fnp_divup(fnp_divup(cap_out, chunks), 128) * 128;   // multiple of every tile height
     if ((long long)chunks * total * 4 > ws_bytes) return FNP_ERR_WORKSPACE;
@@ -330,7 +332,7 @@ extern "C" int fnp_rulebook_transpose(const int *nbr, int nbr_stride, int K, con
 
 extern "C" int64_t fnp_spconv_wgrad_workspace_bytes(int K, int Cin, int Cout) {
     if (K <= 0 || Cin <= 0 || Cout <= 0) return 0;
-    return (int64_t)kMaxChunks * K * Cin * Cout * 4;
+    return (int64_t)max_chunks(Cin, Cout) * K * Cin * Cout * 4;
 }
 
 extern "C" int fnp_spconv_wgrad(const void *feat_in, int in_dtype, const void *grad_out, int grad_dtype, const int *nbr,
