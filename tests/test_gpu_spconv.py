@@ -411,3 +411,55 @@ def test_dropped_voxels_leave_persistent_grids_clean(cuda):
             assert torch.equal(got[k].indices, want[k].indices) and torch.equal(got[k].features, want[k].features), k
     for g in net.engine()._get_grids(2, cuda):
         assert int(g.bits.count_nonzero()) == 0 and int(g.summary.count_nonzero()) == 0
+
+
+@pytest.mark.parametrize("B,shape,n", [(2, [41, 300, 300], 40000),      # 23 k summary words: one wave per word
+                                       (3, [41, 1440, 1440], 150000),   # 67 k: 8 words per wave
+                                       (16, [41, 1440, 1440], 400000)]) # 356 k: 64 words per wave
+def test_rank_grid_prefix_forms_agree(cuda, rng, B, shape, n):
+    """The rank-grid prefix picks its work split (1 / 8 / 64 summary words per wave) from the grid size.  Every
+    split must yield the same thing: rank -> row of a clustered coordinate list is a bijection (a 1x1x1 SubM
+    rulebook maps every row to itself), and the coordinates emitted in rank order by the strided path (1x1x1,
+    stride 1: outputs = inputs) are the input set, each output row fed by the input row with its coordinates."""
+    # clustered occupancy (blobs) so that summary words hold several blocks and blocks several cells
+    centres = np.stack([rng.integers(0, B, 400), rng.integers(0, shape[0], 400), rng.integers(0, shape[1], 400),
+                        rng.integers(0, shape[2], 400)], 1)
+    pick = centres[rng.integers(0, 400, 3 * n)]
+    jit = np.round(rng.standard_normal((3 * n, 4)) * np.array([0, 2, 12, 12])).astype(np.int64)
+    c = pick + jit
+    ok = (c[:, 1] >= 0) & (c[:, 1] < shape[0]) & (c[:, 2] >= 0) & (c[:, 2] < shape[1]) & (c[:, 3] >= 0) & (c[:, 3] < shape[2])
+    c = np.unique(c[ok], axis=0)
+    c = c[rng.permutation(c.shape[0])][:n].astype(np.int32)
+    N = c.shape[0]
+    idx = torch.from_numpy(c).to(cuda)
+    n_dev = S.device_scalar(N, cuda)
+    grid = S.build_grid(idx, n_dev, B, shape)
+    rb = S.rulebook_subm(idx, n_dev, grid, 1)
+    assert torch.equal(rb.nbr[0, :N].cpu(), torch.arange(N, dtype=torch.int32))
+    rbs = S.rulebook_strided(idx, n_dev, grid, 1, 1, 0, N + 7)
+    assert int(rbs.out_n.item()) == N
+    out = rbs.out_indices[:N].cpu().numpy()
+    assert np.array_equal(np.sort(_key(out, shape)), np.sort(_key(c, shape)))
+    src = rbs.nbr[0, :N].cpu().numpy()
+    assert src.min() >= 0 and np.array_equal(c[src], out)
+
+
+@pytest.mark.parametrize("n", [200, 5000])
+def test_window_kernel_equals_gather_kernel(cuda, rng, n):
+    """FNP_HINT_ROWS_RANKED only changes where a 64 -> 64 layer finds its rows (LDS window + the lane-row swap
+    epilogue instead of gathers + the strip epilogue): same products, same order, bit-identical output — also when
+    the rows are NOT in rank order (the hint is a performance statement, never a correctness one)."""
+    B, shape, C = 2, [9, 40, 41], 64
+    feats, idx = _random_sparse(rng, B, shape, n, C)
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    rb = S.rulebook_subm(d_idx, n_dev, S.build_grid(d_idx, n_dev, B, shape), 3)
+    wp = S.pack_weight(torch.from_numpy((rng.standard_normal((C, 3, 3, 3, C)) * 0.1).astype(np.float32)).to(cuda), torch.bfloat16)
+    x = torch.from_numpy(feats).to(cuda).to(torch.bfloat16)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)).to(cuda)
+    sh = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).to(cuda)
+    res = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32)).to(cuda).to(torch.bfloat16)
+    for residual in (None, res):
+        a = S.conv_forward(x, wp, rb, n_dev, scale=sc, shift=sh, residual=residual, relu=True, ranked=False)
+        b = S.conv_forward(x, wp, rb, n_dev, scale=sc, shift=sh, residual=residual, relu=True, ranked=True)
+        assert torch.equal(a[:n], b[:n])
