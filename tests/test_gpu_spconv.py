@@ -463,3 +463,37 @@ def test_window_kernel_equals_gather_kernel(cuda, rng, n):
         a = S.conv_forward(x, wp, rb, n_dev, scale=sc, shift=sh, residual=residual, relu=True, ranked=False)
         b = S.conv_forward(x, wp, rb, n_dev, scale=sc, shift=sh, residual=residual, relu=True, ranked=True)
         assert torch.equal(a[:n], b[:n])
+
+
+def test_forward_points_edge_batches(cuda):
+    """Ragged and degenerate batches through the fused path: a scene with no points between two scenes, points that
+    all fall outside the range, a single point.  A scene's result does not depend on what else is in the batch
+    (same coordinates, bit-identical features), whatever rows and tiles its sites land on."""
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 0).to(cuda).eval()
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+    p0 = syn.make_scene(0)
+
+    def run(pts, off, B):
+        with torch.no_grad():
+            return net.forward_points(torch.from_numpy(pts).to(cuda), torch.from_numpy(np.array(off, np.int32)).to(cuda), B, cfg)
+
+    a = run(p0, [0, len(p0)], 1)
+    b = run(np.concatenate([p0, p0]), [0, len(p0), len(p0), 2 * len(p0)], 3)     # scene 1 is empty
+    assert b["counts"] == [2 * c for c in a["counts"]]
+    key = lambda i: (i[:, 1].astype(np.int64) * 4096 + i[:, 2]) * 4096 + i[:, 3]
+    for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out"):
+        ia, ib = a[name].indices.cpu().numpy(), b[name].indices.cpu().numpy()
+        fa, fb = a[name].features.float().cpu().numpy(), b[name].features.float().cpu().numpy()
+        assert (ib[:, 0] != 1).all()
+        oa = np.argsort(key(ia))
+        for s in (0, 2):
+            m = ib[:, 0] == s
+            ob = np.argsort(key(ib[m]))
+            assert np.array_equal(ia[oa][:, 1:], ib[m][ob][:, 1:]), (name, s)
+            assert np.array_equal(fa[oa], fb[m][ob]), (name, s)
+    c = run(np.full((100, 5), 1e6, np.float32), [0, 100], 1)
+    assert c["counts"] == [0, 0, 0, 0, 0] and c["out"].features.shape == (0, 128)
+    d = run(p0[:1], [0, 1], 1)
+    assert d["counts"][0] == 1 and d["counts"][4] >= 1
