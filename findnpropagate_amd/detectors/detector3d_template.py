@@ -35,31 +35,32 @@ class Detector3DTemplate:
                 for stem in ('roi_%s', 'rcnn_%s', 'rcnn_3known_%s', 'rcnn_6known_%s', 'rcnn_4unknown_%s', 'rcnn_7unknown_%s'):
                     recall_dict[stem % str(cur_thresh)] = 0
 
-        # strip the all-zero padding rows at the end (detector3d_template.py:342-346): one reduction
-        nonzero = (gt_boxes.sum(dim=1) != 0)
-        if gt_boxes.shape[0] > 0 and bool(nonzero.any()):
-            k = int(torch.nonzero(nonzero).max()) + 1
-        else:
-            k = 0
-        cur_gt = gt_boxes[:k]
-        if cur_gt.shape[0] == 0:
+        # the all-zero padding rows at the end (detector3d_template.py:342-346) are masked out on the device
+        # instead of sliced off (slicing needs their count on the host: two more synchronisations per frame)
+        if gt_boxes.shape[0] == 0:
             return recall_dict
-
-        dev = cur_gt.device
+        dev = gt_boxes.device
+        nonzero = (gt_boxes.sum(dim=1) != 0).to(torch.int32)
+        valid = torch.flip(torch.cummax(torch.flip(nonzero, [0]), 0)[0], [0]).bool()    # row i: some non-zero row at or after i
+        cur_gt = gt_boxes
         labels = cur_gt[:, -1].long()
-        known3 = torch.isin(labels, torch.tensor(known3_labels, device=dev))
-        known6 = torch.isin(labels, torch.tensor(known6_labels, device=dev))
+        known3 = torch.isin(labels, torch.tensor(known3_labels, device=dev)) & valid
+        known6 = torch.isin(labels, torch.tensor(known6_labels, device=dev)) & valid
+        unk3, unk6 = valid & ~known3, valid & ~known6
         th = torch.tensor([float(t) for t in thresh_list], dtype=torch.float32, device=dev)
 
-        counters = [known3.sum(), known6.sum(), (~known3).sum(), (~known6).sum()]
+        counters = [valid.sum(), known3.sum(), known6.sum(), unk3.sum(), unk6.sum()]
         if box_preds.shape[0] > 0:
             iou3d_rcnn = iou3d_nms_utils.boxes_iou3d_gpu(box_preds[:, 0:7].contiguous().float(), cur_gt[:, 0:7].contiguous().float())
-            hit = iou3d_rcnn.max(dim=0)[0][None, :] > th[:, None]                 # (T, G)
-            counters += [hit.sum(1), (hit & known3).sum(1), (hit & known6).sum(1), (hit & ~known3).sum(1), (hit & ~known6).sum(1)]
+            hit = (iou3d_rcnn.max(dim=0)[0][None, :] > th[:, None]) & valid[None, :]    # (T, G)
+            counters += [hit.sum(1), (hit & known3).sum(1), (hit & known6).sum(1), (hit & unk3).sum(1), (hit & unk6).sum(1)]
         if rois is not None:
             iou3d_roi = iou3d_nms_utils.boxes_iou3d_gpu(rois[:, 0:7].contiguous().float(), cur_gt[:, 0:7].contiguous().float())
-            counters.append((iou3d_roi.max(dim=0)[0][None, :] > th[:, None]).sum(1))
+            counters.append(((iou3d_roi.max(dim=0)[0][None, :] > th[:, None]) & valid[None, :]).sum(1))
         flat = torch.cat([c.reshape(-1).long() for c in counters]).cpu().tolist()   # the one host sync
+        n_gt, flat = flat[0], flat[1:]
+        if n_gt == 0:
+            return recall_dict
 
         recall_dict['num_3known'] += flat[0]
         recall_dict['num_6known'] += flat[1]
@@ -74,5 +75,5 @@ class Detector3DTemplate:
         if rois is not None:
             for i, cur_thresh in enumerate(thresh_list):
                 recall_dict['roi_%s' % str(cur_thresh)] += flat[pos + i]
-        recall_dict['gt'] += cur_gt.shape[0]
+        recall_dict['gt'] += n_gt
         return recall_dict
