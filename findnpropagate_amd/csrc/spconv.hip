@@ -180,7 +180,12 @@ struct MfmaCfg {
     static constexpr int SLAB = COUT * CH;                // chunks per slab
     static constexpr int SW = (CH == 8 || CH == 4) ? 1 : 0;
     static constexpr bool ALLK = KVOL > 0 && (long long)KEFF * SLAB * 16 <= 65536;
-    static constexpr int LDS_BYTES = (ALLK ? KEFF : 2) * SLAB * 16;
+    // WPAIR (128 -> 128, 8-wave workgroups): a ring of four slab buffers and ONE barrier per two offsets
+#ifndef FNP_WPAIR
+#define FNP_WPAIR 0
+#endif
+    static constexpr bool WPAIR = FNP_WPAIR && !ALLK && CIN == 128 && COUT == 128;
+    static constexpr int LDS_BYTES = (ALLK ? KEFF : WPAIR ? 4 : 2) * SLAB * 16;
     static constexpr int KS = (CIN + 31) / 32;            // 32-wide K steps of the MFMA
     // gather prefetch distance in kernel offsets: 16 gathers in flight per wave
     static constexpr int PFK = ALLK ? (KS == 1 ? 4 : 2) : 1;
@@ -199,7 +204,7 @@ struct MfmaCfg {
 #ifndef FNP_WIDE_EPI
 #define FNP_WIDE_EPI 1
 #endif
-    static constexpr bool WIDE = FNP_WIDE_EPI && COUT >= 32;
+    static constexpr bool WIDE = FNP_WIDE_EPI && COUT >= 32 && !WPAIR;   // (WPAIR: no LDS left for the strips -> swap form)
     static constexpr int ESTRIDE = COUT * 2 + 16;   // bytes per staged row
     static constexpr int epi_sites(bool win) { return win ? 8 : 16; }   // sites per strip pass (window kernels: LDS is tight)
     static constexpr int epi_bytes(int nw, bool win, bool out16) { return (WIDE && out16 && !win) ? nw * epi_sites(win) * ESTRIDE : 0; }
@@ -290,6 +295,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
 #define FNP_WD4 1
 #endif
     constexpr bool WD4 = FNP_WD4 && !ALLK && NW == 8 && NCH == KS && NCH == 4;
+    constexpr bool WPAIR = Cfg::WPAIR && WD4;
     static_assert(CIN % 16 == 0 && COUT % 16 == 0, "channel counts must be multiples of 16");
     static_assert(ALLK || SLAB % NT == 0 || SLAB < NT, "unsupported slab size");
 
@@ -483,6 +489,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                 for (int j = 0; j < NCH; ++j) {
                     const int p = tid + j * NT;
                     if (SLAB % NT == 0 || p < SLAB) wl[st_pos0 + j * NT] = reinterpret_cast<const uint4 *>(w)[p];
+                    if (WPAIR) wl[SLAB + st_pos0 + j * NT] = reinterpret_cast<const uint4 *>(w + (size_t)(K > 1 ? 1 : 0) * COUT * CIN)[p];
                 }
             }
             __syncthreads();
@@ -505,7 +512,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
 
         uint4 wd0 = make_uint4(0u, 0u, 0u, 0u), wd1 = wd0, wd2 = wd0, wd3 = wd0;   // (named: see wcur0)
         if (WD4 && !(FNP_ABLATE & 2)) {
-            const uint4 *w1 = reinterpret_cast<const uint4 *>(w + (size_t)(K > 1 ? 1 : 0) * COUT * CIN);
+            const uint4 *w1 = reinterpret_cast<const uint4 *>(w + (size_t)(WPAIR ? (K > 2 ? 2 : 0) : (K > 1 ? 1 : 0)) * COUT * CIN);
             wd0 = w1[tid]; wd1 = w1[tid + NT]; wd2 = w1[tid + 2 * NT]; wd3 = w1[tid + 3 * NT];
         }
         for (int k0 = 0; k0 < K; k0 += PFK) {
@@ -514,7 +521,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                 const int k = k0 + u;
                 if (k >= K) break;  // wave-uniform
                 u32x4 xl_nx[WIN ? KS : 1][WIN ? MBT : 1];
-                const uint4 *wk = wl + (ALLK ? k : (k & 1)) * SLAB;
+                const uint4 *wk = wl + (ALLK ? k : WPAIR ? (k & 3) : (k & 1)) * SLAB;
                 const uint4 *wsrc = reinterpret_cast<const uint4 *>(w + (size_t)(k + 1 < K ? k + 1 : k) * COUT * CIN);
                 // rulebook entries for offset k + 3*PFK: requested FIRST in the round, so that they are
                 // older than this round's gathers (VMEM returns in order: a young index load in
@@ -542,9 +549,11 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                 for (int ks = 0; ks < KS; ++ks) {
                     if (WD4 && !(FNP_ABLATE & 2)) {
                         uint4 &wd = ks == 0 ? wd0 : ks == 1 ? wd1 : ks == 2 ? wd2 : wd3;
-                        wl[((k + 1) & 1) * SLAB + st_pos0 + ks * NT] = wd;                    // chunk ks of W_{k+1}
-                        const uint4 *w2 = reinterpret_cast<const uint4 *>(w + (size_t)(k + 2 < K ? k + 2 : k) * COUT * CIN);
-                        wd = w2[tid + ks * NT];                                               // chunk ks of W_{k+2}
+                        // chunk ks of W_{k+1} (WPAIR: of W_{k+2}, into the ring slot nobody has read since the last barrier)
+                        wl[(WPAIR ? ((k + 2) & 3) : ((k + 1) & 1)) * SLAB + st_pos0 + ks * NT] = wd;
+                        constexpr int AH = WPAIR ? 3 : 2;
+                        const uint4 *w2 = reinterpret_cast<const uint4 *>(w + (size_t)(k + AH < K ? k + AH : k) * COUT * CIN);
+                        wd = w2[tid + ks * NT];                                               // chunk ks of W_{k+2} (WPAIR: W_{k+3})
                     }
                     // (1) previous step's weight chunks -> other LDS buffer; (2) request this step's
                     if (!ALLK && !WDEEP && !WD4 && !(FNP_ABLATE & 2)) {
@@ -633,7 +642,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                                 wl[((k + 1) & 1) * SLAB + st_pos0 + c * NT] = (j == 0 ? wreg0 : wreg1);
                         }
                     }
-                    __syncthreads();  // plain loads stay in flight across it; only the LDS writes are waited for
+                    if (!WPAIR || (k & 1) || k == K - 1) __syncthreads();  // plain loads stay in flight across it; only the LDS writes are waited for
                 }
             }
         }
@@ -706,7 +715,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                     }
                 }
             }
-        } else if constexpr (FNP_SWAP_EPI && WIN && sizeof(TOut) == 2 && NB % 2 == 0) {
+        } else if constexpr (FNP_SWAP_EPI && (WIN || Cfg::WPAIR) && sizeof(TOut) == 2 && NB % 2 == 0) {
             // window kernel (its LDS is busy with the other resident workgroup's window reads: the strip form
             // measured slower): the 8-byte pieces of channel blocks k and k + 1 are exchanged between the lane
             // rows q, q ^ 1 of a site (v_permlane16_swap: odd rows of the first register <-> even rows of the
