@@ -250,7 +250,7 @@ template <int CIN, int COUT> struct MfmaOcc;
 template <int CIN, int COUT> struct MfmaWg { static constexpr int NW = (COUT == 128 && CIN >= FNP_NW_MINCIN) ? FNP_NW128 : (CIN == 32 && COUT == 32) ? FNP_NW32 : (CIN == 64 && COUT == 64) ? FNP_NW64 : 4; };
 
 #ifndef FNP_OCC1616
-#define FNP_OCC1616 2
+#define FNP_OCC1616 4
 #endif
 #ifndef FNP_OCC3232
 #define FNP_OCC3232 4
