@@ -116,14 +116,26 @@ __global__ __launch_bounds__(kThreads) void strided_mark2_kernel(const int *__re
     const int lane = fnp_lane();
     const int span = order ? cap_in : n;   // ranks of dropped / absent cells map to -1
     const int nround = (span + (int)(gridDim.x * kThreads) - 1) / (int)(gridDim.x * kThreads);
-    for (int it = 0; it < nround; ++it) {   // (whole waves stay in the loop: the shuffles below need them)
+    // the row id and coordinates of the NEXT round are requested before this round's dependent chain
+    // (occupancy-word read -> atomic -> summary atomic) is walked: two of its five memory round trips overlap
+    auto fetch = [&](int it, int &row, int4 &c) {
         const int i = (it * gridDim.x + blockIdx.x) * kThreads + threadIdx.x;
+        row = (it < nround && i < span) ? i : -1;
+        if (order && row >= 0) row = order[row];
+        if (!(row >= 0 && row < n)) row = -1;
+        c = make_int4(0, 0, 0, 0);
+        if (row >= 0) c = reinterpret_cast<const int4 *>(in_coords)[row];
+    };
+    int row_n;
+    int4 c_n;
+    fetch(0, row_n, c_n);
+    for (int it = 0; it < nround; ++it) {   // (whole waves stay in the loop: the shuffles below need them)
         long long blk0 = -1;          // block of the first outputs (corner 0,0,0) and its bits
         unsigned long long m0 = 0ull;
-        int row = i < span ? i : -1;
-        if (order && row >= 0) row = order[row];
-        if (row >= 0 && row < n) {
-            const int4 c = reinterpret_cast<const int4 *>(in_coords)[row];
+        const int row = row_n;
+        const int4 c = c_n;
+        fetch(it + 1, row_n, c_n);
+        if (row >= 0) {
             const AxisOut az = axis_outputs<SZ>(c.y, ge.k[0], ge.s[0], ge.p[0], go.d.D);
             const AxisOut ay = axis_outputs<SY>(c.z, ge.k[1], ge.s[1], ge.p[1], go.d.H);
             const AxisOut ax = axis_outputs<SX>(c.w, ge.k[2], ge.s[2], ge.p[2], go.d.W);
