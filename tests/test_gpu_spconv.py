@@ -497,3 +497,27 @@ def test_forward_points_edge_batches(cuda):
     assert c["counts"] == [0, 0, 0, 0, 0] and c["out"].features.shape == (0, 128)
     d = run(p0[:1], [0, 1], 1)
     assert d["counts"][0] == 1 and d["counts"][4] >= 1
+
+
+@pytest.mark.parametrize("Cin,Cout,n", [(32, 16, 700), (64, 32, 1300), (128, 64, 900),   # transposed pairs (data gradients)
+                                        (48, 48, 500), (16, 64, 300), (8, 24, 100),     # no MFMA instance: VALU kernel
+                                        (64, 64, 0), (128, 128, 17), (32, 64, 255), (16, 32, 257)])
+def test_conv_bf16_other_shapes_and_sizes(cuda, oracle, rng, Cin, Cout, n):
+    """Channel pairs outside the backbone's forward set (the data-gradient instances, shapes that fall back to the
+    VALU kernel), an empty tensor, sizes around the tile borders: bf16 in, f32 out against the oracle."""
+    B, shape = 2, [7, 24, 25]
+    feats, idx = _random_sparse(rng, B, shape, max(n, 1), Cin)
+    feats, idx = feats[:n], idx[:n]
+    w = (rng.standard_normal((Cout, 3, 3, 3, Cin)) * 0.1).astype(np.float32)
+    oracle.round_bf16(feats)
+    oracle.round_bf16(w)
+    d_idx = torch.from_numpy(np.ascontiguousarray(idx if n else np.zeros((1, 4), np.int32))).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    rb = S.rulebook_subm(d_idx, n_dev, S.build_grid(d_idx, n_dev, B, shape), 3)
+    wp = S.pack_weight(torch.from_numpy(w).to(cuda), torch.bfloat16)
+    x = torch.from_numpy(np.ascontiguousarray(feats if n else np.zeros((1, Cin), np.float32))).to(cuda).to(torch.bfloat16)
+    got = S.conv_forward(x, wp, rb, n_dev, out_dtype=torch.float32)
+    if n == 0:
+        return   # nothing to compare: the launch must simply be harmless
+    want = oracle.subm_conv(oracle.SparseTensor(feats, idx, shape, B), w).features
+    np.testing.assert_allclose(got[:n].cpu().numpy(), want, rtol=1e-4, atol=1e-4)
