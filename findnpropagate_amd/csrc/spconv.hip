@@ -215,7 +215,7 @@ struct MfmaCfg {
 // 2 = no weight staging, 4 = no MFMA, 8 = window kernels issue no global gathers, 16 = no window reads,
 // 32 = rulebook entries read from a 64 KiB (cache-resident) slice of the table, 64 = window address taken
 // from the entry without arithmetic (timing probe for pre-computed addresses), 128 = no output stores,
-// 256 = no residual loads.  The shipped library is built with FNP_ABLATE == 0.
+// 256 = no residual loads, 512 = no rulebook loads (every neighbour row + k - 13 present).  The shipped library is built with FNP_ABLATE == 0.
 #ifndef FNP_ABLATE
 #define FNP_ABLATE 0
 #endif
@@ -350,6 +350,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
         const int rc = r < r_end ? r : r_end - 1;
         const int kr = PAIR ? 2 * k + qk : k, KR = PAIR ? KVOL : K;
         const int kc = kr < KR ? kr : KR - 1;
+        if (FNP_ABLATE & 512) return rc + kc - 13;   // (probe: no rulebook loads at all)
         return nbr[(FNP_ABLATE & 32) ? (size_t)((kc * 64 + rc) & 0x3fff) : (size_t)kc * nbr_stride + rc];
     };
     // is the lane's offset of step k a real one (raw entries are validated where they are consumed)
