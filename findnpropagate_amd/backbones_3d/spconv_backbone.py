@@ -406,6 +406,15 @@ class FusedResBackbone:
             tag = (int(w.shape[2]), int(w.shape[1]), int(w.shape[0]), residual is not None, ranked)  # Cin, Cout, K, res
             if self.rulebook_log is not None:
                 self.rulebook_log.append((tag, rb, n))
+            if rb.nbr is None:   # fused strided layer
+                if self.profile is None or (self.profile_only is not None and tag[:3] not in self.profile_only):
+                    return S.conv_forward_strided(x, w, rb, scale=sc, shift=sh, relu=True)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                y = S.conv_forward_strided(x, w, rb, scale=sc, shift=sh, relu=True)
+                e1.record()
+                self.profile.append((tag, e0, e1))
+                return y
             if self.profile is None or (self.profile_only is not None and tag[:3] not in self.profile_only):
                 return S.conv_forward(x, w, rb, n, out_dtype=out_dtype, scale=sc, shift=sh, residual=residual, relu=True,
                                       ranked=ranked)
@@ -432,8 +441,13 @@ class FusedResBackbone:
         for li, (down_key, blk_key, dconv) in enumerate((('down2', 'blocks2', m.conv2[0][0]),
                                                           ('down3', 'blocks3', m.conv3[0][0]),
                                                           ('down4', 'blocks4', m.conv4[0][0]))):
+            # the down-sampling layers resolve their neighbours inside the convolution (their rulebook has no other
+            # user): no (27, cap) table; the table path stays for f32 and when the rulebooks are being logged
+            wd = P[down_key][0]
+            fused = (act == torch.bfloat16 and self.rulebook_log is None and tuple(dconv.kernel_size) == (3, 3, 3)
+                     and (int(wd.shape[2]), int(wd.shape[1])) in S.FUSED_STRIDED_SHAPES)
             rbs = S.rulebook_strided(idx_prev, n_prev, g_prev, dconv.kernel_size, dconv.stride, dconv.padding,
-                                     caps[li + 1], out_grid=grids[li + 1])
+                                     caps[li + 1], out_grid=grids[li + 1], want_nbr=not fused)
             x = conv(x_prev, P[down_key], rbs, rbs.out_n)
             rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3)
             # stages 2-4: rows are in rank-grid order on both sides of the SubM convolutions

@@ -196,80 +196,6 @@ __global__ __launch_bounds__(kThreads) void strided_nbr_kernel(const int *__rest
     }
 }
 
-// One thread per output row for all K = KZ*KY*KX offsets (kernel sizes 1 or 3 per axis): the input
-// cells of a row span at most two blocks per axis, so the thread loads the <= 8 occupancy words and
-// prefixes once (independent loads, all in flight together) and resolves the K cells with bit
-// operations, instead of K threads each re-reading the coordinates and one word.  Stores stay
-// coalesced: for a fixed offset, consecutive threads write consecutive entries of nbr[k][.].
-// lo = first input cell per axis (SubM: c - k/2; strided: c*s - p).
-// The K entries of a row go to a wave-private LDS strip ([k][lane]); nbr_flush then writes the strip out 16 bytes
-// per lane, four offsets (4 x 256 contiguous bytes) per wave instruction instead of one: the 4-byte form was
-// bound by the number of store instructions, not by bytes.
-template <int KZ, int KY, int KX>
-__device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, int lox, int *__restrict__ strip) {
-    const int bz0 = loz >> 2, by0 = loy >> 2, bx0 = lox >> 2;   // (arithmetic shift: -1 -> block -1, outside)
-    unsigned long long w[2][2][2];
-    unsigned base[2][2][2];
-#pragma unroll
-    for (int cz = 0; cz < 2; ++cz)
-#pragma unroll
-        for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-            for (int cx = 0; cx < 2; ++cx) {
-                const int bz = bz0 + cz, by = by0 + cy, bx = bx0 + cx;
-                const bool need = (cz == 0 || ((loz + KZ - 1) >> 2) != bz0) && (cy == 0 || ((loy + KY - 1) >> 2) != by0) &&
-                                  (cx == 0 || ((lox + KX - 1) >> 2) != bx0);
-                const bool in = bz >= 0 && bz < g.d.bd && by >= 0 && by < g.d.bh && bx >= 0 && bx < g.d.bw;
-                unsigned long long ww = 0ull;
-                unsigned bb = 0u;
-                if (need && in) {
-                    const long long blk = rg_block_of(g.d, b, bz << 2, by << 2, bx << 2);
-                    ww = g.bits[blk];
-                    bb = g.base[blk];   // (defined only where ww != 0; unused otherwise)
-                }
-                w[cz][cy][cx] = ww;
-                base[cz][cy][cx] = bb;
-            }
-#pragma unroll
-    for (int jz = 0; jz < KZ; ++jz) {
-        const int z = loz + jz;
-        const bool cz = (z >> 2) != bz0;
-        const bool vz = z >= 0 && z < g.d.D;
-        unsigned long long wz[2][2];
-        unsigned bsz[2][2];
-#pragma unroll
-        for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-            for (int cx = 0; cx < 2; ++cx) {
-                wz[cy][cx] = cz ? w[1][cy][cx] : w[0][cy][cx];
-                bsz[cy][cx] = cz ? base[1][cy][cx] : base[0][cy][cx];
-            }
-#pragma unroll
-        for (int jy = 0; jy < KY; ++jy) {
-            const int y = loy + jy;
-            const bool cy = (y >> 2) != by0;
-            const bool vy = vz && y >= 0 && y < g.d.H;
-            const unsigned long long wy0 = cy ? wz[1][0] : wz[0][0], wy1 = cy ? wz[1][1] : wz[0][1];
-            const unsigned by0v = cy ? bsz[1][0] : bsz[0][0], by1v = cy ? bsz[1][1] : bsz[0][1];
-#pragma unroll
-            for (int jx = 0; jx < KX; ++jx) {
-                const int x = lox + jx;
-                const bool cx = (x >> 2) != bx0;
-                const bool v = vy && x >= 0 && x < g.d.W;
-                const unsigned long long ww = cx ? wy1 : wy0;
-                const unsigned bb = cx ? by1v : by0v;
-                const int bit = rg_bit_of(z, y, x);
-                int r = -1;
-                if (v && ((ww >> bit) & 1ull)) {
-                    r = (int)bb + __popcll(ww & ((1ull << bit) - 1ull));
-                    if (g.perm) r = g.perm[r];
-                }
-                strip[((jz * KY + jy) * KX + jx) * 64] = r;
-            }
-        }
-    }
-}
-
 // strip -> nbr[k][o0 .. o0 + 63] for the K offsets (table stride `cap`); rows >= n are never written
 template <int K>
 __device__ __forceinline__ void nbr_flush(const int *__restrict__ strip_wave, int o0, int n, int cap, int *__restrict__ nbr) {
@@ -307,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_kernel(const int *__res
         const int o = base + threadIdx.x;
         if (o < n) {
             const int4 c = reinterpret_cast<const int4 *>(coords)[o];
-            nbr_row<KZ, KY, KX>(g, c.x, c.y - KZ / 2, c.z - KY / 2, c.w - KX / 2, strip_wave + fnp_lane());
+            nbr_row<KZ, KY, KX>(g, c.x, c.y - KZ / 2, c.z - KY / 2, c.w - KX / 2, strip_wave + fnp_lane(), 64);
         }
         nbr_flush<K>(strip_wave, base + (threadIdx.x & ~63), n, cap, nbr);
     }
@@ -325,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void strided_nbr_row_kernel(const int *__
         const int o = base + threadIdx.x;
         if (o < n) {
             const int4 c = reinterpret_cast<const int4 *>(out_coords)[o];
-            nbr_row<KZ, KY, KX>(gi, c.x, c.y * ge.s[0] - ge.p[0], c.z * ge.s[1] - ge.p[1], c.w * ge.s[2] - ge.p[2], strip_wave + fnp_lane());
+            nbr_row<KZ, KY, KX>(gi, c.x, c.y * ge.s[0] - ge.p[0], c.z * ge.s[1] - ge.p[1], c.w * ge.s[2] - ge.p[2], strip_wave + fnp_lane(), 64);
         }
         nbr_flush<K>(strip_wave, base + (threadIdx.x & ~63), n, cap_out, nbr);
     }
@@ -380,7 +306,7 @@ extern "C" int fnp_rulebook_strided(const int *in_coords, const int *n_in, int c
                                     fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!in_coords || !n_in || cap_in <= 0 || cap_out <= 0 || !geom_ok(geom) || !fnp_rg_valid(in_grid) ||
-        !fnp_rg_valid(out_grid) || !out_coords || !n_out || !nbr || !workspace)
+        !fnp_rg_valid(out_grid) || !out_coords || !n_out || !workspace)
         return FNP_ERR_ARG;
     if (in_grid->B != out_grid->B || !shape_is(in_grid, geom->in_shape) || !shape_is(out_grid, geom->out_shape))
         return FNP_ERR_ARG;
@@ -409,6 +335,7 @@ extern "C" int fnp_rulebook_strided(const int *in_coords, const int *n_in, int c
     FNP_LAUNCH_CHECK();
     int rc = fnp_scan::rank_grid(go, n_out, workspace, s, out_coords, cap_out);   // ranks + coordinates in rank order
     if (rc) return rc;
+    if (!nbr) return FNP_OK;   // grid + coordinates only (the convolution resolves its neighbours itself)
     const dim3 rgrid(fnp_grid_for(cap_out, kThreads));
     if (ge.k[0] == 3 && ge.k[1] == 3 && ge.k[2] == 3)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_nbr_row_kernel<3, 3, 3>), rgrid, dim3(kThreads), 0, s, out_coords, n_out,

@@ -18,7 +18,7 @@
 //   * f32 validation path on the VALU: a k-ascending, cin-ascending fmaf chain per output
 //     element, the same chain the CPU oracle evaluates, so it is bit-comparable.
 // No atomics anywhere: every output row is written once, results are run-to-run identical.
-#include "common.h"
+#include "rankgrid.cuh"
 #include <type_traits>
 
 namespace {
@@ -263,15 +263,28 @@ template <int CIN, int COUT> struct MfmaWg { static constexpr int NW = (COUT == 
 #endif
 template <int CIN, int COUT> struct MfmaOcc { static constexpr int WAVES = (CIN == 128 && COUT == 128) ? FNP_OCC128 : (CIN == 16 && COUT == 16) ? FNP_OCC1616 : (CIN == 32 && COUT == 32) ? FNP_OCC3232 : (CIN == 64 && COUT == 64) ? FNP_OCC6464 : (CIN == 16 && COUT == 32) ? 4 : ((CIN < COUT && COUT <= 64) || MfmaWg<CIN, COUT>::NW == 6) ? 3 : 2; };
 
-template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut>
+// FUSED (strided 3x3x3 layers of the fused backbone): the rulebook of such a layer is used exactly once, so the
+// kernel computes the 27 entries of its rows itself — each wave, at the top of a tile, one lane per row with the
+// same nbr_row() the rulebook kernels use (coordinates -> <= 8 occupancy words of the INPUT grid -> bit
+// arithmetic), into a wave-private LDS strip that the offset sweep then reads instead of the table.  No
+// 108-byte-per-row table is written and read back (0.5 GB per step at 64 scenes), and the index fetches leave
+// the in-order VMEM queue.
+struct FusedRb {
+    RG gi;                    // input rank grid (rows = ranks: perm unused unless the grid carries one)
+    int s[3], p[3];           // stride, padding (kernel 3x3x3)
+    const int *out_coords;    // (cap, 4) [b, z, y, x] of the output rows
+};
+
+template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut, bool FUSED = false>
 __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const __bf16 *__restrict__ x, int x_bytes,
                                                              const __bf16 *__restrict__ w,
                                                              const int *__restrict__ nbr, int nbr_stride, int Krt,
                                                              const int *__restrict__ n_out, int cap,
                                                              TOut *__restrict__ y, const float *__restrict__ scale,
                                                              const float *__restrict__ shift,
-                                                             const TOut *__restrict__ residual, int relu, int hints) {
+                                                             const TOut *__restrict__ residual, int relu, int hints, FusedRb frb) {
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
+    static_assert(!FUSED || (KVOL == 27 && !WIN), "fused rulebook: 3x3x3 strided layers");
     constexpr int CH = Cfg::CH, SLAB = Cfg::SLAB, SW = Cfg::SW, KS = Cfg::KS, PFK = Cfg::PFK;
     constexpr bool ALLK = Cfg::ALLK;
     constexpr int XLB = Cfg::XLB, WROWS = Cfg::win_rows(MfmaWg<CIN, COUT>::NW, MB), WH = Cfg::WH;
@@ -336,10 +349,17 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     // rulebook entry of row r for offset k; rows past the range and offsets past K read a valid
     // address and yield -1 (no data-dependent branch around a load)
     // (PAIR: step k stands for the offsets 2k and 2k + 1; the lane's own one is 2k + qk, absent past KVOL - 1)
+    // (FUSED: the entries of the wave's tile rows sit in its LDS strip [offset][row of the tile], -1 for rows past
+    //  the range)
+    constexpr int SR = MB * 16;   // rows of a wave tile
+    int *const fstrip = reinterpret_cast<int *>(fnp_smem + Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN) +
+                                                Cfg::epi_bytes(MfmaWg<CIN, COUT>::NW, WIN, sizeof(TOut) == 2)) + wave * (27 * SR);
+    int frow0 = 0;                // first row of the wave's current tile (set by the tile body)
     auto nbr_at = [&](int k, int r, int r_end) -> int {
         const int rc = r < r_end ? r : r_end - 1;
         const int kr = PAIR ? 2 * k + qk : k, KR = PAIR ? KVOL : K;
         const int kc = kr < KR ? kr : KR - 1;
+        if constexpr (FUSED) return kr < KR ? fstrip[kc * SR + (r - frow0)] : -1;
         const int v = nbr[(FNP_ABLATE & 32) ? (size_t)((kc * 64 + rc) & 0x3fff) : (size_t)kc * nbr_stride + rc];
         return (r < r_end && kr < KR) ? v : -1;
     };
@@ -351,6 +371,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
         const int kr = PAIR ? 2 * k + qk : k, KR = PAIR ? KVOL : K;
         const int kc = kr < KR ? kr : KR - 1;
         if (FNP_ABLATE & 512) return rc + kc - 13;   // (probe: no rulebook loads at all)
+        if constexpr (FUSED) return fstrip[kc * SR + (r - frow0)];
         return nbr[(FNP_ABLATE & 32) ? (size_t)((kc * 64 + rc) & 0x3fff) : (size_t)kc * nbr_stride + rc];
     };
     // is the lane's offset of step k a real one (raw entries are validated where they are consumed)
@@ -426,6 +447,21 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     auto run_tile = [&](auto mbt_tag, const int tile_base) __attribute__((always_inline)) {
         constexpr int MBT = decltype(mbt_tag)::value;
         const int row0 = tile_base + wave * (MBT * 16);
+        if constexpr (FUSED) {
+            // rulebook rows of this wave's tile: lane j resolves the 27 input cells of row row0 + j
+            frow0 = row0;
+            if (lane < MBT * 16) {
+                const int r = row0 + lane;
+                if (r < row_end) {
+                    const int4 c = reinterpret_cast<const int4 *>(frb.out_coords)[r];
+                    nbr_row<3, 3, 3>(frb.gi, c.x, c.y * frb.s[0] - frb.p[0], c.z * frb.s[1] - frb.p[1], c.w * frb.s[2] - frb.p[2],
+                                     fstrip + lane, SR);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) fstrip[k * SR + lane] = -1;
+                }
+            }
+        }
         // feature window of this tile: WROWS consecutive input rows around the tile's own rows.  With
         // rows in rank-grid order ~96 % of a tile's neighbours lie in it, each fetched once instead
         // of once per (site, offset) pair that references it.
@@ -821,9 +857,10 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     if constexpr (MB > 3) { if (tper == 3) run_tile(std::integral_constant<int, 3>{}, tail_base); }
 }
 
-template <int CIN, int COUT, int KVOL, bool WIN, typename TOut>
+template <int CIN, int COUT, int KVOL, bool WIN, typename TOut, bool FUSED = false>
 int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
-                  void *y, const float *scale, const float *shift, const void *residual, int relu, int hints, hipStream_t s) {
+                  void *y, const float *scale, const float *shift, const void *residual, int relu, int hints, hipStream_t s,
+                  const FusedRb *frb_in = nullptr) {
     // 16-site blocks per wave: 4 (64 sites); 3 for 128 output channels (accumulators = COUT/16 * MB * 4
     // registers; 4 spills heavily, 3 spills ~16 registers outside the offset loop and measured 13 %
     // faster than 2 on MI355X: fewer weight-slab sweeps per site); 2 for the 16 -> 16 layers
@@ -839,9 +876,18 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
 #endif
     constexpr int MB = COUT >= 128 ? FNP_MB128 : (CIN == 16 && COUT <= 32) ? 2 : (CIN == 32 && COUT == 32) ? FNP_MB3232 : (CIN == 64 && COUT == 64) ? FNP_MB6464 : 4;
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
-    auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut>;
-    constexpr int lds = Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN) + Cfg::epi_bytes(MfmaWg<CIN, COUT>::NW, WIN, sizeof(TOut) == 2);
-    static_assert(lds * MfmaOcc<CIN, COUT>::WAVES * 4 / MfmaWg<CIN, COUT>::NW <= 160 * 1024, "LDS budget of the resident workgroups");
+    auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut, FUSED>;
+    constexpr int lds = Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN) + Cfg::epi_bytes(MfmaWg<CIN, COUT>::NW, WIN, sizeof(TOut) == 2) +
+                        (FUSED ? MfmaWg<CIN, COUT>::NW * 27 * MB * 16 * 4 : 0);
+    FusedRb frb{};
+    if (FUSED) {
+        if (!frb_in) return FNP_ERR_ARG;
+        frb = *frb_in;
+    }
+    // workgroups a CU holds: by the register budget (launch bounds), and for the fused-rulebook form by its larger LDS
+    constexpr int wg_regs = MfmaOcc<CIN, COUT>::WAVES * 4 / MfmaWg<CIN, COUT>::NW;
+    constexpr int wg_per_cu = FUSED && lds * wg_regs > 160 * 1024 ? 160 * 1024 / lds : wg_regs;
+    static_assert(wg_per_cu >= 1 && lds * wg_per_cu <= 160 * 1024, "LDS budget of the resident workgroups");
     if (lds > 64 * 1024) {
         static bool raised = false;  // (idempotent; a race only repeats the call)
         if (!raised) {
@@ -854,10 +900,10 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
     // persistent grid: two workgroups per CU are resident (register / LDS budget of the wide
     // layers); the narrow ALLK layers stage all weights once per workgroup, so keep them few too.
     // The kernel splits the rows evenly over whatever grid it gets.
-    const int resident = 256 * MfmaOcc<CIN, COUT>::WAVES * 4 / MfmaWg<CIN, COUT>::NW;
+    const int resident = 256 * wg_per_cu;
     const int grid = tiles < resident ? tiles : resident;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MfmaWg<CIN, COUT>::NW * 64), lds, s, (const __bf16 *)x, x_bytes, (const __bf16 *)w,
-                       nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu, hints);
+                       nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu, hints, frb);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
@@ -969,3 +1015,40 @@ extern "C" int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_ro
     }
     return FNP_ERR_ARG;
 }
+
+// Strided 3x3x3 convolution with its rulebook computed inside the kernel (see FusedRb): for a layer whose rulebook
+// has no other user.  bf16 in/out, channel pairs 16->32, 32->64, 64->128; anything else returns FNP_ERR_ARG and the
+// caller takes the table path (fnp_rulebook_strided with nbr + fnp_spconv_forward).
+extern "C" int fnp_spconv_forward_strided(const void *feat_in, int in_dtype, int n_in_rows, const void *weight,
+                                          const fnp_rankgrid *in_grid, const fnp_conv_geom *geom, const int *out_coords,
+                                          const int *n_out, int cap_out, void *feat_out, int out_dtype, const float *scale,
+                                          const float *shift, int relu, int Cin, int Cout, fnp_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!feat_in || !weight || !geom || !out_coords || !n_out || !feat_out || cap_out <= 0 || n_in_rows <= 0 ||
+        !fnp_rg_valid(in_grid))
+        return FNP_ERR_ARG;
+    if ((scale == nullptr) != (shift == nullptr)) return FNP_ERR_ARG;
+    if (in_dtype != FNP_BF16 || out_dtype != FNP_BF16) return FNP_ERR_ARG;
+    for (int d = 0; d < 3; ++d)
+        if (geom->ksize[d] != 3 || geom->stride[d] <= 0 || geom->padding[d] < 0) return FNP_ERR_ARG;
+    if (in_grid->D != geom->in_shape[0] || in_grid->H != geom->in_shape[1] || in_grid->W != geom->in_shape[2]) return FNP_ERR_ARG;
+    const long long xb = (long long)n_in_rows * Cin * 2;
+    if (xb <= 0 || xb >= 0x7fffffffll) return FNP_ERR_ARG;
+    FusedRb frb;
+    frb.gi = fnp_rg_view(in_grid);
+    for (int d = 0; d < 3; ++d) {
+        frb.s[d] = geom->stride[d];
+        frb.p[d] = geom->padding[d];
+    }
+    frb.out_coords = out_coords;
+#define FNP_FCASE(CI, CO)                                                                                                   \
+    if (Cin == CI && Cout == CO)                                                                                            \
+        return launch_mfma_k<CI, CO, 27, false, __bf16, true>(feat_in, (int)xb, weight, nullptr, cap_out, 27, n_out, cap_out, feat_out, \
+                                                              scale, shift, nullptr, relu, 0, s, &frb);
+    FNP_FCASE(16, 32)
+    FNP_FCASE(32, 64)
+    FNP_FCASE(64, 128)
+#undef FNP_FCASE
+    return FNP_ERR_ARG;
+}
+

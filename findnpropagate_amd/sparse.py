@@ -59,6 +59,7 @@ class Rulebook:
     out_n: Optional[torch.Tensor] = None
     out_grid: Optional[RankGrid] = None
     out_shape: Optional[List[int]] = None
+    in_grid: Optional[RankGrid] = None           # strided, nbr is None: the grid the convolution looks its inputs up in
 
 
 def num_blocks(batch_size, shape):
@@ -187,9 +188,11 @@ def rulebook_subm(indices, n_dev, grid, ksize):
     return Rulebook(nbr=nbr, K=K, cap_out=cap, geom=geom)
 
 
-def rulebook_strided(indices, n_dev, grid, ksize, stride, padding, cap_out, out_grid=None):
+def rulebook_strided(indices, n_dev, grid, ksize, stride, padding, cap_out, out_grid=None, want_nbr=True):
     """Builds out grid + out indices (rank order) + nbr.  out_n is the TRUE count (may exceed
-    cap_out: the caller checks it when it synchronises)."""
+    cap_out: the caller checks it when it synchronises).  want_nbr=False: grid and coordinates only, for a layer
+    that resolves its neighbours inside the convolution (conv_forward_strided); Rulebook.nbr is then None and
+    Rulebook.in_grid the input grid."""
     L = _l.load()
     dev = indices.device
     cap_in = max(indices.shape[0], 1)
@@ -200,14 +203,14 @@ def rulebook_strided(indices, n_dev, grid, ksize, stride, padding, cap_out, out_
     cap_out = max(int(cap_out), 1)
     out_idx = torch.empty((cap_out, 4), dtype=torch.int32, device=dev)
     out_n = torch.empty((1,), dtype=torch.int32, device=dev)    # always written by fnp_rulebook_strided
-    nbr = torch.empty((K, cap_out), dtype=torch.int32, device=dev)
+    nbr = torch.empty((K, cap_out), dtype=torch.int32, device=dev) if want_nbr else None
     ws = torch.empty((int(L.fnp_rankgrid_workspace_bytes(grid.batch_size, *out_shape)),), dtype=torch.uint8, device=dev)
     rc = L.fnp_rulebook_strided(_l.ptr(indices), _l.ptr(n_dev), cap_in, geom, grid.c(), out_grid.c(with_perm=False),
                                 _l.ptr(out_idx), _l.ptr(out_n), cap_out, _l.ptr(nbr), _l.ptr(ws), ws.numel(),
                                 _l.stream())
     _l.check(rc, "fnp_rulebook_strided")
     return Rulebook(nbr=nbr, K=K, cap_out=cap_out, geom=geom, out_indices=out_idx, out_n=out_n, out_grid=out_grid,
-                    out_shape=out_shape)
+                    out_shape=out_shape, in_grid=None if want_nbr else grid)
 
 
 # --------------------------------------------------------------------------------- convolution
@@ -245,6 +248,30 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
                               int(bool(relu)), HINT_ROWS_RANKED if ranked else 0, Cin, Cout, _l.stream())
     _l.check(rc, "fnp_spconv_forward")
     return out
+
+
+def conv_forward_strided(feat_in, w_packed, rb, scale=None, shift=None, relu=False, out=None):
+    """A strided 3x3x3 convolution whose rulebook rows are computed inside the kernel (rb from
+    rulebook_strided(..., want_nbr=False)).  bf16, (Cin, Cout) in {(16,32), (32,64), (64,128)}.  Same result as
+    conv_forward on the table.  No host sync."""
+    L = _l.load()
+    _l.require_device(feat_in, w_packed, rb.out_indices, rb.out_n)
+    K, Cout, Cin = w_packed.shape
+    assert rb.nbr is None and rb.in_grid is not None and K == 27 and feat_in.shape[1] == Cin
+    assert feat_in.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and feat_in.is_contiguous()
+    if out is None:
+        out = torch.empty((rb.cap_out, Cout), dtype=torch.bfloat16, device=feat_in.device)
+    rc = L.fnp_spconv_forward_strided(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
+                                      rb.in_grid.c(), rb.geom, _l.ptr(rb.out_indices), _l.ptr(rb.out_n), rb.cap_out,
+                                      _l.ptr(out), _l.dtype_code(out), _l.ptr(scale), _l.ptr(shift), int(bool(relu)),
+                                      Cin, Cout, _l.stream())
+    _l.check(rc, "fnp_spconv_forward_strided")
+    return out
+
+
+# layers the fused backbone runs this way (16 -> 32 is built and tested too, but measured 2.5 % slower end to end than its table
+# path: its input grid carries the voxeliser's permutation and its LDS strip costs a resident workgroup)
+FUSED_STRIDED_SHAPES = {(32, 64), (64, 128)}
 
 
 # --------------------------------------------------------------------------------- backward

@@ -192,7 +192,8 @@ int fnp_rulebook_subm(const int *coords, const int *n_rows, int cap, const fnp_c
 
 /* Strided SparseConv3d: builds the output rank grid (bits/summary zero on entry; perm unused),
  * the output coordinate list (rows in rank-grid order: spatially blocked, deterministic) and
- * nbr.  workspace: fnp_rankgrid_workspace_bytes of the output grid. */
+ * nbr (nullable: only grid + coordinates, for fnp_spconv_forward_strided).  workspace:
+ * fnp_rankgrid_workspace_bytes of the output grid. */
 int fnp_rulebook_strided(const int *in_coords, const int *n_in, int cap_in, const fnp_conv_geom *geom,
                          const fnp_rankgrid *in_grid, const fnp_rankgrid *out_grid,
                          int *out_coords, int *n_out, int cap_out, int *nbr,
@@ -218,6 +219,17 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
                        void *feat_out, int out_dtype,
                        const float *scale, const float *shift, const void *residual, int relu,
                        int hints, int Cin, int Cout, fnp_stream_t stream);
+
+/* The same convolution for a STRIDED 3x3x3 layer whose rulebook has no other user (the three down-sampling
+ * layers of VoxelResBackBone8x, spconv_backbone.py:207,214,221): the kernel computes the rulebook rows of its
+ * tiles itself from the input rank grid and the output coordinates (fnp_rulebook_strided with nbr = NULL builds
+ * those), so no (27, cap) table is written and read back.  bf16 in/out, (Cin, Cout) in {(16,32), (32,64),
+ * (64,128)}; FNP_ERR_ARG otherwise (take the table path).  Results are identical to the table path. */
+int fnp_spconv_forward_strided(const void *feat_in, int in_dtype, int n_in_rows, const void *weight,
+                               const fnp_rankgrid *in_grid, const fnp_conv_geom *geom, const int *out_coords,
+                               const int *n_out, int cap_out, void *feat_out, int out_dtype,
+                               const float *scale, const float *shift, int relu, int Cin, int Cout,
+                               fnp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Backward of the sparse convolution (spconv's autograd behind SubMConv3d / SparseConv3d in the

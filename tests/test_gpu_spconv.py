@@ -521,3 +521,28 @@ def test_conv_bf16_other_shapes_and_sizes(cuda, oracle, rng, Cin, Cout, n):
         return   # nothing to compare: the launch must simply be harmless
     want = oracle.subm_conv(oracle.SparseTensor(feats, idx, shape, B), w).features
     np.testing.assert_allclose(got[:n].cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("Cin,Cout", [(16, 32), (32, 64), (64, 128)])
+@pytest.mark.parametrize("pad", [(1, 1, 1), (0, 1, 1)])
+def test_strided_conv_with_in_kernel_rulebook_equals_table_path(cuda, rng, Cin, Cout, pad):
+    """fnp_spconv_forward_strided computes the rulebook rows of a strided 3x3x3 layer inside the kernel: same output
+    coordinates, bit-identical features as fnp_rulebook_strided's table + fnp_spconv_forward — on a grid whose rows
+    are ranks and on one that carries a permutation (the voxeliser's grid)."""
+    B, shape, n = 2, [11, 60, 61], 9000
+    feats, idx = _random_sparse(rng, B, shape, n, Cin)
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    grid = S.build_grid(d_idx, n_dev, B, shape)            # keeps the (random) row order: perm != None
+    x = torch.from_numpy(feats).to(cuda).to(torch.bfloat16)
+    wp = S.pack_weight(torch.from_numpy((rng.standard_normal((Cout, 3, 3, 3, Cin)) * 0.1).astype(np.float32)).to(cuda), torch.bfloat16)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32)).to(cuda)
+    sh = torch.from_numpy(rng.standard_normal(Cout).astype(np.float32)).to(cuda)
+    a = S.rulebook_strided(d_idx, n_dev, grid, 3, 2, pad, 4 * n)
+    ya = S.conv_forward(x, wp, a, a.out_n, scale=sc, shift=sh, relu=True)
+    b = S.rulebook_strided(d_idx, n_dev, grid, 3, 2, pad, 4 * n, want_nbr=False)
+    yb = S.conv_forward_strided(x, wp, b, scale=sc, shift=sh, relu=True)
+    m = int(a.out_n.item())
+    assert m == int(b.out_n.item()) and m > n // 4
+    assert torch.equal(a.out_indices[:m], b.out_indices[:m])
+    assert torch.equal(ya[:m], yb[:m])
