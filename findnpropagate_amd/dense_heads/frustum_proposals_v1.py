@@ -227,9 +227,13 @@ class FrustumProposerOG(nn.Module):
                                      self.mags.to(dev).contiguous())
         return self._dev_tables[key]
 
-    def get_proposals(self, batch_dict, debug=False):
-        """-> proposal_boxes (K,7) device f32, frust_labels (K,) long CPU, frust_scores (K,) f32 CPU,
-        frust_batch_idx (K,) long CPU — the tuple of :1055-1067."""
+    def launch(self, batch_dict, debug=False):
+        """Enqueue the Box Seeker for every frustum of the batch and return WITHOUT synchronising:
+        dict(frustums (F,8) f32 HOST rows [scene, cam, x1, y1, x2, y2, label, score] in the reference's enumeration
+        order, d_frustums (the same on the device), out_valid (F,) i32, out_box (F,7), out_score (F,), out_best (F,) on
+        the device, debug tensors), or None when the batch has no frustum.  batch_dict may carry 'points_per_scene' (host list of
+        ints, the per-scene row counts the collate already knows): without it a batch of more than one scene costs one
+        host sync for the scene sizes."""
         L = _l.load()
         points = batch_dict['points']
         _l.require_device(points)
@@ -238,21 +242,26 @@ class FrustumProposerOG(nn.Module):
         B = int(batch_dict['batch_size'])
         frusts = self.enumerate_frustums(batch_dict)
         F = frusts.shape[0]
-        empty = (torch.zeros((0, 7), device=dev), torch.zeros((0,), dtype=torch.long), torch.zeros((0,)),
-                 torch.zeros((0,), dtype=torch.long))
         if F == 0:
-            return empty
+            return None
         # scenes are contiguous row ranges of the collated point tensor (dataset.py:221-245)
+        pps = batch_dict.get('points_per_scene')
         if B == 1:      # the extraction script's batch size (:36,54): the scene is the whole tensor, no sync needed
-            offsets = torch.tensor([0, points.shape[0]], dtype=torch.int32, device=dev)
-            max_pts = int(points.shape[0])
+            pps = [int(points.shape[0])]
+        if pps is not None:
+            assert len(pps) == B and sum(int(v) for v in pps) == points.shape[0]
+            offs = [0]
+            for v in pps:
+                offs.append(offs[-1] + int(v))
+            offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+            max_pts = max(int(v) for v in pps)
         else:
             counts = torch.bincount(points[:, 0].long(), minlength=B)[:B]
             offsets = torch.zeros((B + 1,), dtype=torch.int32, device=dev)
             offsets[1:] = torch.cumsum(counts, 0).int()
-            max_pts = int(counts.max().item())                                 # host sync 1
+            max_pts = int(counts.max().item())                                 # host sync (scene sizes)
         scene_m, cam_m = self._matrices(batch_dict)
-        scene_m, cam_m, d_fr = scene_m.to(dev), cam_m.to(dev), frusts.to(dev)
+        scene_m, cam_m, d_fr = scene_m.to(dev, non_blocking=True), cam_m.to(dev, non_blocking=True), frusts.to(dev, non_blocking=True)
         prm = self._params(points.shape[1], 1)
         NC = self.num_mags * self.num_rotations * self.num_sizes
         ws = torch.empty((int(L.fnp_boxseeker_workspace_bytes(F, max_pts)),), dtype=torch.uint8, device=dev)
@@ -274,9 +283,23 @@ class FrustumProposerOG(nn.Module):
                              _l.ptr(dbg.get('npts')), _l.ptr(dbg.get('frust')), _l.ptr(dbg.get('cand')),
                              _l.ptr(dbg.get('iou')), _l.ptr(dbg.get('count')), _l.ptr(dbg.get('valid')), _l.stream())
         _l.check(rc, "fnp_boxseeker")
-        valid = out_valid.bool().cpu()                                          # host sync 2
+        # (the launch is asynchronous: the tensors it reads must outlive this call)
+        return dict(frustums=frusts, d_frustums=d_fr, out_valid=out_valid, out_box=out_box, out_score=out_score,
+                    out_best=out_best, dbg=dbg, _keep=(points, offsets, scene_m, cam_m, ws))
+
+    def get_proposals(self, batch_dict, debug=False):
+        """-> proposal_boxes (K,7) device f32, frust_labels (K,) long CPU, frust_scores (K,) f32 CPU,
+        frust_batch_idx (K,) long CPU — the tuple of :1055-1067."""
+        dev = batch_dict['points'].device
+        empty = (torch.zeros((0, 7), device=dev), torch.zeros((0,), dtype=torch.long), torch.zeros((0,)),
+                 torch.zeros((0,), dtype=torch.long))
+        r = self.launch(batch_dict, debug=debug)
+        if r is None:
+            return empty
+        frusts, out_box = r['frustums'], r['out_box']
+        valid = r['out_valid'].bool().cpu()                                     # host sync (result read-back)
         if debug:
-            self.last_debug = dict(frustums=frusts, has_box=valid, second_stage_scores=out_score, best=out_best, **dbg)
+            self.last_debug = dict(frustums=frusts, has_box=valid, second_stage_scores=r['out_score'], best=r['out_best'], **r['dbg'])
         if not bool(valid.any()):
             return empty
         proposal_boxes = out_box[valid.to(dev)].reshape(-1, 7)

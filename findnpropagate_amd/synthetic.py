@@ -203,11 +203,117 @@ def make_detections(boxes, cls, cams, rng, batch_idx=0, duplicates=True):
             np.full((len(out),), batch_idx, np.int64), np.array([o[3] for o in out], np.int64))
 
 
-def make_seeker_scene(seed):
-    """Everything FrustumProposerOG.get_proposals reads for one scene (batch size 1)."""
+# Scene variants of the Box Seeker parity set (tests/golden/make_boxseeker_golden.py): which edge case a seed carries.
+#   aug          non-identity lidar_aug_matrix (world rotation / scaling / translation [/ flip] as the reference's
+#                augmentor accumulates them; points are handed over in the augmented frame)
+#   empty_cam    two cameras without any detection
+#   lone_point   one extra lidar return above every beam + a large detection that contains only that point
+#                (all three depth quantiles equal, clamp_bottom collapses the frustum: frustum_proposals_v1.py:616-629,817-826),
+#                a sub-pixel detection around one ordinary return and one around two returns (interpolated quantile)
+#   no_dets      the detector returns nothing (early return :694-700);  low_scores: everything under score_thr
+SEEKER_VARIANTS = {3: ("aug",), 4: ("aug", "flip"), 5: ("aug", "empty_cam"), 6: ("empty_cam",), 7: ("lone_point",),
+                   8: (), 9: (), 10: ("aug", "flip", "empty_cam", "lone_point"), 11: ("no_dets",), 12: ("low_scores",),
+                   13: ("aug", "lone_point")}
+LONE_POINT = np.array([15.0, 0.3, 4.5], np.float32)      # elevation 16.7 deg: above the top beam (10.67 deg)
+
+
+def _project(L, xyz):
+    p = xyz.astype(np.float64) @ L[:3, :3].T.astype(np.float64) + L[:3, 3].astype(np.float64)
+    return p[:, 0] / p[:, 2], p[:, 1] / p[:, 2], p[:, 2]
+
+
+def make_seeker_scene(seed, variant=None):
+    """Everything FrustumProposerOG.get_proposals reads for one scene (batch size 1).
+    variant: tuple of SEEKER_VARIANTS flags (default: the seed's entry, () for seeds 0-2)."""
+    flags = tuple(SEEKER_VARIANTS.get(seed, ())) if variant is None else tuple(variant)
     pts, boxes, cls = make_scene(seed, return_boxes=True)
     rng = np.random.default_rng(10_000 + seed)
     cams = make_cameras(1)
     dets = make_detections(boxes, cls, cams, rng)
+    if "lone_point" in flags:
+        lone = np.zeros((1, 5), np.float32)
+        lone[0, :3], lone[0, 3] = LONE_POINT, 17.0
+        pts = np.concatenate([pts[:1000], lone, pts[1000:]])
+        H, W = IMAGE_SIZE
+        extra = []
+        u, v, _ = _project(cams["lidar2image"][0, 0], LONE_POINT[None])
+        extra.append((np.array([u[0] - 115.0, max(v[0] - 58.0, 0.0), u[0] + 115.0, v[0] + 57.0]), 1, 0.93, 0))
+        # sub-pixel boxes around one / two ordinary returns seen by camera 3 (the back camera)
+        L3 = cams["lidar2image"][0, 3]
+        u, v, d = _project(L3, pts[:, :3])
+        vis = np.nonzero((d > 3.0) & (u > 50) & (u < W - 50) & (v > 50) & (v < H - 50))[0]
+        i0 = vis[len(vis) // 3]
+        extra.append((np.array([u[i0] - 0.4, v[i0] - 0.4, u[i0] + 0.4, v[i0] + 0.4]), 9, 0.91, 3))
+        # two returns: the nearest neighbour of another return in the image plane
+        i1 = vis[2 * len(vis) // 3]
+        dist = (u[vis] - u[i1]) ** 2 + (v[vis] - v[i1]) ** 2
+        dist[vis == i1] = np.inf
+        i2 = vis[int(np.argmin(dist))]
+        lo_u, hi_u, lo_v, hi_v = min(u[i1], u[i2]), max(u[i1], u[i2]), min(v[i1], v[i2]), max(v[i1], v[i2])
+        extra.append((np.array([lo_u - 0.3, lo_v - 0.3, hi_u + 0.3, hi_v + 0.3]), 10, 0.9, 3))
+        dets = (np.concatenate([dets[0], np.stack([e[0] for e in extra]).astype(np.float32)]),
+                np.concatenate([dets[1], np.array([e[1] for e in extra], np.int64)]),
+                np.concatenate([dets[2], np.array([e[2] for e in extra], np.float32)]),
+                np.concatenate([dets[3], np.zeros(len(extra), np.int64)]),
+                np.concatenate([dets[4], np.array([e[3] for e in extra], np.int64)]))
+    if "empty_cam" in flags:
+        keep = (dets[4] != 1) & (dets[4] != 5)
+        dets = tuple(d[keep] for d in dets)
+    if "no_dets" in flags:
+        dets = tuple(d[:0] for d in dets)
+    if "low_scores" in flags:
+        dets = (dets[0], dets[1], (dets[2] * 0.4).astype(np.float32), dets[3], dets[4])
+    if "aug" in flags:
+        # DataAugmentor order: flip, rotation, scaling, translation, each left-multiplied into lidar_aug_matrix
+        th, sc = rng.uniform(-0.785, 0.785), rng.uniform(0.9, 1.1)
+        A = np.eye(4)
+        if "flip" in flags:
+            A = np.diag([1.0, -1.0, 1.0, 1.0]) @ A
+        Rz = np.eye(4)
+        Rz[:2, :2] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]
+        A = Rz @ A
+        A = np.diag([sc, sc, sc, 1.0]) @ A
+        T = np.eye(4)
+        T[:3, 3] = rng.normal(0.0, 0.5, size=3)
+        A = (T @ A).astype(np.float32)
+        pts = pts.copy()
+        pts[:, :3] = (pts[:, :3].astype(np.float64) @ A[:3, :3].T.astype(np.float64) + A[:3, 3]).astype(np.float32)
+        cams["lidar_aug_matrix"] = A[None].copy()
     points = np.concatenate([np.zeros((pts.shape[0], 1), np.float32), pts], axis=1)   # collate_batch: [b, x, y, z, i, t]
-    return {"points": points, "gt_boxes": boxes, "gt_cls": cls, "dets": dets, **cams}
+    return {"points": points, "gt_boxes": boxes, "gt_cls": cls, "dets": dets, "variant": flags, **cams}
+
+
+class SeekerScenes:
+    """A dataset of synthetic Box Seeker scenes in the collated single-scene form tools/extract_pseudo_labels.py:115
+    iterates (batch_size 1; 'points' (N,6) [b,x,y,z,i,t], camera matrices (1,6,4,4), 'lidar_aug_matrix' (1,4,4),
+    'gt_boxes' (1,G,10) with the 1-based class last, 'frame_id'), plus 'dets' = the 5-tuple a PreprocessedGLIP-like
+    detector returns (give the head image_detector=lambda bd: bd['dets']).  `distinct` scenes (seeds seed0 ..) resident
+    on `device`, cycled to `n` frames with distinct frame ids."""
+
+    def __init__(self, n, distinct, device, seed0=0, variants=None):
+        import torch
+
+        self.n, self.base, self.raw = n, [], []
+        for s in range(distinct):
+            sc = make_seeker_scene(seed0 + s, variant=None if variants is None else variants[s % len(variants)])
+            self.raw.append(sc)
+            d = {"points": torch.from_numpy(sc["points"]).to(device), "batch_size": 1,
+                 "dets": tuple(torch.from_numpy(a) for a in sc["dets"])}
+            for k in ("camera_intrinsics", "camera2lidar", "lidar2image", "lidar_aug_matrix"):
+                d[k] = torch.from_numpy(sc[k]).to(device)
+            g = np.zeros((1, sc["gt_boxes"].shape[0], 10), np.float32)
+            g[0, :, :7] = sc["gt_boxes"]
+            g[0, :, 9] = sc["gt_cls"] + 1
+            d["gt_boxes"] = torch.from_numpy(g).to(device)
+            self.base.append(d)
+
+    def __len__(self):
+        return self.n
+
+    def frame_id(self, i):
+        return f"synthetic-{i:06d}.pcd.bin"
+
+    def __getitem__(self, i):
+        d = dict(self.base[i % len(self.base)])
+        d["frame_id"] = self.frame_id(i)
+        return d

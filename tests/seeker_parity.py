@@ -1,0 +1,64 @@
+"""Shared Box Seeker parity rule (tests/test_oracle_boxseeker.py on the CPU oracle, tests/test_gpu_boxseeker.py on the
+HIP kernel) against the golden vectors the reference's own get_proposals produced
+(tests/golden/make_boxseeker_golden.py).
+
+For every frustum that yields a box the implementation under test reports which candidate it chose.  The rule:
+  * that candidate is one of the candidates the reference scored, and its REFERENCE second-stage score
+    (frustum_proposals_v1.py:997, recorded at the nms_normal_gpu call) lies within `tol` of the reference's maximum,
+    where tol = 1e-4 (2D-IoU rounding, rtol 1e-4 on values <= 1) + 2 * (largest point-count difference between the
+    implementation and the reference inside this frustum) / (reference max count): zero count differences leave only
+    the float noise, so a wrong choice cannot hide behind the tolerance;
+  * the returned box equals the reference's own box of THAT candidate (the row it handed to points_in_boxes_gpu)
+    in all 7 components to BOX_ATOL;
+  * when the reference's top score is unique beyond tol the box therefore equals the reference's output box.
+Exact ties (yaw 0 vs pi footprints, the six identical depth samples of a collapsed frustum) are the only freedom left:
+the reference's own unstable sort (iou3d_nms_utils.py:146) decides them.
+"""
+import numpy as np
+
+BOX_ATOL = 1e-4      # north_star: box regressions within 1e-4 (f32); coordinates reach 54 m (ulp 3.8e-6)
+
+
+def ragged(d, key):
+    off = d[key + "_off"]
+    return [d[key][off[i]:off[i + 1]] for i in range(len(off) - 1)]
+
+
+def check_choices(d, out_boxes, chosen):
+    """d: golden npz; out_boxes (K,7); chosen: per output box (scored candidate ids ascending, chosen candidate id,
+    point counts of the scored candidates)."""
+    ws = ragged(d, "nms3d_scores") if "nms3d_scores" in d.files else []
+    assert len(ws) == out_boxes.shape[0] == len(chosen) == d["out_boxes"].shape[0]
+    offs = np.cumsum([0] + [len(w) for w in ws])
+    n_unique = 0
+    for k, (cand_ids, best, counts) in enumerate(chosen):
+        w = ws[k][:, 0]
+        seg = slice(offs[k], offs[k + 1])
+        ref_boxes, ref_counts = d["pib_box"][seg], d["pib_count"][seg]
+        assert len(cand_ids) == len(w), f"frustum {k}: scored candidate sets differ"
+        pos = list(cand_ids).index(best)
+        dcount = np.abs(np.asarray(counts, np.int64) - ref_counts).max()
+        tol = 1e-4 + 2.0 * dcount / max(int(ref_counts.max()), 1)
+        assert w[pos] >= w.max() - tol, f"frustum {k}: chose a candidate {w.max() - w[pos]:.3e} below the reference's best (tol {tol:.1e})"
+        np.testing.assert_allclose(out_boxes[k], ref_boxes[pos], rtol=0, atol=BOX_ATOL, err_msg=f"frustum {k}")
+        top = np.sort(w)[::-1]
+        if len(top) == 1 or top[0] - top[1] > tol:
+            n_unique += 1
+            np.testing.assert_allclose(out_boxes[k], d["out_boxes"][k], rtol=0, atol=BOX_ATOL, err_msg=f"frustum {k}")
+    return n_unique
+
+
+def check_choices_oracle(trace, out_boxes, chosen):
+    """The same rule against a trace of oracle/boxseeker.get_proposals (fresh scenes, parameter variants): the chosen
+    candidate's ORACLE score within tol of the oracle's best, and the box equal to the oracle's box of that candidate."""
+    scored = [t for t in trace if "scores" in t]
+    assert len(scored) == out_boxes.shape[0] == len(chosen)
+    for k, (t, (cand_ids, best, counts)) in enumerate(zip(scored, chosen)):
+        assert list(cand_ids) == list(t["idx_final"]), f"frustum {k}: scored candidate sets differ"
+        pos = list(cand_ids).index(best)
+        dcount = np.abs(np.asarray(counts, np.int64) - t["counts"].astype(np.int64)).max()
+        assert dcount <= 2
+        tol = 1e-4 + 2.0 * dcount / max(int(t["counts"].max()), 1)
+        w = t["scores"]
+        assert w[pos] >= w.max() - tol, f"frustum {k}: {w.max() - w[pos]:.3e} below the oracle's best (tol {tol:.1e})"
+        np.testing.assert_allclose(out_boxes[k], t["cand_boxes"][best], rtol=0, atol=BOX_ATOL, err_msg=f"frustum {k}")

@@ -1,0 +1,23 @@
+"""The host entry points of libfnp_hip.so (fnp_host_*: rotated BEV IoU, PseudoSampler.points_in_boxes, the pseudo-label
+readers, the dataloader processors) are plain CPU code, tested in the CPU suite (tests/test_host_iou.py,
+tests/test_pseudo_loader.py, tests/test_data_processor.py, tests/test_preprocessed_detector.py ...).  This module runs
+the SAME test functions in the `-m gpu` set too, so that the driver's GPU-box run loads and exercises that native code
+as well (host-ABI tests were deselected from the driver-run set)."""
+import pytest
+
+import test_data_processor as _dp
+import test_host_iou as _hi
+import test_pseudo_loader as _pl
+
+pytestmark = pytest.mark.gpu
+
+
+def _reexport(mod, prefix):
+    for name in dir(mod):
+        if name.startswith("test_"):
+            globals()[f"test_{prefix}_{name[5:]}"] = getattr(mod, name)
+
+
+_reexport(_hi, "host_iou")
+_reexport(_pl, "pseudo_loader")
+_reexport(_dp, "data_processor")

@@ -32,63 +32,70 @@ def test_constructor_tables_match_reference(bs):
     assert bs.linspace_f32(0, 1, 6).tolist() == pytest.approx([0, 0.2, 0.4, 0.6, 0.8, 1.0], abs=1e-7)
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 7, 10])
 def test_stage_values_match_reference(bs, seed):
     d = np.load(os.path.join(GOLD, f"boxseeker_seed{seed}.npz"))
     sc = syn.make_seeker_scene(seed)
     # 2D batched NMS per camera, in image_order
-    for ci, c in enumerate(bs.IMAGE_ORDER):
-        boxes, scores, labels = _ragged(d, "nms2d_in_boxes")[ci], _ragged(d, "nms2d_in_scores")[ci][:, 0], _ragged(d, "nms2d_in_labels")[ci][:, 0]
+    ci = 0
+    for c in bs.IMAGE_ORDER:
         m = sc["dets"][4] == c
+        if not m.any():          # the reference skips batched_nms for a camera without detections (:586)
+            continue
+        boxes, scores, labels = _ragged(d, "nms2d_in_boxes")[ci], _ragged(d, "nms2d_in_scores")[ci][:, 0], _ragged(d, "nms2d_in_labels")[ci][:, 0]
         assert np.array_equal(boxes, sc["dets"][0][m])
         keep = bs.batched_nms_2d(boxes, scores, labels, 0.4)
         assert keep.tolist() == _ragged(d, "nms2d_keep")[ci][:, 0].tolist()
+        ci += 1
+    assert ci == len(d["nms2d_keep_off"]) - 1
     # back-projection (get_geometry_at_image_coords) on every recorded call
     gin, gout, gcam = _ragged(d, "geom_in"), _ragged(d, "geom_out"), d["geom_cam"]
     for a, b, c in zip(gin, gout, gcam):
         got = bs.geometry_at_image_coords(a, sc["camera2lidar"][0, c], sc["camera_intrinsics"][0, c], sc["lidar_aug_matrix"][0])
         np.testing.assert_allclose(got, b, rtol=1e-5, atol=2e-4)
     # corner projection + 2D IoU (calc_iou) on every recorded call
-    cams_of_iou = [c for c, n in zip(d["proj_cam"], d["proj_n"]) if n <= 600]
+    cams_of_iou = [c for c, n in zip(d["proj_cam"], d["proj_n"]) if n <= 600]   # (the corner projections of calc_iou)
     for corners, box, want, c in zip(_ragged(d, "iou_corners"), _ragged(d, "iou_box"), _ragged(d, "iou_out"), cams_of_iou):
         got, _ = bs.calc_iou(corners.reshape(-1, 8, 3), box[:, 0], sc["lidar_aug_matrix"][0], sc["lidar2image"][0, c])
         np.testing.assert_allclose(got, want[:, 0], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2])
+SEEDS = list(range(14))    # 0-2 plain, 3-13 the edge cases of synthetic.SEEKER_VARIANTS
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_get_proposals_matches_reference(bs, seed):
+    from seeker_parity import check_choices
+
     d = np.load(os.path.join(GOLD, f"boxseeker_seed{seed}.npz"))
     sc = syn.make_seeker_scene(seed)
+    assert ",".join(sc["variant"]) == str(d["variant"])
     trace = []
     boxes, labels, scores = bs.get_proposals(sc, trace=trace)
     assert boxes.shape == d["out_boxes"].shape
     assert labels.tolist() == d["out_labels"].tolist()
     np.testing.assert_allclose(scores, d["out_scores"], rtol=0, atol=1e-7)
+    if boxes.shape[0] == 0:      # no_dets / low_scores: the early return of :694-700
+        assert "pib_count" not in d.files
+        return
     # candidate point counts (the reference's per-candidate points_in_boxes_gpu calls), in call order
     mine = np.concatenate([t["counts"] for t in trace if "counts" in t]).astype(np.int64)
     want = d["pib_count"]
     assert mine.shape == want.shape
     assert (mine != want).mean() < 0.01 and np.abs(mine - want).max() <= 2      # face-grazing points only
     cand = np.concatenate([t["cand_boxes"][t["idx_final"]] for t in trace if "idx_final" in t])
-    np.testing.assert_allclose(cand, d["pib_box"], rtol=1e-5, atol=2e-4)
-    # chosen boxes: identical up to float noise, except where the reference's own scores tie
-    # (yaw 0 vs pi give the same footprint)
-    want_scores = _ragged(d, "nms3d_scores")
-    k = 0
-    for t in trace:
-        if "scores" not in t:
-            continue
-        ws = want_scores[k][:, 0]
-        np.testing.assert_allclose(t["scores"], ws, rtol=0, atol=2e-3)
-        top = np.sort(ws)[::-1]
-        tie = len(top) > 1 and (top[0] - top[1]) < 2e-3
-        a, b = boxes[k], d["out_boxes"][k]
-        if tie:
-            assert np.allclose(a[3:6], b[3:6], atol=1e-5)
-        else:
-            np.testing.assert_allclose(a, b, rtol=1e-5, atol=2e-4)
-        k += 1
-    assert k == boxes.shape[0]
+    np.testing.assert_allclose(cand, d["pib_box"], rtol=0, atol=1e-4)
+    k0 = 0
+    for t, ws in zip([t for t in trace if "scores" in t], _ragged(d, "nms3d_scores")):
+        ref = want[k0:k0 + len(ws)]
+        k0 += len(ws)
+        dcount = np.abs(t["counts"].astype(np.int64) - ref).max()
+        np.testing.assert_allclose(t["scores"], ws[:, 0], rtol=0, atol=1e-4 + 2.0 * dcount / max(ref.max(), 1))
+    chosen = [(t["idx_final"], t["best"], t["counts"]) for t in trace if "scores" in t]
+    n_unique = check_choices(d, boxes, chosen)
+    if "lone_point" in sc["variant"]:
+        assert any(t["n_points"] == 1 and "scores" in t for t in trace), "the single-return frustum reaches the scoring stage"
+    assert n_unique >= 0.5 * boxes.shape[0]
 
 
 def test_quantile_matches_torch(bs):

@@ -14,7 +14,7 @@ import numpy as np, torch
 from findnpropagate_amd import extract as E, synthetic as syn
 from findnpropagate_amd.dense_heads import FrustumProposerOG
 
-ap = argparse.ArgumentParser(); ap.add_argument("--scenes", type=int, default=64); ap.add_argument("--distinct", type=int, default=8)
+ap = argparse.ArgumentParser(); ap.add_argument("--scenes", type=int, default=64); ap.add_argument("--distinct", type=int, default=8); ap.add_argument("--per-step", type=int, default=1); ap.add_argument("--sync", action="store_true", help="plain synchronous loop instead of the pipeline")
 args = ap.parse_args()
 rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 torch.cuda.set_device(local); dev = torch.device("cuda", local)
@@ -26,24 +26,7 @@ PARAMS = {'lq': 0.0, 'uq': 0.25, 'cq': 1.0, 'iou_w': 1.0, 'nms_normal': 1.0, 'ds
           'min_cam_iou': 0.3, 'score_thr': 0.45, 'nms_2d': 0.4, 'nms_3d': 0.0, 'clamp_bottom': 1, 'num_sizes': 1}
 
 
-class Scenes:
-    """`distinct` synthetic scenes resident on the device, cycled to `n` frames (frame ids differ)."""
-    def __init__(self, n, distinct):
-        self.n, self.base = n, []
-        for s in range(distinct):
-            sc = syn.make_seeker_scene(s)
-            d = {"points": torch.from_numpy(sc["points"]).to(dev), "batch_size": 1, "dets": tuple(torch.from_numpy(a) for a in sc["dets"])}
-            for k in ("camera_intrinsics", "camera2lidar", "lidar2image", "lidar_aug_matrix"):
-                d[k] = torch.from_numpy(sc[k]).to(dev)
-            g = np.zeros((1, sc["gt_boxes"].shape[0], 10), np.float32)
-            g[0, :, :7] = sc["gt_boxes"]; g[0, :, 9] = sc["gt_cls"] + 1
-            d["gt_boxes"] = torch.from_numpy(g).to(dev)
-            self.base.append(d)
-    def __len__(self): return self.n
-    def frame_id(self, i): return f"synthetic-{i:06d}.pcd.bin"
-    def __getitem__(self, i):
-        d = dict(self.base[i % len(self.base)]); d["frame_id"] = self.frame_id(i)
-        return d
+Scenes = lambda n, distinct: syn.SeekerScenes(n, distinct, dev)
 
 
 data = Scenes(args.scenes, args.distinct)
@@ -51,17 +34,17 @@ cur = {}
 head = FrustumProposerOG(model_cfg={"PARAMS": PARAMS, "PREDS_PATH": "PreprocessedGLIP", "BOX_FORMAT": "xyxy"},
                          image_detector=lambda bd: bd["dets"]).eval()
 with tempfile.TemporaryDirectory() as warm:
-    E.extract_pseudo_labels(Scenes(2 * world, args.distinct), head, warm, dev, dist=dist, write="own")
+    E.extract_pseudo_labels(Scenes(2 * world * args.per_step, args.distinct), head, warm, dev, dist=dist, write="own", scenes_per_step=args.per_step, pipeline=False if args.sync else None)
 out_dir = tempfile.mkdtemp(prefix="fnp_extract_")
 rec = {}
 torch.cuda.synchronize(); t0 = time.perf_counter()
-written = E.extract_pseudo_labels(data, head, out_dir, dev, dist=dist, write="own", recall=rec)
+written = E.extract_pseudo_labels(data, head, out_dir, dev, dist=dist, write="own", recall=rec, scenes_per_step=args.per_step, pipeline=False if args.sync else None)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 if dist is not None:
     t = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
 if rank == 0:
     print(json.dumps({"workload": "pseudo-label extraction: Box Seeker per scene + all-gather + recall + .pth", "n_gpus": world,
-                      "scenes": args.scenes, "seconds": round(dt, 3), "scenes_per_s": round(args.scenes / dt, 1),
+                      "scenes": args.scenes, "scenes_per_step": args.per_step, "pipeline": not args.sync, "seconds": round(dt, 3), "scenes_per_s": round(args.scenes / dt, 1),
                       "ms_per_scene_per_gpu": round(1e3 * dt * world / args.scenes, 3),
                       "recall": {k: round(v, 3) for k, v in rec.items() if k.startswith("recall_")}, "gt": rec.get("gt")}))
 import shutil; shutil.rmtree(out_dir, ignore_errors=True)
