@@ -415,7 +415,66 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
         for (int c = tid; c < NC; c += kThreads) dbg_valid[(size_t)f * NC + c] = S.cvalid[c];
 }
 
+// Exchange records of the sharded extraction (findnpropagate_amd/extract.py): scene s of the batch gets one
+// (rows_per_scene, 9) f32 record, row 0 = [count, tag, 0 ...], rows 1.. = [box (7), detection score, label] of its
+// frustums that yielded a box, in frustum order; every other row is zeroed.  One workgroup per scene; the position of
+// a box is the number of valid frustums of its scene before it (ballot + prefix), so the packing needs no host-side
+// knowledge of which frustums survived.
+struct PackTags { float tag[64]; };
+
+__global__ __launch_bounds__(kThreads) void seeker_pack_kernel(const float *__restrict__ frusts, const int *__restrict__ out_valid,
+                                                               const float *__restrict__ out_box, int F, PackTags tags,
+                                                               int rows_per_scene, float *__restrict__ rec) {
+    __shared__ int wave_cnt[kThreads / 64];
+    __shared__ int base_s;
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *my = rec + (size_t)s * rows_per_scene * 9;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int f0 = 0; f0 < F; f0 += kThreads) {
+        const int f = f0 + tid;
+        const bool v = f < F && (int)frusts[(size_t)f * 8] == s && out_valid[f] != 0;
+        const unsigned long long m = __ballot(v);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = base_s;
+        for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+        const int pos = before + __popcll(m & ((1ull << lane) - 1ull));
+        if (v && pos + 1 < rows_per_scene) {
+            float *row = my + (size_t)(pos + 1) * 9;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) row[j] = out_box[(size_t)f * 7 + j];
+            row[7] = frusts[(size_t)f * 8 + 7];
+            row[8] = frusts[(size_t)f * 8 + 6];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < kThreads / 64; ++w) tot += wave_cnt[w];
+            base_s += tot;
+        }
+        __syncthreads();
+    }
+    const int count = base_s;
+    for (int i = tid; i < 9; i += kThreads) my[i] = i == 0 ? (float)count : i == 1 ? tags.tag[s] : 0.f;
+    const int first_free = min(count, rows_per_scene - 1) + 1;
+    for (int i = first_free * 9 + tid; i < rows_per_scene * 9; i += kThreads) my[i] = 0.f;
+}
+
 }  // namespace
+
+extern "C" int fnp_seeker_pack_records(const float *frustums, const int *out_valid, const float *out_box, int num_frustums,
+                                       const float *tags, int num_scenes, int rows_per_scene, float *records,
+                                       fnp_stream_t stream) {
+    if (num_frustums < 0 || num_scenes <= 0 || num_scenes > 64 || rows_per_scene < 1 || !tags || !records) return FNP_ERR_ARG;
+    if (num_frustums > 0 && (!frustums || !out_valid || !out_box)) return FNP_ERR_ARG;
+    PackTags t{};
+    for (int s = 0; s < num_scenes; ++s) t.tag[s] = tags[s];
+    hipLaunchKernelGGL(seeker_pack_kernel, dim3(num_scenes), dim3(kThreads), 0, (hipStream_t)stream, frustums, out_valid,
+                       out_box, num_frustums, t, rows_per_scene, records);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
 
 // Host side of the frustum enumeration (:561-594): per scene, per camera in image_order, the
 // reference runs torchvision.batched_nms on a few dozen CPU boxes and drops low scores.  Same

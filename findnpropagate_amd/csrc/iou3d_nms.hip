@@ -140,6 +140,21 @@ __host__ __device__ __forceinline__ float iou_from_overlap(const float *a, const
     return ov / fmaxf(sa + sb - ov, 1e-8f);
 }
 
+// boxes_iou3d_gpu, iou3d_nms_utils.py:59-80: BEV overlap x height overlap / union, z = box centre
+__host__ __device__ __forceinline__ float iou3d_from_overlap(const float *a, const float *b, float ov) {
+    const float a_max = a[2] + a[5] / 2, a_min = a[2] - a[5] / 2;
+    const float b_max = b[2] + b[5] / 2, b_min = b[2] - b[5] / 2;
+    const float max_of_min = a_min > b_min ? a_min : b_min;
+    const float min_of_max = a_max < b_max ? a_max : b_max;
+    float oh = min_of_max - max_of_min;
+    if (oh < 0.f) oh = 0.f;
+    const float o3 = ov * oh;
+    const float va = a[3] * a[4] * a[5], vb = b[3] * b[4] * b[5];
+    float den = va + vb - o3;
+    if (den < 1e-6f) den = 1e-6f;
+    return o3 / den;
+}
+
 __device__ __forceinline__ float iou_axis_aligned(const float *a, const float *b) {
     const float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
     const float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
@@ -177,18 +192,8 @@ __global__ __launch_bounds__(256) void pairwise_kernel(const float *__restrict__
         r = ov;
     } else if (MODE == MODE_IOU_BEV) {
         r = iou_from_overlap(A.raw, B.raw, ov);
-    } else {  // boxes_iou3d_gpu, iou3d_nms_utils.py:59-80
-        const float a_max = A.raw[2] + A.raw[5] / 2, a_min = A.raw[2] - A.raw[5] / 2;
-        const float b_max = B.raw[2] + B.raw[5] / 2, b_min = B.raw[2] - B.raw[5] / 2;
-        const float max_of_min = a_min > b_min ? a_min : b_min;
-        const float min_of_max = a_max < b_max ? a_max : b_max;
-        float oh = min_of_max - max_of_min;
-        if (oh < 0.f) oh = 0.f;
-        const float o3 = ov * oh;
-        const float va = A.raw[3] * A.raw[4] * A.raw[5], vb = B.raw[3] * B.raw[4] * B.raw[5];
-        float den = va + vb - o3;
-        if (den < 1e-6f) den = 1e-6f;
-        r = o3 / den;
+    } else {
+        r = iou3d_from_overlap(A.raw, B.raw, ov);
     }
     out[(size_t)ai * nb + bi] = r;
 }
@@ -285,6 +290,95 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long 
     if (lane == 0) *num_keep = nk;
 }
 
+// boxes_aligned_iou3d_gpu (iou3d_nms_utils.py:83-117) in one launch
+__global__ __launch_bounds__(64) void aligned_iou3d_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                           int n, float *__restrict__ out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    RBox A, B;
+    prep_box(a + (size_t)i * 7, A);
+    prep_box(b + (size_t)i * 7, B);
+    out[i] = iou3d_from_overlap(A.raw, B.raw, overlap_area(A, B));
+}
+
+// Recall bookkeeping of one frame (Detector3DTemplate.generate_recall_record, detector3d_template.py:342-397) in ONE
+// workgroup, accumulated into a device-resident counter vector: no host synchronisation per frame (the reference does
+// ~6 `.item()` per IoU threshold plus one per ground-truth box).  Layout of `counters` (int64):
+//   [gt, num_3known, num_6known, num_4unknown, num_7unknown] then per threshold
+//   [roi, rcnn, rcnn_3known, rcnn_6known, rcnn_4unknown, rcnn_7unknown].
+struct RecallCfg {
+    int T;
+    float thr[8];
+    unsigned known3_bits, known6_bits;   // bit l set: class label l (1-based) is a "known" class
+};
+
+__global__ __launch_bounds__(256) void recall_kernel(const float *__restrict__ preds, int pred_stride, int max_preds,
+                                                     const float *__restrict__ pred_count,
+                                                     const float *__restrict__ gt, int G, int gt_stride,
+                                                     const float *__restrict__ rois, int n_rois, int rois_stride,
+                                                     RecallCfg cfg, unsigned long long *__restrict__ counters) {
+    __shared__ RBox sa[16], sb[16];
+    __shared__ int best[16], best_roi[16];
+    __shared__ int last_nonzero;
+    __shared__ int acc[5 + 6 * 8];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    if (tid == 0) last_nonzero = -1;
+    if (tid < 5 + 6 * 8) acc[tid] = 0;
+    __syncthreads();
+    // trailing all-zero rows are padding (:342-346): row j counts iff some row at or after it has a non-zero sum
+    for (int j = tid; j < G; j += 256) {
+        float sum = 0.f;
+        for (int c = 0; c < gt_stride; ++c) sum += gt[(size_t)j * gt_stride + c];
+        if (sum != 0.f) atomicMax(&last_nonzero, j);
+    }
+    __syncthreads();
+    const int n_gt = last_nonzero + 1;
+    int n_pred = max_preds;
+    if (pred_count) n_pred = min(max_preds, max(0, (int)*pred_count));
+    for (int g0 = 0; g0 < n_gt; g0 += 16) {
+        if (tid < 16) {
+            best[tid] = 0;       // IoUs are >= 0: their float bits order like ints
+            best_roi[tid] = 0;
+            if (g0 + tid < n_gt) prep_box(gt + (size_t)(g0 + tid) * gt_stride, sb[tid]);
+        }
+        for (int pass = 0; pass < 2; ++pass) {
+            const float *src = pass ? rois : preds;
+            const int n_src = pass ? (rois ? n_rois : 0) : n_pred, stride = pass ? rois_stride : pred_stride;
+            for (int p0 = 0; p0 < n_src; p0 += 16) {
+                __syncthreads();
+                if (tid < 16 && p0 + tid < n_src) prep_box(src + (size_t)(p0 + tid) * stride, sa[tid]);
+                __syncthreads();
+                if (p0 + ty < n_src && g0 + tx < n_gt) {
+                    const float iou = iou3d_from_overlap(sa[ty].raw, sb[tx].raw, overlap_area(sa[ty], sb[tx]));
+                    atomicMax(pass ? &best_roi[tx] : &best[tx], __float_as_int(iou));
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 16 && g0 + tid < n_gt) {
+            const int label = (int)(long long)gt[(size_t)(g0 + tid) * gt_stride + (gt_stride - 1)];
+            const bool k3 = label >= 0 && label < 32 && ((cfg.known3_bits >> label) & 1u);
+            const bool k6 = label >= 0 && label < 32 && ((cfg.known6_bits >> label) & 1u);
+            atomicAdd(&acc[0], 1);
+            atomicAdd(&acc[k3 ? 1 : 4], 1);      // num_3known | num_7unknown
+            atomicAdd(&acc[k6 ? 2 : 3], 1);      // num_6known | num_4unknown
+            const float b = __int_as_float(best[tid]), br = __int_as_float(best_roi[tid]);
+            for (int t = 0; t < cfg.T; ++t) {
+                int *a = acc + 5 + 6 * t;
+                if (rois && br > cfg.thr[t]) atomicAdd(&a[0], 1);
+                if (n_pred > 0 && b > cfg.thr[t]) {
+                    atomicAdd(&a[1], 1);
+                    atomicAdd(&a[k3 ? 2 : 5], 1);    // rcnn_3known | rcnn_7unknown
+                    atomicAdd(&a[k6 ? 3 : 4], 1);    // rcnn_6known | rcnn_4unknown
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid < 5 + 6 * cfg.T && acc[tid]) atomicAdd(&counters[tid], (unsigned long long)acc[tid]);
+}
+
 template <int MODE>
 int launch_pairwise(const float *a, int na, const float *b, int nb, float *out, fnp_stream_t stream) {
     if (na < 0 || nb < 0) return FNP_ERR_ARG;
@@ -331,6 +425,31 @@ extern "C" int fnp_boxes_aligned_overlap_bev(const float *a, const float *b, int
     if (n == 0) return FNP_OK;
     if (!a || !b || !out) return FNP_ERR_ARG;
     hipLaunchKernelGGL(aligned_overlap_kernel, dim3(fnp_divup(n, 64)), dim3(64), 0, (hipStream_t)s, a, b, n, out);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+extern "C" int fnp_boxes_aligned_iou3d(const float *a, const float *b, int n, float *out, fnp_stream_t s) {
+    if (n < 0) return FNP_ERR_ARG;
+    if (n == 0) return FNP_OK;
+    if (!a || !b || !out) return FNP_ERR_ARG;
+    hipLaunchKernelGGL(aligned_iou3d_kernel, dim3(fnp_divup(n, 64)), dim3(64), 0, (hipStream_t)s, a, b, n, out);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+extern "C" int fnp_recall_counters(const float *preds, int pred_stride, int max_preds, const float *pred_count,
+                                   const float *gt, int num_gt, int gt_stride, const float *rois, int num_rois,
+                                   int rois_stride, const float *thresh, int num_thresh, unsigned known3_bits,
+                                   unsigned known6_bits, int64_t *counters, fnp_stream_t s) {
+    if (max_preds < 0 || num_gt < 0 || num_rois < 0 || num_thresh < 1 || num_thresh > 8 || !thresh || !counters) return FNP_ERR_ARG;
+    if (num_gt == 0) return FNP_OK;
+    if (!gt || gt_stride < 8 || (max_preds > 0 && (!preds || pred_stride < 7)) || (rois && rois_stride < 7)) return FNP_ERR_ARG;
+    RecallCfg cfg{};
+    cfg.T = num_thresh;
+    for (int t = 0; t < num_thresh; ++t) cfg.thr[t] = thresh[t];
+    cfg.known3_bits = known3_bits;
+    cfg.known6_bits = known6_bits;
+    hipLaunchKernelGGL(recall_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, preds, pred_stride, max_preds, pred_count, gt,
+                       num_gt, gt_stride, rois, num_rois, rois_stride, cfg, (unsigned long long *)counters);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }

@@ -23,39 +23,45 @@ class Detector3DTemplate:
     post_processing, checkpoint loading) stays the reference's own."""
 
     @staticmethod
-    def recall_counter_vector(box_preds, gt_boxes, thresh_list, rois=None, pred_count=None):
-        """The counters one frame adds to the recall record (detector3d_template.py:342-397) as ONE device vector,
-        no host synchronisation: [gt, num_3known, num_6known, num_4unknown, num_7unknown] then per threshold
-        [roi, rcnn, rcnn_3known, rcnn_6known, rcnn_4unknown, rcnn_7unknown] (int64).  box_preds (K,7+); gt_boxes
-        (G, >=8) with the class label last; pred_count: optional device scalar, rows >= it are padding."""
+    def recall_counter_vector(box_preds, gt_boxes, thresh_list, rois=None, pred_count=None, out=None):
+        """The counters one frame adds to the recall record (detector3d_template.py:342-397) as ONE device vector and
+        ONE launch (fnp_recall_counters), no host synchronisation: [gt, num_3known, num_6known, num_4unknown,
+        num_7unknown] then per threshold [roi, rcnn, rcnn_3known, rcnn_6known, rcnn_4unknown, rcnn_7unknown] (int64).
+        box_preds (K, >=7) rows may be strided views (e.g. the body of an extraction record); gt_boxes (G, >=8) with
+        the class label last; pred_count: optional device f32 scalar, rows >= it are padding; out: vector to add into."""
+        import ctypes
+
+        from .. import lib as _l
+
+        L = _l.load()
         dev = gt_boxes.device
         T = len(thresh_list)
-        out = torch.zeros((5 + 6 * T,), dtype=torch.int64, device=dev)
+        if out is None:
+            out = torch.zeros((5 + 6 * T,), dtype=torch.int64, device=dev)
         if gt_boxes.shape[0] == 0:
             return out
-        # the all-zero padding rows at the end (:342-346) are masked out on the device instead of sliced off
-        nonzero = (gt_boxes.sum(dim=1) != 0).to(torch.int32)
-        valid = torch.flip(torch.cummax(torch.flip(nonzero, [0]), 0)[0], [0]).bool()    # row i: some non-zero row at or after i
-        labels = gt_boxes[:, -1].long()
-        known3 = torch.isin(labels, torch.tensor(known3_labels, device=dev)) & valid
-        known6 = torch.isin(labels, torch.tensor(known6_labels, device=dev)) & valid
-        unk3, unk6 = valid & ~known3, valid & ~known6
-        th = torch.tensor([float(t) for t in thresh_list], dtype=torch.float32, device=dev)
-        out[0:5] = torch.stack([valid.sum(), known3.sum(), known6.sum(), unk6.sum(), unk3.sum()])
-        per = torch.zeros((T, 6), dtype=torch.int64, device=dev)
-        gt7 = gt_boxes[:, 0:7].contiguous().float()
-        if box_preds.shape[0] > 0:
-            iou = iou3d_nms_utils.boxes_iou3d_gpu(box_preds[:, 0:7].contiguous().float(), gt7)
-            if pred_count is not None:
-                live = torch.arange(box_preds.shape[0], device=dev)[:, None] < pred_count.reshape(1, 1)
-                iou = torch.where(live, iou, torch.zeros_like(iou))
-            hit = (iou.max(dim=0)[0][None, :] > th[:, None]) & valid[None, :]    # (T, G)
-            per[:, 1:6] = torch.stack([hit.sum(1), (hit & known3).sum(1), (hit & known6).sum(1), (hit & unk6).sum(1),
-                                       (hit & unk3).sum(1)], dim=1)
-        if rois is not None:
-            iou_roi = iou3d_nms_utils.boxes_iou3d_gpu(rois[:, 0:7].contiguous().float(), gt7)
-            per[:, 0] = ((iou_roi.max(dim=0)[0][None, :] > th[:, None]) & valid[None, :]).sum(1)
-        out[5:] = per.reshape(-1)
+        _l.require_device(gt_boxes)
+        gt = gt_boxes if (gt_boxes.dtype == torch.float32 and gt_boxes.is_contiguous()) else gt_boxes.float().contiguous()
+
+        def rows(t):
+            """(pointer, row stride in floats, rows) of a 2-D f32 tensor whose rows are contiguous"""
+            if t is None or t.shape[0] == 0:
+                return None, 7, 0
+            if t.dtype != torch.float32 or t.stride(1) != 1:
+                t = t.float().contiguous()
+            keep.append(t)
+            return t.data_ptr(), t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 7), t.shape[0]
+
+        keep = []
+        p_ptr, p_stride, p_n = rows(box_preds)
+        r_ptr, r_stride, r_n = rows(rois)
+        th = (ctypes.c_float * T)(*[float(t) for t in thresh_list])
+        bits = lambda labels: sum(1 << int(l) for l in labels)
+        rc = L.fnp_recall_counters(p_ptr, p_stride, p_n, None if pred_count is None else pred_count.data_ptr(),
+                                   gt.data_ptr(), gt.shape[0], gt.shape[1], r_ptr, r_n, r_stride,
+                                   ctypes.cast(th, ctypes.c_void_p), T, bits(known3_labels), bits(known6_labels),
+                                   out.data_ptr(), _l.stream())
+        _l.check(rc, "fnp_recall_counters")
         return out
 
     @staticmethod

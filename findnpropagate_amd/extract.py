@@ -144,35 +144,25 @@ def collate_scenes(scenes):
 
 
 def _records_from_launch(r, index_tags, device):
-    """Pack the fused head's fixed-shape output into (S, K_MAX + 1, 9) records ON THE DEVICE (no host sync):
-    row position of a box = number of valid frustums of its scene before it."""
+    """Pack the fused head's fixed-shape output into (S, K_MAX + 1, 9) records ON THE DEVICE with one launch
+    (fnp_seeker_pack_records; no host sync): a box's row = number of valid frustums of its scene before it."""
+    import ctypes
+
+    from . import lib as _l
+
     S = len(index_tags)
-    rows_total = S * RECORD_ROWS
-    rec = torch.zeros((rows_total + 1, RECORD_WIDTH), dtype=torch.float32, device=device)   # last row: dump slot
-    hdr = torch.zeros((S, RECORD_WIDTH), dtype=torch.float32)
-    hdr[:, 1] = torch.tensor([float(t) for t in index_tags])
+    rec = torch.empty((S, RECORD_ROWS, RECORD_WIDTH), dtype=torch.float32, device=device)
+    tags = (ctypes.c_float * S)(*[float(t) for t in index_tags])
     if r is not None:
         fr = r["frustums"]                                   # host (F, 8)
         per_scene = torch.bincount(fr[:, 0].long(), minlength=S)
         if int(per_scene.max()) > K_MAX:
             raise ValueError(f"{int(per_scene.max())} frustums in one scene exceed the exchange record ({K_MAX}); raise extract.K_MAX")
-        scene = r["d_frustums"][:, 0].long()
-        valid = r["out_valid"].long()
-        start = torch.zeros((S,), dtype=torch.int64)
-        start[1:] = torch.cumsum(per_scene, 0)[:-1]          # frustums are enumerated scene by scene
-        start = start.to(device, non_blocking=True)
-        before = torch.cumsum(valid, 0) - valid              # valid frustums before this one, whole batch
-        pos = before - before[start[scene]]                  # ... within its scene
-        row = torch.where(valid > 0, scene * RECORD_ROWS + 1 + pos, torch.full_like(pos, rows_total))
-        body = torch.cat([r["out_box"], r["d_frustums"][:, 7:8], r["d_frustums"][:, 6:7]], dim=1)
-        rec.index_copy_(0, row, body)
-        counts = torch.zeros((S,), dtype=torch.float32, device=device).index_add_(0, scene, valid.float())
-        hdr_d = hdr.to(device, non_blocking=True)
-        hdr_d[:, 0] = counts
+        args = (_l.ptr(r["d_frustums"]), _l.ptr(r["out_valid"]), _l.ptr(r["out_box"]), int(fr.shape[0]))
     else:
-        hdr_d = hdr.to(device, non_blocking=True)
-    rec = rec[:rows_total].view(S, RECORD_ROWS, RECORD_WIDTH)
-    rec[:, 0, :] = hdr_d
+        args = (None, None, None, 0)
+    rc = _l.load().fnp_seeker_pack_records(*args, ctypes.cast(tags, ctypes.c_void_p), S, RECORD_ROWS, _l.ptr(rec), _l.stream())
+    _l.check(rc, "fnp_seeker_pack_records")
     return rec
 
 
@@ -253,7 +243,7 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
     steps = [mine[i:i + S] for i in range(0, len(mine), S)]
     keys = recall_keys()
     rec_local = {}
-    rec_vec = torch.zeros((len(keys),), dtype=torch.float64, device=device)
+    rec_vec = torch.zeros((len(keys),), dtype=torch.int64, device=device)
     writer = _Writer(out_dir, dataset, resume, enabled=pipeline)
     side = torch.cuda.Stream(device=device) if pipeline else None
     pending = None       # (host records, event) of the previous step
@@ -295,9 +285,8 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
                         for b, g in enumerate(batch["gt_boxes_list"]):
                             if dup[b]:
                                 continue
-                            rec_vec += Detector3DTemplate.recall_counter_vector(
-                                rec[b, 1:, :7], g.to(device), list(RECALL_THRESH),
-                                pred_count=rec[b, 0, 0]).double()
+                            Detector3DTemplate.recall_counter_vector(rec[b, 1:], g.to(device), list(RECALL_THRESH),
+                                                                     pred_count=rec[b, 0, 0:1], out=rec_vec)
                 else:
                     rec = _records_from_launch(None, slot_tags, device)
                 cur = torch.cuda.current_stream(device)
@@ -342,7 +331,7 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
     written = writer.close()
     if recall is not None:
         if not pipeline:
-            rec_vec = torch.tensor([float(rec_local.get(k, 0)) for k in keys], dtype=torch.float64, device=device)
+            rec_vec = torch.tensor([int(rec_local.get(k, 0)) for k in keys], dtype=torch.int64, device=device)
         if dist is not None and dist.is_initialized() and world > 1:
             dist.all_reduce(rec_vec)
         recall.clear()

@@ -52,6 +52,15 @@ def boxes_iou3d_gpu(boxes_a, boxes_b, ans_iou):
     return 1
 
 
+def boxes_aligned_iou3d_gpu(boxes_a, boxes_b, ans_iou):
+    """Extension: fused iou3d_nms_utils.boxes_aligned_iou3d_gpu, ans_iou (N,1)."""
+    _check(boxes_a, boxes_b, ans_iou)
+    assert boxes_a.shape[0] == boxes_b.shape[0] == ans_iou.numel()
+    rc = _l.load().fnp_boxes_aligned_iou3d(_l.ptr(boxes_a), _l.ptr(boxes_b), boxes_a.shape[0], _l.ptr(ans_iou), _l.stream())
+    _l.check(rc, "fnp_boxes_aligned_iou3d")
+    return 1
+
+
 def _nms_device(boxes, thresh, rotated):
     """boxes sorted by score desc (device) -> (keep int64 device (N,), num_keep int32 device (1,))."""
     L = _l.load()

@@ -21,22 +21,12 @@ def boxes_iou3d_gpu(boxes_a, boxes_b):
 
 
 def boxes_aligned_iou3d_gpu(boxes_a, boxes_b):
-    """(N,7),(N,7) -> (N,1), iou3d_nms_utils.py:83-117."""
+    """(N,7),(N,7) -> (N,1) 3D IoU of pair i (iou3d_nms_utils.py:83-117), one fused launch."""
     assert boxes_a.shape[0] == boxes_b.shape[0]
     assert boxes_a.shape[1] == boxes_b.shape[1] == 7
-    boxes_a_height_max = (boxes_a[:, 2] + boxes_a[:, 5] / 2).view(-1, 1)
-    boxes_a_height_min = (boxes_a[:, 2] - boxes_a[:, 5] / 2).view(-1, 1)
-    boxes_b_height_max = (boxes_b[:, 2] + boxes_b[:, 5] / 2).view(-1, 1)
-    boxes_b_height_min = (boxes_b[:, 2] - boxes_b[:, 5] / 2).view(-1, 1)
-    overlaps_bev = torch.zeros((boxes_a.shape[0], 1), dtype=torch.float32, device=boxes_a.device)
-    iou3d_nms_cuda.boxes_aligned_overlap_bev_gpu(boxes_a.contiguous(), boxes_b.contiguous(), overlaps_bev)
-    max_of_min = torch.max(boxes_a_height_min, boxes_b_height_min)
-    min_of_max = torch.min(boxes_a_height_max, boxes_b_height_max)
-    overlaps_h = torch.clamp(min_of_max - max_of_min, min=0)
-    overlaps_3d = overlaps_bev * overlaps_h
-    vol_a = (boxes_a[:, 3] * boxes_a[:, 4] * boxes_a[:, 5]).view(-1, 1)
-    vol_b = (boxes_b[:, 3] * boxes_b[:, 4] * boxes_b[:, 5]).view(-1, 1)
-    return overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-6)
+    ans = torch.zeros((boxes_a.shape[0], 1), dtype=torch.float32, device=boxes_a.device)
+    iou3d_nms_cuda.boxes_aligned_iou3d_gpu(boxes_a.contiguous(), boxes_b.contiguous(), ans)
+    return ans
 
 
 def _nms(boxes, scores, thresh, rotated, pre_maxsize=None):

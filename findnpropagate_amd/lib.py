@@ -10,7 +10,7 @@ and every call is enqueued on ``torch.cuda.current_stream()``.
 import ctypes
 import os
 import re
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FNP_LIB_PATH: development override used by tools/ to A/B kernel builds; never set in production
@@ -89,6 +89,9 @@ SIGNATURES = {
     "fnp_boxes_iou_bev": (c_int, [P, c_int, P, c_int, P, P]),
     "fnp_boxes_aligned_overlap_bev": (c_int, [P, P, c_int, P, P]),
     "fnp_boxes_iou3d": (c_int, [P, c_int, P, c_int, P, P]),
+    "fnp_boxes_aligned_iou3d": (c_int, [P, P, c_int, P, P]),
+    "fnp_recall_counters": (c_int, [P, c_int, c_int, P, P, c_int, c_int, P, c_int, c_int, P, c_int, c_uint, c_uint, P, P]),
+    "fnp_seeker_pack_records": (c_int, [P, P, P, c_int, P, c_int, c_int, P, P]),
     "fnp_host_points_in_boxes_frame": (c_int, [P, c_int, c_int, P, c_int, P, P]),
     "fnp_host_boxes_iou_bev": (c_int, [P, c_int, P, c_int, P]),
     "fnp_host_boxes_aligned_iou_bev": (c_int, [P, P, c_int, P]),

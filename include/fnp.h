@@ -83,6 +83,23 @@ int fnp_boxes_aligned_overlap_bev(const float *boxes_a, const float *boxes_b, in
 int fnp_boxes_iou3d(const float *boxes_a, int num_a, const float *boxes_b, int num_b,
                     float *ans_iou, fnp_stream_t stream);
 
+/* boxes_aligned_iou3d_gpu (iou3d_nms_utils.py:83-117) fused: a (N,7), b (N,7) -> ans (N,) 3D IoU of pair i. */
+int fnp_boxes_aligned_iou3d(const float *boxes_a, const float *boxes_b, int num, float *ans_iou, fnp_stream_t stream);
+
+/* Recall bookkeeping of one frame, Detector3DTemplate.generate_recall_record
+ * (pcdet/models/detectors/detector3d_template.py:314-399, called per frame by tools/extract_pseudo_labels.py:124),
+ * accumulated on the device: counters (5 + 6*num_thresh) int64 DEVICE, layout
+ *   [gt, num_3known, num_6known, num_4unknown, num_7unknown] then per threshold
+ *   [roi, rcnn, rcnn_3known, rcnn_6known, rcnn_4unknown, rcnn_7unknown]   (added to, never zeroed here).
+ * preds: rows of pred_stride floats starting with a (7) box; pred_count: DEVICE float holding the number of live rows
+ * (the header cell of an extraction record) or NULL = max_preds.  gt (num_gt, gt_stride >= 8): box (7) ... class label
+ * (1-based) in the LAST column; trailing all-zero rows are padding (:342-346).  rois: optional (num_rois, rois_stride).
+ * thresh: HOST floats (num_thresh <= 8).  known3_bits / known6_bits: bit l set iff label l is a known class. */
+int fnp_recall_counters(const float *preds, int pred_stride, int max_preds, const float *pred_count,
+                        const float *gt, int num_gt, int gt_stride, const float *rois, int num_rois, int rois_stride,
+                        const float *thresh, int num_thresh, unsigned known3_bits, unsigned known6_bits,
+                        int64_t *counters, fnp_stream_t stream);
+
 /* Host-side dense point-in-box test of the pseudo-label mixing (PseudoSampler.points_in_boxes,
  * pcdet/datasets/augmentor/pseudo_loader.py:270-316): points (N,C>=3), boxes (T,7) -> in_box (T,N) u8 with
  * INCLUSIVE faces, and optionally the points in each box frame (T,N,C) (points_out may be NULL). */
@@ -333,6 +350,14 @@ int fnp_boxseeker(const float *points, const int *scene_offsets, int num_scenes,
                   int *out_valid, float *out_box, float *out_score, int *out_best,
                   int *dbg_npts, float *dbg_frust, float *dbg_cand, float *dbg_iou, int *dbg_count, int *dbg_valid,
                   fnp_stream_t stream);
+
+/* Exchange records of the sharded extraction (BASELINE.json configs[3]; the reference gathers pickled objects or files,
+ * pcdet/utils/commu_utils.py:50-111, common_utils.py:229-250): packs the fnp_boxseeker outputs of a batch of scenes
+ * into records (num_scenes, rows_per_scene, 9) f32 — row 0 = [count, tags[scene], 0 ...], rows 1.. =
+ * [box (7), 2D detection score, label] of the scene's frustums with out_valid != 0, in frustum order; all other rows
+ * zero.  frustums / out_valid / out_box as in fnp_boxseeker (device); tags: HOST floats (num_scenes <= 64). */
+int fnp_seeker_pack_records(const float *frustums, const int *out_valid, const float *out_box, int num_frustums,
+                            const float *tags, int num_scenes, int rows_per_scene, float *records, fnp_stream_t stream);
 
 /* Capacity overflow: data-dependent counts (n_voxels, n_out) always hold the TRUE count; every
  * kernel clamps to the capacity it was given, so a count larger than its capacity means rows

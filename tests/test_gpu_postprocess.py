@@ -65,3 +65,37 @@ def test_class_agnostic_and_multi_class_nms(cuda, oracle, rng, nms_type, score_t
         ws.append(cls[s_k, k]); wl.append(np.full(len(s_k), k, np.int64)); wb.append(boxes9[s_k])
     assert np.array_equal(ps.cpu().numpy(), np.concatenate(ws)) and np.array_equal(pl.cpu().numpy(), np.concatenate(wl))
     assert np.array_equal(pb.cpu().numpy(), np.concatenate(wb))
+
+
+def test_recall_counter_vector_on_record_rows(cuda, oracle, rng):
+    """The extraction pipeline's form: predictions are the strided body rows of a (K_MAX + 1, 9) record, the live-row
+    count is a device float (the record header), counters accumulate on the device; a zero row in the MIDDLE of the
+    ground truth is not padding (only trailing zero rows are, detector3d_template.py:342-346)."""
+    from findnpropagate_amd.detectors import Detector3DTemplate
+    from findnpropagate_amd import extract as E
+    gt = _gt(rng, 37, 5)
+    gt[4] = 0
+    preds = np.concatenate([gt[:20, :7] + rng.normal(scale=0.1, size=(20, 7)).astype(np.float32), syn.random_boxes(rng, 13, 15.0)])
+    pd = dict(pred_boxes=torch.from_numpy(preds), pred_scores=torch.rand(33), pred_labels=torch.ones(33, dtype=torch.int32))
+    rec = E.pack_record(pd, 5, cuda)
+    rec[34:, :7] = torch.from_numpy(gt[30, :7]).to(cuda)      # garbage past the live rows must not count
+    vec = torch.zeros((23,), dtype=torch.int64, device=cuda)
+    for _ in range(3):
+        Detector3DTemplate.recall_counter_vector(rec[1:], torch.from_numpy(gt).to(cuda), THRESH, pred_count=rec[0, 0:1], out=vec)
+    want = {}
+    for _ in range(3):
+        want = oracle.generate_recall_record(preds, want, gt, None, THRESH)
+    assert dict(zip(E.recall_keys(), vec.cpu().tolist())) == want
+    assert want["gt"] == 3 * 37 and want["rcnn_0.5"] > 0
+
+
+def test_boxes_aligned_iou3d(cuda, rng):
+    from findnpropagate_amd.iou3d_nms import iou3d_nms_utils as U
+    a = syn.random_boxes(rng, 200, centre_range=10.0)
+    b = a + rng.normal(scale=0.3, size=a.shape).astype(np.float32)
+    b[100:] = syn.random_boxes(rng, 100, centre_range=10.0)
+    ta, tb = torch.from_numpy(a).to(cuda), torch.from_numpy(b).to(cuda)
+    got = U.boxes_aligned_iou3d_gpu(ta, tb)
+    assert got.shape == (200, 1)
+    assert torch.equal(got[:, 0], torch.diagonal(U.boxes_iou3d_gpu(ta, tb)))     # same device function, same bits
+    assert (got[:100] > 0.2).any() and U.boxes_aligned_iou3d_gpu(ta[:0], tb[:0]).shape == (0, 1)
