@@ -34,7 +34,9 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph (small batches "
                                                           "are launch-bound); per-kernel events are not recorded")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--cpu-scenes", type=int, default=12, help="scenes timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-scenes", type=int, default=8, help="scenes timed through the CPU oracle on ONE thread (0 = skip the CPU baseline)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU leg (0 = min(physical cores, 16): "
+                                                              "a one-GPU box grants 16 cores)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket conv launches with events")
     return ap.parse_args()
 
@@ -48,13 +50,72 @@ def algorithmic_bytes(tag, P, n_out, b):
     return v
 
 
+def host_cpu():
+    """CPU model, physical cores (sockets x cores per socket) and the cores this process may use."""
+    import subprocess
+    model, phys = "unknown", None
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":", 1)[0].strip(): l.split(":", 1)[1].strip() for l in txt.splitlines() if ":" in l}
+        model = kv.get("Model name", model)
+        phys = int(kv["Socket(s)"]) * int(kv["Core(s) per socket"])
+    except Exception:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return model, phys or usable, usable
+
+
+def cpu_baseline(args, net, syn):
+    """oracle/ (the CPU restatement: sequential voxeliser, hash rulebooks, gather-GEMM-scatter f32 — spconv's native CPU
+    algorithm) timed on this host: (i) ONE thread, what a dataloader worker running spconv's CPU voxeliser + a CPU model
+    would use; (ii) all cores granted to this job, one scene per thread (scenes are independent; the conv kernel
+    releases the GIL).  Scenes are synthesised BEFORE the clocks start.  BASELINE.md section 3."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as O
+
+    sd = {k: t.detach().cpu().numpy() for k, t in net.state_dict().items()}
+    O.lib()
+    model, phys, usable = host_cpu()
+    threads = args.cpu_threads if args.cpu_threads > 0 else max(1, min(phys, usable, 16))
+    n_multi = max(args.cpu_scenes, 2 * threads)
+    scenes = [syn.make_scene(s) for s in range(n_multi)]
+
+    def one(p):
+        v, c, n = O.voxelize(p, syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, syn.MAX_POINTS_PER_VOXEL, syn.MAX_VOXELS_TEST)
+        f = O.mean_vfe(v, n)
+        idx = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+        O.backbone_forward(sd, f, idx, 1, net.sparse_shape)
+
+    O.set_threads(1)
+    one(scenes[0])                                         # warm-up (page faults, lazy loads)
+    t0 = time.perf_counter()
+    for p in scenes[:args.cpu_scenes]:
+        one(p)
+    t1 = time.perf_counter() - t0
+    single = args.cpu_scenes / t1
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        list(pool.map(one, scenes[:threads]))              # warm-up of the pool
+        t0 = time.perf_counter()
+        list(pool.map(one, scenes))
+        tm = time.perf_counter() - t0
+    multi = n_multi / tm
+    return {"value": multi, "unit": "scenes/s", "cores": threads, "kind": "port",
+            "sample": f"{n_multi} of the same synthetic scenes, batch 1, f32, voxelize + MeanVFE + VoxelResBackBone8x "
+                      f"through oracle/ (sequential voxeliser, hash rulebook, gather-GEMM-scatter), one scene per thread "
+                      f"on {threads} threads, {tm:.1f} s; single-thread leg: {args.cpu_scenes} scenes in {t1:.1f} s",
+            "single_thread": {"value": single, "cores": 1, "seconds": t1, "scenes": args.cpu_scenes},
+            "host_cores": phys, "host_cores_usable": usable, "cpu_model": model}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 under torch.distributed.run "
+                         f"(--nproc-per-node {args.gpus}); refusing to report a number for a different GPU count")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path for the product)")
     torch.cuda.set_device(local)
@@ -216,21 +277,7 @@ def main():
         }
 
     if rank == 0 and world == 1 and args.cpu_scenes > 0:   # (baseline leg: N = 1 only)
-        from oracle import oracle as O
-
-        sd = {k: t.detach().cpu().numpy() for k, t in net.state_dict().items()}
-        O.lib()
-        tc0 = time.perf_counter()
-        for s in range(args.cpu_scenes):
-            p = syn.make_scene(s)
-            v, c, n = O.voxelize(p, syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, syn.MAX_POINTS_PER_VOXEL, syn.MAX_VOXELS_TEST)
-            f = O.mean_vfe(v, n)
-            idx = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
-            O.backbone_forward(sd, f, idx, 1, net.sparse_shape)
-        tc = time.perf_counter() - tc0
-        out["cpu_baseline"] = {"value": args.cpu_scenes / tc, "unit": "scenes/s", "cores": 1, "kind": "port",
-                               "sample": f"{args.cpu_scenes} of the same synthetic scenes, batch 1, f32, voxelize + "
-                                         f"MeanVFE + VoxelResBackBone8x through oracle/ (gather-GEMM-scatter), {tc:.1f} s"}
+        out["cpu_baseline"] = cpu_baseline(args, net, syn)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

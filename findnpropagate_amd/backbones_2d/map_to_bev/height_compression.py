@@ -4,7 +4,9 @@ encoded tensor (B sites x 128 ch on a (2, 180, 180) grid) becomes the dense BEV 
 Same constructor, attributes (`num_bev_features`) and batch_dict keys.  The densification is one pass of
 `fnp_sparse_to_dense` that writes the whole map once (zeros included) from a cell -> row index map; the
 module keeps the index map and, with `REUSE_OUTPUT: True` in the model cfg (our addition, default off: the
-reference returns a fresh tensor per call), also the output buffer."""
+reference returns a fresh tensor per call), also the output buffer.  `spatial_features` has the dtype of the encoded
+tensor's features — float32 by default (VoxelResBackBone8x FNP_OUT_DTYPE, the reference contract); OUT_DTYPE in this
+module's cfg ('fp32' | 'bf16' | 'fp16') overrides it (the features are cast before the one densifying pass)."""
 import torch.nn as nn
 
 from ... import sparse as S
@@ -16,12 +18,17 @@ class HeightCompression(nn.Module):
         self.model_cfg = model_cfg
         self.num_bev_features = _get(model_cfg, "NUM_BEV_FEATURES")
         self.reuse_output = bool(_get(model_cfg, "REUSE_OUTPUT", False))
+        od = _get(model_cfg, "OUT_DTYPE", "keep")
+        import torch
+        self.out_dtype = {"keep": None, "fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[str(od).lower()]
         self._ws = None
         self._out = None
 
     def forward(self, batch_dict):
         t = batch_dict["encoded_spconv_tensor"]
         feats = t.features.contiguous()
+        if self.out_dtype is not None and feats.dtype != self.out_dtype:
+            feats = feats.to(self.out_dtype)
         need = int(S._l.load().fnp_sparse_to_dense_workspace_bytes(t.batch_size, *t.spatial_shape))
         if self._ws is None or self._ws.numel() < need or self._ws.device != feats.device:
             import torch

@@ -88,8 +88,19 @@ class _BackboneBase(nn.Module):
         self.sparse_shape[0] += 1  # grid_size[::-1] + [1, 0, 0], spconv_backbone.py:191
         # 'bf16' (MFMA, default) or 'fp32' (validation mode, VALU fma chains)
         self.fnp_dtype = str(_cfg_get(model_cfg, 'FNP_DTYPE', 'bf16')).lower()
+        # dtype of what crosses the reference boundary (encoded_spconv_tensor, multi_scale_3d_features): the reference
+        # contract is float32 (its BaseBEVBackbone / heads are f32 modules), so that is the default whatever the
+        # engine computes in; 'native' hands out the engine's own storage dtype (bf16) without a cast
+        self.fnp_out_dtype = str(_cfg_get(model_cfg, 'FNP_OUT_DTYPE', 'fp32')).lower()
+
+    def _boundary_dtype(self):
+        return {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16,
+                'native': None}[self.fnp_out_dtype]
 
     def _pack_outputs(self, batch_dict, out, x1, x2, x3, x4):
+        dt = self._boundary_dtype()
+        if dt is not None:
+            out, x1, x2, x3, x4 = [t if t.features.dtype == dt else t.replace_feature(t.features.to(dt)) for t in (out, x1, x2, x3, x4)]
         batch_dict.update({'encoded_spconv_tensor': out, 'encoded_spconv_tensor_stride': 8})
         batch_dict.update({'multi_scale_3d_features': {'x_conv1': x1, 'x_conv2': x2, 'x_conv3': x3, 'x_conv4': x4}})
         batch_dict.update({'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}})
@@ -216,7 +227,8 @@ class VoxelResBackBone8x(_BackboneBase):
         feats = feats.detach().float().contiguous()
         coords = coords.int().contiguous()
         n = S.device_scalar(feats.shape[0], dev)
-        res = self.engine().run(feats, coords, n, batch_size, grid1=None)
+        # (conv_out's epilogue writes the boundary dtype directly: no cast pass over the encoded tensor)
+        res = self.engine().run(feats, coords, n, batch_size, grid1=None, final_dtype=self._boundary_dtype())
         return self._pack_outputs(batch_dict, res['out'], res['x_conv1'], res['x_conv2'], res['x_conv3'], res['x_conv4'])
 
     # ---------------------------------------------------------------- fused device path
@@ -382,18 +394,21 @@ class FusedResBackbone:
                 'out': tensors[4], 'counts': counts, 'voxel_coords': g.vox['coords'][:n1],
                 'voxel_num_points': g.vox['num_points'][:n1], 'voxel_features': g.vox['mean'][:n1]}
 
-    def run(self, feats, indices, n1, batch_size, grid1=None, sync=True, n_cells=None):
+    def run(self, feats, indices, n1, batch_size, grid1=None, sync=True, n_cells=None, final_dtype=None):
         """feats (cap1,Cin) f32, indices (cap1,4) i32, n1 (1,) i32 device.
-        n_cells: rows [n1, n_cells) of indices list further cells set in grid1 (voxels the voxeliser dropped)."""
+        n_cells: rows [n1, n_cells) of indices list further cells set in grid1 (voxels the voxeliser dropped).
+        final_dtype: dtype conv_out writes (default: the engine's activation dtype)."""
         while True:
-            res = self._run_once(feats, indices, n1, batch_size, grid1, sync, n_cells)
+            res = self._run_once(feats, indices, n1, batch_size, grid1, sync, n_cells, final_dtype)
             if res is not None:
                 return res
             # overflow: capacities were grown and grids cleared; rebuild grid1 from the indices
             grid1 = None
 
-    def _run_once(self, feats, indices, n1, batch_size, grid1, sync, n_cells=None):
+    def _run_once(self, feats, indices, n1, batch_size, grid1, sync, n_cells=None, final_dtype=None):
         m, P, act = self.m, self.prepare(), self.act
+        if final_dtype not in (None, act, torch.float32):
+            final_dtype = None       # (the conv epilogue writes the activation dtype or f32; anything else is cast by the caller)
         dev = feats.device
         grids = self._get_grids(batch_size, dev)
         cap1 = max(indices.shape[0], 1)
@@ -457,7 +472,7 @@ class FusedResBackbone:
         oconv = m.conv_out[0]
         rbo = S.rulebook_strided(idx_prev, n_prev, g_prev, oconv.kernel_size, oconv.stride, oconv.padding, caps[4],
                                  out_grid=grids[4])
-        xo = conv(x_prev, P['out'], rbo, rbo.out_n)
+        xo = conv(x_prev, P['out'], rbo, rbo.out_n, out_dtype=final_dtype or act)
         stage.append((xo, rbo.out_indices, rbo.out_n, rbo.out_grid))
 
         # leave every persistent grid zeroed for the next call (O(rows) sparse clear)

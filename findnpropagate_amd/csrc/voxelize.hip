@@ -387,3 +387,60 @@ extern "C" int fnp_rankgrid_clear(const int *coords, const int *n_rows, int cap,
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
+
+// ---- host entry point ---------------------------------------------------------------------------------------------
+// The dataloader-side voxeliser (spconv.utils.Point2VoxelCPU3d.point_to_voxel as DataProcessor calls it inside
+// DataLoader workers, pcdet/datasets/processor/data_processor.py:38-61,255-302): a plain host loop with the
+// reference's own sequential first-come semantics, no device, no stream — safe in forked worker processes, where a
+// GPU context cannot be (re)created.  A hash map over the linear cell id stands in for spconv's dense
+// coordinate -> voxel table (340 MB for a 41 x 1440 x 1440 grid).  Same coordinate arithmetic as vox_mark_kernel:
+// f32 subtract, f32 divide, floor.  Returns the number of voxels, or a negative error code.
+#include <vector>
+
+extern "C" int fnp_host_voxelize(const float *points, int n, const fnp_voxel_cfg *cfg, float *voxels, int *coords,
+                                 int *num_points, int max_rows) {
+    if (!cfg || n < 0 || max_rows < 0 || cfg->num_features < 3 || cfg->max_points <= 0 || (n > 0 && !points)) return FNP_ERR_ARG;
+    if (n > 0 && max_rows > 0 && (!voxels || !coords || !num_points)) return FNP_ERR_ARG;
+    const int C = cfg->num_features, P = cfg->max_points;
+    const int cap_rows = cfg->max_voxels < max_rows ? cfg->max_voxels : max_rows;
+    size_t tbl = 64;
+    while (tbl < (size_t)(n > 0 ? n : 1) * 2) tbl <<= 1;
+    std::vector<long long> keys(tbl, -1ll);
+    std::vector<int> vals(tbl, 0);
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const float *p = points + (size_t)i * C;
+        int c[3];
+        bool ok = true;
+        for (int j = 0; j < 3; ++j) {
+            const float q = (p[j] - cfg->range_min[j]) / cfg->voxel_size[j];
+            const float f = floorf(q);
+            ok = ok && (f >= 0.f) && (f < (float)cfg->grid[j]);
+            c[j] = (int)f;
+        }
+        if (!ok) continue;
+        const long long key = ((long long)c[2] * cfg->grid[1] + c[1]) * cfg->grid[0] + c[0];
+        size_t h = (size_t)((unsigned long long)key * 0x9E3779B97F4A7C15ull) & (tbl - 1);
+        while (keys[h] != -1ll && keys[h] != key) h = (h + 1) & (tbl - 1);
+        int row;
+        if (keys[h] == key) {
+            row = vals[h];
+        } else {
+            if (m >= cap_rows) continue;             // `continue` of spconv >= 1.2 / 2.x
+            row = m++;
+            keys[h] = key;
+            vals[h] = row;
+            coords[(size_t)row * 3] = c[2];
+            coords[(size_t)row * 3 + 1] = c[1];
+            coords[(size_t)row * 3 + 2] = c[0];
+            num_points[row] = 0;
+            for (int k = 0; k < P * C; ++k) voxels[(size_t)row * P * C + k] = 0.f;
+        }
+        if (num_points[row] < P) {
+            float *dst = voxels + ((size_t)row * P + num_points[row]) * C;
+            for (int k = 0; k < C; ++k) dst[k] = p[k];
+            num_points[row]++;
+        }
+    }
+    return m;
+}

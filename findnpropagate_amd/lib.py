@@ -106,6 +106,7 @@ SIGNATURES = {
     "fnp_voxelize_workspace_bytes": (c_int64, [c_int64, POINTER(VoxelCfg), POINTER(RankGridC)]),
     "fnp_voxelize": (c_int, [P, c_int, P, POINTER(VoxelCfg), POINTER(RankGridC), P, c_int64,
                              P, P, P, P, P, P, c_int, P]),
+    "fnp_host_voxelize": (c_int, [P, c_int, POINTER(VoxelCfg), P, P, P, c_int]),
     "fnp_rulebook_subm": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, P]),
     "fnp_rulebook_strided": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), POINTER(RankGridC),
                                      P, P, c_int, P, P, c_int64, P]),

@@ -5,22 +5,23 @@
 
 `VoxelGeneratorWrapper(vsize_xyz, coors_range_xyz, num_point_features, max_num_points_per_voxel,
 max_num_voxels).generate(points)` returns (voxels (M,P,C) f32, coordinates (M,3) int32 [z,y,x],
-num_points (M,) int32) with the reference's sequential first-come semantics, computed on the
-MI355X.
+num_points (M,) int32) with the reference's sequential first-come semantics.  Like the reference's it is a HOST
+generator (fnp_host_voxelize): DataProcessor creates it lazily inside DataLoader workers, where no GPU context may
+be created after a fork; pass device="cuda" for the device voxeliser (main process / spawn workers only).
 """
 from functools import partial
 
 import numpy as np
 
-from ..spconv.utils import Point2VoxelCPU3d
+from ..spconv.utils import Point2VoxelCPU3d, Point2VoxelGPU3d
 
 
 class VoxelGeneratorWrapper:
-    def __init__(self, vsize_xyz, coors_range_xyz, num_point_features, max_num_points_per_voxel, max_num_voxels):
+    def __init__(self, vsize_xyz, coors_range_xyz, num_point_features, max_num_points_per_voxel, max_num_voxels, device=None):
         self.spconv_ver = 2
-        self._voxel_generator = Point2VoxelCPU3d(
-            vsize_xyz=vsize_xyz, coors_range_xyz=coors_range_xyz, num_point_features=num_point_features,
-            max_num_points_per_voxel=max_num_points_per_voxel, max_num_voxels=max_num_voxels)
+        kw = dict(vsize_xyz=vsize_xyz, coors_range_xyz=coors_range_xyz, num_point_features=num_point_features,
+                  max_num_points_per_voxel=max_num_points_per_voxel, max_num_voxels=max_num_voxels)
+        self._voxel_generator = Point2VoxelCPU3d(**kw) if device is None else Point2VoxelGPU3d(device=device, **kw)
 
     def generate(self, points):
         tv_voxels, tv_coordinates, tv_num_points = self._voxel_generator.point_to_voxel(points)

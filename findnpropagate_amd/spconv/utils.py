@@ -1,7 +1,7 @@
-"""spconv.utils voxel generators (call sites pcdet/datasets/processor/data_processor.py:17-62),
-backed by the GPU voxeliser.  Inputs/outputs are host numpy arrays like the CPU originals, so
-each call is H2D -> kernels -> D2H; the fused model path (backbones_3d.VoxelResBackBone8x
-.forward_points) keeps everything on the device instead.
+"""spconv.utils voxel generators (call sites pcdet/datasets/processor/data_processor.py:17-62).
+Point2VoxelCPU3d / VoxelGenerator run the library's HOST voxeliser (safe in DataLoader workers, like the
+originals); Point2VoxelGPU3d runs the device one.  Inputs/outputs are host numpy arrays in both cases; the fused
+model path (backbones_3d.VoxelResBackBone8x.forward_points) keeps everything on the device instead.
 """
 import numpy as np
 import torch
@@ -31,13 +31,49 @@ def _as_numpy(points):
 
 
 class Point2VoxelCPU3d:
-    """spconv 2.x signature (data_processor.py:38-44)."""
+    """spconv 2.x signature (data_processor.py:38-44).  HOST voxeliser (the library's fnp_host_voxelize): no GPU is
+    touched, so it works inside forked DataLoader workers exactly like spconv's CPU class.  Results equal the GPU
+    voxeliser's (Point2VoxelGPU3d / sparse.voxelize) bit for bit."""
 
     def __init__(self, vsize_xyz, coors_range_xyz, num_point_features, max_num_voxels, max_num_points_per_voxel):
         self.cfg = S.make_voxel_cfg(vsize_xyz, coors_range_xyz, num_point_features, max_num_points_per_voxel,
                                     max_num_voxels)
         self.grid_size = [self.cfg.grid[0], self.cfg.grid[1], self.cfg.grid[2]]
-        self._device = torch.device("cuda", torch.cuda.current_device())
+
+    def __getstate__(self):      # ctypes structs do not pickle (DataLoader workers under spawn)
+        c = self.cfg
+        return dict(vs=list(c.voxel_size), rng=list(c.range_min) + [c.range_min[d] + c.voxel_size[d] * c.grid[d] for d in range(3)],
+                    nf=c.num_features, mp=c.max_points, mv=c.max_voxels)
+
+    def __setstate__(self, st):
+        self.__init__(st["vs"], st["rng"], st["nf"], st["mv"], st["mp"])
+
+    def point_to_voxel(self, points):
+        pts = np.ascontiguousarray(_as_numpy(points), dtype=np.float32)
+        n = pts.shape[0]
+        C, P = self.cfg.num_features, self.cfg.max_points
+        assert pts.ndim == 2 and pts.shape[1] == C
+        rows = max(min(n, self.cfg.max_voxels), 1)
+        voxels = np.empty((rows, P, C), np.float32)
+        coords = np.empty((rows, 3), np.int32)
+        num = np.empty((rows,), np.int32)
+        L = S._l.load()
+        m = L.fnp_host_voxelize(pts.ctypes.data, n, self.cfg, voxels.ctypes.data, coords.ctypes.data, num.ctypes.data, rows)
+        if m < 0:
+            S._l.check(m, "fnp_host_voxelize")
+        return _HostArray(voxels[:m]), _HostArray(coords[:m]), _HostArray(num[:m])
+
+
+class Point2VoxelGPU3d:
+    """The same generator on the device (spconv 2.x has this class too): host arrays in and out, H2D -> kernels -> D2H
+    per call.  Needs a GPU context in the calling process (num_workers = 0 or the spawn start method); the fused model
+    path (backbones_3d.VoxelResBackBone8x.forward_points) keeps everything on the device instead."""
+
+    def __init__(self, vsize_xyz, coors_range_xyz, num_point_features, max_num_voxels, max_num_points_per_voxel, device=None):
+        self.cfg = S.make_voxel_cfg(vsize_xyz, coors_range_xyz, num_point_features, max_num_points_per_voxel,
+                                    max_num_voxels)
+        self.grid_size = [self.cfg.grid[0], self.cfg.grid[1], self.cfg.grid[2]]
+        self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
 
     def point_to_voxel(self, points):
         pts = np.ascontiguousarray(_as_numpy(points), dtype=np.float32)

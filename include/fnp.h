@@ -189,6 +189,14 @@ int fnp_voxelize(const float *points, int n_points, const int *batch_offsets,
                  int *coords, int *num_points, float *mean_feats, float *voxels,
                  int *n_voxels, int *n_cells, int cap, fnp_stream_t stream);
 
+/* HOST voxeliser (no device, no stream; host pointers): spconv.utils.Point2VoxelCPU3d.point_to_voxel as DataProcessor
+ * calls it inside DataLoader worker processes (data_processor.py:38-61,255-302), where a GPU context cannot be created
+ * after a fork.  One scene: points (n, C) -> voxels (max_rows, max_points, C) zero padded, coords (max_rows, 3) [z,y,x],
+ * num_points (max_rows); rows = first-come order, capped at min(cfg->max_voxels, max_rows).  Returns the number of
+ * voxels or a negative error code.  Results equal fnp_voxelize's bit for bit. */
+int fnp_host_voxelize(const float *points, int n_points, const fnp_voxel_cfg *cfg, float *voxels, int *coords,
+                      int *num_points, int max_rows);
+
 /* ------------------------------------------------------------------------------------------
  * Rulebooks — replace spconv's indice-pair generation for SubMConv3d / SparseConv3d
  * (call sites pcdet/models/backbones_3d/spconv_backbone.py:12-17,39-46,193-234).

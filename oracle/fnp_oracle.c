@@ -24,6 +24,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORC_API __attribute__((visibility("default")))
 
@@ -455,6 +458,9 @@ ORC_API int orc_rulebook_strided(const int *coords, int n, const int *shape, con
     return n_out;
 }
 
+static int orc_threads = 1; /* OpenMP threads of orc_spconv_apply (a global, not the per-thread OpenMP ICV: the
+                             * python side may call from a thread pool, one scene per thread) */
+
 /* Gather -> GEMM -> scatter-add, f32, fused multiply-add in (k, pair, cin) order.
  * weight layout = spconv 2.x (Cout, K, Cin) (detector3d_template.py:401-433 describes both
  * layouts; the python side converts 1.x checkpoints).  out must be zero on entry. */
@@ -465,6 +471,10 @@ ORC_API void orc_spconv_apply(const float *feat_in, const float *weight, const i
         if (pair_n[k] == 0) continue;
         for (int ci = 0; ci < Cin; ++ci)
             for (int co = 0; co < Cout; ++co) wk[(size_t)ci * Cout + co] = weight[((size_t)co * K + k) * Cin + ci];
+        /* all-core leg of the CPU baseline: within one kernel offset every output row
+         * occurs in at most one pair, so the pairs of an offset are independent; the per-element fmaf chain
+         * (k, then cin ascending) and therefore the result do not depend on the thread count. */
+#pragma omp parallel for schedule(static) num_threads(orc_threads) if (orc_threads > 1 && pair_n[k] > 2048)
         for (int p = 0; p < pair_n[k]; ++p) {
             const float *x = feat_in + (size_t)pairs_in[(size_t)k * pair_stride + p] * Cin;
             float *y = out + (size_t)pairs_out[(size_t)k * pair_stride + p] * Cout;
@@ -476,6 +486,16 @@ ORC_API void orc_spconv_apply(const float *feat_in, const float *weight, const i
         }
     }
     free(wk);
+}
+
+/* threads used by the OpenMP loops above (default 1: set by oracle.py when the library is loaded) */
+ORC_API void orc_set_threads(int n) { orc_threads = n > 0 ? n : 1; }
+ORC_API int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }
 
 /* BatchNorm1d eval (eps 1e-3, spconv_backbone.py:189) folded the way torch's CPU inference

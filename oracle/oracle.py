@@ -34,7 +34,14 @@ def lib():
         _lib.orc_nms.restype = c_int
         _lib.orc_voxelize.restype = c_int
         _lib.orc_rulebook_strided.restype = c_int
+        _lib.orc_max_threads.restype = c_int
+        _lib.orc_set_threads(1)      # deterministic default; bench.py's all-core leg raises it
     return _lib
+
+
+def set_threads(n):
+    """Threads of the OpenMP loop in orc_spconv_apply (results do not depend on it)."""
+    lib().orc_set_threads(int(n))
 
 
 def _f32(a):

@@ -7,6 +7,7 @@ import pytest
 
 import test_data_processor as _dp
 import test_host_iou as _hi
+import test_host_voxelize as _hv
 import test_pseudo_loader as _pl
 
 pytestmark = pytest.mark.gpu
@@ -21,3 +22,4 @@ def _reexport(mod, prefix):
 _reexport(_hi, "host_iou")
 _reexport(_pl, "pseudo_loader")
 _reexport(_dp, "data_processor")
+_reexport(_hv, "host_voxelize")

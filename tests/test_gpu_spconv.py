@@ -234,7 +234,20 @@ def test_fused_backbone_bf16(cuda, oracle, rng):
     bd = {"voxel_features": torch.from_numpy(feats).to(cuda), "voxel_coords": torch.from_numpy(idx).to(cuda), "batch_size": 2}
     with torch.no_grad():
         out = net(bd)
-    assert out["encoded_spconv_tensor"].features.dtype == torch.bfloat16
+    # what crosses the reference boundary is float32 (the reference's BEV backbone and heads are f32 modules), whatever the
+    # engine stores internally; conv_out's epilogue writes it directly (its last rounding to bf16 is simply skipped)
+    assert out["encoded_spconv_tensor"].features.dtype == torch.float32
+    assert all(t.features.dtype == torch.float32 for t in out["multi_scale_3d_features"].values())
+    net.fnp_out_dtype = "native"
+    with torch.no_grad():
+        nat = net({"voxel_features": bd["voxel_features"], "voxel_coords": bd["voxel_coords"], "batch_size": 2})
+    net.fnp_out_dtype = "fp32"
+    assert nat["encoded_spconv_tensor"].features.dtype == torch.bfloat16
+    assert torch.equal(nat["encoded_spconv_tensor"].features, out["encoded_spconv_tensor"].features.bfloat16())
+    assert torch.equal(nat["multi_scale_3d_features"]["x_conv3"].features.float(), out["multi_scale_3d_features"]["x_conv3"].features)
+    from findnpropagate_amd.backbones_2d import HeightCompression
+    bev = HeightCompression({"NUM_BEV_FEATURES": 256})(dict(out))["spatial_features"]
+    assert bev.dtype == torch.float32 and list(bev.shape) == [2, 256, shape[1] // 8, shape[2] // 8]
     # vs the bf16-emulating oracle: differences are isolated bf16 rounding flips (<= 1 bf16 ulp,
     # 2^-8 relative) that propagate through 21 layers
     for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):

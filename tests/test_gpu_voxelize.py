@@ -91,12 +91,13 @@ def test_voxel_generator_wrapper_dropin(cuda, oracle):
     from findnpropagate_amd.processor import VoxelGeneratorWrapper
 
     p = syn.make_scene(3)
-    g = VoxelGeneratorWrapper(vsize_xyz=syn.VOXEL_SIZE, coors_range_xyz=syn.POINT_CLOUD_RANGE, num_point_features=5,
-                              max_num_points_per_voxel=10, max_num_voxels=120000)
-    voxels, coords, num = g.generate(p)
     v, c, n = oracle.voxelize(p, syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 10, 120000)
-    assert coords.dtype == np.int32 and coords.shape[1] == 3
-    assert np.array_equal(coords, c) and np.array_equal(num, n) and np.array_equal(voxels, v)
+    for device in ("cuda", None):      # the device generator and the host generator (dataloader workers) agree bit for bit
+        g = VoxelGeneratorWrapper(vsize_xyz=syn.VOXEL_SIZE, coors_range_xyz=syn.POINT_CLOUD_RANGE, num_point_features=5,
+                                  max_num_points_per_voxel=10, max_num_voxels=120000, device=device)
+        voxels, coords, num = g.generate(p)
+        assert coords.dtype == np.int32 and coords.shape[1] == 3
+        assert np.array_equal(coords, c) and np.array_equal(num, n) and np.array_equal(voxels, v)
 
 
 def test_rerun_is_deterministic(cuda):
