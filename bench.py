@@ -253,28 +253,39 @@ def main():
         flops = 2.0 * float(np.mean([stats[("tags", tag)][0][0] for _, tag in per[cls]])) * cin * cout
         win = "true" if (per[cls][0][1][4] and K == 27 and (cin, cout) == (64, 64)) else "false"
         mb = 3 if cout >= 128 else 2 if (cin, cout) in ((16, 16), (16, 32), (32, 32), (64, 64)) else 4   # launch_mfma_k
+        mb32 = 4 if cout <= 32 else 2                                                                    # launch_f32
         kname = (f"spconv_mfma_kernel<{cin},{cout},{mb},{K if K == 27 else 0},{win},bf16>"
-                 if args.dtype == "bf16" else "spconv_valu_kernel")
+                 if args.dtype == "bf16" else f"spconv_mfma_f32_kernel<{cin},{cout},{mb32}>")
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
         # WRITE_SIZE in separate runs of this same command, gfx950 FETCH_SIZE x2 correction applied:
-        # profiles/r01_pmc_traffic_b<B>.json); only quoted when a profile of this batch size is committed, else null
+        # profiles/r0N_pmc_traffic_<dtype>_b<B>.json); only quoted when a profile of this batch size is committed, else null
         traffic = None
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{B}.json")))
-            if pj.get("batch") == B and kname in pj["kernels"]:
-                traffic = pj["kernels"][kname]["hbm_bytes_corrected"]
-        except Exception:
-            traffic = None
-        out["roofline"] = {
-            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+        for name in (f"r02_pmc_traffic_{args.dtype}_b{B}.json", f"r01_pmc_traffic_b{B}.json" if args.dtype == "bf16" else ""):
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if pj.get("batch") == B and kname in pj["kernels"]:
+                    traffic = pj["kernels"][kname]["hbm_bytes_corrected"]
+                    break
+            except Exception:
+                continue
+        common = {
             "traffic": traffic,
             "kernel": kname,
             "avg_launch_ms": avg_ms, "launches_timed": len(ms), "algorithmic_bytes_per_launch": avg_bytes,
-            "mfma_tflops_algorithmic": flops / (avg_ms * 1e-3) / 1e12,
+            "algorithmic_flops_per_launch": flops,
             "time_share_of_step": sum(ms) / (1e3 * elapsed),
             "all_conv_classes_ms_per_step": {f"{k[0]}x{k[1]}k{k[2]}": v for k, v in (per_class_ms or {}).items()},
             "all_conv_classes_note": "median of 5 untimed steps with every conv launch bracketed; the timed region brackets the dominant class only",
         }
+        tflops = flops / (avg_ms * 1e-3) / 1e12
+        if args.dtype == "bf16":
+            # the bf16 layers are bound by the gather path (HBM/L2 bytes), far from the 2.5 PFLOP/s matrix peak
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                               "mfma_tflops_algorithmic": tflops, **common}
+        else:
+            # f32 runs on v_mfma_f32_16x16x4_f32 at the f32 vector rate (157.3 TFLOP/s dense): that pipe, not memory, bounds it
+            out["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s", "frac": tflops / 157.3,
+                               "hbm_gbs_algorithmic": achieved, **common}
 
     if rank == 0 and world == 1 and args.cpu_scenes > 0:   # (baseline leg: N = 1 only)
         out["cpu_baseline"] = cpu_baseline(args, net, syn)

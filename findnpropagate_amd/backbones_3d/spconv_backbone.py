@@ -86,12 +86,18 @@ class _BackboneBase(nn.Module):
         self.model_cfg = model_cfg
         self.sparse_shape = [int(v) for v in (list(grid_size[::-1]))]
         self.sparse_shape[0] += 1  # grid_size[::-1] + [1, 0, 0], spconv_backbone.py:191
-        # 'bf16' (MFMA, default) or 'fp32' (validation mode, VALU fma chains)
+        # storage / matrix-instruction dtype of the engine: 'bf16' (default), 'fp16' (the reference's AMP mode) — both
+        # with fp32 accumulation on v_mfma_f32_16x16x32 — or 'fp32' (v_mfma_f32_16x16x4_f32: the reference's default
+        # precision, bit-comparable with the CPU oracle, BASELINE.json's 1e-4 mode)
         self.fnp_dtype = str(_cfg_get(model_cfg, 'FNP_DTYPE', 'bf16')).lower()
+        assert self.fnp_dtype in ('bf16', 'fp16', 'fp32'), self.fnp_dtype
         # dtype of what crosses the reference boundary (encoded_spconv_tensor, multi_scale_3d_features): the reference
         # contract is float32 (its BaseBEVBackbone / heads are f32 modules), so that is the default whatever the
-        # engine computes in; 'native' hands out the engine's own storage dtype (bf16) without a cast
+        # engine computes in; 'native' hands out the engine's own storage dtype (bf16 / fp16) without a cast
         self.fnp_out_dtype = str(_cfg_get(model_cfg, 'FNP_OUT_DTYPE', 'fp32')).lower()
+
+    def _act_dtype(self):
+        return {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[self.fnp_dtype]
 
     def _boundary_dtype(self):
         return {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16,
@@ -144,7 +150,7 @@ class VoxelBackBone8x(_BackboneBase):
 def _module_forward(self, batch_dict):
     voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
     batch_size = batch_dict['batch_size']
-    act = torch.float32 if self.fnp_dtype == 'fp32' else torch.bfloat16
+    act = self._act_dtype()
     x_in = spconv.SparseConvTensor(features=voxel_features.float().contiguous(), indices=voxel_coords.int().contiguous(),
                                    spatial_shape=self.sparse_shape, batch_size=batch_size)
     # first conv consumes f32 point features; activations then live in `act`
@@ -284,7 +290,7 @@ class FusedResBackbone:
 
     def __init__(self, module: VoxelResBackBone8x):
         self.m = module
-        self.act = torch.float32 if module.fnp_dtype == 'fp32' else torch.bfloat16
+        self.act = module._act_dtype()
         self._prep = None
         self._prep_key = None
         self._grids = {}
@@ -459,7 +465,7 @@ class FusedResBackbone:
             # the down-sampling layers resolve their neighbours inside the convolution (their rulebook has no other
             # user): no (27, cap) table; the table path stays for f32 and when the rulebooks are being logged
             wd = P[down_key][0]
-            fused = (act == torch.bfloat16 and self.rulebook_log is None and tuple(dconv.kernel_size) == (3, 3, 3)
+            fused = (act in (torch.bfloat16, torch.float16) and self.rulebook_log is None and tuple(dconv.kernel_size) == (3, 3, 3)
                      and (int(wd.shape[2]), int(wd.shape[1])) in S.FUSED_STRIDED_SHAPES)
             rbs = S.rulebook_strided(idx_prev, n_prev, g_prev, dconv.kernel_size, dconv.stride, dconv.padding,
                                      caps[li + 1], out_grid=grids[li + 1], want_nbr=not fused)

@@ -23,16 +23,30 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// 16-bit activation types of the MFMA path: bf16 (default) and fp16 (the reference's AMP mode, train_utils.py:172:
+// autocast makes spconv run fp16 features with fp32 accumulation).  Same kernel, same fragment layouts
+// (v_mfma_f32_16x16x32_bf16 / _f16 take the same cycles); only the matrix instruction and the conversions differ.
+template <typename T> struct Vec16 {
+    typedef T v8 __attribute__((ext_vector_type(8)));
+    typedef T v4 __attribute__((ext_vector_type(4)));
+};
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t mfma16(Vec16<__bf16>::v8 a, Vec16<__bf16>::v8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mfma16(Vec16<_Float16>::v8 a, Vec16<_Float16>::v8 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+__device__ __forceinline__ float to_f32(_Float16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+template <> __device__ __forceinline__ _Float16 from_f32<_Float16>(float v) { return (_Float16)v; }
 
 // ------------------------------------------------------------------------------------------
 // VALU path (any Cin/Cout, any dtype mix): thread per (row, cout).
@@ -275,15 +289,18 @@ struct FusedRb {
     const int *out_coords;    // (cap, 4) [b, z, y, x] of the output rows
 };
 
-template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut, bool FUSED = false>
-__global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const __bf16 *__restrict__ x, int x_bytes,
-                                                             const __bf16 *__restrict__ w,
+template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut, bool FUSED = false, typename TAct = __bf16>
+__global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const TAct *__restrict__ x, int x_bytes,
+                                                             const TAct *__restrict__ w,
                                                              const int *__restrict__ nbr, int nbr_stride, int Krt,
                                                              const int *__restrict__ n_out, int cap,
                                                              TOut *__restrict__ y, const float *__restrict__ scale,
                                                              const float *__restrict__ shift,
                                                              const TOut *__restrict__ residual, int relu, int hints, FusedRb frb) {
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
+    using bf16x8 = typename Vec16<TAct>::v8;   // (named after the default activation type)
+    using bf16x4 = typename Vec16<TAct>::v4;
+    static_assert(sizeof(TOut) == 4 || std::is_same<TOut, TAct>::value, "16-bit outputs have the activation type");
     static_assert(!FUSED || (KVOL == 27 && !WIN), "fused rulebook: 3x3x3 strided layers");
     constexpr int CH = Cfg::CH, SLAB = Cfg::SLAB, SW = Cfg::SW, KS = Cfg::KS, PFK = Cfg::PFK;
     constexpr bool ALLK = Cfg::ALLK;
@@ -640,7 +657,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                                 if ((FNP_ABLATE & 4)) {
                                     asm volatile("" ::"v"(wa[j]), "v"(xv));
                                 } else {
-                                    acc[h + j][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], xv, acc[h + j][mb], 0, 0, 0);
+                                    acc[h + j][mb] = mfma16(wa[j], xv, acc[h + j][mb]);
                                 }
                             }
                         }
@@ -741,7 +758,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.f ? 0.f : v[j];
                             }
-                            *slot = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                            *slot = bf16x4{(TAct)v[0], (TAct)v[1], (TAct)v[2], (TAct)v[3]};
                         }
                     }
 #pragma unroll
@@ -796,7 +813,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.f ? 0.f : v[j];
                         }
-                        const bf16x4 ob = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        const bf16x4 ob = {(TAct)v[0], (TAct)v[1], (TAct)v[2], (TAct)v[3]};
                         o[h] = *reinterpret_cast<const uint2 *>(&ob);
                     }
                     auto t0 = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
@@ -836,7 +853,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                 TOut *yp = y + (size_t)r * COUT + c0;
                 if (FNP_ABLATE & 128) { if (v[0] == 12345.678f) yp[0] = from_f32<TOut>(v[1] + v[2] + v[3]); continue; }   // (probe: no stores)
                 if constexpr (sizeof(TOut) == 2) {
-                    bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    bf16x4 o = {(TAct)v[0], (TAct)v[1], (TAct)v[2], (TAct)v[3]};
                     *reinterpret_cast<bf16x4 *>(yp) = o;
                 } else {
                     *reinterpret_cast<float4 *>(yp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -857,7 +874,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     if constexpr (MB > 3) { if (tper == 3) run_tile(std::integral_constant<int, 3>{}, tail_base); }
 }
 
-template <int CIN, int COUT, int KVOL, bool WIN, typename TOut, bool FUSED = false>
+template <int CIN, int COUT, int KVOL, bool WIN, typename TOut, bool FUSED = false, typename TAct = __bf16>
 int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
                   void *y, const float *scale, const float *shift, const void *residual, int relu, int hints, hipStream_t s,
                   const FusedRb *frb_in = nullptr) {
@@ -876,7 +893,7 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
 #endif
     constexpr int MB = COUT >= 128 ? FNP_MB128 : (CIN == 16 && COUT <= 32) ? 2 : (CIN == 32 && COUT == 32) ? FNP_MB3232 : (CIN == 64 && COUT == 64) ? FNP_MB6464 : 4;
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
-    auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut, FUSED>;
+    auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut, FUSED, TAct>;
     constexpr int lds = Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN) + Cfg::epi_bytes(MfmaWg<CIN, COUT>::NW, WIN, sizeof(TOut) == 2) +
                         (FUSED ? MfmaWg<CIN, COUT>::NW * 27 * MB * 16 * 4 : 0);
     FusedRb frb{};
@@ -902,7 +919,7 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
     // The kernel splits the rows evenly over whatever grid it gets.
     const int resident = 256 * wg_per_cu;
     const int grid = tiles < resident ? tiles : resident;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MfmaWg<CIN, COUT>::NW * 64), lds, s, (const __bf16 *)x, x_bytes, (const __bf16 *)w,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MfmaWg<CIN, COUT>::NW * 64), lds, s, (const TAct *)x, x_bytes, (const TAct *)w,
                        nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu, hints, frb);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
@@ -921,20 +938,20 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
 #endif
 template <int CIN, int COUT> struct HasWindow { static constexpr bool value = (FNP_WIN64 && CIN == 64 && COUT == 64) || (FNP_WIN32 && CIN == 32 && COUT == 32); };
 
-template <int CIN, int COUT, typename TOut>
+template <int CIN, int COUT, typename TOut, typename TAct>
 int launch_mfma(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out,
                 int cap, void *y, const float *scale, const float *shift, const void *residual, int relu, int hints,
                 hipStream_t s) {
     if (K == 27) {
         if constexpr (HasWindow<CIN, COUT>::value) {
             if (hints & FNP_HINT_ROWS_RANKED)
-                return launch_mfma_k<CIN, COUT, 27, true, TOut>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale,
+                return launch_mfma_k<CIN, COUT, 27, true, TOut, false, TAct>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale,
                                                                 shift, residual, relu, hints, s);
         }
-        return launch_mfma_k<CIN, COUT, 27, false, TOut>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift,
+        return launch_mfma_k<CIN, COUT, 27, false, TOut, false, TAct>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift,
                                                          residual, relu, hints, s);
     }
-    return launch_mfma_k<CIN, COUT, 0, false, TOut>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual,
+    return launch_mfma_k<CIN, COUT, 0, false, TOut, false, TAct>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual,
                                                     relu, hints, s);
 }
 
@@ -950,15 +967,15 @@ int launch_valu(const void *x, const void *w, const int *nbr, int nbr_stride, in
     return FNP_OK;
 }
 
-template <typename TOut>
-int dispatch_bf16(const void *x, long long n_in, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
+template <typename TAct, typename TOut>
+int dispatch_16(const void *x, long long n_in, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
                   void *y, const float *scale, const float *shift, const void *residual, int relu, int hints, int Cin,
                   int Cout, hipStream_t s) {
     const long long xb = n_in * Cin * 2;
     const bool fits = xb > 0 && xb < 0x7fffffffll;   // 32-bit buffer offsets of the MFMA path
 #define FNP_CASE(CI, CO)                                                                                       \
     if (fits && Cin == CI && Cout == CO)                                                                       \
-        return launch_mfma<CI, CO, TOut>(x, (int)xb, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual,\
+        return launch_mfma<CI, CO, TOut, TAct>(x, (int)xb, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual,\
                                          relu, hints, s);
     FNP_CASE(16, 16)
     FNP_CASE(16, 32)
@@ -972,10 +989,14 @@ int dispatch_bf16(const void *x, long long n_in, const void *w, const int *nbr, 
     FNP_CASE(64, 32)
     FNP_CASE(128, 64)
 #undef FNP_CASE
-    return launch_valu<__bf16, TOut>(x, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual, relu, Cin, Cout, s);
+    return launch_valu<TAct, TOut>(x, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual, relu, Cin, Cout, s);
 }
 
 }  // namespace
+
+int fnp_spconv_forward_f32_mfma(const void *feat_in, long long n_in_rows, const void *weight, const int *nbr, int nbr_stride,
+                                int K, const int *n_out, int cap_out, void *feat_out, const float *scale, const float *shift,
+                                const void *residual, int relu, int Cin, int Cout, hipStream_t s);   // spconv_f32.hip
 
 extern "C" int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const void *weight, const int *nbr,
                                   int nbr_stride, int K, const int *n_out, int cap_out, void *feat_out, int out_dtype,
@@ -993,24 +1014,46 @@ extern "C" int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_ro
         if (out_dtype == FNP_BF16)
             return launch_first<__bf16>(feat_in, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
                                         residual, relu, Cin, s);
+        if (out_dtype == FNP_F16)
+            return launch_first<_Float16>(feat_in, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
+                                          residual, relu, Cin, s);
         return FNP_ERR_ARG;
     }
     if (in_dtype == FNP_F32) {
+        if (out_dtype == FNP_F32 && !(hints & FNP_HINT_VALU)) {
+            // f32 on the matrix pipe (v_mfma_f32_16x16x4_f32: the same fmaf chain, bit for bit); shapes it does not
+            // cover fall through to the thread-per-element chain
+            const int rc = fnp_spconv_forward_f32_mfma(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out,
+                                                       scale, shift, residual, relu, Cin, Cout, s);
+            if (rc != FNP_ERR_ARG) return rc;
+        }
         if (out_dtype == FNP_F32)
             return launch_valu<float, float>(feat_in, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
                                              residual, relu, Cin, Cout, s);
         if (out_dtype == FNP_BF16)
             return launch_valu<float, __bf16>(feat_in, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale,
                                               shift, residual, relu, Cin, Cout, s);
+        if (out_dtype == FNP_F16)
+            return launch_valu<float, _Float16>(feat_in, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale,
+                                                shift, residual, relu, Cin, Cout, s);
         return FNP_ERR_ARG;
     }
     if (in_dtype == FNP_BF16) {
         if (out_dtype == FNP_BF16)
-            return dispatch_bf16<__bf16>(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
-                                         residual, relu, hints, Cin, Cout, s);
+            return dispatch_16<__bf16, __bf16>(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
+                                               residual, relu, hints, Cin, Cout, s);
         if (out_dtype == FNP_F32)
-            return dispatch_bf16<float>(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
-                                        residual, relu, hints, Cin, Cout, s);
+            return dispatch_16<__bf16, float>(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
+                                              residual, relu, hints, Cin, Cout, s);
+        return FNP_ERR_ARG;
+    }
+    if (in_dtype == FNP_F16) {   // fp16 features / weights, fp32 accumulate: the reference's AMP mode
+        if (out_dtype == FNP_F16)
+            return dispatch_16<_Float16, _Float16>(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale,
+                                                   shift, residual, relu, hints, Cin, Cout, s);
+        if (out_dtype == FNP_F32)
+            return dispatch_16<_Float16, float>(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
+                                                residual, relu, hints, Cin, Cout, s);
         return FNP_ERR_ARG;
     }
     return FNP_ERR_ARG;
@@ -1028,7 +1071,7 @@ extern "C" int fnp_spconv_forward_strided(const void *feat_in, int in_dtype, int
         !fnp_rg_valid(in_grid))
         return FNP_ERR_ARG;
     if ((scale == nullptr) != (shift == nullptr)) return FNP_ERR_ARG;
-    if (in_dtype != FNP_BF16 || out_dtype != FNP_BF16) return FNP_ERR_ARG;
+    if ((in_dtype != FNP_BF16 && in_dtype != FNP_F16) || out_dtype != in_dtype) return FNP_ERR_ARG;
     for (int d = 0; d < 3; ++d)
         if (geom->ksize[d] != 3 || geom->stride[d] <= 0 || geom->padding[d] < 0) return FNP_ERR_ARG;
     if (in_grid->D != geom->in_shape[0] || in_grid->H != geom->in_shape[1] || in_grid->W != geom->in_shape[2]) return FNP_ERR_ARG;
@@ -1042,9 +1085,13 @@ extern "C" int fnp_spconv_forward_strided(const void *feat_in, int in_dtype, int
     }
     frb.out_coords = out_coords;
 #define FNP_FCASE(CI, CO)                                                                                                   \
-    if (Cin == CI && Cout == CO)                                                                                            \
+    if (Cin == CI && Cout == CO) {                                                                                          \
+        if (in_dtype == FNP_F16)                                                                                            \
+            return launch_mfma_k<CI, CO, 27, false, _Float16, true, _Float16>(feat_in, (int)xb, weight, nullptr, cap_out, 27, n_out, \
+                                                                              cap_out, feat_out, scale, shift, nullptr, relu, 0, s, &frb); \
         return launch_mfma_k<CI, CO, 27, false, __bf16, true>(feat_in, (int)xb, weight, nullptr, cap_out, 27, n_out, cap_out, feat_out, \
-                                                              scale, shift, nullptr, relu, 0, s, &frb);
+                                                              scale, shift, nullptr, relu, 0, s, &frb);                     \
+    }
     FNP_FCASE(16, 32)
     FNP_FCASE(32, 64)
     FNP_FCASE(64, 128)

@@ -11,6 +11,7 @@
 //             block in registers from LDS-staged row tiles (f32), writes a partial, and a second kernel
 //             adds the partials in chunk order -> bit-reproducible gradients.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(kThreads) void transpose_rulebook_kernel(const int 
 
 __device__ __forceinline__ float ld_f32(const float *p) { return *p; }
 __device__ __forceinline__ float ld_f32(const __bf16 *p) { return (float)*p; }
+__device__ __forceinline__ float ld_f32(const _Float16 *p) { return (float)*p; }
 
 // grid (chunks, K).  TR rows per tile; LDS: dy tile (TR x Cout) + x tile (TR x Cin), f32.
 // Thread t owns the pairs p = t + 256 j (co = p / Cin, ci = p % Cin), at most PMAX of them.
@@ -106,11 +108,19 @@ __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float *__r
 // LDS writes, 16-way bank-conflicted: 1.03 ms for the 128 x 128 layer against 0.12 ms for its forward.)
 // Workgroup = 4 waves = WB waves across the COUT/16 row blocks of dW x WK = 4/WB row slices of the tile
 // (k-split); tiles are double-buffered, one barrier per tile; the WK partial sums meet in LDS at the end.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <typename T> struct Frag8 { typedef T type __attribute__((ext_vector_type(8))); };
+__device__ __forceinline__ f32x4_t wg_mfma(Frag8<__bf16>::type a, Frag8<__bf16>::type b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t wg_mfma(Frag8<_Float16>::type a, Frag8<_Float16>::type b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy,
+// T16: __bf16 or _Float16 (the reference's AMP mode): the images are moved as raw 16-bit elements, only the matrix
+// instruction differs
+template <int CIN, int COUT, typename T16>
+__global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const T16 *__restrict__ x, const T16 *__restrict__ dy,
                                                               const int *__restrict__ nbr, int nbr_stride,
                                                               const int *__restrict__ n_out, int cap_out, int /*unused*/,
                                                               float *__restrict__ partial) {
@@ -122,7 +132,8 @@ __global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const __bf16 *__re
     constexpr int GT = WB * 64;                     // threads of one k-split group
     constexpr int XCH = CIN / 8, YCH = COUT / 8;    // 16-byte chunks per row
     constexpr int SY = COUT * 2 + 16, SX = CIN * 2 + 16;   // bytes per staged row (dy / x)
-    constexpr int SLICE = (SY + SX) * TR / 2;       // bf16 elements of one slice image: dy rows then x rows
+    constexpr int SLICE = (SY + SX) * TR / 2;       // 16-bit elements of one slice image: dy rows then x rows
+    using bf16x8_t = typename Frag8<T16>::type;
     static_assert(NBO % WB == 0 && CIN % 16 == 0 && COUT % 16 == 0, "channel counts");
     extern __shared__ __attribute__((aligned(16))) unsigned char fnp_wg_smem[];
     __bf16 *lds = reinterpret_cast<__bf16 *>(fnp_wg_smem);     // [2 buffers][WK slices][SLICE]
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const __bf16 *__re
         for (int a = 0; a < OB; ++a) {
             const bf16x8_t afr = tr_frag(img, SY, (wb * OB + a) * 16);
 #pragma unroll
-            for (int b = 0; b < NBI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < NBI; ++b) acc[a][b] = wg_mfma(afr, bfr[b], acc[a][b]);
         }
         if (t + 1 < tiles) stage((t + 1) & 1);
         __syncthreads();
@@ -255,10 +266,10 @@ constexpr size_t wgrad_mfma_lds() {
     return tiles > red ? tiles : red;
 }
 
-template <int CIN, int COUT>
-void launch_wgrad_mfma(dim3 grid, hipStream_t s, const __bf16 *x, const __bf16 *dy, const int *nbr, int nbr_stride,
+template <int CIN, int COUT, typename T16>
+void launch_wgrad_mfma(dim3 grid, hipStream_t s, const T16 *x, const T16 *dy, const int *nbr, int nbr_stride,
                        const int *n_out, int cap_out, int rows_per_chunk, float *partial) {
-    auto kern = wgrad_mfma_kernel<CIN, COUT>;
+    auto kern = wgrad_mfma_kernel<CIN, COUT, T16>;
     const size_t lds = wgrad_mfma_lds<CIN, COUT>();
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, x, dy, nbr, nbr_stride, n_out, cap_out, rows_per_chunk, partial);
 }
@@ -280,10 +291,10 @@ int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int
     const size_t lds = (size_t)16 * (Cin + Cout) * 4;
     const dim3 grid(chunks, K);
     float *partial = (float *)ws;
-    if constexpr (sizeof(TX) == 2 && sizeof(TY) == 2) {
+    if constexpr (sizeof(TX) == 2 && std::is_same<TX, TY>::value) {
         bool done = true;
 #define FNP_WM(CI, CO)                                                                                         \
-    else if (Cin == CI && Cout == CO) launch_wgrad_mfma<CI, CO>(grid, s, (const __bf16 *)x, (const __bf16 *)dy, nbr,     \
+    else if (Cin == CI && Cout == CO) launch_wgrad_mfma<CI, CO, TX>(grid, s, (const TX *)x, (const TX *)dy, nbr,         \
                                                                 nbr_stride, n_out, cap_out, rows_per_chunk, partial)
         if (false) {}
         FNP_WM(16, 16);
@@ -348,6 +359,9 @@ extern "C" int fnp_spconv_wgrad(const void *feat_in, int in_dtype, const void *g
     if (in_dtype == FNP_BF16 && grad_dtype == FNP_BF16)
         return run_wgrad<__bf16, __bf16>(feat_in, grad_out, nbr, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
                                          workspace_bytes, s);
+    if (in_dtype == FNP_F16 && grad_dtype == FNP_F16)
+        return run_wgrad<_Float16, _Float16>(feat_in, grad_out, nbr, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout,
+                                             workspace, workspace_bytes, s);
     if (in_dtype == FNP_F32 && grad_dtype == FNP_BF16)
         return run_wgrad<float, __bf16>(feat_in, grad_out, nbr, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
                                         workspace_bytes, s);

@@ -223,12 +223,14 @@ def pack_weight(weight, dtype):
 
 
 HINT_ROWS_RANKED = 1   # fnp.h FNP_HINT_ROWS_RANKED
+HINT_VALU = 2          # fnp.h FNP_HINT_VALU
 
 
 def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, shift=None, residual=None, relu=False,
-                 out=None, ranked=False):
+                 out=None, ranked=False, valu=False):
     """feat_out (cap_out, Cout) = act(conv * scale + shift + residual).  No host sync.
-    ranked: input and output rows are both in rank-grid order (performance hint only)."""
+    ranked: input and output rows are both in rank-grid order (performance hint only).
+    valu: f32 only — the thread-per-element chain instead of the f32 MFMA kernel (same bits)."""
     L = _l.load()
     _l.require_device(feat_in, w_packed, rb.nbr, n_out_dev)
     K, Cout, Cin = w_packed.shape
@@ -245,22 +247,23 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
     rc = L.fnp_spconv_forward(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
                               _l.ptr(rb.nbr), rb.nbr.shape[1], K, _l.ptr(n_out_dev), cap_out,
                               _l.ptr(out), _l.dtype_code(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual),
-                              int(bool(relu)), HINT_ROWS_RANKED if ranked else 0, Cin, Cout, _l.stream())
+                              int(bool(relu)), (HINT_ROWS_RANKED if ranked else 0) | (HINT_VALU if valu else 0), Cin, Cout,
+                              _l.stream())
     _l.check(rc, "fnp_spconv_forward")
     return out
 
 
 def conv_forward_strided(feat_in, w_packed, rb, scale=None, shift=None, relu=False, out=None):
     """A strided 3x3x3 convolution whose rulebook rows are computed inside the kernel (rb from
-    rulebook_strided(..., want_nbr=False)).  bf16, (Cin, Cout) in {(16,32), (32,64), (64,128)}.  Same result as
+    rulebook_strided(..., want_nbr=False)).  bf16 or fp16, (Cin, Cout) in {(16,32), (32,64), (64,128)}.  Same result as
     conv_forward on the table.  No host sync."""
     L = _l.load()
     _l.require_device(feat_in, w_packed, rb.out_indices, rb.out_n)
     K, Cout, Cin = w_packed.shape
     assert rb.nbr is None and rb.in_grid is not None and K == 27 and feat_in.shape[1] == Cin
-    assert feat_in.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and feat_in.is_contiguous()
+    assert feat_in.dtype in (torch.bfloat16, torch.float16) and w_packed.dtype == feat_in.dtype and feat_in.is_contiguous()
     if out is None:
-        out = torch.empty((rb.cap_out, Cout), dtype=torch.bfloat16, device=feat_in.device)
+        out = torch.empty((rb.cap_out, Cout), dtype=feat_in.dtype, device=feat_in.device)
     rc = L.fnp_spconv_forward_strided(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
                                       rb.in_grid.c(), rb.geom, _l.ptr(rb.out_indices), _l.ptr(rb.out_n), rb.cap_out,
                                       _l.ptr(out), _l.dtype_code(out), _l.ptr(scale), _l.ptr(shift), int(bool(relu)),

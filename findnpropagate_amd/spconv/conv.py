@@ -23,8 +23,8 @@ def _triple(v):
 class SparseConvFunction(torch.autograd.Function):
     """out (cap_out, Cout) = sum_k W_k^T x[nbr[k]]  with autograd (features and weight).
 
-    weight is the module parameter (Cout, kD, kH, kW, Cin); computation dtype = features dtype (f32 or
-    bf16), weight gradient accumulated in f32 and returned in the parameter's dtype."""
+    weight is the module parameter (Cout, kD, kH, kW, Cin); computation dtype = features dtype (f32, bf16 or
+    fp16), weight gradient accumulated in f32 and returned in the parameter's dtype."""
 
     @staticmethod
     def forward(ctx, feats, weight, rb, n_out_dev, n_in_dev):
@@ -99,7 +99,11 @@ class SparseConvolution(SparseModule):
         assert isinstance(input, SparseConvTensor)
         with_grad = torch.is_grad_enabled() and (self.weight.requires_grad or input.features.requires_grad)
         feats = input.features if with_grad else input.features.detach()
-        if feats.dtype not in (torch.float32, torch.bfloat16):
+        if torch.is_autocast_enabled():
+            # the reference trains under torch.cuda.amp (tools/train_utils/train_utils.py:172): spconv then runs its
+            # features and weights in the autocast dtype (fp16) with fp32 accumulation — same here
+            feats = feats.to(torch.get_autocast_gpu_dtype())
+        if feats.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             feats = feats.to(torch.bfloat16)
         feats = feats.contiguous()
         w = None if with_grad else self.packed_weight(feats.dtype)

@@ -230,14 +230,18 @@ int fnp_rulebook_strided(const int *in_coords, const int *n_in, int cap_in, cons
  *   feat_in  (n_in_rows, Cin) in_dtype  weight (K, Cout, Cin) packed, w_dtype = in_dtype
  *   feat_out (n_out, Cout) out_dtype    residual (n_out, Cout) out_dtype or NULL
  *   scale/shift (Cout,) f32 or NULL (identity).  out = act(acc*scale + shift + residual)
- * bf16 x bf16 -> fp32 accumulate runs on MFMA (v_mfma_f32_16x16x32_bf16); f32 runs on VALU
- * fma chains (validation mode).
+ * bf16 x bf16 -> fp32 accumulate runs on MFMA (v_mfma_f32_16x16x32_bf16); f32 x f32 runs on the f32 MFMA
+ * (v_mfma_f32_16x16x4_f32: bit for bit the offset-ascending, channel-ascending fmaf chain of the CPU oracle) for the
+ * backbone's channel pairs, on VALU fma chains of the same order otherwise.
  * hints: performance only, never changes results.  FNP_HINT_ROWS_RANKED states that neighbour row
  * ids lie close to the output row ids (input and output rows both in rank-grid order, i.e. a
  * SubM convolution on the output of fnp_rulebook_strided): the kernel then keeps a window of
  * input rows in LDS instead of gathering every (site, offset) pair from L2.
  * ------------------------------------------------------------------------------------------ */
 #define FNP_HINT_ROWS_RANKED 1
+/* f32 only: take the thread-per-element fmaf chain (validation path) instead of the f32 MFMA kernel; the two are
+ * bit-identical, this only selects which one computes */
+#define FNP_HINT_VALU 2
 int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const void *weight,
                        const int *nbr, int nbr_stride, int K,
                        const int *n_out, int cap_out,

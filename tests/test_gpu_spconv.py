@@ -76,10 +76,14 @@ def test_strided_rulebook_bit_exact(cuda, oracle, rng, k, s, p):
     assert mine == want
 
 
-@pytest.mark.parametrize("Cin,Cout", [(5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (24, 40)])
-def test_conv_f32_bit_exact_vs_oracle(cuda, oracle, rng, Cin, Cout):
-    """f32 validation path: k-ascending, cin-ascending fmaf chain == oracle's chain."""
-    B, shape, n = 2, [9, 30, 31], 1500
+@pytest.mark.parametrize("n", [1, 63, 1500])
+@pytest.mark.parametrize("Cin,Cout", [(5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (24, 40),
+                                      (32, 16), (64, 32), (128, 64)])
+def test_conv_f32_bit_exact_vs_oracle(cuda, oracle, rng, Cin, Cout, n):
+    """f32 path == the oracle's k-ascending, cin-ascending fmaf chain, bit for bit: on the f32 MFMA kernel
+    (v_mfma_f32_16x16x4_f32: the backbone's channel pairs and their transposes for the data gradients), on the first-layer
+    kernel (5 -> 16) and on the thread-per-element chain (other shapes, and every shape with valu=True)."""
+    B, shape = 2, [9, 30, 31]
     feats, idx = _random_sparse(rng, B, shape, n, Cin)
     w = (rng.standard_normal((Cout, 3, 3, 3, Cin)) * 0.1).astype(np.float32)
     scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
@@ -96,28 +100,36 @@ def test_conv_f32_bit_exact_vs_oracle(cuda, oracle, rng, Cin, Cout):
     assert np.array_equal(got.cpu().numpy(), want)
     raw = S.conv_forward(torch.from_numpy(feats).to(cuda), wp, rb, n_dev)
     assert np.array_equal(raw.cpu().numpy(), y.features)
+    valu = S.conv_forward(torch.from_numpy(feats).to(cuda), wp, rb, n_dev, scale=torch.from_numpy(scale).to(cuda),
+                          shift=torch.from_numpy(shift).to(cuda), residual=torch.from_numpy(res).to(cuda), relu=True, valu=True)
+    assert torch.equal(valu, got), "matrix-pipe and thread-per-element chains are the same bits"
 
 
+def _round16(a, td):
+    a[...] = torch.from_numpy(a).to(td).float().numpy()
+
+
+@pytest.mark.parametrize("td,out_tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)])
 @pytest.mark.parametrize("Cin,Cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128)])
 @pytest.mark.parametrize("n", [1, 63, 1500])
-def test_conv_bf16_mfma_vs_oracle(cuda, oracle, rng, Cin, Cout, n):
-    """bf16 x bf16 products are exact in f32; only the f32 summation order differs from the oracle
-    (which is fed the same bf16-rounded inputs): tolerance 1e-4 relative to the row scale + one bf16
+def test_conv_bf16_mfma_vs_oracle(cuda, oracle, rng, Cin, Cout, n, td, out_tol):
+    """bf16 x bf16 (and fp16 x fp16: the reference's AMP mode) products are exact in f32; only the f32 summation order
+    differs from the oracle (which is fed the same rounded inputs): tolerance 1e-4 relative to the row scale + one
     rounding of the stored output."""
     B, shape = 2, [9, 30, 31]
     feats, idx = _random_sparse(rng, B, shape, n, Cin)
     w = (rng.standard_normal((Cout, 3, 3, 3, Cin)) * 0.1).astype(np.float32)
-    oracle.round_bf16(feats)
-    oracle.round_bf16(w)
+    _round16(feats, td)
+    _round16(w, td)
     scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
     shift = rng.standard_normal(Cout).astype(np.float32)
     res = rng.standard_normal((n, Cout)).astype(np.float32)
-    oracle.round_bf16(res)
+    _round16(res, td)
     d_idx = torch.from_numpy(idx).to(cuda)
     n_dev = S.device_scalar(n, cuda)
     rb = S.rulebook_subm(d_idx, n_dev, S.build_grid(d_idx, n_dev, B, shape), 3)
-    wp = S.pack_weight(torch.from_numpy(w).to(cuda), torch.bfloat16)
-    x = torch.from_numpy(feats).to(cuda).to(torch.bfloat16)
+    wp = S.pack_weight(torch.from_numpy(w).to(cuda), td)
+    x = torch.from_numpy(feats).to(cuda).to(td)
     y = oracle.subm_conv(oracle.SparseTensor(feats, idx, shape, B), w)
     want = oracle.scale_shift_act(y.features, scale, shift, res, relu=True)
     # f32 output: isolates the accumulation-order difference
@@ -127,9 +139,9 @@ def test_conv_bf16_mfma_vs_oracle(cuda, oracle, rng, Cin, Cout, n):
     # bf16 output: one extra rounding
     got16 = S.conv_forward(x, wp, rb, n_dev, scale=torch.from_numpy(scale).to(cuda),
                            shift=torch.from_numpy(shift).to(cuda),
-                           residual=torch.from_numpy(res).to(cuda).to(torch.bfloat16), relu=True)
-    assert got16.dtype == torch.bfloat16
-    np.testing.assert_allclose(got16.float().cpu().numpy(), want, rtol=1e-2, atol=1e-2)
+                           residual=torch.from_numpy(res).to(cuda).to(td), relu=True)
+    assert got16.dtype == td
+    np.testing.assert_allclose(got16.float().cpu().numpy(), want, rtol=out_tol, atol=out_tol)
     # run-to-run bit stability (no atomics)
     again = S.conv_forward(x, wp, rb, n_dev, out_dtype=torch.float32, scale=torch.from_numpy(scale).to(cuda),
                            shift=torch.from_numpy(shift).to(cuda), residual=torch.from_numpy(res).to(cuda), relu=True)
@@ -536,9 +548,10 @@ def test_conv_bf16_other_shapes_and_sizes(cuda, oracle, rng, Cin, Cout, n):
     np.testing.assert_allclose(got[:n].cpu().numpy(), want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("td", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("Cin,Cout", [(16, 32), (32, 64), (64, 128)])
 @pytest.mark.parametrize("pad", [(1, 1, 1), (0, 1, 1)])
-def test_strided_conv_with_in_kernel_rulebook_equals_table_path(cuda, rng, Cin, Cout, pad):
+def test_strided_conv_with_in_kernel_rulebook_equals_table_path(cuda, rng, Cin, Cout, pad, td):
     """fnp_spconv_forward_strided computes the rulebook rows of a strided 3x3x3 layer inside the kernel: same output
     coordinates, bit-identical features as fnp_rulebook_strided's table + fnp_spconv_forward — on a grid whose rows
     are ranks and on one that carries a permutation (the voxeliser's grid)."""
@@ -547,8 +560,8 @@ def test_strided_conv_with_in_kernel_rulebook_equals_table_path(cuda, rng, Cin, 
     d_idx = torch.from_numpy(idx).to(cuda)
     n_dev = S.device_scalar(n, cuda)
     grid = S.build_grid(d_idx, n_dev, B, shape)            # keeps the (random) row order: perm != None
-    x = torch.from_numpy(feats).to(cuda).to(torch.bfloat16)
-    wp = S.pack_weight(torch.from_numpy((rng.standard_normal((Cout, 3, 3, 3, Cin)) * 0.1).astype(np.float32)).to(cuda), torch.bfloat16)
+    x = torch.from_numpy(feats).to(cuda).to(td)
+    wp = S.pack_weight(torch.from_numpy((rng.standard_normal((Cout, 3, 3, 3, Cin)) * 0.1).astype(np.float32)).to(cuda), td)
     sc = torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32)).to(cuda)
     sh = torch.from_numpy(rng.standard_normal(Cout).astype(np.float32)).to(cuda)
     a = S.rulebook_strided(d_idx, n_dev, grid, 3, 2, pad, 4 * n)
@@ -559,3 +572,34 @@ def test_strided_conv_with_in_kernel_rulebook_equals_table_path(cuda, rng, Cin, 
     assert m == int(b.out_n.item()) and m > n // 4
     assert torch.equal(a.out_indices[:m], b.out_indices[:m])
     assert torch.equal(ya[:m], yb[:m])
+
+
+def test_fused_backbone_fp16_and_autocast(cuda, oracle, rng):
+    """FNP_DTYPE fp16 (the reference's AMP mode: fp16 features and weights, fp32 accumulate): the fused engine against
+    the f32 oracle (fp16 storage keeps 11 bits: 10x closer than bf16), and the module path under torch autocast takes
+    the fp16 kernels by itself (train_utils.py:172)."""
+    from findnpropagate_amd import spconv
+    net = _small_net(cuda, "fp16")
+    shape = net.sparse_shape
+    feats, idx = _random_sparse(rng, 2, shape, 6000, 5)
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    want32 = oracle.backbone_forward(sd, feats, idx, 2, shape)
+    bd = {"voxel_features": torch.from_numpy(feats).to(cuda), "voxel_coords": torch.from_numpy(idx).to(cuda), "batch_size": 2}
+    net.fnp_out_dtype = "native"
+    with torch.no_grad():
+        out = net(dict(bd))
+    assert out["encoded_spconv_tensor"].features.dtype == torch.float16
+    g, _ = _by_coord(out["encoded_spconv_tensor"].features.float().cpu().numpy(), out["encoded_spconv_tensor"].indices.cpu().numpy(), want32["out"].spatial_shape)
+    w, _ = _by_coord(want32["out"].features, want32["out"].indices, want32["out"].spatial_shape)
+    rel16 = np.abs(g - w).max() / (np.abs(w).max() + 1e-6)
+    assert rel16 < 2e-2, rel16
+    # autocast: an f32 SubMConv3d module runs its features in fp16 and returns fp16
+    conv = spconv.SubMConv3d(16, 32, 3, padding=1, bias=False, indice_key="k").to(cuda)
+    f16, i16 = _random_sparse(rng, 2, [9, 30, 31], 1500, 16)
+    x = spconv.SparseConvTensor(torch.from_numpy(f16).to(cuda), torch.from_numpy(i16).to(cuda), [9, 30, 31], 2)
+    with torch.no_grad():
+        y32 = conv(x).features
+        with torch.autocast("cuda", dtype=torch.float16):
+            y16 = conv(x).features
+    assert y32.dtype == torch.float32 and y16.dtype == torch.float16
+    np.testing.assert_allclose(y16.float().cpu().numpy(), y32.cpu().numpy(), rtol=2e-2, atol=2e-2)
