@@ -996,7 +996,7 @@ int dispatch_16(const void *x, long long n_in, const void *w, const int *nbr, in
 
 int fnp_spconv_forward_f32_mfma(const void *feat_in, long long n_in_rows, const void *weight, const int *nbr, int nbr_stride,
                                 int K, const int *n_out, int cap_out, void *feat_out, const float *scale, const float *shift,
-                                const void *residual, int relu, int Cin, int Cout, hipStream_t s);   // spconv_f32.hip
+                                const void *residual, int relu, int wperm, int Cin, int Cout, hipStream_t s);   // spconv_f32.hip
 
 extern "C" int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const void *weight, const int *nbr,
                                   int nbr_stride, int K, const int *n_out, int cap_out, void *feat_out, int out_dtype,
@@ -1024,9 +1024,10 @@ extern "C" int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_ro
             // f32 on the matrix pipe (v_mfma_f32_16x16x4_f32: the same fmaf chain, bit for bit); shapes it does not
             // cover fall through to the thread-per-element chain
             const int rc = fnp_spconv_forward_f32_mfma(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out,
-                                                       scale, shift, residual, relu, Cin, Cout, s);
+                                                       scale, shift, residual, relu, (hints & FNP_HINT_W_PERMUTED) != 0, Cin, Cout, s);
             if (rc != FNP_ERR_ARG) return rc;
         }
+        if (hints & FNP_HINT_W_PERMUTED) return FNP_ERR_ARG;   // the other f32 kernels read the plain layout
         if (out_dtype == FNP_F32)
             return launch_valu<float, float>(feat_in, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift,
                                              residual, relu, Cin, Cout, s);

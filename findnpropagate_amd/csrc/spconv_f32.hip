@@ -37,8 +37,16 @@ __device__ __forceinline__ void transpose4(u32x4 &v) {
     v.w = t1[1];
 }
 
-template <int CIN, int COUT, int MB>
-__global__ __launch_bounds__(256, 2) void spconv_mfma_f32_kernel(const float *__restrict__ x, int x_bytes,
+// waves per SIMD the register budget is held to: the narrow layers have little matrix work per rulebook entry and are
+// bound by the latency of their index -> gather chain, so they run 4 waves per SIMD; the wide ones are bound by the
+// matrix pipe and need the registers (2 waves per SIMD)
+template <int COUT> struct F32Occ { static constexpr int WAVES = COUT <= 32 ? 4 : 2; };
+
+// WPERM: the weight rows are stored with every group of 16 input channels transposed 4 x 4 (position 4q + r holds
+// channel 4r + q; sparse.pack_weight(..., mfma_f32=True), FNP_HINT_W_PERMUTED): a lane's 16-byte load then already
+// holds its channels of the chunk's four MFMA steps and the weights need no lane exchange.  Same products, same order.
+template <int CIN, int COUT, int MB, bool WPERM>
+__global__ __launch_bounds__(256, (F32Occ<COUT>::WAVES)) void spconv_mfma_f32_kernel(const float *__restrict__ x, int x_bytes,
                                                                  const float *__restrict__ w,
                                                                  const int *__restrict__ nbr, int nbr_stride, int K,
                                                                  const int *__restrict__ n_out, int cap,
@@ -139,7 +147,8 @@ __global__ __launch_bounds__(256, 2) void spconv_mfma_f32_kernel(const float *__
                 for (int mb = 0; mb < MB; ++mb) any = any || pres[mb];
                 if (any) {
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) transpose4(a[nb]);
+                    for (int nb = 0; nb < NB; ++nb)
+                        if (!WPERM) transpose4(a[nb]);
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) {
                         if (!pres[mb]) continue;   // wave-uniform
@@ -197,16 +206,28 @@ __global__ __launch_bounds__(256, 2) void spconv_mfma_f32_kernel(const float *__
 
 template <int CIN, int COUT>
 int launch_f32(const void *x, long long x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
-               void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s) {
-    // sites per wave: 4 blocks for the narrow layers (their one or two weight fragments per chunk then serve 64 sites),
-    // 2 for 64 / 128 output channels (accumulators = COUT/16 * MB * 4 registers)
-    constexpr int MB = COUT <= 32 ? 4 : 2;
+               void *y, const float *scale, const float *shift, const void *residual, int relu, bool wperm, hipStream_t s) {
+    // sites per wave: 4 blocks up to 64 output channels (a weight fragment then serves 64 sites), 3 for 128
+    // (accumulators = COUT/16 * MB * 4 registers; measured on MI355X at 64 scenes: 128 -> 128 4.54 -> 4.30 ms with 3
+    // instead of 2, 64 -> 64 2.96 -> 2.68 ms with 4 instead of 2)
+#ifndef FNP_F32_MB128
+#define FNP_F32_MB128 3
+#endif
+#ifndef FNP_F32_MB64
+#define FNP_F32_MB64 4
+#endif
+    constexpr int MB = COUT <= 32 ? 4 : COUT == 64 ? FNP_F32_MB64 : FNP_F32_MB128;
     const int tiles = fnp_divup(cap, 4 * MB * 16);
-    const int resident = 256 * 2;
+    const int resident = 256 * F32Occ<COUT>::WAVES;      // one 4-wave workgroup per CU and wave slot
     const int grid = tiles < resident ? tiles : resident;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(spconv_mfma_f32_kernel<CIN, COUT, MB>), dim3(grid), dim3(256), 0, s, (const float *)x,
-                       (int)x_bytes, (const float *)w, nbr, nbr_stride, K, n_out, cap, (float *)y, scale, shift,
-                       (const float *)residual, relu);
+    if (wperm)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spconv_mfma_f32_kernel<CIN, COUT, MB, true>), dim3(grid), dim3(256), 0, s,
+                           (const float *)x, (int)x_bytes, (const float *)w, nbr, nbr_stride, K, n_out, cap, (float *)y, scale,
+                           shift, (const float *)residual, relu);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(spconv_mfma_f32_kernel<CIN, COUT, MB, false>), dim3(grid), dim3(256), 0, s,
+                           (const float *)x, (int)x_bytes, (const float *)w, nbr, nbr_stride, K, n_out, cap, (float *)y, scale,
+                           shift, (const float *)residual, relu);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
@@ -216,12 +237,12 @@ int launch_f32(const void *x, long long x_bytes, const void *w, const int *nbr, 
 // f32 in / f32 out on the matrix pipe; FNP_ERR_ARG when the shape is not built (the caller falls back to the VALU chain)
 int fnp_spconv_forward_f32_mfma(const void *feat_in, long long n_in_rows, const void *weight, const int *nbr, int nbr_stride,
                                 int K, const int *n_out, int cap_out, void *feat_out, const float *scale, const float *shift,
-                                const void *residual, int relu, int Cin, int Cout, hipStream_t s) {
+                                const void *residual, int relu, int wperm, int Cin, int Cout, hipStream_t s) {
     const long long xb = n_in_rows * Cin * 4;
     if (xb <= 0 || xb >= 0x7fffffffll || (long long)K * Cin * Cout * 4 >= 0x7fffffffll) return FNP_ERR_ARG;
 #define FNP_CASE(CI, CO)              \
     if (Cin == CI && Cout == CO)      \
-        return launch_f32<CI, CO>(feat_in, xb, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift, residual, relu, s);
+        return launch_f32<CI, CO>(feat_in, xb, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift, residual, relu, wperm != 0, s);
     FNP_CASE(16, 16)
     FNP_CASE(16, 32)
     FNP_CASE(32, 32)

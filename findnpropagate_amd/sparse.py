@@ -214,16 +214,30 @@ def rulebook_strided(indices, n_dev, grid, ksize, stride, padding, cap_out, out_
 
 
 # --------------------------------------------------------------------------------- convolution
-def pack_weight(weight, dtype):
+F32_MFMA_SHAPES = {(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (32, 16), (64, 32), (128, 64)}
+
+
+class PermutedWeight(torch.Tensor):
+    """Marker type: a packed f32 weight whose 16-channel groups are stored 4 x 4 transposed (fnp.h FNP_HINT_W_PERMUTED)."""
+
+
+def pack_weight(weight, dtype, mfma_f32=False):
     """spconv 2.x layout (Cout,kD,kH,kW,Cin) -> packed (K, Cout, Cin) contiguous in `dtype`.
-    (spconv 1.x (kD,kH,kW,Cin,Cout) is converted by the module loader, see spconv/conv.py.)"""
+    (spconv 1.x (kD,kH,kW,Cin,Cout) is converted by the module loader, see spconv/conv.py.)
+    mfma_f32: f32 weights of a shape the f32 MFMA kernel covers are stored with every group of 16 input channels
+    transposed 4 x 4 (position 4q + r <- channel 4r + q): the layout that kernel reads without lane exchanges; the result
+    is tagged (PermutedWeight) so that conv_forward passes FNP_HINT_W_PERMUTED."""
     Cout, Cin = weight.shape[0], weight.shape[-1]
     K = weight.shape[1] * weight.shape[2] * weight.shape[3]
-    return weight.detach().reshape(Cout, K, Cin).permute(1, 0, 2).contiguous().to(dtype)
+    w = weight.detach().reshape(Cout, K, Cin).permute(1, 0, 2).contiguous().to(dtype)
+    if mfma_f32 and dtype == torch.float32 and (Cin, Cout) in F32_MFMA_SHAPES:
+        w = w.view(K, Cout, Cin // 16, 4, 4).transpose(3, 4).contiguous().view(K, Cout, Cin).as_subclass(PermutedWeight)
+    return w
 
 
 HINT_ROWS_RANKED = 1   # fnp.h FNP_HINT_ROWS_RANKED
 HINT_VALU = 2          # fnp.h FNP_HINT_VALU
+HINT_W_PERMUTED = 4    # fnp.h FNP_HINT_W_PERMUTED
 
 
 def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, shift=None, residual=None, relu=False,
@@ -247,8 +261,8 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
     rc = L.fnp_spconv_forward(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
                               _l.ptr(rb.nbr), rb.nbr.shape[1], K, _l.ptr(n_out_dev), cap_out,
                               _l.ptr(out), _l.dtype_code(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual),
-                              int(bool(relu)), (HINT_ROWS_RANKED if ranked else 0) | (HINT_VALU if valu else 0), Cin, Cout,
-                              _l.stream())
+                              int(bool(relu)), (HINT_ROWS_RANKED if ranked else 0) | (HINT_VALU if valu else 0) |
+                              (HINT_W_PERMUTED if isinstance(w_packed, PermutedWeight) else 0), Cin, Cout, _l.stream())
     _l.check(rc, "fnp_spconv_forward")
     return out
 

@@ -86,12 +86,13 @@ class SparseConvolution(SparseModule):
                 f"padding={self.padding}, subm={self.subm}, indice_key={self.indice_key}")
 
     def packed_weight(self, dtype):
-        """(K, Cout, Cin) contiguous copy in `dtype`, refreshed when the parameter changes."""
+        """(K, Cout, Cin) contiguous copy in `dtype`, refreshed when the parameter changes (f32 copies of the shapes the
+        f32 MFMA kernel covers are stored in that kernel's channel order: sparse.pack_weight(mfma_f32=True))."""
         key = (dtype, self.weight.device)
         ver = (self.weight._version, self.weight.data_ptr())
         hit = self._packed.get(key)
         if hit is None or hit[0] != ver:
-            hit = (ver, S.pack_weight(self.weight, dtype))
+            hit = (ver, S.pack_weight(self.weight, dtype, mfma_f32=True))
             self._packed[key] = hit
         return hit[1]
 

@@ -242,6 +242,11 @@ int fnp_rulebook_strided(const int *in_coords, const int *n_in, int cap_in, cons
 /* f32 only: take the thread-per-element fmaf chain (validation path) instead of the f32 MFMA kernel; the two are
  * bit-identical, this only selects which one computes */
 #define FNP_HINT_VALU 2
+/* f32 MFMA path only: `weight` is stored with every group of 16 input channels transposed 4 x 4 — position 4q + r of a
+ * group holds channel 4r + q (q, r in 0..3) — so that a lane's 16-byte load holds its channels of four consecutive
+ * MFMA steps.  Layout statement, not a numerical option: results are bit-identical to the plain layout.  Shapes the
+ * f32 MFMA kernel does not cover return FNP_ERR_ARG with this hint (the other kernels read the plain layout). */
+#define FNP_HINT_W_PERMUTED 4
 int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const void *weight,
                        const int *nbr, int nbr_stride, int K,
                        const int *n_out, int cap_out,

@@ -103,6 +103,11 @@ def test_conv_f32_bit_exact_vs_oracle(cuda, oracle, rng, Cin, Cout, n):
     valu = S.conv_forward(torch.from_numpy(feats).to(cuda), wp, rb, n_dev, scale=torch.from_numpy(scale).to(cuda),
                           shift=torch.from_numpy(shift).to(cuda), residual=torch.from_numpy(res).to(cuda), relu=True, valu=True)
     assert torch.equal(valu, got), "matrix-pipe and thread-per-element chains are the same bits"
+    wperm = S.pack_weight(torch.from_numpy(w).to(cuda), torch.float32, mfma_f32=True)
+    assert isinstance(wperm, S.PermutedWeight) == ((Cin, Cout) in S.F32_MFMA_SHAPES)
+    perm = S.conv_forward(torch.from_numpy(feats).to(cuda), wperm, rb, n_dev, scale=torch.from_numpy(scale).to(cuda),
+                          shift=torch.from_numpy(shift).to(cuda), residual=torch.from_numpy(res).to(cuda), relu=True)
+    assert torch.equal(perm, got), "the pre-permuted weight layout is a layout, not a different sum"
 
 
 def _round16(a, td):
