@@ -9,8 +9,8 @@ of the `.pth` files the extraction writes.  Same name
                                   tools/extract_pseudo_labels.py:134-137 / findnpropagate_amd.extract.save_frame)
   points_in_boxes       :270-316  PseudoSampler.points_in_boxes: dense (T, N) membership + box-frame points
 
-The stateful policy around them (EMA score thresholds, per-class quotas, the copy-paste queue) stays the
-reference's own Python: it is dataset bookkeeping, not an operator."""
+The stateful policy around them (EMA score thresholds, per-class quotas, the copy-paste queue: PseudoLoader,
+PseudoSampler, ObjectSample) follows further down in this file."""
 import os
 from pathlib import Path
 
@@ -67,3 +67,315 @@ def points_in_boxes(points, boxes3d):
     rc = _l.load().fnp_host_points_in_boxes_frame(points.ctypes.data, N, C, boxes.ctypes.data, T, in_box.ctypes.data, out.ctypes.data)
     _l.check(rc, "fnp_host_points_in_boxes_frame")
     return in_box.astype(bool), out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The stateful half of the pseudo-label mixing: PseudoLoader.load_pseudos /
+# load_frustum_pseudos / load_selftrain_pseudos / copy_and_paste and the copy-paste queue (PseudoSampler, ObjectSample),
+# pcdet/datasets/augmentor/pseudo_loader.py:57-840.  Dataloader-worker host code in the reference and here: numpy +
+# the library's host entry points (rotated BEV IoU, dense point-in-box), no GPU.  Behaviour is kept call for call —
+# including the ORDER in which np.random is consumed, so that a seeded run reproduces the reference's samples — with
+# the per-box Python loops replaced by array operations where the order of side effects allows it.
+# ------------------------------------------------------------------------------------------------------------------
+ALL_CLASS_NAMES = ['car', 'truck', 'construction_vehicle', 'bus', 'trailer',
+                   'barrier', 'motorcycle', 'bicycle', 'pedestrian', 'traffic_cone']
+
+
+def rotate_points_along_z(points, angle):
+    """pcdet/utils/common_utils.py:35-57 (numpy in -> float32 numpy out, torch in -> torch out)."""
+    is_numpy = isinstance(points, np.ndarray)
+    if is_numpy:
+        points = torch.from_numpy(points).float()
+    if isinstance(angle, np.ndarray):
+        angle = torch.from_numpy(angle).float()
+    cosa, sina = torch.cos(angle), torch.sin(angle)
+    zeros, ones = angle.new_zeros(points.shape[0]), angle.new_ones(points.shape[0])
+    rot = torch.stack((cosa, sina, zeros, -sina, cosa, zeros, zeros, zeros, ones), dim=1).view(-1, 3, 3).float()
+    out = torch.cat((torch.matmul(points[:, :, 0:3], rot), points[:, :, 3:]), dim=-1)
+    return out.numpy() if is_numpy else out
+
+
+def _bev_iou(a, b):
+    """rotated BEV IoU (n,7) x (m,7) on the host, numpy in / numpy out"""
+    return iou3d_nms_utils.boxes_bev_iou_cpu(np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32))
+
+
+class ObjectSample(object):
+    """One object of the copy-paste queue (:57-224): its points in the box frame + the box it came from."""
+
+    def __init__(self, relative_points, box, conf):
+        self.conf = conf
+        self.num_points = relative_points.shape[0]
+        self.label = box[..., -1].item()
+        box = box.copy().reshape(1, 8)
+        self.l, self.w, self.h = [v.item() for v in box[0, [3, 4, 5]]]
+        self.x, self.y, self.z = [v.item() for v in box[0, 0:3]]
+        self.ry = box[:, 6].item()
+        box[:, 0:3] = 0      # centred, unrotated
+        box[:, 6] = 0
+        self.points, self.box = relative_points, box
+
+    def dropout_points(self, dropout=0.5, min_points=5):
+        if self.points.shape[0] <= min_points * 2:
+            return self.points.copy()
+        points = self.points.copy()
+        if np.random.rand() < dropout:
+            n = len(points)
+            keep = np.random.randint(n // 2, n)
+            points = points[np.random.randint(0, n, size=keep)]
+        return points
+
+    def get_sample_points(self, sample_box, dropout=0.5):
+        points = self.dropout_points(dropout)
+        points = rotate_points_along_z(points[None], sample_box[:, 6]).reshape(-1, 5)
+        points[:, :3] += np.repeat(sample_box[:, 0:3], repeats=points.shape[0], axis=0)
+        return points
+
+    def sample(self, gt_boxes_tensor, pseudo_boxes, max_iou=0.1, dropout=0.5, min_dist=4.5, rot_noise=np.pi / 4.0,
+               trans_noise=2.0):
+        """Jittered copy that collides neither with the ground truth (+ ego box) nor with the pseudo boxes placed so
+        far; up to 10 tries (:164-221).  -> (box (1,8), points (n,5)) or (None, None)."""
+        gt = gt_boxes_tensor.numpy() if isinstance(gt_boxes_tensor, torch.Tensor) else np.asarray(gt_boxes_tensor)
+        for _ in range(10):
+            X, Y, Z = np.random.randn(3)
+            x, y, z = self.x + trans_noise * X, self.y + trans_noise * Y, self.z + trans_noise * Z
+            if np.linalg.norm([x, y, z]) < min_dist:
+                continue
+            alpha = self.ry + rot_noise * np.random.rand()
+            box = torch.tensor([x, y, z, self.l, self.w, self.h, alpha, self.label], dtype=torch.float32).reshape(1, 8).numpy()
+            ok = True
+            if gt.shape[0] or pseudo_boxes.shape[0]:
+                iou_gt = _bev_iou(box[:, :7], gt[:, :7])
+                if iou_gt.shape[1] > 0 and iou_gt.max() >= max_iou:
+                    ok = False
+                elif pseudo_boxes.shape[0]:
+                    iou_ps = _bev_iou(box[:, :7], pseudo_boxes[:, :7])
+                    ok = iou_ps.size == 0 or bool(iou_ps.max() < max_iou)
+            if ok:
+                return box, self.get_sample_points(box, dropout=dropout)
+        return None, None
+
+    def __repr__(self):
+        return (f"ObjectSample[Class: {self.label}] ({self.x:.2f}, {self.y:.2f}, {self.z:.2f})) {self.ry:.2f}) "
+                f"[{self.l:.2f}, {self.w:.2f}, {self.h:.2f}] {self.num_points} points")
+
+
+class PseudoSampler(object):
+    """Copy-paste sampler for the unknown classes (:226-485): a per-class queue of the best pseudo-labelled objects
+    seen so far, pasted into later frames so that every unknown class is seen about as often as a known one."""
+    min_pts = 5
+    min_dist = 3.0
+    pseudo_nms_thresh = 1e-7
+    ego_vehicle = None
+    queue_metric = 'num_pts'
+    rot_noise = np.pi / 4.0
+    trans_noise = 2.0
+    validate_pseudos = True
+    timestamp = None
+
+    def __init__(self, class_labels, known_class_labels, unknown_class_labels, max_queue_size_per_class=100,
+                 num_classes=10, dropout=0.5, mom=0.9):
+        self.known_class_labels, self.unknown_class_labels = known_class_labels, unknown_class_labels
+        self.max_queue_size_per_class, self.class_labels = max_queue_size_per_class, class_labels
+        self.dropout, self.mom, self.num_classes = dropout, mom, num_classes
+        self.unknown_queue = {l: [] for l in unknown_class_labels}
+        self.prop_per_unk = {l: 1.0 / float(len(unknown_class_labels)) for l in unknown_class_labels}
+        self.known_to_unknown_ratio = len(unknown_class_labels) / (num_classes - len(unknown_class_labels) + 1e-6)
+
+    def calc_seen_per_class(self, pseudo_boxes, gt_boxes):
+        labels = pseudo_boxes[..., -1].reshape(-1).astype(np.int32)
+        total = float(max(labels.size, 1e-7))
+        for l in self.unknown_class_labels:      # EMA of each unknown class's share of the pseudo boxes
+            self.prop_per_unk[l] = self.prop_per_unk[l] * self.mom + ((labels == l).sum() / total) * (1.0 - self.mom)
+
+    def points_in_boxes(self, points, boxes3d):
+        return points_in_boxes(points, boxes3d)
+
+    def __call__(self, batch_dict, pseudo_boxes, pseudo_scores, gt_boxes, sample_buffer_num=5, fix_cp=None):
+        self.calc_seen_per_class(pseudo_boxes, gt_boxes)
+        in_queue = {l: len(q) for l, q in self.unknown_queue.items()}
+        num_scaled = max(int(gt_boxes.shape[0] * self.known_to_unknown_ratio), pseudo_boxes.shape[0])
+        num_proposals = num_scaled + (sample_buffer_num if fix_cp is None else fix_cp)
+        cur_points = batch_dict['points'].copy()
+        if pseudo_boxes.size == 0:
+            return pseudo_boxes, np.zeros((0), dtype=bool)
+        gt_plus_ego = torch.cat((torch.tensor(gt_boxes.copy(), dtype=torch.float32)[:, :7], self.ego_vehicle), dim=0)
+        inside, rel_pts = self.points_in_boxes(cur_points, pseudo_boxes[:, :7])
+        n_in = inside.sum(axis=1)
+        order = np.argsort(-n_in, axis=0) if self.queue_metric == 'num_pts' else np.argsort(-pseudo_scores, axis=0)
+        max_per_unknown = gt_boxes.shape[0] / max(len(self.known_class_labels), 1)
+        seen = {l: 0 for l in self.unknown_class_labels}
+        valid_idx = []
+        for i in order:                          # feed the queue, best objects first (:373-418)
+            box = pseudo_boxes[i]
+            lbl = int(box[..., -1])
+            if not self.validate_pseudos:
+                valid_idx.append(i)
+            if n_in[i] < self.min_pts or np.linalg.norm(box[:3]) < self.min_dist:
+                continue
+            seen[lbl] += 1
+            if self.validate_pseudos:
+                valid_idx.append(i)
+            queue, conf = self.unknown_queue[lbl], pseudo_scores[i]
+            if in_queue[lbl] >= self.max_queue_size_per_class:
+                if self.queue_metric == 'num_pts':          # replace the sparsest object
+                    queue[int(np.argmin([o.num_points for o in queue]))] = ObjectSample(rel_pts[i, inside[i]], box.copy(), conf=conf)
+                else:                                       # replace the least confident one, if this one beats it
+                    confs = np.array([o.conf for o in queue])
+                    j = int(np.argmin(confs))
+                    if conf > confs[j]:
+                        queue[j] = ObjectSample(rel_pts[i, inside[i]], box.copy(), conf=conf)
+            else:
+                queue.append(ObjectSample(rel_pts[i, inside[i]], box.copy(), conf=conf))
+        n_valid = len(valid_idx)
+        out = np.zeros((num_proposals, 8))
+        out[:n_valid] = pseudo_boxes[valid_idx]
+        mask = np.zeros((num_proposals), dtype=bool)
+        num_samples = max(num_proposals - n_valid, 0) if fix_cp is None else fix_cp
+        if num_samples <= 0 or max(in_queue) == 0:          # (max over the dict's KEYS, as in the reference :437)
+            return out[:n_valid], mask[:n_valid]
+        pos = n_valid
+        pasted = {l: 0 for l in self.unknown_class_labels}
+        extra_points = [cur_points]
+        for _ in range(num_samples):
+            lbl = np.random.choice(self.unknown_class_labels)
+            if in_queue[lbl] == 0 or (seen[lbl] + pasted[lbl]) >= max_per_unknown:
+                continue
+            obj = self.unknown_queue[lbl][np.random.choice(len(self.unknown_queue[lbl]))]
+            box, pts = obj.sample(gt_plus_ego, out[:pos], min_dist=self.min_dist, rot_noise=self.rot_noise,
+                                  trans_noise=self.trans_noise)
+            if box is None:
+                continue
+            out[pos], mask[pos] = box, True
+            pasted[lbl] += 1
+            pos += 1
+            extra_points.append(pts)
+        batch_dict['points'] = np.concatenate(extra_points, axis=0)
+        return out, mask
+
+
+class PseudoLoader(object):
+    """Loads the pseudo labels of the unknown classes for the current frame and mixes them with the ground truth of
+    the known ones (:487-840).  Hooked into the data augmentor (data_augmentor.py:327-360)."""
+    max_num_gt_class = 20.0
+
+    def __init__(self, known_class_names, pseudo_path='pseudo_labels/frustum_proposals/', self_train_path=None,
+                 dropout=0.5, min_score=0.1, pseudo_nms_thresh=1e-7, max_selftrain_per_class=None, fix_cp=None, mom=0.9,
+                 copy_st_only=False, sampler_val=True):
+        self.all_class_names = list(ALL_CLASS_NAMES)
+        self.known_class_names = known_class_names
+        self.num_classes = len(self.all_class_names)
+        self.max_selftrain_per_class, self.fix_cp, self.mom, self.copy_st_only = max_selftrain_per_class, fix_cp, mom, copy_st_only
+        self.training = len(known_class_names) != self.num_classes      # open vocabulary: fewer classes in training
+        self.class_labels = list(range(1, self.num_classes + 1))
+        self.unknown_class_labels = [i + 1 for i, n in enumerate(self.all_class_names) if n not in known_class_names]
+        self.known_class_labels = [i for i in self.class_labels if i not in self.unknown_class_labels]
+        self.is_known = {i: (i in self.known_class_labels) for i in self.class_labels}
+        assert set(self.unknown_class_labels) | set(self.known_class_labels) == set(self.class_labels)
+        self.ego_vehicle = torch.tensor([[0, -1.0, (-5.0 + 3.0) / 2.0, 5.0, 3.0, 8.0, np.pi / 2.0]], dtype=torch.float32)
+        self.gt_known_to_full_labels = {(i + 1): (j + 1) for i, kn in enumerate(known_class_names)
+                                        for j, an in enumerate(self.all_class_names) if kn == an}
+        self.full_labels_to_gt_known = {v: k for k, v in self.gt_known_to_full_labels.items()}
+        self.unknown_score_ema = {l: min_score for l in self.unknown_class_labels}
+        self.pseudos_missing = set()
+        self.dropout, self.min_score, self.pseudo_nms_thresh = dropout, min_score, pseudo_nms_thresh
+        self.pseudo_folder, self.self_training_folder = pseudo_path, self_train_path
+        self.copy_boxes = self.copy_scores = self.pseudo_types = None
+        self.sampler = PseudoSampler(class_labels=self.class_labels, known_class_labels=self.known_class_labels,
+                                     unknown_class_labels=self.unknown_class_labels, max_queue_size_per_class=100,
+                                     dropout=dropout, mom=mom)
+        self.sampler.pseudo_nms_thresh = pseudo_nms_thresh
+        self.sampler.ego_vehicle = self.ego_vehicle
+        self.sampler.validate_pseudos = sampler_val
+
+    def load_pseudos(self, batch_dict, unknowns_only=True, folder=None, record_missing=True, filter_by_score=True):
+        """-> pseudo boxes (M,8) [box (7), label], scores (M,) of this frame's file (:561-679).  With filter_by_score
+        every unknown-class box updates its class's EMA score (in file order) and must reach max(per-class top-k
+        threshold, that EMA, min_score) to stay."""
+        frame_id = batch_dict['frame_id']
+        folder = self.pseudo_folder if folder is None else folder
+        path = Path(folder) / f"{frame_id.replace('.', '_')}.pth"
+        empty = (np.zeros((0, 8)), np.zeros((0)))
+        if not os.path.exists(path):
+            if record_missing:
+                self.pseudos_missing.add(str(path))
+            return empty
+        got = read_pseudo_file(folder, frame_id)
+        if got is None:
+            return empty
+        boxes, scores, labels = got
+        thresh = {l: 0.0 for l in self.unknown_class_labels}
+        if self.max_selftrain_per_class is not None:
+            for l in self.unknown_class_labels:
+                s = scores[labels == l]
+                if s.size == 0:
+                    continue
+                if s.size < self.max_selftrain_per_class:
+                    thresh[l] = np.min(s)
+                else:      # the max_selftrain_per_class'th highest score
+                    thresh[l] = float(s[np.argsort(-s, axis=0)[int(min(self.max_selftrain_per_class, s.shape[0]) - 1)]])
+        if unknowns_only:
+            keep = np.isin(labels, self.unknown_class_labels)
+            if filter_by_score:
+                for i in np.nonzero(keep)[0]:               # sequential: the EMA moves with every box
+                    l = labels[i]
+                    self.unknown_score_ema[l] = self.unknown_score_ema[l] * self.mom + (1.0 - self.mom) * scores[i]
+                    keep[i] = scores[i] >= np.array([thresh[l], self.unknown_score_ema[l], self.min_score]).max()
+            boxes, scores, labels = boxes[keep], scores[keep], labels[keep]
+        if boxes.shape[0] == 0:
+            return empty
+        out = np.zeros((boxes.shape[0], 8), dtype=np.float32)
+        out[:, :7] = boxes[:, :7]                            # (velocity etc. dropped)
+        out[:, -1] = labels
+        return out, scores
+
+    def load_frustum_pseudos(self, batch_dict):
+        boxes, scores = self.load_pseudos(batch_dict, filter_by_score=False)   # the score is the image detector's: no filter
+        batch_dict['pseudo_boxes'], batch_dict['pseudo_scores'] = boxes, scores
+        batch_dict['pseudo_samples_mask'] = np.zeros((len(boxes),), dtype=bool)
+        self.copy_boxes, self.copy_scores = boxes.copy(), scores.copy()
+        return batch_dict
+
+    def load_selftrain_pseudos(self, batch_dict):
+        """Adds last round's self-training predictions to the frustum pseudos, de-duplicates them (rotated BEV NMS at
+        0.1), drops what touches the ground truth or the ego box, drops empty boxes (:681-819)."""
+        if not self.training:
+            return batch_dict
+        if 'pseudo_boxes' in batch_dict:
+            boxes, scores = batch_dict.pop('pseudo_boxes', np.zeros((0, 8))), batch_dict.pop('pseudo_scores', np.zeros((0)))
+        else:
+            boxes, scores = np.zeros((0, 8)), np.zeros((0))
+        st_boxes, st_scores = self.load_pseudos(batch_dict, folder=self.self_training_folder, record_missing=False)
+        n_frustum = len(boxes)
+        if len(st_boxes) > 0:
+            boxes, scores = np.concatenate([boxes, st_boxes], axis=0), np.concatenate([scores, st_scores], axis=0)
+        b_t, s_t = torch.tensor(boxes, dtype=torch.float32), torch.tensor(scores, dtype=torch.float32)
+        types = torch.ones((len(boxes),), dtype=torch.long)      # 0 = frustum pseudo, 1 = self-training
+        types[:n_frustum] = 0
+        keep = bev_nms_cpu(b_t[:, :7], s_t, thresh=0.1)
+        b_t, s_t, types = b_t[keep], s_t[keep], types[keep]
+        gt = torch.cat((torch.tensor(batch_dict['gt_boxes'].copy(), dtype=torch.float32)[:, :7], self.ego_vehicle), dim=0)
+        if gt.numel() > 0 and b_t.numel() > 0:
+            free = torch.from_numpy(_bev_iou(b_t[..., :7].numpy(), gt.numpy()).max(axis=1) <= self.pseudo_nms_thresh)
+            b_t, s_t, types = b_t[free], s_t[free], types[free]
+        boxes, non_empty = remove_empty(b_t.numpy())
+        scores, types = s_t.numpy()[non_empty], types.numpy()[non_empty]
+        batch_dict['pseudo_boxes'], batch_dict['pseudo_scores'] = boxes, scores
+        self.pseudo_types = types
+        sel = (types == 1) if self.copy_st_only else slice(None)
+        self.copy_boxes, self.copy_scores = boxes[sel].copy(), scores[sel].copy()
+        batch_dict['pseudo_samples_mask'] = np.zeros((len(boxes),), dtype=bool)
+        return batch_dict
+
+    def copy_and_paste(self, batch_dict):
+        boxes, mask = self.sampler(batch_dict, self.copy_boxes, self.copy_scores, batch_dict['gt_boxes'], fix_cp=self.fix_cp)
+        boxes, non_empty = remove_empty(boxes)
+        mask = mask[non_empty]
+        if self.copy_st_only:                   # the frustum pseudos were kept out of the sampler: add them back
+            frustum = batch_dict['pseudo_boxes'][self.pseudo_types == 0]
+            boxes = np.concatenate([boxes, frustum], axis=0)
+            mask = np.concatenate([mask, np.zeros((len(frustum),), dtype=bool)], axis=0)
+        assert mask.shape[0] == boxes.shape[0]
+        batch_dict.pop('pseudo_scores')
+        batch_dict['pseudo_boxes'], batch_dict['pseudo_samples_mask'] = boxes, mask
+        return batch_dict

@@ -143,14 +143,14 @@ class FrustumProposerOG(nn.Module):
 
     @staticmethod
     def _default_detector(model_cfg, class_names):
-        """PreprocessedGLIP / PreprocessedDetector of the host OpenPCDet tree (:254-267), if present."""
-        try:
-            from pcdet.models.preprocessed_detector import PreprocessedDetector, PreprocessedGLIP   # type: ignore
-        except Exception:
-            return None
+        """PreprocessedGLIP / PreprocessedDetector as the reference constructs them (:254-267), from this package's
+        own loaders (findnpropagate_amd.preprocessed_detector: no maskrcnn_benchmark needed to read the GLIP file)."""
+        from ..preprocessed_detector import PreprocessedDetector, PreprocessedGLIP
         preds_path = _get(model_cfg, 'PREDS_PATH', '')
         if 'PreprocessedGLIP' in preds_path:
-            return PreprocessedGLIP(class_names=class_names)
+            kw = {k: _get(model_cfg, key) for k, key in (('pred_pth', 'GLIP_PRED_PTH'), ('meta_coco', 'GLIP_META_COCO'))
+                  if _get(model_cfg, key) is not None}      # (optional overrides of the reference's hard-coded paths)
+            return PreprocessedGLIP(class_names=class_names, **kw)
         cams = ['CAM_BACK', 'CAM_BACK_LEFT', 'CAM_BACK_RIGHT', 'CAM_FRONT', 'CAM_FRONT_LEFT', 'CAM_FRONT_RIGHT']
         paths = _get(model_cfg, 'PREDS_PATHS', [preds_path + f"{c}.json" for c in cams])
         return PreprocessedDetector(paths, class_names=class_names)

@@ -8,7 +8,9 @@ import pytest
 import test_data_processor as _dp
 import test_host_iou as _hi
 import test_host_voxelize as _hv
+import test_preprocessed_detector as _pd
 import test_pseudo_loader as _pl
+import test_pseudo_mixing as _pm
 
 pytestmark = pytest.mark.gpu
 
@@ -21,5 +23,7 @@ def _reexport(mod, prefix):
 
 _reexport(_hi, "host_iou")
 _reexport(_pl, "pseudo_loader")
+_reexport(_pm, "pseudo_mixing")
 _reexport(_dp, "data_processor")
 _reexport(_hv, "host_voxelize")
+_reexport(_pd, "preprocessed_detector")
