@@ -147,6 +147,21 @@ class VoxelBackBone8x(_BackboneBase):
         return _module_forward(self, batch_dict)
 
 
+def _bn_relu(bn, relu, x, act, residual=None):
+    """features of `x` through BatchNorm1d -> (+ residual) -> ReLU, stored in `act`.  Training-mode BatchNorm takes the
+    fused kernels (spconv/norm.py: one autograd node, two passes per direction); a frozen (eval) one inside a training
+    run, or a shape the kernels do not take, goes through the torch modules in f32 like the reference."""
+    from ..spconv import norm as N
+    f = x.features
+    if N.fusable(bn) and relu is not None and f.is_cuda and f.dtype in (act, torch.float32):
+        res = None if residual is None else residual.to(f.dtype)
+        return N.bn_act(f, x.n_dev(), bn, residual=res, relu=True).to(act)   # (f32 in: the first layer's conv output)
+    y = bn(f.float())
+    if residual is not None:
+        y = y.to(act).float() + residual.float()
+    return (relu(y) if relu is not None else y).to(act)
+
+
 def _module_forward(self, batch_dict):
     voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
     batch_size = batch_dict['batch_size']
@@ -156,7 +171,7 @@ def _module_forward(self, batch_dict):
     # first conv consumes f32 point features; activations then live in `act`
     conv0 = self.conv_input[0]
     x = conv0(x_in)
-    x = x.replace_feature(self.conv_input[2](self.conv_input[1](x.features.float())).to(act))
+    x = x.replace_feature(_bn_relu(self.conv_input[1], self.conv_input[2], x, act))
     x_conv1 = _seq_forward(self.conv1, x, act)
     x_conv2 = _seq_forward(self.conv2, x_conv1, act)
     x_conv3 = _seq_forward(self.conv3, x_conv2, act)
@@ -167,17 +182,24 @@ def _module_forward(self, batch_dict):
 
 def _seq_forward(seq, x, act):
     """SparseSequential forward with dense modules evaluated in f32 and stored back in `act`."""
-    for m in seq._modules.values():
+    mods = list(seq._modules.values())
+    skip = False
+    for i, m in enumerate(mods):
+        if skip:                      # the ReLU folded into the BatchNorm before it
+            skip = False
+            continue
+        if isinstance(m, nn.BatchNorm1d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+            x = x.replace_feature(_bn_relu(m, mods[i + 1], x, act))
+            skip = True
+            continue
         if isinstance(m, spconv.SparseSequential):
             x = _seq_forward(m, x, act)
         elif isinstance(m, SparseBasicBlock):
             identity = x
             o = m.conv1(x)
-            o = o.replace_feature(m.relu(m.bn1(o.features.float())).to(act))
+            o = o.replace_feature(_bn_relu(m.bn1, m.relu, o, act))
             o = m.conv2(o)
-            f = m.bn2(o.features.float()).to(act)
-            f = (f.float() + identity.features.float())
-            x = o.replace_feature(m.relu(f).to(act))
+            x = o.replace_feature(_bn_relu(m.bn2, m.relu, o, act, residual=identity.features))
         elif isinstance(m, spconv.SparseModule):
             x = m(x)
         else:

@@ -284,6 +284,29 @@ int fnp_spconv_wgrad(const void *feat_in, int in_dtype, const void *grad_out, in
                      void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * BatchNorm1d in TRAINING mode on sparse rows, fused with the ReLU / residual add that follow it in post_act_block and
+ * SparseBasicBlock (pcdet/models/backbones_3d/spconv_backbone.py:8-27,51-67; norm_fn = BatchNorm1d(eps 1e-3, momentum
+ * 0.01), :189) — forward and backward of the dense part of the self-training step (tools/train_st.py).
+ *   x, residual, y, grad_* : (cap, C) rows of `dtype` (f32 / bf16 / fp16), C in {8, 16, 32, 64, 128, 256}; the n_rows valid
+ *   rows (DEVICE scalar) form the batch.  gamma, beta, running_*, save_*, grad_gamma, grad_beta: (C,) f32.
+ *   forward : y = act((x - mean) * invstd * gamma + beta [+ residual]); biased variance for the normalisation, running
+ *             statistics updated in place like torch (momentum, unbiased variance); running_* may both be NULL.
+ *   backward: g = grad_out * [y > 0] (relu) ; grad_beta = sum g ; grad_gamma = sum g * xhat ;
+ *             grad_x = gamma * invstd * (g - grad_beta / n - xhat * grad_gamma / n) ; grad_residual (nullable) = g.
+ * Two passes per direction, f64 partial sums added in a fixed order: deterministic, no atomics, no host sync.
+ * workspace: fnp_bn_workspace_bytes(C).
+ * ------------------------------------------------------------------------------------------ */
+int64_t fnp_bn_workspace_bytes(int C);
+int fnp_bn_train_forward(const void *x, int dtype, const int *n_rows, int cap, int C, const float *gamma, const float *beta,
+                         float *running_mean, float *running_var, float momentum, float eps, const void *residual, int relu,
+                         void *y, float *save_mean, float *save_invstd, void *workspace, int64_t workspace_bytes,
+                         fnp_stream_t stream);
+int fnp_bn_train_backward(const void *grad_out, const void *x, const void *y, int dtype, const int *n_rows, int cap, int C,
+                          const float *gamma, const float *save_mean, const float *save_invstd, int relu, void *grad_x,
+                          void *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, int64_t workspace_bytes,
+                          fnp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * CLIP-crop scoring, geometry half (CLIPBoxClassification.forward,
  * pcdet/models/dense_heads/clip_box_classification.py:230-379): which camera sees which box and the
  * square image crop CLIP looks at.

@@ -115,12 +115,26 @@ def test_backbone_training_step_runs_and_matches_torch_reference_ops(cuda, rng):
         loss_b, grads_b = run()
     finally:
         C.SparseConvFunction = real
-    assert abs(loss_a - loss_b) <= 1e-4 * abs(loss_b)
-    assert set(grads_a) == set(grads_b) and len(grads_a) > 60
-    for name in grads_a:
-        ga, gb = grads_a[name].float().cpu().numpy(), grads_b[name].float().cpu().numpy()
-        assert np.isfinite(ga).all(), name
-        assert np.abs(ga - gb).max() <= 2e-3 * max(np.abs(gb).max(), 1e-6), (name, np.abs(ga - gb).max(), np.abs(gb).max())
+    # ... and when, on top of that, BatchNorm / ReLU / residual run as the reference's separate torch modules
+    from findnpropagate_amd.spconv import norm as N
+    N.ENABLED = False
+    C.SparseConvFunction = RefFn
+    try:
+        loss_c, grads_c = run()
+    finally:
+        C.SparseConvFunction = real
+        N.ENABLED = True
+    assert set(grads_a) == set(grads_b) == set(grads_c) and len(grads_a) > 60
+    # gradients pass through 21 ReLUs and 21 batch normalisations: a summation-order difference of 1e-7 in a
+    # pre-activation next to zero flips its mask, so the comparison is relative to each tensor's scale, 5e-3
+    for tag, loss_x, grads_x in (("torch convs", loss_b, grads_b), ("torch convs + torch BN modules", loss_c, grads_c)):
+        assert abs(loss_a - loss_x) <= 1e-4 * abs(loss_x), tag
+        for name in grads_a:
+            ga, gb = grads_a[name].float().cpu().numpy(), grads_x[name].float().cpu().numpy()
+            assert np.isfinite(ga).all(), name
+            assert np.abs(ga - gb).max() <= 5e-3 * max(np.abs(gb).max(), 1e-6), (tag, name, np.abs(ga - gb).max(), np.abs(gb).max())
+            if ga.size >= 1000:     # (whole weight tensors: the typical element is far closer than the worst one)
+                assert np.abs(ga - gb).mean() <= 3e-4 * max(np.abs(gb).max(), 1e-6), (tag, name)
 
 
 def test_ddp_wraps_the_backbone(cuda, rng):
@@ -152,3 +166,60 @@ def test_ddp_wraps_the_backbone(cuda, rng):
             assert torch.equal(got[k], want[k]), k          # deterministic kernels + world size 1: identical
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("bf16", 2e-2), ("fp16", 3e-3)])
+@pytest.mark.parametrize("C,n,with_res", [(16, 2, False), (32, 777, True), (64, 20000, True), (128, 5001, False)])
+def test_fused_bn_relu_residual_matches_torch(cuda, rng, dtype, tol, C, n, with_res):
+    """spconv/norm.bn_act (csrc/bnorm.hip) == nn.BatchNorm1d(train) -> (+ residual) -> ReLU evaluated by torch in f32 on
+    the same stored values: output, input / residual / affine gradients, running statistics, num_batches_tracked;
+    rows beyond the device-side row count are ignored; two runs are bit-identical."""
+    from findnpropagate_amd.spconv import norm as N
+    from findnpropagate_amd import sparse as S
+    td = {"f32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dtype]
+    cap = n + 37
+    x0 = torch.from_numpy((rng.standard_normal((cap, C)) * 1.7 + rng.standard_normal(C)).astype(np.float32)).to(cuda).to(td)
+    r0 = torch.from_numpy(rng.standard_normal((cap, C)).astype(np.float32)).to(cuda).to(td) if with_res else None
+    dy = torch.from_numpy(rng.standard_normal((cap, C)).astype(np.float32)).to(cuda).to(td)
+    bn_a = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(cuda).train()
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)))
+        bn_a.bias.copy_(torch.from_numpy(rng.standard_normal(C).astype(np.float32)))
+    import copy
+    bn_b = copy.deepcopy(bn_a)
+    n_dev = S.device_scalar(n, cuda)
+
+    def fused(bn):
+        x = x0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if with_res else None
+        y = N.bn_act(x, n_dev, bn, residual=r, relu=True)
+        (y[:n].float() * dy[:n].float()).sum().backward()
+        return y.detach(), x.grad, None if r is None else r.grad
+
+    y_a, dx_a, dr_a = fused(bn_a)
+    x = x0[:n].float().clone().requires_grad_(True)
+    r = r0[:n].float().clone().requires_grad_(True) if with_res else None
+    z_t = bn_b(x)
+    z_t = z_t + r if with_res else z_t
+    y_t = torch.relu(z_t)
+    (y_t * dy[:n].float()).sum().backward()
+    scale = lambda t: max(float(t.abs().max()), 1e-6)
+    assert (y_a[:n].float() - y_t.detach()).abs().max() <= tol * scale(y_t)
+    # a pre-activation within rounding of zero may take the other side of the ReLU: those elements (a handful) carry a
+    # whole dy instead of none; everything else must agree
+    sure = z_t.detach().abs() > 4 * tol * scale(y_t)
+    assert n < 100 or float((~sure).float().mean()) < 0.05
+    assert ((dx_a[:n].float() - x.grad).abs() * sure).max() <= tol * scale(x.grad) + 2.0 * float((~sure).sum()) / n * scale(dy.float())
+    if with_res:
+        assert ((dr_a[:n].float() - r.grad).abs() * sure).max() <= tol * scale(r.grad)
+    assert (bn_a.weight.grad - bn_b.weight.grad).abs().max() <= max(tol, 1e-4) * scale(bn_b.weight.grad)
+    assert (bn_a.bias.grad - bn_b.bias.grad).abs().max() <= max(tol, 1e-4) * scale(bn_b.bias.grad)
+    assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 1
+    bn_c = copy.deepcopy(bn_b)
+    bn_c.load_state_dict(bn_a.state_dict())
+    bn_d = copy.deepcopy(bn_c)
+    y1, dx1, _ = fused(bn_c)
+    y2, dx2, _ = fused(bn_d)
+    assert torch.equal(y1[:n], y2[:n]) and torch.equal(dx1[:n], dx2[:n]) and torch.equal(bn_c.weight.grad, bn_d.weight.grad)
