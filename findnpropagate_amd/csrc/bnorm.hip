@@ -18,6 +18,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxParts = 256;   // statistics workgroups (one per CU)
+constexpr int kFinC = 16;        // channels per finishing workgroup
 
 __device__ __forceinline__ float ldf(const float *p, size_t i) { return p[i]; }
 __device__ __forceinline__ float ldf(const __bf16 *p, size_t i) { return (float)p[i]; }
@@ -127,8 +128,8 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T *__restrict_
     }
 }
 
-// One workgroup adds the partials: thread (slice, c) sums the partials p = slice, slice + S, ... of channel c (S = 256 / C
-// slices), the slices meet in an LDS tree — a fixed order, whatever the timing.  Forward: mean / invstd / running
+// A workgroup per 16 channels adds the partials: thread (slice, c) sums the partials p = slice, slice + S, ... of channel c
+// (S = 16 slices), the slices meet in an LDS tree — a fixed order, whatever the timing.  Forward: mean / invstd / running
 // statistics.  Backward: dbeta = sum g, dgamma = sum g * xhat.
 __global__ __launch_bounds__(kThreads) void bn_finish_kernel(const double *__restrict__ part, int parts, int C,
                                                              const int *__restrict__ n_rows, int cap, int mode, float eps,
@@ -137,8 +138,10 @@ __global__ __launch_bounds__(kThreads) void bn_finish_kernel(const double *__res
                                                              float *__restrict__ running_var) {
     __shared__ double ra[kThreads], rb[kThreads];
     const int n = min(*n_rows, cap);
-    const int S = kThreads / C;                       // (C is a power of two <= 256)
-    const int c = threadIdx.x % C, slice = threadIdx.x / C;
+    // a workgroup finishes kFinC channels (grid = C / kFinC workgroups; C is a power of two >= 8)
+    const int CW = C < kFinC ? C : kFinC, S = kThreads / CW;
+    const int cl = threadIdx.x % CW, slice = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + cl;
     double a = 0.0, b = 0.0;
     for (int p = slice; p < parts; p += S) {
         a += part[((size_t)p * C + c) * 2];
@@ -149,14 +152,14 @@ __global__ __launch_bounds__(kThreads) void bn_finish_kernel(const double *__res
     __syncthreads();
     for (int s = S / 2; s > 0; s >>= 1) {
         if (slice < s) {
-            ra[threadIdx.x] += ra[threadIdx.x + s * C];
-            rb[threadIdx.x] += rb[threadIdx.x + s * C];
+            ra[threadIdx.x] += ra[threadIdx.x + s * CW];
+            rb[threadIdx.x] += rb[threadIdx.x + s * CW];
         }
         __syncthreads();
     }
     if (slice == 0) {
-        a = ra[c];
-        b = rb[c];
+        a = ra[cl];
+        b = rb[cl];
         if (mode == 0) {
             const double m = n > 0 ? a / n : 0.0;
             double var = n > 0 ? b / n - m * m : 0.0;
@@ -249,7 +252,7 @@ int run_forward(const void *x, const int *n_rows, int cap, int C, const float *g
                        (const T *)x, (const T *)nullptr, (const T *)nullptr, n_rows, cap, C, (const float *)nullptr,
                        (const float *)nullptr, 0, (double *)ws);
     FNP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(1), dim3(kThreads), 0, s, (const double *)ws, g, C, n_rows, cap, 0, eps, momentum,
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(C <= kFinC ? 1 : C / kFinC), dim3(kThreads), 0, s, (const double *)ws, g, C, n_rows, cap, 0, eps, momentum,
                        save_mean, save_invstd, rm, rv);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_apply_kernel<T>), dim3(fnp_grid_for((long long)cap * (C / 8), kThreads, 2048)), dim3(kThreads), 0,
@@ -266,7 +269,7 @@ int run_backward(const void *dy, const void *x, const void *y, const int *n_rows
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_stats_kernel<T, 1>), dim3(g), dim3(kThreads), kThreads * 16 * sizeof(double), s,
                        (const T *)x, (const T *)dy, (const T *)y, n_rows, cap, C, save_mean, save_invstd, relu, (double *)ws);
     FNP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(1), dim3(kThreads), 0, s, (const double *)ws, g, C, n_rows, cap, 1, 0.f, 0.f, dbeta,
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(C <= kFinC ? 1 : C / kFinC), dim3(kThreads), 0, s, (const double *)ws, g, C, n_rows, cap, 1, 0.f, 0.f, dbeta,
                        dgamma, (float *)nullptr, (float *)nullptr);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_backward_apply_kernel<T>), dim3(fnp_grid_for((long long)cap * (C / 8), kThreads, 2048)),

@@ -42,8 +42,15 @@ class SparseConvFunction(torch.autograd.Function):
         K, Cout, Cin = rb.K, weight.shape[0], weight.shape[-1]
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            nbr_t = S.rulebook_transpose(rb, n_out_dev, feats.shape[0])
-            dx = S.conv_dgrad(grad_out, S.pack_weight(weight, feats.dtype), nbr_t, n_in_dev, feats.shape[0])
+            wp = S.pack_weight(weight, feats.dtype)
+            if rb.out_indices is None and rb.cap_out == feats.shape[0]:
+                # SubM: the rulebook is its own transpose up to the mirror of the offsets (input i feeds output o through
+                # offset k  <=>  o is the neighbour of i at offset K-1-k): same table, weight slabs in mirrored order
+                dx = S.conv_dgrad(grad_out, wp.flip(0), rb.nbr, n_in_dev, feats.shape[0])
+            else:
+                if getattr(rb, "_nbr_t", None) is None or rb._nbr_t.shape[1] != feats.shape[0]:
+                    rb._nbr_t = S.rulebook_transpose(rb, n_out_dev, feats.shape[0])   # (kept with the rulebook: one per layer)
+                dx = S.conv_dgrad(grad_out, wp, rb._nbr_t, n_in_dev, feats.shape[0])
         if ctx.needs_input_grad[1]:
             dwp = S.conv_wgrad(feats, grad_out, rb, n_out_dev, Cin, Cout)               # (K, Cout, Cin) f32
             dw = dwp.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
