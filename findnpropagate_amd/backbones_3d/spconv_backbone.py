@@ -300,6 +300,8 @@ class _PointsGraph:
 
     def _body(self, voxel_cfg):
         e = self.engine
+        e._ensure_clean()
+        e._dirty = True
         grids = e._get_grids(self.batch_size, self.pts.device)
         vox = S.voxelize(self.pts, self.off, self.batch_size, voxel_cfg, grid=grids[0], workspace=e._vox_ws)
         e._vox_ws = vox['workspace']
@@ -320,6 +322,7 @@ class FusedResBackbone:
         self.cap_factor = [3.0, 2.0, 1.0, 1.0]
         self._vox_ws = None
         self._graphs = {}
+        self._dirty = False      # a forward is in flight or died before its sparse clear: grids may hold stale bits
         # measurement hooks (bench.py): when `profile` is a list every conv launch is bracketed by
         # stream events, (tag, start, end) appended; `rulebook_log` receives (tag, Rulebook, n_dev)
         self.profile = None
@@ -372,7 +375,16 @@ class FusedResBackbone:
         return g
 
     # ---- execution ------------------------------------------------------------------------
+    def _ensure_clean(self):
+        if self._dirty:
+            for gs in self._grids.values():
+                for g in gs:
+                    g.zero_()
+            self._dirty = False
+
     def run_points(self, points, batch_offsets, batch_size, voxel_cfg, sync=True):
+        self._ensure_clean()
+        self._dirty = True
         grids = self._get_grids(batch_size, points.device)
         vox = S.voxelize(points, batch_offsets, batch_size, voxel_cfg, grid=grids[0], workspace=self._vox_ws)
         self._vox_ws = vox['workspace']
@@ -434,6 +446,12 @@ class FusedResBackbone:
             grid1 = None
 
     def _run_once(self, feats, indices, n1, batch_size, grid1, sync, n_cells=None, final_dtype=None):
+        # The persistent rank grids must be all-zero on entry and are only cleared sparsely at the end of a run: if a
+        # previous run died in between (FnpError, out of memory, KeyboardInterrupt), wipe them before they are reused
+        # (run_points checks before it voxelises into grid1)
+        if grid1 is None:
+            self._ensure_clean()
+        self._dirty = True
         m, P, act = self.m, self.prepare(), self.act
         if final_dtype not in (None, act, torch.float32):
             final_dtype = None       # (the conv epilogue writes the activation dtype or f32; anything else is cast by the caller)
@@ -503,9 +521,9 @@ class FusedResBackbone:
         xo = conv(x_prev, P['out'], rbo, rbo.out_n, out_dtype=final_dtype or act)
         stage.append((xo, rbo.out_indices, rbo.out_n, rbo.out_grid))
 
-        # leave every persistent grid zeroed for the next call (O(rows) sparse clear)
-        for l, (_, idx, n, g) in enumerate(stage):
-            S.clear_grid(g, idx, n_cells if (l == 0 and n_cells is not None) else n)
+        # leave every persistent grid zeroed for the next call (O(rows) sparse clear, all five grids in one launch)
+        S.clear_grids([(g, idx, n_cells if (l == 0 and n_cells is not None) else n) for l, (_, idx, n, g) in enumerate(stage)])
+        self._dirty = False
 
         shapes = self._stage_shapes()
         if not sync:
@@ -521,6 +539,7 @@ class FusedResBackbone:
             # wipe the persistent grids before the retry with larger buffers
             for g in grids:
                 g.zero_()
+            self._dirty = False
             return None
         tensors = []
         for l, (x, idx, n, g) in enumerate(stage):

@@ -121,7 +121,7 @@ __device__ __forceinline__ int rg_lookup(const RG &g, int b, int z, int y, int x
 // per lane, four offsets (4 x 256 contiguous bytes) per wave instruction instead of one: the 4-byte form was
 // bound by the number of store instructions, not by bytes.
 template <int KZ, int KY, int KX>
-__device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, int lox, int *__restrict__ strip, int sstride) {
+__device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, int lox, int *strip, int sstride) {   // (strip: LDS shared by the lanes of a wave - no __restrict__)
     const int bz0 = loz >> 2, by0 = loy >> 2, bx0 = lox >> 2;   // (arithmetic shift: -1 -> block -1, outside)
     unsigned long long w[2][2][2];
     unsigned base[2][2][2];

@@ -465,7 +465,11 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
         constexpr int MBT = decltype(mbt_tag)::value;
         const int row0 = tile_base + wave * (MBT * 16);
         if constexpr (FUSED) {
-            // rulebook rows of this wave's tile: lane j resolves the 27 input cells of row row0 + j
+            // rulebook rows of this wave's tile: lane j resolves the 27 input cells of row row0 + j.  The strip is
+            // written by lane j and read by every lane of the wave (and overwritten by the next tile): wave-level
+            // fences + barriers on both sides pin the order of those LDS accesses whatever the compiler schedules.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             frow0 = row0;
             if (lane < MBT * 16) {
                 const int r = row0 + lane;
@@ -478,6 +482,9 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                     for (int k = 0; k < 27; ++k) fstrip[k * SR + lane] = -1;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         // feature window of this tile: WROWS consecutive input rows around the tile's own rows.  With
         // rows in rank-grid order ~96 % of a tile's neighbours lie in it, each fetched once instead

@@ -388,6 +388,45 @@ extern "C" int fnp_rankgrid_clear(const int *coords, const int *n_rows, int cap,
     return FNP_OK;
 }
 
+// All persistent grids of a forward in ONE launch (blockIdx.y = grid): the fused backbone clears five of them per step.
+struct ClearJob {
+    const int *coords, *n_rows;
+    int cap;
+    RG g;
+};
+struct ClearJobs { ClearJob j[8]; };
+
+__global__ __launch_bounds__(kThreads) void rg_clear_multi_kernel(ClearJobs jobs) {
+    const ClearJob &J = jobs.j[blockIdx.y];
+    const int n = min(*J.n_rows, J.cap);
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const int4 c = reinterpret_cast<const int4 *>(J.coords)[i];
+        if (!coord_ok(J.g.d, c)) continue;
+        const long long blk = rg_block_of(J.g.d, c.x, c.y, c.z, c.w);
+        J.g.bits[blk] = 0ull;
+        J.g.summ[blk >> 6] = 0ull;
+    }
+}
+
+extern "C" int fnp_rankgrid_clear_multi(int count, const int *const *coords, const int *const *n_rows, const int *caps,
+                                        const fnp_rankgrid *grids, fnp_stream_t stream) {
+    if (count <= 0 || count > 8 || !coords || !n_rows || !caps || !grids) return FNP_ERR_ARG;
+    ClearJobs jobs{};
+    int cap_max = 1;
+    for (int i = 0; i < count; ++i) {
+        if (!coords[i] || !n_rows[i] || caps[i] <= 0 || !fnp_rg_valid(&grids[i])) return FNP_ERR_ARG;
+        jobs.j[i].coords = coords[i];
+        jobs.j[i].n_rows = n_rows[i];
+        jobs.j[i].cap = caps[i];
+        jobs.j[i].g = fnp_rg_view(&grids[i]);
+        if (caps[i] > cap_max) cap_max = caps[i];
+    }
+    hipLaunchKernelGGL(rg_clear_multi_kernel, dim3(fnp_grid_for(cap_max, kThreads, 512), count), dim3(kThreads), 0,
+                       (hipStream_t)stream, jobs);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
 // ---- host entry point ---------------------------------------------------------------------------------------------
 // The dataloader-side voxeliser (spconv.utils.Point2VoxelCPU3d.point_to_voxel as DataProcessor calls it inside
 // DataLoader workers, pcdet/datasets/processor/data_processor.py:38-61,255-302): a plain host loop with the

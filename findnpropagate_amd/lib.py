@@ -103,6 +103,7 @@ SIGNATURES = {
     "fnp_rankgrid_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "fnp_rankgrid_build": (c_int, [P, P, c_int, POINTER(RankGridC), P, c_int64, P]),
     "fnp_rankgrid_clear": (c_int, [P, P, c_int, POINTER(RankGridC), P]),
+    "fnp_rankgrid_clear_multi": (c_int, [c_int, P, P, P, P, P]),
     "fnp_voxelize_workspace_bytes": (c_int64, [c_int64, POINTER(VoxelCfg), POINTER(RankGridC)]),
     "fnp_voxelize": (c_int, [P, c_int, P, POINTER(VoxelCfg), POINTER(RankGridC), P, c_int64,
                              P, P, P, P, P, P, c_int, P]),

@@ -176,6 +176,20 @@ def clear_grid(grid, indices, n_dev):
     _l.check(rc, "fnp_rankgrid_clear")
 
 
+def clear_grids(jobs):
+    """clear_grid for several grids in ONE launch.  jobs: list of (grid, indices, n_dev), at most 8."""
+    L = _l.load()
+    k = len(jobs)
+    P = ctypes.c_void_p * k
+    coords = P(*[_l.ptr(idx) for _, idx, _ in jobs])
+    rows = P(*[_l.ptr(n) for _, _, n in jobs])
+    caps = (ctypes.c_int * k)(*[max(idx.shape[0], 1) for _, idx, _ in jobs])
+    grids = (_l.RankGridC * k)(*[g.c() for g, _, _ in jobs])
+    rc = L.fnp_rankgrid_clear_multi(k, ctypes.cast(coords, ctypes.c_void_p), ctypes.cast(rows, ctypes.c_void_p),
+                                    ctypes.cast(caps, ctypes.c_void_p), ctypes.cast(grids, ctypes.c_void_p), _l.stream())
+    _l.check(rc, "fnp_rankgrid_clear_multi")
+
+
 # --------------------------------------------------------------------------------- rulebooks
 def rulebook_subm(indices, n_dev, grid, ksize):
     L = _l.load()

@@ -154,6 +154,10 @@ int fnp_rankgrid_build(const int *coords, const int *n_rows, int cap, const fnp_
 int fnp_rankgrid_clear(const int *coords, const int *n_rows, int cap, const fnp_rankgrid *grid,
                        fnp_stream_t stream);
 
+/* fnp_rankgrid_clear for up to 8 grids in one launch (HOST arrays of `count` device pointers / capacities / grids). */
+int fnp_rankgrid_clear_multi(int count, const int *const *coords, const int *const *n_rows, const int *caps,
+                             const fnp_rankgrid *grids, fnp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Voxelisation + MeanVFE — replaces spconv.utils.Point2VoxelCPU3d.point_to_voxel as called
  * at pcdet/datasets/processor/data_processor.py:38-61 and MeanVFE.forward

@@ -17,8 +17,11 @@ pytestmark = pytest.mark.gpu
 
 def _reexport(mod, prefix):
     for name in dir(mod):
+        obj = getattr(mod, name)
         if name.startswith("test_"):
-            globals()[f"test_{prefix}_{name[5:]}"] = getattr(mod, name)
+            globals()[f"test_{prefix}_{name[5:]}"] = obj
+        elif "fixture" in type(obj).__name__.lower() or hasattr(obj, "_pytestfixturefunction") or hasattr(obj, "_fixture_function_marker"):
+            globals()[name] = obj          # module-level fixtures the re-exported tests ask for
 
 
 _reexport(_hi, "host_iou")
