@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU leg (0 = min(physical cores, 16): "
                                                               "a one-GPU box grants 16 cores)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket conv launches with events")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the extra small-batch measurements (1 and 8 scenes per step)")
     return ap.parse_args()
 
 
@@ -286,6 +287,32 @@ def main():
             # f32 runs on v_mfma_f32_16x16x4_f32 at the f32 vector rate (157.3 TFLOP/s dense): that pipe, not memory, bounds it
             out["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s", "frac": tflops / 157.3,
                                "hbm_gbs_algorithmic": achieved, **common}
+
+    if rank == 0 and world == 1 and not args.no_sweep and not args.graph:
+        # Extra fields (the headline stays `value` at --batch): the same path at 1 and 8 scenes per step — batch size 1 is
+        # what the reference's extraction script and configs[0] run — as stream launches and replayed from a hipGraph.
+        sweep = {}
+        for b in (1, 8):
+            if b == B:
+                continue
+            p_np, o_np = syn.make_batch(list(range(b)))
+            p_b, o_b = torch.from_numpy(p_np).to(dev), torch.from_numpy(o_np).to(dev)
+            row = {}
+            for mode in ("stream", "graph"):
+                fn = (lambda: net.forward_points(p_b, o_b, b, cfg)) if mode == "stream" else (lambda: net.forward_points_graphed(p_b, o_b, b, cfg))
+                with torch.no_grad():
+                    for _ in range(5):
+                        fn()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(50):
+                        fn()
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / 50
+                row[f"ms_per_step_{mode}"] = 1e3 * dt
+                row[f"scenes_per_s_{mode}"] = b / dt
+            sweep[str(b)] = row
+        out["batch_sweep"] = sweep
 
     if rank == 0 and world == 1 and args.cpu_scenes > 0:   # (baseline leg: N = 1 only)
         out["cpu_baseline"] = cpu_baseline(args, net, syn)

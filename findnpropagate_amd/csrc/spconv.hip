@@ -925,7 +925,11 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
     // layers); the narrow ALLK layers stage all weights once per workgroup, so keep them few too.
     // The kernel splits the rows evenly over whatever grid it gets.
     const int resident = 256 * wg_per_cu;
-    const int grid = tiles < resident ? tiles : resident;
+    // Small inputs (a single scene: the reference's extraction runs batch size 1): with fewer full tiles than resident
+    // workgroups most CUs would idle while a few sweep MB blocks per wave — split finer instead, down to one 16-site
+    // block per wave (the kernel runs such a range as a partial tile).  The split never changes results.
+    const int fine = fnp_divup(cap, MfmaWg<CIN, COUT>::NW * 16);
+    const int grid = tiles >= resident ? resident : (fine < resident ? fine : resident);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MfmaWg<CIN, COUT>::NW * 64), lds, s, (const TAct *)x, x_bytes, (const TAct *)w,
                        nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu, hints, frb);
     FNP_LAUNCH_CHECK();

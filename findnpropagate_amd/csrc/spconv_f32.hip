@@ -75,7 +75,13 @@ __global__ __launch_bounds__(256, (F32Occ<COUT>::WAVES)) void spconv_mfma_f32_ke
     // byte offset of this lane's 16 bytes in weight row co = nb*16 + l15 of offset 0, chunk 0
     const unsigned woff0 = (unsigned)(l15 * CIN + q * 4) * 4u;
 
-    for (int tile = row_begin + wave * ROWS_PER_WAVE; tile < row_end; tile += ROWS_PER_WG) {
+    // a range shorter than one workgroup tile (small inputs, finer grid) is cut evenly over the four waves
+    const int nblk_wg = (row_end - row_begin + 15) >> 4;
+    const bool small = nblk_wg < NW * MB;
+    const int bpw = (nblk_wg + NW - 1) / NW;
+    const int tile0 = row_begin + wave * (small ? bpw * 16 : ROWS_PER_WAVE);
+    const int row_end_w = small ? min(row_end, tile0 + bpw * 16) : row_end;
+    for (int tile = tile0; tile < row_end_w; tile += small ? (1 << 30) : ROWS_PER_WG) {
         f32x4 acc[NB][MB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -84,9 +90,9 @@ __global__ __launch_bounds__(256, (F32Occ<COUT>::WAVES)) void spconv_mfma_f32_ke
 
         auto entry = [&](int k, int mb) -> int {
             const int r = tile + mb * 16 + l15;
-            const int rc = r < row_end ? r : row_end - 1, kc = k < K ? k : K - 1;
+            const int rc = r < row_end_w ? r : row_end_w - 1, kc = k < K ? k : K - 1;
             const int v = nbr[(size_t)kc * nbr_stride + rc];
-            return (r < row_end && k < K) ? v : -1;
+            return (r < row_end_w && k < K) ? v : -1;
         };
         auto row_off = [&](int id) -> unsigned { return id < 0 ? 0x80000000u : (unsigned)id * (unsigned)(CIN * 4) + (unsigned)q * 16u; };
         auto load_b = [&](unsigned roff, int c) -> u32x4 { return __builtin_amdgcn_raw_buffer_load_b128(xrsrc, roff + (unsigned)c * 64u, 0, 0); };
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256, (F32Occ<COUT>::WAVES)) void spconv_mfma_f32_ke
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const int r = tile + mb * 16 + l15;
-                if (r >= row_end) continue;
+                if (r >= row_end_w) continue;
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = scale ? acc[nb][mb][j] * sc[j] + sh[j] : acc[nb][mb][j];
@@ -219,7 +225,8 @@ int launch_f32(const void *x, long long x_bytes, const void *w, const int *nbr, 
     constexpr int MB = COUT <= 32 ? 4 : COUT == 64 ? FNP_F32_MB64 : FNP_F32_MB128;
     const int tiles = fnp_divup(cap, 4 * MB * 16);
     const int resident = 256 * F32Occ<COUT>::WAVES;      // one 4-wave workgroup per CU and wave slot
-    const int grid = tiles < resident ? tiles : resident;
+    const int fine = fnp_divup(cap, 4 * 16);            // small inputs: down to one 16-site block per wave
+    const int grid = tiles >= resident ? resident : (fine < resident ? fine : resident);
     if (wperm)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(spconv_mfma_f32_kernel<CIN, COUT, MB, true>), dim3(grid), dim3(256), 0, s,
                            (const float *)x, (int)x_bytes, (const float *)w, nbr, nbr_stride, K, n_out, cap, (float *)y, scale,
