@@ -172,3 +172,37 @@ def test_edge_cases(cuda):
     assert torch.equal(a[0], c[0])
     with pytest.raises(NotImplementedError):
         _head(lambda _: dets, dict(PARAMS, topk=3))
+
+
+def test_head_reads_glip_files_through_its_default_detector(cuda, tmp_path):
+    """a12 end to end: FrustumProposerOG built WITHOUT an injected detector constructs PreprocessedGLIP itself
+    (frustum_proposals_v1.py:254-267) from a GLIP prediction file + COCO meta json and yields the same proposals as the
+    same detections handed over directly."""
+    import json
+    from findnpropagate_amd.dense_heads import FrustumProposerOG
+
+    scenes = [syn.make_seeker_scene(s) for s in (60, 61)]
+    bd, dets = _batch(scenes, cuda)
+    cams = ['CAM_BACK', 'CAM_BACK_LEFT', 'CAM_BACK_RIGHT', 'CAM_FRONT', 'CAM_FRONT_LEFT', 'CAM_FRONT_RIGHT']
+    preds, images, paths = [], [], []
+    for b, sc in enumerate(scenes):
+        paths.append([])
+        for c in range(6):
+            m = sc["dets"][4] == c
+            preds.append({"bbox": torch.from_numpy(sc["dets"][0][m]), "scores": torch.from_numpy(sc["dets"][2][m]),
+                          "labels": torch.from_numpy(sc["dets"][1][m])})
+            name = f"samples/{cams[c]}/scene{b}_{c}.jpg"
+            images.append({"id": len(images), "token": f"tok{b}", "file_name": name})
+            paths[-1].append(name)
+    torch.save(preds, tmp_path / "glip.pth")
+    json.dump({"images": images, "categories": []}, open(tmp_path / "meta.json", "w"))
+    cfg = {"PARAMS": dict(PARAMS), "PREDS_PATH": "PreprocessedGLIP", "BOX_FORMAT": "xyxy",
+           "GLIP_PRED_PTH": str(tmp_path / "glip.pth"), "GLIP_META_COCO": str(tmp_path / "meta.json")}
+    head = FrustumProposerOG(model_cfg=cfg).eval()
+    bd2 = dict(bd, image_paths=paths, metadata=[{"token": "tok0"}, {"token": "tok1"}])
+    with torch.no_grad():
+        a = head.get_proposals(bd2)
+        b = _head(lambda _: dets).get_proposals(dict(bd))
+    assert a[0].shape[0] > 10
+    for x, y in zip(a, b):
+        assert torch.equal(x.cpu(), y.cpu())

@@ -25,6 +25,12 @@ def short(k):
     m = re.search(r'spconv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (__bf16|float)>', k)
     if m:
         return "spconv_mfma_kernel<%s,%s,%s,%s,%s,%s>" % (*m.groups()[:5], "bf16" if m.group(6) == "__bf16" else "f32")
+    m = re.search(r'spconv_mfma_f32_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E', k)
+    if m:
+        return "spconv_mfma_f32_kernel<%s,%s,%s>" % (m.group(1), m.group(2), m.group(3))
+    m = re.search(r'spconv_mfma_f32_kernel<(\d+), (\d+), (\d+), (true|false)>', k)
+    if m:
+        return "spconv_mfma_f32_kernel<%s,%s,%s>" % m.groups()[:3]
     return re.sub(r'\(.*', '', k)[:80]
 
 
