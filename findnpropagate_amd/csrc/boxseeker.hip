@@ -33,8 +33,10 @@ __device__ __forceinline__ void mat3_apply(const float *M, float x, float y, flo
     oz = M[6] * x + M[7] * y + M[8] * z;
 }
 
-// project_to_camera (:1431-1475) for one point; cam = 24 floats: L33 (9) | Lt (3) | combine (9) | c2l_t (3)
-__device__ __forceinline__ void project(const float *aug_inv, const float *aug_t, const float *cam, float x, float y,
+constexpr int kCam = 45;   // floats per (scene, camera): L33 (9) | Lt (3) | combine (9) | c2l_t (3) | post_rot (9) | post_trans (3) | post_rot^-1 (9)
+
+// project_to_camera (:1431-1475) for one point; img_aug: the image-plane augmentation of :1456-1458 is applied
+__device__ __forceinline__ void project(const float *aug_inv, const float *aug_t, const float *cam, bool img_aug, float x, float y,
                                         float z, float &u, float &v, float &d) {
     float px, py, pz, qx, qy, qz;
     mat3_apply(aug_inv, x - aug_t[0], y - aug_t[1], z - aug_t[2], px, py, pz);
@@ -45,11 +47,25 @@ __device__ __forceinline__ void project(const float *aug_inv, const float *aug_t
     d = fminf(fmaxf(qz, 1e-5f), 1e5f);
     u = qx / d;
     v = qy / d;
+    if (img_aug) {
+        float a, b, c;
+        mat3_apply(cam + 24, u, v, d, a, b, c);
+        u = a + cam[33];
+        v = b + cam[34];
+        d = c + cam[35];
+    }
 }
 
-// get_geometry_at_image_coords (:1509-1545, no post_rots)
-__device__ __forceinline__ void backproject(const float *aug_R, const float *aug_t, const float *cam, float u, float v,
+// get_geometry_at_image_coords (:1509-1545); img_aug: the post-transformation is undone first (:1525-1527)
+__device__ __forceinline__ void backproject(const float *aug_R, const float *aug_t, const float *cam, bool img_aug, float u, float v,
                                             float d, float &x, float &y, float &z) {
+    if (img_aug) {
+        float a, b, c;
+        mat3_apply(cam + 36, u - cam[33], v - cam[34], d - cam[35], a, b, c);
+        u = a;
+        v = b;
+        d = c;
+    }
     float cx, cy, cz;
     mat3_apply(cam + 12, u * d, v * d, d, cx, cy, cz);
     cx += cam[21];
@@ -65,7 +81,7 @@ struct Shared {
     unsigned hist[256];
     unsigned sel_prefix, sel_mask, sel_k;
     unsigned count, scratch_u;
-    float cam[24], aug_R[9], aug_inv[9], aug_t[3];
+    float cam[kCam], aug_R[9], aug_inv[9], aug_t[3];
     float fr[8][3];
     float ext_min[3], ext_max[3];
     float bev_pts[16][3];
@@ -148,7 +164,7 @@ __device__ float quantile(Shared &S, const float *__restrict__ list, int m, floa
 __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
     const float *__restrict__ points, const int *__restrict__ scene_off, const fnp_seeker_params prm,
     const float *__restrict__ scene_mats,   // (S, 21): aug_R 9 | aug_inv 9 | aug_t 3
-    const float *__restrict__ cam_mats,     // (S, 6, 24)
+    const float *__restrict__ cam_mats,     // (S, 6, kCam)
     const float *__restrict__ frusts,       // (F, 8): scene, cam, x1, y1, x2, y2, label, score
     const float *__restrict__ base_boxes,   // (10, R, 7)
     const float *__restrict__ base_corners, // (10, R, 8, 3)
@@ -163,7 +179,8 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
     const int scene = (int)fr[0], cam = (int)fr[1], label = (int)fr[6];
     const float x1 = fr[2], y1 = fr[3], x2 = fr[4], y2 = fr[5];
     const int R = prm.num_rotations * prm.num_sizes, NC = prm.num_mags * R;
-    if (tid < 24) S.cam[tid] = cam_mats[((size_t)scene * 6 + cam) * 24 + tid];
+    if (tid < kCam) S.cam[tid] = cam_mats[((size_t)scene * 6 + cam) * kCam + tid];
+    const bool ia = prm.has_img_aug != 0;
     if (tid < 9) {
         S.aug_R[tid] = scene_mats[(size_t)scene * 21 + tid];
         S.aug_inv[tid] = scene_mats[(size_t)scene * 21 + 9 + tid];
@@ -182,7 +199,7 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
         float u = 0, v = 0, d = 0;
         if (i < p1) {
             const float *p = points + (size_t)i * prm.point_stride + prm.xyz_offset;
-            project(S.aug_inv, S.aug_t, S.cam, p[0], p[1], p[2], u, v, d);
+            project(S.aug_inv, S.aug_t, S.cam, ia, p[0], p[1], p[2], u, v, d);
             const bool on_img = (v < (float)prm.image_h) && (v >= 0.f) && (u < (float)prm.image_w) && (u >= 0.f);
             in = on_img && (v < y2) && (v >= y1) && (u < x2) && (u >= x1);
         }
@@ -221,16 +238,16 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
         const float sg[3] = {sx[tid], sy[tid], sz[tid]};
 #pragma unroll
         for (int a = 0; a < 3; ++a) c3[a] = (hi3[a] - lo3[a]) * (sg[a] / 2.0f) + (hi3[a] + lo3[a]) / 2.0f;   // :128-140
-        backproject(S.aug_R, S.aug_t, S.cam, c3[0], c3[1], c3[2], S.fr[tid][0], S.fr[tid][1], S.fr[tid][2]);
+        backproject(S.aug_R, S.aug_t, S.cam, ia, c3[0], c3[1], c3[2], S.fr[tid][0], S.fr[tid][1], S.fr[tid][2]);
     }
     if (tid == 8)
-        backproject(S.aug_R, S.aug_t, S.cam, (x1 + x2) / 2.0f, (y1 + y2) / 2.0f, qc, S.wc[0], S.wc[1], S.wc[2]);   // :630-632
+        backproject(S.aug_R, S.aug_t, S.cam, ia, (x1 + x2) / 2.0f, (y1 + y2) / 2.0f, qc, S.wc[0], S.wc[1], S.wc[2]);   // :630-632
 
     // ---- D: back-project the selected points, per-axis extent --------------------------------
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = tid; i < m; i += kThreads) {
         float x, y, z;
-        backproject(S.aug_R, S.aug_t, S.cam, list[(size_t)i * 3], list[(size_t)i * 3 + 1], list[(size_t)i * 3 + 2], x, y, z);
+        backproject(S.aug_R, S.aug_t, S.cam, ia, list[(size_t)i * 3], list[(size_t)i * 3 + 1], list[(size_t)i * 3 + 2], x, y, z);
         lxyz[(size_t)i * 3] = x;
         lxyz[(size_t)i * 3 + 1] = y;
         lxyz[(size_t)i * 3 + 2] = z;
@@ -322,7 +339,7 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float u, v, d;
-            project(S.aug_inv, S.aug_t, S.cam, cor[k][0] + f2c[0], cor[k][1] + f2c[1], cor[k][2] + f2c[2], u, v, d);
+            project(S.aug_inv, S.aug_t, S.cam, ia, cor[k][0] + f2c[0], cor[k][1] + f2c[1], cor[k][2] + f2c[2], u, v, d);
             u = fminf(fmaxf(u, 0.f), (float)prm.image_w);
             v = fminf(fmaxf(v, 0.f), (float)prm.image_h);
             bx1 = fminf(bx1, u); by1 = fminf(by1, v); bx2 = fmaxf(bx2, u); by2 = fmaxf(by2, v);
@@ -376,7 +393,7 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
     // ---- H: second-stage score, best candidate ------------------------------------------------
     if (tid == 0) {
         int nmax = 0, any = 0;
-        float dmin = INFINITY, dmax = -INFINITY;
+        float dmin = INFINITY, dmax = -INFINITY, emax = -INFINITY;
         for (int c = 0; c < NC; ++c) {
             if (S.cvalid[c] >= 1) {   // dists are ranked over the distance-filtered set (:886-893)
                 dmin = fminf(dmin, S.cdist[c]);
@@ -385,6 +402,8 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
             if (S.cvalid[c] == 2) {
                 any = 1;
                 nmax = max(nmax, S.ccount[c]);
+                if (prm.ego_w > 0.f)   // distance of the candidate's centre to the ego vehicle (:1017-1019)
+                    emax = fmaxf(emax, sqrtf(S.cbox[c][0] * S.cbox[c][0] + S.cbox[c][1] * S.cbox[c][1] + S.cbox[c][2] * S.cbox[c][2]));
             }
         }
         int best = -1;
@@ -393,8 +412,17 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
             if (S.cvalid[c] != 2) continue;
             const float soft = (float)S.ccount[c] / ((float)nmax + 1e-8f);
             const float dr = 1.0f - (S.cdist[c] - dmin) / (dmax - dmin + 1e-8f);
-            float s = soft * prm.dns_w + S.ciou[c] * prm.iou_w;
-            s = s + dr * prm.dst_w;
+            float s;
+            if (!prm.mult) {          // :997
+                s = soft * prm.dns_w + S.ciou[c] * prm.iou_w;
+                s = s + dr * prm.dst_w;
+            } else {                  // MULT, :999
+                s = soft * prm.dns_w * S.ciou[c] * prm.iou_w * dr * prm.dst_w;
+            }
+            if (prm.ego_w > 0.f) {    // :1017-1021
+                const float ego = sqrtf(S.cbox[c][0] * S.cbox[c][0] + S.cbox[c][1] * S.cbox[c][1] + S.cbox[c][2] * S.cbox[c][2]);
+                s = s + prm.ego_w * (ego / emax);
+            }
             if (s > best_s) {   // first maximum = order of a stable descending sort
                 best_s = s;
                 best = c;

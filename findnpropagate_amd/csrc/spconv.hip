@@ -929,7 +929,11 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
     // workgroups most CUs would idle while a few sweep MB blocks per wave — split finer instead, down to one 16-site
     // block per wave (the kernel runs such a range as a partial tile).  The split never changes results.
     const int fine = fnp_divup(cap, MfmaWg<CIN, COUT>::NW * 16);
+#ifdef FNP_NO_FINE   // (development switch)
+    const int grid = tiles < resident ? tiles : resident;
+#else
     const int grid = tiles >= resident ? resident : (fine < resident ? fine : resident);
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MfmaWg<CIN, COUT>::NW * 64), lds, s, (const TAct *)x, x_bytes, (const TAct *)w,
                        nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu, hints, frb);
     FNP_LAUNCH_CHECK();

@@ -110,8 +110,11 @@ class FrustumProposerOG(nn.Module):
         self.lq, self.uq, self.cq = lq, uq, cq
         self.iou_w, self.dst_w, self.dns_w, self.min_cam_iou = iou_w, dst_w, dns_w, min_cam_iou
         self.box_fmt = _get(model_cfg, 'BOX_FORMAT', 'xyxy')
-        unsupported = [n for n, v in (("MULTICAM_IOU", self.MULTICAM_IOU), ("OCCL_MULT", self.OCCL_MULT), ("MULT", self.MULT),
-                                       ("aln_w", self.aln_w), ("ego_w", self.ego_w), ("occl_w", self.occl_w),
+        # not built: MULTICAM_IOU / OCCL_MULT / occl_w (the reference's calc_occl_scores and multicam_ious paths), aln_w (a
+        # randomised torch.pca_lowrank per candidate: not reproducible), topk > 1, rand_center, search_depth — none of them
+        # is set by a shipped config (tools/cfgs/nuscenes_box_seeker_proposals.yaml:83)
+        unsupported = [n for n, v in (("MULTICAM_IOU", self.MULTICAM_IOU), ("OCCL_MULT", self.OCCL_MULT),
+                                       ("aln_w", self.aln_w), ("occl_w", self.occl_w),
                                        ("rand_center", self.rand_center), ("search_depth", self.search_depth),
                                        ("topk != 1", self.topk != 1), ("num_mags < 1", self.num_mags < 1),
                                        ("BOX_FORMAT != xyxy", self.box_fmt != 'xyxy')) if v]
@@ -165,6 +168,7 @@ class FrustumProposerOG(nn.Module):
         p.topk, p.clamp_bottom = 1, int(self.clamp_bottom)
         p.image_h, p.image_w = int(self.image_size[0]), int(self.image_size[1])
         p.point_stride, p.xyz_offset = int(point_stride), int(xyz_offset)
+        p.has_img_aug, p.mult, p.ego_w = 0, int(bool(self.MULT)), float(self.ego_w)
         return p
 
     def enumerate_frustums(self, batch_dict):
@@ -193,18 +197,16 @@ class FrustumProposerOG(nn.Module):
 
     @staticmethod
     def _matrices(batch_dict):
-        """(B,21) scene and (B,6,24) camera matrices in f32, computed like :1431-1475 / :1509-1545."""
+        """(B,21) scene and (B,6,45) camera matrices in f32, computed like :1431-1475 / :1509-1545, and whether a
+        non-identity img_aug_matrix is among them."""
         aug = batch_dict['lidar_aug_matrix'].detach().cpu().float()
         l2i = batch_dict['lidar2image'].detach().cpu().float()
         c2l = batch_dict['camera2lidar'].detach().cpu().float()
         K = batch_dict['camera_intrinsics'].detach().cpu().float()
-        if 'img_aug_matrix' in batch_dict:
-            ia = batch_dict['img_aug_matrix'].detach().cpu().float()
-            eye = torch.eye(4).expand_as(ia)
-            if not torch.equal(ia, eye):
-                raise NotImplementedError("img_aug_matrix != identity is not built (the extraction config has no image aug)")
         B = aug.shape[0]
         R = aug[:, :3, :3]
+        ia = batch_dict['img_aug_matrix'].detach().cpu().float() if 'img_aug_matrix' in batch_dict else None
+        has_ia = ia is not None and not torch.equal(ia, torch.eye(4).expand_as(ia))
         # a few dozen 3x3 inverses: keep LAPACK on one thread (the intra-op pool costs milliseconds to wake up
         # for this; measured 0.9 -> 9 ms per call between 16 and 32 scenes)
         nthreads = torch.get_num_threads()
@@ -212,12 +214,16 @@ class FrustumProposerOG(nn.Module):
         try:
             Rinv = torch.inverse(R)
             Kinv = torch.inverse(K[..., :3, :3])
+            post_inv = torch.inverse(ia[..., :3, :3]) if has_ia else torch.eye(3).expand(B, 6, 3, 3)
         finally:
             torch.set_num_threads(nthreads)
         scene = torch.cat([R.reshape(B, 9), Rinv.reshape(B, 9), aug[:, :3, 3]], dim=1).contiguous()
         combine = c2l[..., :3, :3].matmul(Kinv)
-        cam = torch.cat([l2i[..., :3, :3].reshape(B, 6, 9), l2i[..., :3, 3], combine.reshape(B, 6, 9), c2l[..., :3, 3]], dim=2)
-        return scene, cam.contiguous()
+        post = ia[..., :3, :3] if has_ia else torch.eye(3).expand(B, 6, 3, 3)
+        post_t = ia[..., :3, 3] if has_ia else torch.zeros((B, 6, 3))
+        cam = torch.cat([l2i[..., :3, :3].reshape(B, 6, 9), l2i[..., :3, 3], combine.reshape(B, 6, 9), c2l[..., :3, 3],
+                         post.reshape(B, 6, 9), post_t, post_inv.reshape(B, 6, 9)], dim=2)
+        return scene, cam.contiguous(), has_ia
 
     def _tables(self, dev):
         """Device copies of the constant tables, kept alive across (asynchronous) launches."""
@@ -260,9 +266,10 @@ class FrustumProposerOG(nn.Module):
             offsets = torch.zeros((B + 1,), dtype=torch.int32, device=dev)
             offsets[1:] = torch.cumsum(counts, 0).int()
             max_pts = int(counts.max().item())                                 # host sync (scene sizes)
-        scene_m, cam_m = self._matrices(batch_dict)
+        scene_m, cam_m, has_img_aug = self._matrices(batch_dict)
         scene_m, cam_m, d_fr = scene_m.to(dev, non_blocking=True), cam_m.to(dev, non_blocking=True), frusts.to(dev, non_blocking=True)
         prm = self._params(points.shape[1], 1)
+        prm.has_img_aug = int(has_img_aug)
         NC = self.num_mags * self.num_rotations * self.num_sizes
         ws = torch.empty((int(L.fnp_boxseeker_workspace_bytes(F, max_pts)),), dtype=torch.uint8, device=dev)
         out_valid = torch.zeros((F,), dtype=torch.int32, device=dev)

@@ -60,6 +60,7 @@ class SeekerParams(ctypes.Structure):
         ("num_mags", c_int), ("num_rotations", c_int), ("num_sizes", c_int),
         ("topk", c_int), ("clamp_bottom", c_int), ("image_h", c_int), ("image_w", c_int),
         ("point_stride", c_int), ("xyz_offset", c_int),
+        ("has_img_aug", c_int), ("mult", c_int), ("ego_w", c_float),
     ]
 
 
@@ -166,8 +167,31 @@ def load():
             raise FnpError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("FNP_TRACE"):
+        lib = _Traced(lib)     # development: name every call and synchronise behind it (attributes a GPU fault to its launch)
     _lib = lib
     return lib
+
+
+class _Traced:
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith("fnp_") or "workspace" in name or name.startswith("fnp_host") or name.startswith("fnp_rankgrid_num"):
+            return fn
+
+        def call(*a):
+            import sys
+            import torch
+            capturing = torch.cuda.is_current_stream_capturing()
+            print(f"[fnp] {name}{' (capture)' if capturing else ''} {[x for x in a if isinstance(x, int) and abs(x) < 1 << 31]}", file=sys.stderr, flush=True)
+            rc = fn(*a)
+            if not capturing and os.environ.get("FNP_TRACE") != "2":     # FNP_TRACE=2: names only, no synchronisation
+                torch.cuda.synchronize()
+            return rc
+        return call
 
 
 def check(code, what):

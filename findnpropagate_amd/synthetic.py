@@ -171,7 +171,18 @@ def box_corners(boxes):
     return np.stack([x, y, c[..., 2]], -1) + boxes[:, None, 0:3]
 
 
-def make_detections(boxes, cls, cams, rng, batch_idx=0, duplicates=True):
+def make_img_aug(rng):
+    """(6,4,4) img_aug_matrix: per camera a mild resize + rotation + shift of the image plane (the form
+    ImageAug3D-style pipelines accumulate: [[s R, t], [0, 1]] acting on (u, v, depth))."""
+    out = np.tile(np.eye(4, dtype=np.float64), (6, 1, 1))
+    for c in range(6):
+        sc, th = rng.uniform(0.85, 1.0), np.deg2rad(rng.uniform(-3.0, 3.0))
+        out[c, :2, :2] = sc * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        out[c, :2, 3] = rng.uniform(-40.0, 40.0, size=2)
+    return out.astype(np.float32)
+
+
+def make_detections(boxes, cls, cams, rng, batch_idx=0, duplicates=True, img_aug=None):
     """Synthetic GLIP-like 2D detections: clipped projection of each cuboid into every camera that
     sees it, jittered +-5 px, score U(0.3, 0.95), label = class + 1 (1-based like
     preprocessed_detector.py:83-85).  Returns float32 (D,4) xyxy, int64 labels, f32 scores,
@@ -186,6 +197,9 @@ def make_detections(boxes, cls, cams, rng, batch_idx=0, duplicates=True):
             if (p[:, 2] < 1.0).any():
                 continue
             uv = p[:, :2] / p[:, 2:3]
+            if img_aug is not None:      # detections live in the augmented image
+                A = img_aug[c].astype(np.float64)
+                uv = uv @ A[:2, :2].T + A[:2, 3]
             x1, y1 = np.clip(uv[:, 0].min(), 0, W), np.clip(uv[:, 1].min(), 0, H)
             x2, y2 = np.clip(uv[:, 0].max(), 0, W), np.clip(uv[:, 1].max(), 0, H)
             if (x2 - x1) < 12 or (y2 - y1) < 12:
@@ -211,9 +225,10 @@ def make_detections(boxes, cls, cams, rng, batch_idx=0, duplicates=True):
 #                (all three depth quantiles equal, clamp_bottom collapses the frustum: frustum_proposals_v1.py:616-629,817-826),
 #                a sub-pixel detection around one ordinary return and one around two returns (interpolated quantile)
 #   no_dets      the detector returns nothing (early return :694-700);  low_scores: everything under score_thr
+#   img_aug      non-identity img_aug_matrix (image-plane resize / rotation / shift, :1456-1458,1525-1527)
 SEEKER_VARIANTS = {3: ("aug",), 4: ("aug", "flip"), 5: ("aug", "empty_cam"), 6: ("empty_cam",), 7: ("lone_point",),
                    8: (), 9: (), 10: ("aug", "flip", "empty_cam", "lone_point"), 11: ("no_dets",), 12: ("low_scores",),
-                   13: ("aug", "lone_point")}
+                   13: ("aug", "lone_point"), 14: ("img_aug",), 15: ("aug", "img_aug", "empty_cam")}
 LONE_POINT = np.array([15.0, 0.3, 4.5], np.float32)      # elevation 16.7 deg: above the top beam (10.67 deg)
 
 
@@ -229,7 +244,9 @@ def make_seeker_scene(seed, variant=None):
     pts, boxes, cls = make_scene(seed, return_boxes=True)
     rng = np.random.default_rng(10_000 + seed)
     cams = make_cameras(1)
-    dets = make_detections(boxes, cls, cams, rng)
+    if "img_aug" in flags:
+        cams["img_aug_matrix"] = make_img_aug(np.random.default_rng(20_000 + seed))[None]
+    dets = make_detections(boxes, cls, cams, rng, img_aug=cams["img_aug_matrix"][0] if "img_aug" in flags else None)
     if "lone_point" in flags:
         lone = np.zeros((1, 5), np.float32)
         lone[0, :3], lone[0, 3] = LONE_POINT, 17.0

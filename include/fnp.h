@@ -359,6 +359,9 @@ typedef struct fnp_seeker_params {
     int image_h, image_w;        /* 900, 1600 (:205) */
     int point_stride;            /* floats per point row */
     int xyz_offset;              /* column of x in a point row */
+    int has_img_aug;             /* cam_mats carries a non-identity img_aug_matrix (:1456-1458, :1525-1527) */
+    int mult;                    /* MODEL_CFG.MULT: product instead of sum of the score terms (:997-1000) */
+    float ego_w;                 /* PARAMS ego_w: + ego_w * ||centre|| / max ||centre|| (:1017-1021) */
 } fnp_seeker_params;
 
 int64_t fnp_boxseeker_workspace_bytes(int num_frustums, int max_points_per_scene);
@@ -376,8 +379,10 @@ int fnp_host_enumerate_frustums(const float *boxes, const int64_t *labels, const
 
 /* points: rows of `point_stride` floats, scenes concatenated; scene_offsets (S+1,) int32.
  * scene_mats (S,21) f32: lidar_aug rotation (9, row major) | its inverse (9) | translation (3).
- * cam_mats (S,6,24) f32: lidar2image[:3,:3] (9) | lidar2image[:3,3] (3) |
- *                        camera2lidar_rot @ inv(intrinsics) (9) | camera2lidar_trans (3)
+ * cam_mats (S,6,45) f32: lidar2image[:3,:3] (9) | lidar2image[:3,3] (3) |
+ *                        camera2lidar_rot @ inv(intrinsics) (9) | camera2lidar_trans (3) |
+ *                        img_aug[:3,:3] (9) | img_aug[:3,3] (3) | inv(img_aug[:3,:3]) (9)   (the last 21 are read only
+ *                        when params->has_img_aug)
  *                        (the matrices of :1431-1475 and :1509-1545, prepared on the host).
  * frustums (F,8) f32: scene, camera, x1, y1, x2, y2, label (1-based), score — already NMS'ed,
  *                        score-filtered and in the reference's enumeration order (:582-594).

@@ -16,7 +16,8 @@ IMAGE_H, IMAGE_W = 900, 1600                           # :205
 ANCHORS = np.array([[4.63, 1.97, 1.74], [6.93, 2.51, 2.84], [6.37, 2.85, 3.19], [10.5, 2.94, 3.47], [12.29, 2.90, 3.87],
                     [0.50, 2.53, 0.98], [2.11, 0.77, 1.47], [1.70, 0.60, 1.28], [0.73, 0.67, 1.77], [0.41, 0.41, 1.07]], F)  # :270-281
 
-DEFAULT_PARAMS = dict(lq=0.0, uq=0.25, cq=1.0, iou_w=1.0, nms_normal=1.0, dst_w=0.0, dns_w=1.0, min_cam_iou=0.3,
+# MULT (model_cfg key, :997-1000) and ego_w (:1017-1021) are accepted in `params` too
+DEFAULT_PARAMS = dict(MULT=False, ego_w=0.0, lq=0.0, uq=0.25, cq=1.0, iou_w=1.0, nms_normal=1.0, dst_w=0.0, dns_w=1.0, min_cam_iou=0.3,
                       score_thr=0.45, nms_2d=0.4, nms_3d=0.0, clamp_bottom=1, num_sizes=1, num_mags=6, num_rotations=10,
                       size_min=0.957, size_max=1.2, ry_min=0.0, ry_max=float(np.pi), max_dist=50.0, topk=1)
 
@@ -55,8 +56,8 @@ def base_proposals(p=DEFAULT_PARAMS):
     return bb.reshape(10, -1, 7), corners
 
 
-def project_to_camera(points, lidar_aug, lidar2image):
-    """:1431-1475 without img_aug_matrix.  Returns coords (N,3) [u,v,depth], on_img (N,)."""
+def project_to_camera(points, lidar_aug, lidar2image, img_aug=None):
+    """:1431-1475 (img_aug: the camera's 4x4 img_aug_matrix or None).  Returns coords (N,3) [u,v,depth], on_img (N,)."""
     cur = points.astype(F).copy()
     cur = cur - lidar_aug[:3, 3]
     cur = np.linalg.inv(lidar_aug[:3, :3].astype(F)).astype(F) @ cur.T
@@ -64,14 +65,20 @@ def project_to_camera(points, lidar_aug, lidar2image):
     cur = cur + lidar2image[:3, 3].reshape(3, 1)
     cur[2] = np.clip(cur[2], F(1e-5), F(1e5))
     cur[:2] = cur[:2] / cur[2:3]
+    if img_aug is not None:                                                  # :1456-1458
+        cur = img_aug[:3, :3].astype(F) @ cur
+        cur = cur + img_aug[:3, 3].astype(F).reshape(3, 1)
     cur = cur.T
     on = (cur[:, 1] < IMAGE_H) & (cur[:, 1] >= 0) & (cur[:, 0] < IMAGE_W) & (cur[:, 0] >= 0)
     return cur.astype(F), on
 
 
-def geometry_at_image_coords(image_coords, c2l, intrins, lidar_aug):
-    """:1509-1545 (no post_rots): (u,v,d) -> lidar xyz."""
+def geometry_at_image_coords(image_coords, c2l, intrins, lidar_aug, img_aug=None):
+    """:1509-1545: (u,v,d) -> lidar xyz (img_aug: the camera's img_aug_matrix; its post-transformation is undone first)."""
     pts = image_coords.astype(F)
+    if img_aug is not None:                                                  # :1525-1527
+        pts = pts - img_aug[:3, 3].astype(F)
+        pts = (np.linalg.inv(img_aug[:3, :3].astype(F)).astype(F) @ pts.T).T
     pts = np.concatenate([pts[:, :2] * pts[:, 2:3], pts[:, 2:3]], -1)
     combine = (c2l[:3, :3].astype(F) @ np.linalg.inv(intrins[:3, :3].astype(F)).astype(F)).astype(F)
     pts = (combine @ pts.T).T + c2l[:3, 3].astype(F)
@@ -128,9 +135,9 @@ def batched_nms_2d(boxes, scores, labels, thr):
     return np.array(keep, np.int64)
 
 
-def calc_iou(corners, cam_box, lidar_aug, lidar2image):
+def calc_iou(corners, cam_box, lidar_aug, lidar2image, img_aug=None):
     """:1392-1411: 2D IoU of the clamped projected corner hull box vs the detection."""
-    pos, _ = project_to_camera(corners.reshape(-1, 3), lidar_aug, lidar2image)
+    pos, _ = project_to_camera(corners.reshape(-1, 3), lidar_aug, lidar2image, img_aug)
     pos = pos[:, :2].reshape(-1, 8, 2)
     pos[..., 0] = np.clip(pos[..., 0], 0, IMAGE_W)
     pos[..., 1] = np.clip(pos[..., 1], 0, IMAGE_H)
@@ -151,6 +158,7 @@ def get_proposals(scene, params=None, trace=None):
     det_boxes, det_labels, det_scores, det_b, det_c = scene["dets"]
     pts = scene["points"][scene["points"][:, 0] == 0][:, 1:4].astype(F)
     aug = scene["lidar_aug_matrix"][0].astype(F)
+    iaug = (lambda c: scene["img_aug_matrix"][0, c].astype(F)) if "img_aug_matrix" in scene else (lambda c: None)
     out_boxes, out_labels, out_scores = [], [], []
     frusts = []
     for c in IMAGE_ORDER:                                                   # :582
@@ -160,7 +168,7 @@ def get_proposals(scene, params=None, trace=None):
             sel = batched_nms_2d(cb, cs, cl, p["nms_2d"])                    # :587
             cb, cl, cs = cb[sel], cl[sel], cs[sel]
         L = scene["lidar2image"][0, c].astype(F)
-        cam_points, on = project_to_camera(pts, aug, L)                      # :590
+        cam_points, on = project_to_camera(pts, aug, L, iaug(c))             # :590
         cam_points = cam_points[on]
         for box, label, score in zip(cb, cl, cs):                            # :593
             if score < p["score_thr"]:
@@ -174,15 +182,15 @@ def get_proposals(scene, params=None, trace=None):
             fmax = quantile(bp[:, 2], p["uq"])
             cz = quantile(bp[:, 2], p["cq"])
             wc_cam = np.array([[(x1 + x2) / F(2), (y1 + y2) / F(2), cz]], F)   # :630
-            wc_xyz = geometry_at_image_coords(wc_cam, scene["camera2lidar"][0, c], scene["camera_intrinsics"][0, c], aug)
+            wc_xyz = geometry_at_image_coords(wc_cam, scene["camera2lidar"][0, c], scene["camera_intrinsics"][0, c], aug, iaug(c))
             fmax = min(fmax, F(p["max_dist"]))                               # :647-648
             fmin = max(fmin, F(2.0))
             xyzxyz = np.array([box[0], box[1], fmin, box[2], box[3], fmax], F)
-            fr = geometry_at_image_coords(cam_frustum(xyzxyz), scene["camera2lidar"][0, c], scene["camera_intrinsics"][0, c], aug)
+            fr = geometry_at_image_coords(cam_frustum(xyzxyz), scene["camera2lidar"][0, c], scene["camera_intrinsics"][0, c], aug, iaug(c))
             frusts.append((fr, c, box.astype(F), bp, int(label), F(score), wc_xyz))
     for fi, (fr, c, box, bp, label, score, wc_xyz) in enumerate(frusts):   # :805
         c2l, K_, L = scene["camera2lidar"][0, c], scene["camera_intrinsics"][0, c], scene["lidar2image"][0, c].astype(F)
-        xyz = geometry_at_image_coords(bp, c2l, K_, aug)                     # :812-815
+        xyz = geometry_at_image_coords(bp, c2l, K_, aug, iaug(c))            # :812-815
         fr = fr.copy()
         if p["clamp_bottom"] > 0:                                            # :817-826
             for d in range(3):
@@ -213,7 +221,7 @@ def get_proposals(scene, params=None, trace=None):
                 trace.append(t)
             continue
         idx = np.nonzero(valid)[0]
-        ious, proj = calc_iou(corners[idx], box, aug, L)                     # :883
+        ious, proj = calc_iou(corners[idx], box, aug, L, iaug(c))            # :883
         dd = np.sqrt(((wfc[idx] - wc_xyz.reshape(1, 3)) ** 2).sum(1)).astype(F)   # :886-893
         dists_ranked = (F(1) - (dd - dd.min()) / (dd.max() - dd.min() + F(1e-8))).astype(F)
         keep = ious > p["min_cam_iou"]                                       # :904
@@ -225,7 +233,13 @@ def get_proposals(scene, params=None, trace=None):
             continue
         counts = O.points_in_boxes_count(xyz, boxes[idx]).astype(F)          # :930-932
         soft = counts / (counts.max() + F(1e-8))                             # :994
-        s2 = (soft * F(p["dns_w"]) + ious * F(p["iou_w"]) + dists_ranked * F(p["dst_w"])).astype(F)   # :997
+        if not p["MULT"]:
+            s2 = (soft * F(p["dns_w"]) + ious * F(p["iou_w"]) + dists_ranked * F(p["dst_w"])).astype(F)   # :997
+        else:
+            s2 = (soft * F(p["dns_w"]) * ious * F(p["iou_w"]) * dists_ranked * F(p["dst_w"])).astype(F)   # :999
+        if p["ego_w"] > 0:                                                   # :1017-1021
+            ego = np.sqrt((boxes[idx, :3] ** 2).sum(1)).astype(F)
+            s2 = (s2 + F(p["ego_w"]) * (ego / ego.max())).astype(F)
         best = int(np.argmax(s2))       # sort desc + [:topk=1]; first maximum = stable order
         t.update(idx_final=idx.copy(), counts=counts.copy(), scores=s2.copy(), best=int(idx[best]))
         if trace is not None:
