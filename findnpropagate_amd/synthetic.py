@@ -229,6 +229,9 @@ def make_detections(boxes, cls, cams, rng, batch_idx=0, duplicates=True, img_aug
 SEEKER_VARIANTS = {3: ("aug",), 4: ("aug", "flip"), 5: ("aug", "empty_cam"), 6: ("empty_cam",), 7: ("lone_point",),
                    8: (), 9: (), 10: ("aug", "flip", "empty_cam", "lone_point"), 11: ("no_dets",), 12: ("low_scores",),
                    13: ("aug", "lone_point"), 14: ("img_aug",), 15: ("aug", "img_aug", "empty_cam")}
+# Parity seeds that run with other than the shipped PARAMS / model_cfg (the reference's optional score terms):
+# key -> (PARAMS overrides, model_cfg overrides)
+SEEKER_PARAM_VARIANTS = {16: ({"dst_w": 0.5}, {"MULT": True}), 17: ({"ego_w": 0.4}, {})}
 LONE_POINT = np.array([15.0, 0.3, 4.5], np.float32)      # elevation 16.7 deg: above the top beam (10.67 deg)
 
 

@@ -168,7 +168,7 @@ def cpu_only_torch():
     torch.Tensor.cuda = lambda self, *a, **k: self
 
 
-SEEDS = tuple(range(14))   # 0-2 plain scenes; 3-13 carry the edge cases of synthetic.SEEKER_VARIANTS
+SEEDS = tuple(range(18))   # 0-2 plain scenes; 3-15 carry the edge cases of synthetic.SEEKER_VARIANTS; 16-17 other PARAMS (SEEKER_PARAM_VARIANTS)
 PARAMS = {'lq': 0.0, 'uq': 0.25, 'cq': 1.0, 'iou_w': 1.0, 'nms_normal': 1.0, 'dst_w': 0.0, 'dns_w': 1.0,
           'min_cam_iou': 0.3, 'score_thr': 0.45, 'nms_2d': 0.4, 'nms_3d': 0.0, 'clamp_bottom': 1, 'num_sizes': 1}
 # tools/cfgs/nuscenes_box_seeker_proposals.yaml:83
@@ -180,8 +180,27 @@ def main():
     class_names = ['car', 'truck', 'construction_vehicle', 'bus', 'trailer', 'barrier', 'motorcycle', 'bicycle',
                    'pedestrian', 'traffic_cone']
     fp.PreprocessedGLIP = lambda class_names=None: None
-    head = fp.FrustumProposerOG(model_cfg=Cfg(PARAMS=PARAMS, PREDS_PATH='PreprocessedGLIP', BOX_FORMAT='xyxy'),
-                                class_names=class_names)
+    def make_head(params_over, cfg_over):
+        prm = dict(PARAMS)
+        prm.update(params_over)
+        h = fp.FrustumProposerOG(model_cfg=Cfg(PARAMS=prm, PREDS_PATH='PreprocessedGLIP', BOX_FORMAT='xyxy', **cfg_over),
+                                 class_names=class_names)
+        record_methods(h)
+        return h
+
+    heads = {}
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    for seed in SEEDS:
+        REC.clear()
+        pv = syn.SEEKER_PARAM_VARIANTS.get(seed, ({}, {}))
+        key = repr(pv)
+        if key not in heads:
+            heads[key] = make_head(*pv)
+        head = heads[key]
+        run_seed(head, seed, out_dir)
+
+
+def record_methods(head):
     # record the reference's own methods as they run
     for name in ("project_to_camera", "get_geometry_at_image_coords", "calc_iou"):
         orig = getattr(head, name)
@@ -207,13 +226,14 @@ def main():
             return wrapped
         setattr(head, name, make(orig, name))
 
-    out_dir = os.path.dirname(os.path.abspath(__file__))
-    for seed in SEEDS:
-        REC.clear()
+
+
+def run_seed(head, seed, out_dir):
+    if True:
         sc = syn.make_seeker_scene(seed)
         dets = tuple(torch.from_numpy(d) for d in sc["dets"])
         head.image_detector = lambda bd: dets
-        bd = {k: torch.from_numpy(sc[k]) for k in ("points", "camera_intrinsics", "camera2lidar", "lidar2image", "lidar_aug_matrix")}
+        bd = {k: torch.from_numpy(sc[k]) for k in ("points", "camera_intrinsics", "camera2lidar", "lidar2image", "lidar_aug_matrix", "img_aug_matrix") if k in sc}
         bd["batch_size"] = 1
         with torch.no_grad():
             boxes, labels, scores, bidx = head.get_proposals(bd)

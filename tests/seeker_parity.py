@@ -24,9 +24,11 @@ def ragged(d, key):
     return [d[key][off[i]:off[i + 1]] for i in range(len(off) - 1)]
 
 
-def check_choices(d, out_boxes, chosen):
+def check_choices(d, out_boxes, chosen, extra_tol=0.0):
     """d: golden npz; out_boxes (K,7); chosen: per output box (scored candidate ids ascending, chosen candidate id,
-    point counts of the scored candidates)."""
+    point counts of the scored candidates).  extra_tol: added to the score tolerance when the distance term is on
+    (dst_w > 0): the reference ranks the candidates by torch.cdist, whose matmul formulation (|a|^2 + |b|^2 - 2ab in f32,
+    used above 25 rows) carries ~1e-3 of relative error on sub-metre distances — not something to reproduce."""
     ws = ragged(d, "nms3d_scores") if "nms3d_scores" in d.files else []
     assert len(ws) == out_boxes.shape[0] == len(chosen) == d["out_boxes"].shape[0]
     offs = np.cumsum([0] + [len(w) for w in ws])
@@ -38,7 +40,7 @@ def check_choices(d, out_boxes, chosen):
         assert len(cand_ids) == len(w), f"frustum {k}: scored candidate sets differ"
         pos = list(cand_ids).index(best)
         dcount = np.abs(np.asarray(counts, np.int64) - ref_counts).max()
-        tol = 1e-4 + 2.0 * dcount / max(int(ref_counts.max()), 1)
+        tol = 1e-4 + extra_tol + 2.0 * dcount / max(int(ref_counts.max()), 1)
         assert w[pos] >= w.max() - tol, f"frustum {k}: chose a candidate {w.max() - w[pos]:.3e} below the reference's best (tol {tol:.1e})"
         np.testing.assert_allclose(out_boxes[k], ref_boxes[pos], rtol=0, atol=BOX_ATOL, err_msg=f"frustum {k}")
         top = np.sort(w)[::-1]
