@@ -1,0 +1,504 @@
+// Sparse convolution for the ranked 32 -> 32 SubM layers (the four 3x3x3 layers of stage 2) on a TILE RULEBOOK: the
+// rulebook of 256-row tiles restated once, relative to the tile, as 16-bit LDS addresses — half the bytes of the (27, cap)
+// int32 table it is built from — so that the convolution holds a tile's whole neighbourhood in LDS and its offset sweep
+// issues no gather at all.
+//
+// spconv_mfma_kernel gathers every (site, offset) fragment from L2 and is bound by the per-CU rate of that gather path
+// (DESIGN.md section 5); its window variant still issues a gather instruction per fragment next to the LDS read.  Rows of a
+// ranked tensor sit next to their neighbours: ~95 % of a tile's neighbour rows lie within +-32 rows of the tile, and the
+// rest are ~40 DISTINCT rows per tile, each referenced several times.  fnp_tile_rulebook_build (one pass per rulebook;
+// the stage-2 rulebook serves four convolutions per forward) therefore writes, per tile:
+//   codes   27 x 256 16-bit entries: the LDS byte address, inside the tile image below, of the neighbour row — a window row
+//           (rows [tile - 32, tile + 288) of the input), an overflow row (a far neighbour, deduplicated through a small
+//           open-addressing table keyed by row id: the slot number is the overflow row), the row of zeros (no neighbour),
+//           or ESCAPE (the tile has more distinct far rows than overflow rows — not seen on rank-ordered inputs, common on
+//           arbitrary ones: the convolution then fetches that fragment through the int32 table; correct for any order);
+//   far     the 256 row ids of the overflow rows (-1: unused);
+//   escape  per 32-row group, whether any of its entries is ESCAPE.
+// The convolution (spconv_tile32_kernel) runs one 1024-thread workgroup per CU over a contiguous run of tiles.  Eight
+// PRODUCER waves only move data: window, codes, overflow rows and flags of the tile after next go from memory to
+// registers, and on to the LDS image the consumers have just left.  Eight CONSUMER waves sweep the 27 offsets of the
+// current tile from LDS only — 32-bit entry pair, 16-byte fragment, MFMA — and run the epilogue.  Two images alternate;
+// they are handed over through counters in LDS, not workgroup barriers (see below).
+// Products, their order (offsets ascending, one 32-wide MFMA step per offset) and the epilogue arithmetic are those of
+// spconv_mfma_kernel: the output is bit-identical (tests/test_gpu_spconv.py::test_tile_kernel_equals_gather_kernel).
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct V16 {
+    typedef T v8 __attribute__((ext_vector_type(8)));
+    typedef T v4 __attribute__((ext_vector_type(4)));
+};
+__device__ __forceinline__ f32x4 tmfma(V16<__bf16>::v8 a, V16<__bf16>::v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 tmfma(V16<_Float16>::v8 a, V16<_Float16>::v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+constexpr int kK = 27, kC = 32, kCH = 4, kRowB = 64;   // offsets, channels, 16-byte chunks and bytes per row
+constexpr int kTile = FNP_TILE_ROWS;                    // rows per tile
+constexpr int kHalo = 32;                               // window rows on either side of the tile (64 holds 20 % fewer far rows, for 8 KB of LDS)
+constexpr int kWin = kTile + 2 * kHalo;
+constexpr int kOvf = 256;                               // overflow rows of a tile image
+constexpr int kZeroRow = kWin + kOvf;
+constexpr unsigned kEscape = 0xFFFFu;
+constexpr int kSlab = kC * kCH;                         // chunks per weight slab
+constexpr int kWBytes = kK * kSlab * 16;                // 55,296: all 27 slabs resident
+constexpr int kXBytes = (kWin + kOvf + 1) * kRowB;      // window + overflow + zero row
+constexpr int kRbBytes = kK * kTile * 2;                // the entries of a tile
+constexpr int kImgBytes = kXBytes + kRbBytes;           // one tile image
+constexpr int kLds = kWBytes + 2 * kImgBytes + 64 + 64; // + escape flags + hand-over counters
+// tile record of the tile rulebook
+constexpr int kRecFar = kRbBytes, kRecEsc = kRecFar + kOvf * 4, kRecBytes = kRecEsc + 16;
+static_assert(kRecBytes == FNP_TILE_RECORD_BYTES && kRecBytes % 16 == 0, "include/fnp.h states the record size");
+static_assert(kLds <= 160 * 1024, "LDS budget");
+static_assert(kZeroRow * kRowB + 48 < 0xFFFF, "16-bit LDS row addresses");
+static_assert(kTile == 256 && kHalo % 32 == 0 && (kWin / 2) % 4 == 0, "shape");
+
+// Entry of the feature row stored at row slot `rs` of an image: its LDS byte address with its swizzle in bits 4-5 — the
+// row stores logical 16-byte chunk c at chunk c ^ (-(rs >> 2) & 3); lane (l15, q) of a fragment read takes chunk q at
+// entry ^ (q << 4).  Window rows: even rows first, then odd rows (see the consumer geometry below).
+__host__ __device__ constexpr unsigned row_code(unsigned rs) { return rs * kRowB + (((0u - (rs >> 2)) & 3u) << 4); }
+__host__ __device__ constexpr unsigned win_slot(unsigned d) { return (d & 1u) * (kWin / 2) + (d >> 1); }
+
+// ------------------------------------------------------------------------------------------ tile rulebook
+// One 256-thread workgroup per tile, thread r = tile row r.  Far rows go through an LDS open-addressing table (compare-
+// and-swap, linear probing): which slot a row gets depends on the order the threads arrive in, the BYTES the convolution
+// reads through it do not.
+__global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restrict__ nbr, int nbr_stride, const int *__restrict__ n_out, int cap,
+                                                            unsigned char *__restrict__ out) {
+    __shared__ int table[kOvf];
+    __shared__ int esc[8];
+    const int n = min(*n_out, cap);
+    const int t = blockIdx.x, tile_base = t * kTile, r = threadIdx.x;
+    if (tile_base >= n) return;
+    table[r] = -1;
+    if (r < 8) esc[r] = 0;
+    __syncthreads();
+    const int wlo = max(0, tile_base - kHalo), row = tile_base + r;
+    int id[kK];
+#pragma unroll
+    for (int k = 0; k < kK; ++k) id[k] = row < n ? nbr[(size_t)k * nbr_stride + row] : -1;
+    unsigned short *codes = reinterpret_cast<unsigned short *>(out + (size_t)t * kRecBytes);
+#pragma unroll
+    for (int k = 0; k < kK; ++k) {
+        const unsigned d = (unsigned)(id[k] - wlo);
+        unsigned code = row_code(kZeroRow);
+        if (id[k] >= 0) {
+            if (d < (unsigned)kWin) {
+                code = row_code(win_slot(d));
+            } else {
+                unsigned h = (unsigned)id[k] & (unsigned)(kOvf - 1);
+                code = kEscape;
+                for (int probe = 0; probe < 64; ++probe) {
+                    const int old = atomicCAS(&table[h], -1, id[k]);
+                    if (old == -1 || old == id[k]) {
+                        code = row_code((unsigned)kWin + h);
+                        break;
+                    }
+                    h = (h + 1) & (unsigned)(kOvf - 1);
+                }
+                if (code == kEscape) esc[r >> 5] = 1;
+            }
+        }
+        codes[k * kTile + r] = (unsigned short)code;
+    }
+    __syncthreads();
+    reinterpret_cast<int *>(out + (size_t)t * kRecBytes + kRecFar)[r] = table[r];
+    if (r < 16) out[(size_t)t * kRecBytes + kRecEsc + r] = r < 8 ? (unsigned char)esc[r] : 0;
+}
+
+// Development-only timing probes (results are wrong; the shipped library has 0): 1 = escape entries are taken as absent,
+// 2 = consumers skip the offset sweep
+#ifndef FNP_TILE_ABLATE
+#define FNP_TILE_ABLATE 0
+#endif
+#ifndef FNP_TILE_DW
+#define FNP_TILE_DW 1
+#endif
+#ifndef FNP_TILE_DX
+#define FNP_TILE_DX 2
+#endif
+
+// Development-only phase clocks (FNP_TILE_STAMP builds): every wave sums the s_memtime ticks it spends in each phase
+// of its role; fnp_debug_tile_stamps() returns and clears the sums.  [role 0 = consumer, 1 = producer][phase]
+#ifdef FNP_TILE_STAMP
+__device__ unsigned long long g_tile_stamps[4][8];   // [role][phase] sums, [2 + role][phase] maxima over waves
+#define FNP_STAMP_NOW(v)                                                       \
+    do {                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                     \
+    } while (0)
+#define FNP_STAMP_DECL                                        \
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev; \
+    FNP_STAMP_NOW(st_prev)
+#define FNP_STAMP(ph)                                                          \
+    do {                                                                       \
+        unsigned long long st_now;                                             \
+        FNP_STAMP_NOW(st_now);                                                 \
+        st_acc[ph] += st_now - st_prev;                                        \
+        st_prev = st_now;                                                      \
+    } while (0)
+#define FNP_STAMP_FLUSH(role)                                                  \
+    do {                                                                       \
+        if (lane == 0)                                                         \
+            for (int ph = 0; ph < 8; ++ph) {                                   \
+                atomicAdd(&g_tile_stamps[role][ph], st_acc[ph]);               \
+                atomicMax(&g_tile_stamps[2 + role][ph], st_acc[ph]);           \
+            }                                                                  \
+    } while (0)
+#else
+#define FNP_STAMP_DECL
+#define FNP_STAMP(ph)
+#define FNP_STAMP_FLUSH(role)
+#endif
+
+// ------------------------------------------------------------------------------------------ convolution
+// Geometry: 8 consumer waves x 32 rows.  Consumer wave w owns tile rows [32 w, 32 w + 32); its MFMA column l15 of block mb
+// is row 32 w + 2 l15 + mb, so the two entries of a lane sit in one 32-bit word of the natural [offset][row] table.
+// Neighbours of such a column set are rows of ONE parity, so the window image keeps even and odd rows in separate halves:
+// what a fragment read touches is then 16 consecutive 64-byte rows, as in a dense tile.
+template <typename TAct>
+__global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__restrict__ x, int x_bytes, const TAct *__restrict__ w,
+                                                                 const unsigned char *__restrict__ tile_rb, int rb_bytes,
+                                                                 const int *__restrict__ nbr, int nbr_stride,
+                                                                 const int *__restrict__ n_out, int cap, TAct *__restrict__ y,
+                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                 const TAct *__restrict__ residual, int relu) {
+    using frag8 = typename V16<TAct>::v8;
+    using act4 = typename V16<TAct>::v4;
+    constexpr int MB = 2, NCW = 8, NPW = 8, NT = 1024, PT = NPW * 64, NB = kC / 16;
+    constexpr int NWL = (kWin * kCH + PT - 1) / PT;          // window chunks per producer thread
+    constexpr int NCL = (kRbBytes / 16 + PT - 1) / PT;       // entry-table chunks per producer thread
+    constexpr int NGL = kOvf / NPW / 16;                     // overflow-row loads per producer thread (4 lanes per row)
+    static_assert(NB == 2 && kTile == NCW * MB * 16 && kOvf == NPW * 32, "shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *wl = reinterpret_cast<uint4 *>(smem);
+    unsigned char *const img0 = smem + kWBytes;
+    int *const esc_flags = reinterpret_cast<int *>(smem + kWBytes + 2 * kImgBytes);   // [image][consumer wave]
+    // Hand-over counters (no workgroup barrier after the prologue: a barrier per tile made every wave wait for the slowest
+    // one of either role, and the fill and drain of each wave's pipeline fell on the same moment for all of them).  Each
+    // counts WAVES that completed an event and only grows; i = tile number inside the workgroup's run, image i & 1:
+    //   READY[i & 1]  producer waves that finished writing the image     consumers of tile i wait for 8 (i / 2 + 1)
+    //   FREED[i & 1]  consumer waves that finished reading the image     producers of tile i wait for 8 (i / 2)
+    // A wait that outlasts kSpinLimit polls raises ABORT, which ends every wave (wrong output instead of a hung GPU).
+    int *const cnt = esc_flags + 16;
+    enum { READY = 0, FREED = 2, ABORT = 8 };
+    constexpr int kSpinLimit = 1 << 22;
+    auto wait_for = [&](int which, int need) -> bool {
+        int spins = 0;
+        while (__atomic_load_n(&cnt[which], __ATOMIC_RELAXED) < need) {
+            if (++spins > kSpinLimit || __atomic_load_n(&cnt[ABORT], __ATOMIC_RELAXED)) {
+                __atomic_store_n(&cnt[ABORT], 1, __ATOMIC_RELAXED);
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return true;
+    };
+    auto signal = [&](int which) {   // after this wave's LDS accesses of the event
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&cnt[which], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    const int n = min(*n_out, cap);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)nbr, 0, kK * nbr_stride * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc((void *)tile_rb, 0, rb_bytes, 0x00020000);
+
+    // contiguous runs of tiles per workgroup, runs of one XCD next to each other (blocks b and b + 8 share an XCD)
+    const int ntiles = (n + kTile - 1) / kTile;
+    const int G = gridDim.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = G >> 3, rem = G & 7;
+    const int range = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
+    const int t_begin = (int)(((long long)ntiles * range) / G), t_end = (int)(((long long)ntiles * (range + 1)) / G);
+    if (t_begin >= t_end) return;   // (whole workgroup, before any barrier)
+    const int nt = t_end - t_begin;
+
+    // Swizzles: a ds_read_b128 is served in four groups of 16 lanes — {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the
+    // same + 32 — i.e. MFMA rows 0-3 and 12-15 of one 8-channel chunk with rows 4-11 of the next.  Weight image: row r
+    // (one output channel, 4 chunks) stores logical chunk c at c ^ ((r >> 1) & 3); feature rows: row_code().  Both are
+    // conflict-free for 16 consecutive rows starting at a multiple of 16.
+    auto wpos = [](int row, int chunk) { return row * kCH + (chunk ^ ((row >> 1) & 3)); };
+    for (int p = tid; p < kK * kSlab; p += NT) {
+        const int kk = p / kSlab, r = p % kSlab;
+        wl[kk * kSlab + wpos(r / kCH, r % kCH)] = reinterpret_cast<const uint4 *>(w)[p];
+    }
+    if (tid < 2 * kCH) reinterpret_cast<uint4 *>(img0 + (tid / kCH) * kImgBytes + kZeroRow * kRowB)[tid % kCH] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 16) cnt[tid] = 0;
+
+    if (wave >= NCW) {
+        // ------------------------------------------------------------------ producer waves: memory -> registers -> image
+        const int ptid = tid - NCW * 64, pw = wave - NCW;
+        u32x4 pwin[NWL], pcod[NCL], g[NGL];
+        int far_id = -1;       // lanes 0-31: row id of overflow row 32 pw + lane of the tile after the one in the registers
+        unsigned pesc = 0;     // producer thread c < 8: escape flag of consumer wave c
+        // LDS offsets (inside an image) of this thread's window chunks and overflow-row pieces
+        unsigned win_dst[NWL], ovf_dst[NGL];
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) {
+            const unsigned p = (unsigned)ptid + j * PT;
+            win_dst[j] = row_code(win_slot(p / kCH)) ^ ((p % kCH) << 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NGL; ++i) ovf_dst[i] = row_code((unsigned)(kWin + pw * 32 + i * 16 + (lane >> 2))) ^ ((unsigned)(lane & 3) << 4);
+        auto rec_off = [&](int t) -> unsigned { return t < t_end ? (unsigned)t * (unsigned)kRecBytes : 0x80000000u; };
+        auto req_far_ids = [&](int t) {
+            far_id = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane < 32 ? rec_off(t) + (unsigned)(kRecFar + (pw * 32 + lane) * 4) : 0x80000000u, 0, 0);
+        };
+        auto req_tile = [&](int t) {   // everything of tile t but its far-row ids, which must be in far_id already
+            const unsigned ro = rec_off(t);
+            const unsigned wbase = t < t_end ? (unsigned)max(0, t * kTile - kHalo) * kRowB + (unsigned)ptid * 16u : 0x80000000u;
+#pragma unroll
+            for (int j = 0; j < NWL; ++j)
+                pwin[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (ptid + j * PT < kWin * kCH) ? wbase + j * (PT * 16) : 0x80000000u, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NCL; ++j)
+                pcod[j] = __builtin_amdgcn_raw_buffer_load_b128(trsrc, (ptid + j * PT < kRbBytes / 16) ? ro + (unsigned)(ptid + j * PT) * 16u : 0x80000000u, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NGL; ++i) {
+                const int key = t < t_end ? __shfl(far_id, i * 16 + (lane >> 2)) : -1;   // (a load that was not issued left 0, which is a row)
+                g[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, key >= 0 ? (unsigned)key * kRowB + (unsigned)(lane & 3) * 16u : 0x80000000u, 0, 0);
+            }
+            pesc = __builtin_amdgcn_raw_buffer_load_b8(trsrc, ptid < 8 ? ro + (unsigned)(kRecEsc + ptid) : 0x80000000u, 0, 0);
+        };
+        auto put_tile = [&](unsigned char *img, int image) {
+#pragma unroll
+            for (int j = 0; j < NCL; ++j)
+                if (ptid + j * PT < kRbBytes / 16) *reinterpret_cast<u32x4 *>(img + kXBytes + (ptid + j * PT) * 16) = pcod[j];
+#pragma unroll
+            for (int i = 0; i < NGL; ++i) *reinterpret_cast<u32x4 *>(img + ovf_dst[i]) = g[i];
+#pragma unroll
+            for (int j = 0; j < NWL; ++j)
+                if (ptid + j * PT < kWin * kCH) *reinterpret_cast<u32x4 *>(img + win_dst[j]) = pwin[j];
+            if (ptid < 8) esc_flags[image * NCW + ptid] = (FNP_TILE_ABLATE & 1) ? 0 : (int)pesc;
+        };
+        // Iteration i: write tile i + 1 (requested last iteration) into its image as soon as the consumers have left it,
+        // request tile i + 2 (its far-row ids were requested last iteration), request the far-row ids of tile i + 3.
+        req_far_ids(t_begin);
+        req_tile(t_begin);
+        req_far_ids(t_begin + 1);
+        __syncthreads();   // weights, zero rows, counters
+        FNP_STAMP_DECL;
+        for (int i = -1; i + 1 < nt; ++i) {
+            const int t = t_begin + i, p = (i + 1) & 1;
+            if (!wait_for(FREED + p, 8 * ((i + 1) / 2))) break;
+            FNP_STAMP(5);
+            put_tile(img0 + p * kImgBytes, p);
+            signal(READY + p);
+            FNP_STAMP(0);
+            req_tile(t + 2);
+            req_far_ids(t + 3);
+            FNP_STAMP(1);
+        }
+        FNP_STAMP_FLUSH(1);
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer waves
+    const int aoff = wpos(l15, q);
+    const int rloc = wave * 32 + 2 * l15;            // this lane's row of block 0 inside the tile (block 1: the next row)
+    const unsigned qx = (unsigned)q << 4;
+    const int poff = (q & 1) * 32 + (q >> 1) * 16;   // epilogue: this lane's 16 bytes of a row
+    float sc[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, sh[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (scale) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sc[h][j] = scale[h * 16 + q * 4 + j];
+                sh[h][j] = shift[h * 16 + q * 4 + j];
+            }
+    }
+    __syncthreads();   // weights, zero rows, counters
+    FNP_STAMP_DECL;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int tile_base = t * kTile, row_end = min(n, tile_base + kTile);
+        const int image = (t - t_begin) & 1;
+        if (!wait_for(READY + image, 8 * ((t - t_begin) / 2 + 1))) break;
+        FNP_STAMP(2);
+        const unsigned char *img = img0 + image * kImgBytes;
+        const unsigned *rb32 = reinterpret_cast<const unsigned *>(img + kXBytes) + wave * 16 + l15;   // both blocks' entries
+        // residual rows requested now, used after the sweep
+        uint4 rv[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int r = tile_base + rloc + mb;
+            rv[mb] = make_uint4(0u, 0u, 0u, 0u);
+            if (residual && r < row_end) rv[mb] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(residual) + (size_t)r * kRowB + poff);
+        }
+        f32x4 acc[NB][MB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto entry = [&](int k) -> unsigned { return rb32[(k < kK ? k : kK - 1) * (kTile / 2)]; };
+        auto weights = [&](int k, frag8 (&wa)[NB]) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const uint4 tw = wl[(k < kK ? k : kK - 1) * kSlab + aoff + nb * 16 * kCH];
+                wa[nb] = *reinterpret_cast<const frag8 *>(&tw);
+            }
+        };
+        // The sweep: weights one offset ahead, fragments two, entries four.  ESC: this wave's entries may hold escapes.
+        auto sweep = [&](auto esc_tag) {
+            constexpr bool ESC = decltype(esc_tag)::value;
+            auto fragments = [&](unsigned e, int k, u32x4 (&xv)[MB]) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const unsigned em = mb ? e >> 16 : e & 0xffffu;
+                    if constexpr (ESC) {
+                        if (__ballot(em == kEscape) != 0ull) {
+                            // more far rows than overflow slots: this fragment comes from memory
+                            unsigned off = 0x80000000u;
+                            if (em == kEscape)
+                                off = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(nrsrc, (unsigned)(tile_base + rloc + mb) * 4u, (unsigned)k * (unsigned)nbr_stride * 4u, 0) * kRowB +
+                                      (unsigned)q * 16u;
+                            const u32x4 gv = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+                            const u32x4 lv = *reinterpret_cast<const u32x4 *>(img + ((em == kEscape ? row_code(kZeroRow) : em) ^ qx));
+                            xv[mb] = gv | lv;
+                            continue;
+                        }
+                    }
+                    xv[mb] = *reinterpret_cast<const u32x4 *>(img + (em ^ qx));
+                }
+            };
+            // LDS reads run ahead of the matrix work: weights DW offsets, fragments DX, entries DX + 2
+            constexpr int DW = FNP_TILE_DW, DX = FNP_TILE_DX;
+            unsigned en[2];
+            frag8 wa[DW + 1][NB];
+            u32x4 xf[DX + 1][MB];
+#pragma unroll
+            for (int u = 0; u < DX; ++u) fragments(entry(u), u, xf[u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) en[(DX + u) & 1] = entry(DX + u);
+#pragma unroll
+            for (int u = 0; u < DW; ++u) weights(u, wa[u]);
+#pragma unroll
+            for (int k = 0; k < ((FNP_TILE_ABLATE & 2) ? 0 : kK); ++k) {
+                if (!(FNP_TILE_ABLATE & 16)) weights(k + DW, wa[(k + DW) % (DW + 1)]);
+                const unsigned e_new = (FNP_TILE_ABLATE & 32) ? en[0] : entry(k + DX + 2);
+                if (k + DX < kK && !(FNP_TILE_ABLATE & 32)) fragments(en[(k + DX) & 1], k + DX, xf[(k + DX) % (DX + 1)]);
+                if constexpr (!ESC) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const frag8 xv = *reinterpret_cast<const frag8 *>(&xf[(FNP_TILE_ABLATE & 32) ? 0 : k % (DX + 1)][mb]);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        if (FNP_TILE_ABLATE & 64) asm volatile("" ::"v"(wa[(FNP_TILE_ABLATE & 16) ? 0 : k % (DW + 1)][nb]), "v"(xv));
+                        else acc[nb][mb] = tmfma(wa[(FNP_TILE_ABLATE & 16) ? 0 : k % (DW + 1)][nb], xv, acc[nb][mb]);
+                    }
+                }
+                if constexpr (!ESC) __builtin_amdgcn_sched_barrier(0);
+                en[(k + DX) & 1] = e_new;
+            }
+        };
+        if (esc_flags[image * NCW + wave]) sweep(std::true_type{});
+        else sweep(std::false_type{});
+        FNP_STAMP(0);
+
+        // epilogue: BatchNorm(eval) scale / shift, residual, ReLU, one rounding — the arithmetic of spconv_mfma_kernel.
+        // The 8-byte pieces of the two channel blocks are exchanged between the lane rows q, q ^ 1 of a site
+        // (v_permlane16_swap), after which a lane holds 16 contiguous bytes of the 64-byte row.
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int r = tile_base + rloc + mb;
+            const bool live = r < row_end;
+            uint2 ra = make_uint2(0u, 0u), rbb = make_uint2(0u, 0u);
+            if (residual) {
+                auto t0 = __builtin_amdgcn_permlane16_swap(rv[mb].x, rv[mb].z, false, false);
+                auto t1 = __builtin_amdgcn_permlane16_swap(rv[mb].y, rv[mb].w, false, false);
+                ra = make_uint2(t0[0], t1[0]);    // block 0, channels q*4 .. q*4+3
+                rbb = make_uint2(t0[1], t1[1]);   // block 1
+            }
+            uint2 o[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[h][mb][j];
+                if (scale) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * sc[h][j] + sh[h][j];
+                }
+                if (residual) {
+                    const uint2 rr = h ? rbb : ra;
+                    const act4 tr = *reinterpret_cast<const act4 *>(&rr);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] + (float)tr[j];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.f ? 0.f : v[j];
+                }
+                const act4 ob = {(TAct)v[0], (TAct)v[1], (TAct)v[2], (TAct)v[3]};
+                o[h] = *reinterpret_cast<const uint2 *>(&ob);
+            }
+            auto t0 = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
+            auto t1 = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);
+            if (live)
+                *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(y) + (size_t)r * kRowB + poff) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+        }
+        signal(FREED + image);
+        FNP_STAMP(1);
+    }
+    FNP_STAMP_FLUSH(0);
+}
+
+
+template <typename TAct>
+int launch_tile32(const void *x, long long x_bytes, const void *w, const void *tile_rb, long long rb_bytes, const int *nbr, int nbr_stride,
+                  const int *n_out, int cap, void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s) {
+    auto kern = spconv_tile32_kernel<TAct>;
+    static bool raised = false;   // (idempotent; a race only repeats the call)
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return FNP_ERR_HIP;
+        raised = true;
+    }
+    const int tiles = fnp_divup(cap, kTile);
+    const int grid = tiles < 256 ? tiles : 256;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), kLds, s, (const TAct *)x, (int)x_bytes, (const TAct *)w, (const unsigned char *)tile_rb, (int)rb_bytes,
+                       nbr, nbr_stride, n_out, cap, (TAct *)y, scale, shift, (const TAct *)residual, relu);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+}  // namespace
+
+#ifdef FNP_TILE_STAMP
+extern "C" int fnp_debug_tile_stamps(unsigned long long *out32) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_tile_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return FNP_ERR_HIP;
+    unsigned long long zero[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stamps), zero, sizeof(zero)) != hipSuccess) return FNP_ERR_HIP;
+    return FNP_OK;
+}
+#endif
+
+extern "C" long long fnp_tile_rulebook_bytes(int cap_out) { return cap_out > 0 ? (long long)fnp_divup(cap_out, kTile) * kRecBytes : 0; }
+
+extern "C" int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, void *tile_rb, fnp_stream_t stream) {
+    if (!nbr || !n_out || !tile_rb || K != kK || cap_out <= 0 || nbr_stride < cap_out) return FNP_ERR_ARG;
+    hipLaunchKernelGGL(tile_rulebook_kernel, dim3(fnp_divup(cap_out, kTile)), dim3(256), 0, (hipStream_t)stream, nbr, nbr_stride, n_out, cap_out,
+                       (unsigned char *)tile_rb);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+extern "C" int fnp_spconv_forward_tiled(const void *feat_in, int dtype, int n_in_rows, const void *weight, const void *tile_rb, const int *nbr,
+                                        int nbr_stride, const int *n_out, int cap_out, void *feat_out, const float *scale, const float *shift,
+                                        const void *residual, int relu, int Cin, int Cout, fnp_stream_t stream) {
+    if (!feat_in || !weight || !tile_rb || !nbr || !n_out || !feat_out || cap_out <= 0 || nbr_stride < cap_out || n_in_rows <= 0) return FNP_ERR_ARG;
+    if ((scale == nullptr) != (shift == nullptr) || Cin != kC || Cout != kC) return FNP_ERR_ARG;
+    const long long xb = (long long)n_in_rows * kC * 2, rbb = fnp_tile_rulebook_bytes(cap_out);
+    // 32-bit buffer offsets into the features, the int32 table (escape fetches) and the tile rulebook
+    if (xb >= 0x7fffffffll || (long long)kK * nbr_stride * 4 >= 0x7fffffffll || rbb >= 0x7fffffffll) return FNP_ERR_ARG;
+    if (((uintptr_t)tile_rb & 15) || ((uintptr_t)feat_in & 15) || ((uintptr_t)feat_out & 15) || ((uintptr_t)weight & 15)) return FNP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FNP_BF16) return launch_tile32<__bf16>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, feat_out, scale, shift, residual, relu, s);
+    if (dtype == FNP_F16) return launch_tile32<_Float16>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, feat_out, scale, shift, residual, relu, s);
+    return FNP_ERR_ARG;
+}

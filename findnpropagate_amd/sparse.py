@@ -12,6 +12,7 @@ Data layout in HBM:
   rulebook  nbr (K, cap) int32: input row per (kernel offset, output row) or -1
 """
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -252,15 +253,35 @@ def pack_weight(weight, dtype, mfma_f32=False):
 HINT_ROWS_RANKED = 1   # fnp.h FNP_HINT_ROWS_RANKED
 HINT_VALU = 2          # fnp.h FNP_HINT_VALU
 HINT_W_PERMUTED = 4    # fnp.h FNP_HINT_W_PERMUTED
+TILE_MIN_ROWS = 131072  # fnp.h FNP_TILE_MIN_ROWS
+# development / tests: force (True) or forbid (False) the tile-rulebook kernel wherever a caller leaves `tile` unset (FNP_TILE=1 / 0)
+TILE_MODE = {"0": False, "1": True}.get(os.environ.get("FNP_TILE", ""))
+
+
+def tile_rulebook(rb, n_out_dev):
+    """The tile rulebook of a 3x3x3 rulebook (fnp_tile_rulebook_build), built on first use and kept with it: valid as long
+    as rb.nbr and the row count are (a Rulebook object is never rewritten in place)."""
+    t = getattr(rb, "_tile_rb", None)
+    if t is None:
+        L = _l.load()
+        t = torch.empty((L.fnp_tile_rulebook_bytes(rb.cap_out),), dtype=torch.uint8, device=rb.nbr.device)
+        rc = L.fnp_tile_rulebook_build(_l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, _l.ptr(n_out_dev), rb.cap_out, _l.ptr(t), _l.stream())
+        _l.check(rc, "fnp_tile_rulebook_build")
+        rb._tile_rb = t
+    return t
 
 
 def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, shift=None, residual=None, relu=False,
-                 out=None, ranked=False, valu=False):
+                 out=None, ranked=False, valu=False, tile=None):
     """feat_out (cap_out, Cout) = act(conv * scale + shift + residual).  No host sync.
     ranked: input and output rows are both in rank-grid order (performance hint only).
-    valu: f32 only — the thread-per-element chain instead of the f32 MFMA kernel (same bits)."""
+    valu: f32 only — the thread-per-element chain instead of the f32 MFMA kernel (same bits).
+    tile: 16-bit 32 -> 32 layers of 3x3x3 kernels — True / False forces / forbids the tile-rulebook kernel (None: ranked
+    tensors of at least TILE_MIN_ROWS rows take it; same bits either way)."""
     L = _l.load()
     _l.require_device(feat_in, w_packed, rb.nbr, n_out_dev)
+    if tile is None:
+        tile = TILE_MODE
     K, Cout, Cin = w_packed.shape
     assert K == rb.K and feat_in.shape[1] == Cin and feat_in.dtype == w_packed.dtype
     assert feat_in.is_contiguous() and w_packed.is_contiguous()
@@ -272,6 +293,13 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
         assert residual.dtype == out.dtype and residual.shape[1] == Cout and residual.is_contiguous()
     if scale is not None:
         assert scale.dtype == torch.float32 and shift.dtype == torch.float32
+    if (K == 27 and Cin == 32 and Cout == 32 and feat_in.dtype in (torch.bfloat16, torch.float16) and out.dtype == feat_in.dtype
+            and (tile or (tile is None and ranked and cap_out >= TILE_MIN_ROWS))):
+        rc = L.fnp_spconv_forward_tiled(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
+                                        _l.ptr(tile_rulebook(rb, n_out_dev)), _l.ptr(rb.nbr), rb.nbr.shape[1], _l.ptr(n_out_dev), cap_out,
+                                        _l.ptr(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual), int(bool(relu)), Cin, Cout, _l.stream())
+        _l.check(rc, "fnp_spconv_forward_tiled")
+        return out
     rc = L.fnp_spconv_forward(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
                               _l.ptr(rb.nbr), rb.nbr.shape[1], K, _l.ptr(n_out_dev), cap_out,
                               _l.ptr(out), _l.dtype_code(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual),

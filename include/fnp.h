@@ -258,6 +258,33 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
                        const float *scale, const float *shift, const void *residual, int relu,
                        int hints, int Cin, int Cout, fnp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The same convolution on a TILE RULEBOOK, for the ranked 16-bit 32 -> 32 layers of 3x3x3 kernels (the four SubM
+ * convolutions of stage 2 of VoxelResBackBone8x, spconv_backbone.py:210-212: one rulebook, indice_key 'subm2' / 'res2',
+ * used four times per forward).  fnp_tile_rulebook_build restates the (27, cap) int32 table once, per tile of
+ * FNP_TILE_ROWS output rows, as 16-bit addresses into an LDS image of the tile's neighbourhood (a window of input rows
+ * around the tile + up to 256 far rows, deduplicated) — FNP_TILE_RECORD_BYTES per tile, 58 bytes per row instead of 108 —
+ * and fnp_spconv_forward_tiled sweeps the offsets from LDS alone.  Bit-identical to fnp_spconv_forward on the int32
+ * table for ANY row order; the tiled form is the faster one when rows are in rank-grid order (FNP_HINT_ROWS_RANKED's
+ * condition) and the tensor has at least FNP_TILE_MIN_ROWS rows (256-row tiles must fill 256 CUs several times over).
+ *   tile_rb  fnp_tile_rulebook_bytes(cap_out) bytes, 16-byte aligned; valid for the (nbr, n_out) it was built from
+ *   nbr      the int32 table itself: read only for entries the tile record could not hold (more than 256 distinct far
+ *            rows in a tile: arbitrary row orders)
+ * K must be 27, Cin == Cout == 32, dtype FNP_BF16 or FNP_F16 (features, weights, residual and output alike);
+ * FNP_ERR_ARG otherwise, and for tensors beyond 32-bit byte offsets.
+ * ------------------------------------------------------------------------------------------ */
+#define FNP_TILE_ROWS 256
+#define FNP_TILE_RECORD_BYTES 14864
+#define FNP_TILE_MIN_ROWS 131072
+long long fnp_tile_rulebook_bytes(int cap_out);
+int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out,
+                            void *tile_rb, fnp_stream_t stream);
+int fnp_spconv_forward_tiled(const void *feat_in, int dtype, int n_in_rows, const void *weight,
+                             const void *tile_rb, const int *nbr, int nbr_stride,
+                             const int *n_out, int cap_out, void *feat_out,
+                             const float *scale, const float *shift, const void *residual, int relu,
+                             int Cin, int Cout, fnp_stream_t stream);
+
 /* The same convolution for a STRIDED 3x3x3 layer whose rulebook has no other user (the three down-sampling
  * layers of VoxelResBackBone8x, spconv_backbone.py:207,214,221): the kernel computes the rulebook rows of its
  * tiles itself from the input rank grid and the output coordinates (fnp_rulebook_strided with nbr = NULL builds

@@ -495,6 +495,59 @@ def test_window_kernel_equals_gather_kernel(cuda, rng, n):
         assert torch.equal(a[:n], b[:n])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,order", [(1, "random"), (200, "random"), (257, "sorted"), (5000, "random"), (5000, "sorted"), (40000, "sorted")])
+def test_tile_kernel_equals_gather_kernel(cuda, rng, n, order, dtype):
+    """The LDS-tile kernel of the ranked 32 -> 32 layers (spconv_tile.hip: window, overflow rows and escape fetches prepared
+    by producer waves) against spconv_mfma_kernel: same products, same order, bit-identical output.  Rows in random
+    order put almost every neighbour outside the window (overflow slots run out: the escape path carries the layer);
+    rows sorted by cell put most of them inside."""
+    B, shape, C = 2, [9, 40, 41] if n <= 5000 else [21, 80, 80], 32
+    feats, idx = _random_sparse(rng, B, shape, n, C)
+    if order == "sorted":
+        idx = idx[np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))]
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    rb = S.rulebook_subm(d_idx, n_dev, S.build_grid(d_idx, n_dev, B, shape), 3)
+    wp = S.pack_weight(torch.from_numpy((rng.standard_normal((C, 3, 3, 3, C)) * 0.1).astype(np.float32)).to(cuda), dtype)
+    x = torch.from_numpy(feats).to(cuda).to(dtype)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)).to(cuda)
+    sh = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).to(cuda)
+    res = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32)).to(cuda).to(dtype)
+    for residual, scale, relu in ((None, sc, True), (res, sc, True), (res, None, False)):
+        shift = sh if scale is not None else None
+        a = S.conv_forward(x, wp, rb, n_dev, scale=scale, shift=shift, residual=residual, relu=relu, ranked=False)
+        b = S.conv_forward(x, wp, rb, n_dev, scale=scale, shift=shift, residual=residual, relu=relu, ranked=True, tile=True)
+        c = S.conv_forward(x, wp, rb, n_dev, scale=scale, shift=shift, residual=residual, relu=relu, ranked=True, tile=False)
+        assert torch.equal(a[:n], b[:n]) and torch.equal(a[:n], c[:n])
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_tile_kernel_in_the_backbone(cuda, mode):
+    """Full-size grid, 3 real-shaped scenes: the backbone with the LDS-tile kernel forced on its ranked 32 -> 32 layers
+    (rows in rank-grid order: the window carries most neighbours, the overflow rows the rest) equals the backbone
+    without it bit for bit, at every stage."""
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 0).to(cuda).eval()
+    net.fnp_dtype = mode
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+    pts, off = syn.make_batch([0, 1, 2])
+    pts, off = torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda)
+    outs = []
+    for tile in (False, True):
+        S.TILE_MODE = tile
+        try:
+            with torch.no_grad():
+                r = net.forward_points(pts, off, 3, cfg)
+            outs.append({k: (r[k].features.clone(), r[k].indices.clone()) for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out")})
+        finally:
+            S.TILE_MODE = None
+    for k in outs[0]:
+        assert torch.equal(outs[0][k][1], outs[1][k][1]), k
+        assert torch.equal(outs[0][k][0], outs[1][k][0]), k
+
+
 def test_forward_points_edge_batches(cuda):
     """Ragged and degenerate batches through the fused path: a scene with no points between two scenes, points that
     all fall outside the range, a single point.  A scene's result does not depend on what else is in the batch

@@ -9,7 +9,11 @@ from findnpropagate_amd import sparse as S, synthetic as syn
 from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--reps", type=int, default=20); ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"]); ap.add_argument("--valu", action="store_true"); ap.add_argument("--identity", action="store_true", help="replace every valid rulebook entry by the output row itself (perfect gather locality, same instruction stream)"); ap.add_argument("--fracs", type=str, default="1.0", help="comma list: time each layer on the first frac*n output rows too (tile staircase)")
+ap.add_argument("--tile", default="auto", choices=["auto", "on", "off"], help="LDS-tile kernel for the ranked 32 -> 32 layers: by size / forced / forbidden")
+ap.add_argument("--only", default="", help="e.g. 32x32: time this layer class only")
+ap.add_argument("--tile-stats", action="store_true", help="far-neighbour statistics of the ranked 32 -> 32 layer per 256-row tile")
 args = ap.parse_args()
+TILE = {"auto": None, "on": True, "off": False}[args.tile]
 dev = torch.device("cuda", 0)
 B = args.batch
 TD = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[args.dtype]
@@ -30,6 +34,7 @@ seen = {}
 for tag, rb, n_dev in log:
     cin, cout, K, has_res, ranked = tag
     if cin == 5 or (cin, cout, K) in seen: continue
+    if args.only and args.only != f"{cin}x{cout}": continue
     seen[(cin, cout, K)] = 1
     n = int(n_dev.item()); pairs = int((rb.nbr[:, :n] >= 0).sum().item())
     n_in = int(rb.nbr[:, :n].max().item()) + 1
@@ -38,19 +43,68 @@ for tag, rb, n_dev in log:
     sc = torch.ones(cout, device=dev); sh = torch.zeros(cout, device=dev)
     resid = torch.randn((rb.cap_out, cout), device=dev).to(TD)
     n_full = n
-    if args.identity and n_in >= n:
-        import copy
-        rb = copy.copy(rb); ar = torch.arange(rb.nbr.shape[1], device=dev, dtype=torch.int32)[None].expand_as(rb.nbr)
-        rb.nbr = torch.where(rb.nbr >= 0, ar, rb.nbr).contiguous()
+    if args.tile_stats and ranked and K == 27:
+        # far rows of spconv_tile.hip's tiles: per producer wave (32 rows x 27 offsets) the unique far row ids
+        T, HALO, WR = 256, 64, 32
+        nt = (n + T - 1) // T
+        nb = torch.full((K, nt * T), -1, dtype=torch.int64, device=dev); nb[:, :n] = rb.nbr[:, :n].long()
+        nb = nb.view(K, nt, T // WR, WR).permute(1, 2, 0, 3).reshape(nt, T // WR, K * WR)     # (tile, wave, entries)
+        base = (torch.arange(nt, device=dev) * T)[:, None, None]
+        lo = (base - HALO).clamp(min=0)
+        far = (nb >= 0) & ((nb < lo) | (nb >= lo + T + 2 * HALO))
+        key = torch.where(far, nb, torch.full_like(nb, -1))
+        srt = key.sort(dim=2).values
+        first = torch.ones_like(srt, dtype=torch.bool); first[..., 1:] = srt[..., 1:] != srt[..., :-1]
+        uniq = (first & (srt >= 0)).sum(2).float()                    # unique far rows per (tile, wave)
+        refs = far.sum(2).float()
+        # unique far rows per tile
+        kt = key.reshape(nt, -1).sort(dim=1).values
+        ft = torch.ones_like(kt, dtype=torch.bool); ft[:, 1:] = kt[:, 1:] != kt[:, :-1]
+        uniq_t = (ft & (kt >= 0)).sum(1).float()
+        q = lambda x, p: round(x.flatten().quantile(p).item(), 1) if x.numel() < 16_000_000 else None
+        print(json.dumps({"tile_stats": f"{cin}x{cout}", "tiles": nt, "far_refs_per_wave_mean": round(refs.mean().item(), 1),
+                          "uniq_far_per_wave": {"mean": round(uniq.mean().item(), 2), "p50": q(uniq, .5), "p90": q(uniq, .9), "p99": q(uniq, .99), "max": uniq.max().item()},
+                          "uniq_far_per_tile": {"mean": round(uniq_t.mean().item(), 1), "p90": q(uniq_t, .9), "p99": q(uniq_t, .99), "max": uniq_t.max().item()},
+                          "waves_over": {c: round((uniq > c).float().mean().item(), 4) for c in (8, 16, 24, 32, 48)},
+                          "tiles_over": {c: round((uniq_t > c).float().mean().item(), 4) for c in (64, 128, 192, 256)}}))
+        for halo in (32, 96, 128):
+            lo2 = (base - halo).clamp(min=0)
+            far2 = (nb >= 0) & ((nb < lo2) | (nb >= lo2 + T + 2 * halo))
+            k2 = torch.where(far2, nb, torch.full_like(nb, -1)).reshape(nt, -1).sort(dim=1).values
+            f2 = torch.ones_like(k2, dtype=torch.bool); f2[:, 1:] = k2[:, 1:] != k2[:, :-1]
+            u2 = (f2 & (k2 >= 0)).sum(1).float()
+            print(json.dumps({"halo": halo, "far_refs_per_tile": round(far2.sum().item() / nt, 1), "uniq_far_per_tile_mean": round(u2.mean().item(), 1), "p99": q(u2, .99)}))
     for frac in [float(f) for f in args.fracs.split(",")]:
         n = int(n_full * frac); n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
         pairs = int((rb.nbr[:, :n] >= 0).sum().item())
-        for _ in range(3): S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True, ranked=ranked, valu=args.valu)
+        for _ in range(3): S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True, ranked=ranked, valu=args.valu, tile=TILE)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record()
-        for _ in range(args.reps): S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True, ranked=ranked, valu=args.valu)
+        for _ in range(args.reps): S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True, ranked=ranked, valu=args.valu, tile=TILE)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
+        if TILE and (cin, cout, K) == (32, 32, 27):   # the one-off restatement of the rulebook
+            L = S._l.load(); tb = torch.empty_like(rb._tile_rb)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(args.reps): L.fnp_tile_rulebook_build(S._l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, S._l.ptr(n_dev), rb.cap_out, S._l.ptr(tb), S._l.stream())
+            e1.record(); torch.cuda.synchronize()
+            esc = tb.view(-1, 14864)[: (n + 255) // 256, 14848:14856]
+            print(json.dumps({"tile_rulebook_build_ms": round(e0.elapsed_time(e1) / args.reps, 4), "wave_tiles_with_escape": round(esc.float().mean().item(), 5),
+                              "far_rows_per_tile": round((tb.view(-1, 14864)[: (n + 255) // 256, 13824:14848].contiguous().view(torch.int32) >= 0).float().sum(1).mean().item(), 1)}))
+        if os.environ.get("FNP_LIB_PATH", "").find("stamp") >= 0 and (cin, cout) == (32, 32):
+            import ctypes
+            raw = ctypes.CDLL(os.environ["FNP_LIB_PATH"])
+            buf = (ctypes.c_ulonglong * 32)()
+            raw.fnp_debug_tile_stamps(buf)
+            S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True, ranked=ranked, valu=args.valu, tile=TILE)
+            torch.cuda.synchronize()
+            raw.fnp_debug_tile_stamps(buf)
+            tiles = (n + 255) // 256
+            # s_memtime ticks (shader cycles) summed over the waves of a role: per tile and wave
+            print(json.dumps({"stamp_cycles_per_tile": {"consumer[sweep,epilogue,barrier]": [round(buf[i] / (tiles * 8)) for i in range(3)],
+                                                     "producer[codes,requests,translate,rows,overflow_req,barrier]": [round(buf[8 + i] / (tiles * 8)) for i in range(6)]},
+                              "slowest_wave_cycles_per_tile": {"consumer": [round(buf[16 + i] / (tiles / 256)) for i in range(3)], "producer": [round(buf[24 + i] / (tiles / 256)) for i in range(6)]},
+                              "producer_wave_tiles_with_escape": round(buf[8 + 6] / (tiles * 8), 4), "far_list_lanes_per_wave_tile(lane0 only)": round(buf[8 + 7] / (tiles * 8), 4)}))
         dense_flop = 2.0 * n * K * cin * cout; alg_flop = 2.0 * pairs * cin * cout
         byts = pairs * (cin * EB + 8) + 2 * n * cout * EB + K * cin * cout * EB
         print(json.dumps({"layer": f"{cin}x{cout}k{K}", "n_out": n, "pairs": pairs, "density": round(pairs / (n * K), 3), "ms": round(ms, 4),
