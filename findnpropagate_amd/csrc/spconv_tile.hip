@@ -63,56 +63,82 @@ __host__ __device__ constexpr unsigned row_code(unsigned rs) { return rs * kRowB
 __host__ __device__ constexpr unsigned win_slot(unsigned d) { return (d & 1u) * (kWin / 2) + (d >> 1); }
 
 // ------------------------------------------------------------------------------------------ tile rulebook
-// One 256-thread workgroup per tile, thread r = tile row r.  Far rows go through an LDS open-addressing table (compare-
-// and-swap, linear probing): which slot a row gets depends on the order the threads arrive in, the BYTES the convolution
-// reads through it do not.
+// One 256-thread workgroup per tile; thread (kq, i) = (tid >> 6, tid & 63) restates rows 4 i .. 4 i + 3 of the offsets
+// kq, kq + 4, ... (16-byte loads of the int32 table, 8-byte stores of the entries).  Far rows go through an LDS
+// open-addressing table (compare-and-swap, linear probing): which slot a row gets depends on the order the threads
+// arrive in, the BYTES the convolution reads through it do not.
 __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restrict__ nbr, int nbr_stride, const int *__restrict__ n_out, int cap,
                                                             unsigned char *__restrict__ out) {
     __shared__ int table[kOvf];
     __shared__ int esc[8];
     const int n = min(*n_out, cap);
-    const int t = blockIdx.x, tile_base = t * kTile, r = threadIdx.x;
+    const int t = blockIdx.x, tile_base = t * kTile, tid = threadIdx.x;
     if (tile_base >= n) return;
-    table[r] = -1;
-    if (r < 8) esc[r] = 0;
+    table[tid] = -1;
+    if (tid < 8) esc[tid] = 0;
     __syncthreads();
-    const int wlo = max(0, tile_base - kHalo), row = tile_base + r;
-    int id[kK];
+    const int wlo = max(0, tile_base - kHalo), kq = tid >> 6, r0 = (tid & 63) * 4, row0 = tile_base + r0;
+    constexpr int NJ = (kK + 3) / 4;
+    int4 id[NJ];
+    const bool wide = !(nbr_stride & 3) && !((uintptr_t)nbr & 15);   // (uniform) table rows are 16-byte aligned
 #pragma unroll
-    for (int k = 0; k < kK; ++k) id[k] = row < n ? nbr[(size_t)k * nbr_stride + row] : -1;
-    unsigned short *codes = reinterpret_cast<unsigned short *>(out + (size_t)t * kRecBytes);
+    for (int j = 0; j < NJ; ++j) {   // (rows past n are masked below)
+        const int k = kq + 4 * j;
+        id[j] = make_int4(-1, -1, -1, -1);
+        if (k < kK && row0 < n) {
+            const int *p = nbr + (size_t)k * nbr_stride + row0;
+            if (wide) id[j] = *reinterpret_cast<const int4 *>(p);
+            else id[j] = make_int4(p[0], row0 + 1 < n ? p[1] : -1, row0 + 2 < n ? p[2] : -1, row0 + 3 < n ? p[3] : -1);
+        }
+    }
+    unsigned char *rec = out + (size_t)t * kRecBytes;
 #pragma unroll
-    for (int k = 0; k < kK; ++k) {
-        const unsigned d = (unsigned)(id[k] - wlo);
-        unsigned code = row_code(kZeroRow);
-        if (id[k] >= 0) {
-            if (d < (unsigned)kWin) {
-                code = row_code(win_slot(d));
-            } else {
-                unsigned h = (unsigned)id[k] & (unsigned)(kOvf - 1);
-                code = kEscape;
-                for (int probe = 0; probe < 64; ++probe) {
-                    const int old = atomicCAS(&table[h], -1, id[k]);
-                    if (old == -1 || old == id[k]) {
-                        code = row_code((unsigned)kWin + h);
-                        break;
+    for (int j = 0; j < NJ; ++j) {
+        const int k = kq + 4 * j;
+        if (k >= kK) break;
+        const int ids[4] = {id[j].x, id[j].y, id[j].z, id[j].w};
+        unsigned code[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int v = row0 + u < n ? ids[u] : -1;
+            const unsigned d = (unsigned)(v - wlo);
+            code[u] = row_code(kZeroRow);
+            if (v >= 0) {
+                if (d < (unsigned)kWin) {
+                    code[u] = row_code(win_slot(d));
+                } else {
+                    unsigned h = (unsigned)v & (unsigned)(kOvf - 1);
+                    code[u] = kEscape;
+                    for (int probe = 0; probe < 64; ++probe) {
+                        const int old = atomicCAS(&table[h], -1, v);
+                        if (old == -1 || old == v) {
+                            code[u] = row_code((unsigned)kWin + h);
+                            break;
+                        }
+                        h = (h + 1) & (unsigned)(kOvf - 1);
                     }
-                    h = (h + 1) & (unsigned)(kOvf - 1);
+                    if (code[u] == kEscape) esc[(r0 + u) >> 5] = 1;
                 }
-                if (code == kEscape) esc[r >> 5] = 1;
             }
         }
-        codes[k * kTile + r] = (unsigned short)code;
+        *reinterpret_cast<uint2 *>(rec + ((size_t)k * kTile + r0) * 2) = make_uint2(code[0] | (code[1] << 16), code[2] | (code[3] << 16));
     }
     __syncthreads();
-    reinterpret_cast<int *>(out + (size_t)t * kRecBytes + kRecFar)[r] = table[r];
-    if (r < 16) out[(size_t)t * kRecBytes + kRecEsc + r] = r < 8 ? (unsigned char)esc[r] : 0;
+    reinterpret_cast<int *>(rec + kRecFar)[tid] = table[tid];
+    if (tid < 16) rec[kRecEsc + tid] = tid < 8 ? (unsigned char)esc[tid] : 0;
 }
 
 // Development-only timing probes (results are wrong; the shipped library has 0): 1 = escape entries are taken as absent,
-// 2 = consumers skip the offset sweep
+// 2 = consumers skip the offset sweep, 4 = producers write the first two tiles only, 16 / 32 = consumers skip weight / fragment reads,
+// 64 = no MFMA
 #ifndef FNP_TILE_ABLATE
 #define FNP_TILE_ABLATE 0
+#endif
+#ifndef FNP_TILE_SCHED
+#define FNP_TILE_SCHED 1
+#endif
+#ifndef FNP_TILE_PSLEEP
+#define FNP_TILE_PSLEEP 8
 #endif
 #ifndef FNP_TILE_DW
 #define FNP_TILE_DW 1
@@ -186,7 +212,7 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
     // A wait that outlasts kSpinLimit polls raises ABORT, which ends every wave (wrong output instead of a hung GPU).
     int *const cnt = esc_flags + 16;
     enum { READY = 0, FREED = 2, ABORT = 8 };
-    constexpr int kSpinLimit = 1 << 22;
+    constexpr int kSpinLimit = 1 << 20;
     auto wait_for = [&](int which, int need) -> bool {
         int spins = 0;
         while (__atomic_load_n(&cnt[which], __ATOMIC_RELAXED) < need) {
@@ -194,7 +220,9 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
                 __atomic_store_n(&cnt[ABORT], 1, __ATOMIC_RELAXED);
                 return false;
             }
-            __builtin_amdgcn_s_sleep(1);
+            // (a poll is an LDS read in the consumers' queue: the producers, a tile ahead, poll slowly)
+            if (which >= FREED) __builtin_amdgcn_s_sleep(FNP_TILE_PSLEEP);
+            else __builtin_amdgcn_s_sleep(1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return true;
@@ -288,11 +316,13 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
             const int t = t_begin + i, p = (i + 1) & 1;
             if (!wait_for(FREED + p, 8 * ((i + 1) / 2))) break;
             FNP_STAMP(5);
-            put_tile(img0 + p * kImgBytes, p);
+            if (!(FNP_TILE_ABLATE & 4) || i < 1) put_tile(img0 + p * kImgBytes, p);
             signal(READY + p);
             FNP_STAMP(0);
-            req_tile(t + 2);
-            req_far_ids(t + 3);
+            if (!(FNP_TILE_ABLATE & 4)) {
+                req_tile(t + 2);
+                req_far_ids(t + 3);
+            }
             FNP_STAMP(1);
         }
         FNP_STAMP_FLUSH(1);
@@ -315,6 +345,7 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
             }
     }
     __syncthreads();   // weights, zero rows, counters
+    if ((FNP_TILE_SCHED == 2 || FNP_TILE_SCHED == 3) && wave >= 4) __builtin_amdgcn_s_sleep(4);
     FNP_STAMP_DECL;
     for (int t = t_begin; t < t_end; ++t) {
         const int tile_base = t * kTile, row_end = min(n, tile_base + kTile);
@@ -383,7 +414,7 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
                 if (!(FNP_TILE_ABLATE & 16)) weights(k + DW, wa[(k + DW) % (DW + 1)]);
                 const unsigned e_new = (FNP_TILE_ABLATE & 32) ? en[0] : entry(k + DX + 2);
                 if (k + DX < kK && !(FNP_TILE_ABLATE & 32)) fragments(en[(k + DX) & 1], k + DX, xf[(k + DX) % (DX + 1)]);
-                if constexpr (!ESC) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!ESC && FNP_TILE_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
                     const frag8 xv = *reinterpret_cast<const frag8 *>(&xf[(FNP_TILE_ABLATE & 32) ? 0 : k % (DX + 1)][mb]);
@@ -393,7 +424,22 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
                         else acc[nb][mb] = tmfma(wa[(FNP_TILE_ABLATE & 16) ? 0 : k % (DW + 1)][nb], xv, acc[nb][mb]);
                     }
                 }
-                if constexpr (!ESC) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!ESC && FNP_TILE_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!ESC && FNP_TILE_SCHED != 0) {
+                    // one iteration = 4 MFMAs with the 5 LDS reads and their address arithmetic spread between them: the two
+                    // consumer waves of a SIMD then keep both pipes busy instead of bursting into each in turn
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);   // (nothing moves between iterations: the read-ahead distances stand)
+                }
                 en[(k + DX) & 1] = e_new;
             }
         };
@@ -482,6 +528,7 @@ extern "C" long long fnp_tile_rulebook_bytes(int cap_out) { return cap_out > 0 ?
 
 extern "C" int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, void *tile_rb, fnp_stream_t stream) {
     if (!nbr || !n_out || !tile_rb || K != kK || cap_out <= 0 || nbr_stride < cap_out) return FNP_ERR_ARG;
+    if ((uintptr_t)tile_rb & 15) return FNP_ERR_ARG;
     hipLaunchKernelGGL(tile_rulebook_kernel, dim3(fnp_divup(cap_out, kTile)), dim3(256), 0, (hipStream_t)stream, nbr, nbr_stride, n_out, cap_out,
                        (unsigned char *)tile_rb);
     FNP_LAUNCH_CHECK();

@@ -253,7 +253,7 @@ def pack_weight(weight, dtype, mfma_f32=False):
 HINT_ROWS_RANKED = 1   # fnp.h FNP_HINT_ROWS_RANKED
 HINT_VALU = 2          # fnp.h FNP_HINT_VALU
 HINT_W_PERMUTED = 4    # fnp.h FNP_HINT_W_PERMUTED
-TILE_MIN_ROWS = 131072  # fnp.h FNP_TILE_MIN_ROWS
+TILE_MIN_ROWS = 1048576  # fnp.h FNP_TILE_MIN_ROWS
 # development / tests: force (True) or forbid (False) the tile-rulebook kernel wherever a caller leaves `tile` unset (FNP_TILE=1 / 0)
 TILE_MODE = {"0": False, "1": True}.get(os.environ.get("FNP_TILE", ""))
 

@@ -266,7 +266,8 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
  * around the tile + up to 256 far rows, deduplicated) — FNP_TILE_RECORD_BYTES per tile, 58 bytes per row instead of 108 —
  * and fnp_spconv_forward_tiled sweeps the offsets from LDS alone.  Bit-identical to fnp_spconv_forward on the int32
  * table for ANY row order; the tiled form is the faster one when rows are in rank-grid order (FNP_HINT_ROWS_RANKED's
- * condition) and the tensor has at least FNP_TILE_MIN_ROWS rows (256-row tiles must fill 256 CUs several times over).
+ * condition) and the tensor's capacity is at least FNP_TILE_MIN_ROWS rows (measured break-even of four tiled convolutions +
+ * one fnp_tile_rulebook_build against four gather convolutions: ~300k live rows, i.e. 8-16 scenes of the backbone's stage 2).
  *   tile_rb  fnp_tile_rulebook_bytes(cap_out) bytes, 16-byte aligned; valid for the (nbr, n_out) it was built from
  *   nbr      the int32 table itself: read only for entries the tile record could not hold (more than 256 distinct far
  *            rows in a tile: arbitrary row orders)
@@ -275,7 +276,7 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
  * ------------------------------------------------------------------------------------------ */
 #define FNP_TILE_ROWS 256
 #define FNP_TILE_RECORD_BYTES 14864
-#define FNP_TILE_MIN_ROWS 131072
+#define FNP_TILE_MIN_ROWS 1048576
 long long fnp_tile_rulebook_bytes(int cap_out);
 int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out,
                             void *tile_rb, fnp_stream_t stream);
