@@ -63,27 +63,44 @@ __host__ __device__ constexpr unsigned row_code(unsigned rs) { return rs * kRowB
 __host__ __device__ constexpr unsigned win_slot(unsigned d) { return (d & 1u) * (kWin / 2) + (d >> 1); }
 
 // ------------------------------------------------------------------------------------------ tile rulebook
-// One 256-thread workgroup per tile; thread (kq, i) = (tid >> 6, tid & 63) restates rows 4 i .. 4 i + 3 of the offsets
-// kq, kq + 4, ... (16-byte loads of the int32 table, 8-byte stores of the entries).  Far rows go through an LDS
-// open-addressing table (compare-and-swap, linear probing): which slot a row gets depends on the order the threads
-// arrive in, the BYTES the convolution reads through it do not.
+// Geometry of a tile image, per channel count.  32 channels: 256-row tiles, window +-32 rows, 256 overflow rows, 64-byte
+// rows.  64 channels (spconv_tile64_kernel below): 128-row tiles, window +-32, 128 overflow rows, 128-byte rows.
+struct G32 {
+    static constexpr int TILE = kTile, HALO = kHalo, WIN = kWin, OVF = kOvf, ZERO = kZeroRow;
+    static constexpr int REC_FAR = kRecFar, REC_ESC = kRecEsc, REC = kRecBytes;
+    __host__ __device__ static constexpr unsigned code(unsigned rs) { return row_code(rs); }
+};
+struct G64 {
+    static constexpr int TILE = 128, HALO = 32, WIN = TILE + 2 * HALO, OVF = 128, ZERO = WIN + OVF, ROWB = 128;
+    static constexpr int REC_FAR = kK * TILE * 2, REC_ESC = REC_FAR + OVF * 4, REC = REC_ESC + 16;
+    // the row at slot rs stores logical 16-byte chunk c (0..7) at chunk c ^ ((rs >> 1) & 7); a lane reads chunk c at entry ^ (c << 4)
+    __host__ __device__ static constexpr unsigned code(unsigned rs) { return rs * ROWB + (((rs >> 1) & 7u) << 4); }
+};
+static_assert(G64::REC == FNP_TILE64_RECORD_BYTES && G64::REC % 16 == 0 && G64::ZERO * G64::ROWB + 112 < 0xFFFF, "64-channel tile record");
+template <typename G> __host__ __device__ constexpr unsigned g_win_slot(unsigned d) { return (d & 1u) * (G::WIN / 2) + (d >> 1); }
+
+// One 256-thread workgroup per tile; a thread restates 4 consecutive rows of the offsets kq, kq + NG, ... (16-byte loads
+// of the int32 table, 8-byte stores of the entries).  Far rows go through an LDS open-addressing table (compare-and-
+// swap, linear probing): which slot a row gets depends on the order the threads arrive in, the BYTES the convolution
+// reads through it do not.
+template <typename G>
 __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restrict__ nbr, int nbr_stride, const int *__restrict__ n_out, int cap,
                                                             unsigned char *__restrict__ out) {
-    __shared__ int table[kOvf];
+    constexpr int RL = G::TILE / 4, NG = 256 / RL, NJ = (kK + NG - 1) / NG;   // lanes per offset, offsets per pass, passes
+    __shared__ int table[G::OVF];
     __shared__ int esc[8];
     const int n = min(*n_out, cap);
-    const int t = blockIdx.x, tile_base = t * kTile, tid = threadIdx.x;
+    const int t = blockIdx.x, tile_base = t * G::TILE, tid = threadIdx.x;
     if (tile_base >= n) return;
-    table[tid] = -1;
+    if (tid < G::OVF) table[tid] = -1;
     if (tid < 8) esc[tid] = 0;
     __syncthreads();
-    const int wlo = max(0, tile_base - kHalo), kq = tid >> 6, r0 = (tid & 63) * 4, row0 = tile_base + r0;
-    constexpr int NJ = (kK + 3) / 4;
+    const int wlo = max(0, tile_base - G::HALO), kq = tid / RL, r0 = (tid % RL) * 4, row0 = tile_base + r0;
     int4 id[NJ];
     const bool wide = !(nbr_stride & 3) && !((uintptr_t)nbr & 15);   // (uniform) table rows are 16-byte aligned
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {   // (rows past n are masked below)
-        const int k = kq + 4 * j;
+        const int k = kq + NG * j;
         id[j] = make_int4(-1, -1, -1, -1);
         if (k < kK && row0 < n) {
             const int *p = nbr + (size_t)k * nbr_stride + row0;
@@ -91,10 +108,10 @@ __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restric
             else id[j] = make_int4(p[0], row0 + 1 < n ? p[1] : -1, row0 + 2 < n ? p[2] : -1, row0 + 3 < n ? p[3] : -1);
         }
     }
-    unsigned char *rec = out + (size_t)t * kRecBytes;
+    unsigned char *rec = out + (size_t)t * G::REC;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int k = kq + 4 * j;
+        const int k = kq + NG * j;
         if (k >= kK) break;
         const int ids[4] = {id[j].x, id[j].y, id[j].z, id[j].w};
         unsigned code[4];
@@ -102,30 +119,30 @@ __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restric
         for (int u = 0; u < 4; ++u) {
             const int v = row0 + u < n ? ids[u] : -1;
             const unsigned d = (unsigned)(v - wlo);
-            code[u] = row_code(kZeroRow);
+            code[u] = G::code(G::ZERO);
             if (v >= 0) {
-                if (d < (unsigned)kWin) {
-                    code[u] = row_code(win_slot(d));
+                if (d < (unsigned)G::WIN) {
+                    code[u] = G::code(g_win_slot<G>(d));
                 } else {
-                    unsigned h = (unsigned)v & (unsigned)(kOvf - 1);
+                    unsigned h = (unsigned)v & (unsigned)(G::OVF - 1);
                     code[u] = kEscape;
                     for (int probe = 0; probe < 64; ++probe) {
                         const int old = atomicCAS(&table[h], -1, v);
                         if (old == -1 || old == v) {
-                            code[u] = row_code((unsigned)kWin + h);
+                            code[u] = G::code((unsigned)G::WIN + h);
                             break;
                         }
-                        h = (h + 1) & (unsigned)(kOvf - 1);
+                        h = (h + 1) & (unsigned)(G::OVF - 1);
                     }
                     if (code[u] == kEscape) esc[(r0 + u) >> 5] = 1;
                 }
             }
         }
-        *reinterpret_cast<uint2 *>(rec + ((size_t)k * kTile + r0) * 2) = make_uint2(code[0] | (code[1] << 16), code[2] | (code[3] << 16));
+        *reinterpret_cast<uint2 *>(rec + ((size_t)k * G::TILE + r0) * 2) = make_uint2(code[0] | (code[1] << 16), code[2] | (code[3] << 16));
     }
     __syncthreads();
-    reinterpret_cast<int *>(rec + kRecFar)[tid] = table[tid];
-    if (tid < 16) rec[kRecEsc + tid] = tid < 8 ? (unsigned char)esc[tid] : 0;
+    if (tid < G::OVF) reinterpret_cast<int *>(rec + G::REC_FAR)[tid] = table[tid];
+    if (tid < 16) rec[G::REC_ESC + tid] = tid < 8 ? (unsigned char)esc[tid] : 0;
 }
 
 // Development-only timing probes (results are wrong; the shipped library has 0): 1 = escape entries are taken as absent,
@@ -496,6 +513,279 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
 }
 
 
+// ------------------------------------------------------------------------------------------ 64 -> 64 channels
+// The same idea for the ranked 64 -> 64 layers (the four SubM convolutions of stage 3).  Their 27 weight slabs (8 KB each)
+// do not fit LDS next to a tile image, so the slabs stream through a two-slot ring, one offset per slot and workgroup
+// barrier, as in spconv_mfma_kernel — what goes is everything else that kernel issues per (site, offset): the int32 entry
+// loads, the row-address arithmetic and the gather instructions, which (not the matrix work) bound it.  128-row tiles,
+// one 256-thread workgroup (4 waves x 32 rows), two workgroups per CU (one fills its image while the other sweeps); the
+// image of the next tile travels memory -> registers during the sweep and registers -> LDS between two sweeps.
+template <typename TAct>
+__global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__restrict__ x, int x_bytes, const TAct *__restrict__ w,
+                                                                const unsigned char *__restrict__ tile_rb, int rb_bytes,
+                                                                const int *__restrict__ nbr, int nbr_stride,
+                                                                const int *__restrict__ n_out, int cap, TAct *__restrict__ y,
+                                                                const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                const TAct *__restrict__ residual, int relu) {
+    using G = G64;
+    using frag8 = typename V16<TAct>::v8;
+    using act4 = typename V16<TAct>::v4;
+    constexpr int C = 64, CH = 8, KS = 2, NB = 4, MB = 2, NW = 4, NT = 256;
+    constexpr int SLABC = C * CH;                                  // 512 chunks (8 KB) per weight slab
+    constexpr int XB = (G::WIN + G::OVF + 1) * G::ROWB;            // feature rows of the image
+    constexpr int EB = kK * G::TILE * 2;                           // entries
+    constexpr int NWL = G::WIN * CH / NT, NEL = (EB / 16 + NT - 1) / NT, NOL = G::OVF * CH / NT, NSL = SLABC / NT;
+    static_assert(G::WIN * CH % NT == 0 && G::OVF * CH % NT == 0 && SLABC % NT == 0 && G::TILE == NW * MB * 16 && G::OVF <= NT, "shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *wl = reinterpret_cast<uint4 *>(smem);                   // [2][SLABC]
+    unsigned char *const img = smem + 2 * SLABC * 16;
+    int *const esc_flags = reinterpret_cast<int *>(img + XB + EB);
+
+    const int n = min(*n_out, cap);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)nbr, 0, kK * nbr_stride * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc((void *)tile_rb, 0, rb_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, kK * C * C * 2, 0x00020000);   // (slab number in an SGPR offset)
+
+    const int ntiles = (n + G::TILE - 1) / G::TILE;
+    const int Gd = gridDim.x;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = Gd >> 3, rem = Gd & 7;
+    const int range = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
+    const int t_begin = (int)(((long long)ntiles * range) / Gd), t_end = (int)(((long long)ntiles * (range + 1)) / Gd);
+    if (t_begin >= t_end) return;   // (whole workgroup, before any barrier)
+
+    // weight slab image: row r (one output channel, 8 chunks) stores logical chunk c at c ^ ((r >> 1) & 7)
+    const int st_pos = (tid / CH) * CH + ((tid % CH) ^ (((tid / CH) >> 1) & 7));   // (+ j * NT: 32 rows further, same swizzle)
+    int aoff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) aoff[ks] = l15 * CH + ((ks * 4 + q) ^ ((l15 >> 1) & 7));
+    if (tid < CH) reinterpret_cast<uint4 *>(img + G::ZERO * G::ROWB)[tid] = make_uint4(0u, 0u, 0u, 0u);
+
+    // the next tile's image on its way: window, entries, overflow rows (4 lanes... 8 chunks per row), flags; far-row ids one tile further
+    u32x4 pwin[NWL], pent[NEL], povf[NOL];
+    int far_id = -1;      // thread s < OVF: row id of overflow row s
+    unsigned pesc = 0;
+    unsigned win_dst[NWL], ovf_dst[NOL];
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) {
+        const unsigned p = (unsigned)tid + j * NT;
+        win_dst[j] = G::code(g_win_slot<G>(p / CH)) ^ ((p % CH) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NOL; ++j) {
+        const unsigned p = (unsigned)tid + j * NT;
+        ovf_dst[j] = G::code((unsigned)G::WIN + p / CH) ^ ((p % CH) << 4);
+    }
+    auto rec_off = [&](int t) -> unsigned { return t < t_end ? (unsigned)t * (unsigned)G::REC : 0x80000000u; };
+    auto req_far_ids = [&](int t) {
+        far_id = __builtin_amdgcn_raw_buffer_load_b32(trsrc, tid < G::OVF ? rec_off(t) + (unsigned)(G::REC_FAR + tid * 4) : 0x80000000u, 0, 0);
+    };
+    int *const id_lds = reinterpret_cast<int *>(img + XB + EB + 16);   // [OVF] far-row ids of the tile being requested
+    auto req_tile = [&](int t) {   // (far_id holds tile t's ids; they pass through LDS to the lanes that fetch the rows)
+        const unsigned ro = rec_off(t);
+        const unsigned wbase = t < t_end ? (unsigned)max(0, t * G::TILE - G::HALO) * G::ROWB + (unsigned)tid * 16u : 0x80000000u;
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) pwin[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, wbase + j * (NT * 16), 0, 0);
+#pragma unroll
+        for (int j = 0; j < NEL; ++j)
+            pent[j] = __builtin_amdgcn_raw_buffer_load_b128(trsrc, (tid + j * NT < EB / 16) ? ro + (unsigned)(tid + j * NT) * 16u : 0x80000000u, 0, 0);
+        pesc = __builtin_amdgcn_raw_buffer_load_b8(trsrc, tid < NW ? ro + (unsigned)(G::REC_ESC + tid) : 0x80000000u, 0, 0);
+        if (tid < G::OVF) id_lds[tid] = t < t_end ? far_id : -1;   // (a load that was not issued left 0, which is a row)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NOL; ++j) {
+            const unsigned p = (unsigned)tid + j * NT;
+            const int key = id_lds[p / CH];
+            povf[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, key >= 0 ? (unsigned)key * G::ROWB + (p % CH) * 16u : 0x80000000u, 0, 0);
+        }
+    };
+    auto put_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < NEL; ++j)
+            if (tid + j * NT < EB / 16) *reinterpret_cast<u32x4 *>(img + XB + (tid + j * NT) * 16) = pent[j];
+#pragma unroll
+        for (int j = 0; j < NOL; ++j) *reinterpret_cast<u32x4 *>(img + ovf_dst[j]) = povf[j];
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) *reinterpret_cast<u32x4 *>(img + win_dst[j]) = pwin[j];
+        if (tid < NW) esc_flags[tid] = (FNP_TILE_ABLATE & 1) ? 0 : (int)pesc;
+    };
+
+    const int rloc = wave * 32 + 2 * l15;            // this lane's row of block 0 inside the tile (block 1: the next row)
+    const int poff = (q & 1) * 32 + (q >> 1) * 16;   // epilogue: this lane's 16 bytes of a 64-byte channel-block pair
+    req_far_ids(t_begin);
+    req_tile(t_begin);
+    req_far_ids(t_begin + 1);
+    for (int t = t_begin; t < t_end; ++t) {
+        const int tile_base = t * G::TILE, row_end = min(n, tile_base + G::TILE);
+        // slabs 0 and 1 requested before the image is written: they land meanwhile
+        u32x4 wreg[NSL], wslab[2][NSL];   // wslab[k & 1]: slab k + 1 on its way to LDS, requested an offset before it is stored
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) wreg[j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) wslab[0][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)(C * C * 2), 0);
+        __syncthreads();   // every wave has left the previous tile's image and slabs
+        put_tile();
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[st_pos + j * NT]) = wreg[j];
+        __syncthreads();
+        req_tile(t + 1);        // (one more barrier inside: the ids' pass through LDS)
+        req_far_ids(t + 2);
+        f32x4 acc[NB][MB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned *rb32 = reinterpret_cast<const unsigned *>(img + XB) + wave * 16 + l15;   // both blocks' entries
+        auto entry = [&](int k) -> unsigned { return rb32[(k < kK ? k : kK - 1) * (G::TILE / 2)]; };
+        auto sweep = [&](auto esc_tag) {
+            constexpr bool ESC = decltype(esc_tag)::value;
+            // fragments of one offset: [ks][mb]; lane (l15, q) takes chunk 4 ks + q of its row
+            auto fragments = [&](unsigned e, int k, u32x4 (&xv)[KS][MB]) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const unsigned em = mb ? e >> 16 : e & 0xffffu;
+                    if constexpr (ESC) {
+                        if (__ballot(em == kEscape) != 0ull) {
+                            // more far rows than overflow slots: these fragments come from memory
+                            unsigned off = 0x80000000u;
+                            if (em == kEscape)
+                                off = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(nrsrc, (unsigned)(tile_base + rloc + mb) * 4u, (unsigned)k * (unsigned)nbr_stride * 4u, 0) * G::ROWB +
+                                      (unsigned)q * 16u;
+                            const unsigned la = em == kEscape ? G::code(G::ZERO) : em;
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks) {
+                                const u32x4 gv = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off + ks * 64u, 0, 0);
+                                xv[ks][mb] = gv | *reinterpret_cast<const u32x4 *>(img + (la ^ ((unsigned)(ks * 4 + q) << 4)));
+                            }
+                            continue;
+                        }
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) xv[ks][mb] = *reinterpret_cast<const u32x4 *>(img + (em ^ ((unsigned)(ks * 4 + q) << 4)));
+                }
+            };
+            unsigned en[2];
+            u32x4 xf[2][KS][MB];
+            fragments(entry(0), 0, xf[0]);
+            en[1] = entry(1);
+            en[0] = entry(2);
+#pragma unroll
+            for (int k = 0; k < ((FNP_TILE_ABLATE & 2) ? 0 : kK); ++k) {
+                const uint4 *wk = wl + (k & 1) * SLABC;
+                // slab k + 2: requested now, stored to LDS behind the NEXT offset's matrix work (an L2 round trip is longer
+                // than one offset's)
+                if (k + 2 < kK) {
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j)
+                        wslab[(k + 1) & 1][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)(k + 2) * (C * C * 2), 0);
+                }
+                const unsigned e_new = entry(k + 3);
+                if (k + 1 < kK) fragments(en[(k + 1) & 1], k + 1, xf[(k + 1) & 1]);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    frag8 wa[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const uint4 tw = wk[aoff[ks] + nb * 16 * CH];
+                        wa[nb] = *reinterpret_cast<const frag8 *>(&tw);
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const frag8 xv = *reinterpret_cast<const frag8 *>(&xf[k & 1][ks][mb]);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = tmfma(wa[nb], xv, acc[nb][mb]);
+                    }
+                }
+                en[(k + 1) & 1] = e_new;
+                if (k + 1 < kK) {
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[((k + 1) & 1) * SLABC + st_pos + j * NT]) = wslab[k & 1][j];
+                    __syncthreads();
+                }
+            }
+        };
+        if (esc_flags[wave]) sweep(std::true_type{});
+        else sweep(std::false_type{});
+
+        // epilogue: the arithmetic of spconv_mfma_kernel (scale / shift, residual, ReLU, one rounding), 16 bytes per lane
+        uint4 rv[MB][NB / 2];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int kp = 0; kp < NB / 2; ++kp) {
+                const int r = tile_base + rloc + mb;
+                rv[mb][kp] = make_uint4(0u, 0u, 0u, 0u);
+                if (residual && r < row_end)
+                    rv[mb][kp] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(residual) + (size_t)r * (C * 2) + kp * 64 + poff);
+            }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int r = tile_base + rloc + mb;
+            const bool live = r < row_end;
+#pragma unroll
+            for (int kp = 0; kp < NB / 2; ++kp) {
+                uint2 ra = make_uint2(0u, 0u), rbb = make_uint2(0u, 0u);
+                if (residual) {
+                    auto t0 = __builtin_amdgcn_permlane16_swap(rv[mb][kp].x, rv[mb][kp].z, false, false);
+                    auto t1 = __builtin_amdgcn_permlane16_swap(rv[mb][kp].y, rv[mb][kp].w, false, false);
+                    ra = make_uint2(t0[0], t1[0]);    // block 2 kp,     channels q*4 .. q*4+3
+                    rbb = make_uint2(t0[1], t1[1]);   // block 2 kp + 1
+                }
+                uint2 o[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nb = 2 * kp + h, c0 = nb * 16 + q * 4;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[nb][mb][j];
+                    if (scale) {
+                        const float4 s4 = *reinterpret_cast<const float4 *>(scale + c0);
+                        const float4 h4 = *reinterpret_cast<const float4 *>(shift + c0);
+                        v[0] = v[0] * s4.x + h4.x; v[1] = v[1] * s4.y + h4.y; v[2] = v[2] * s4.z + h4.z; v[3] = v[3] * s4.w + h4.w;
+                    }
+                    if (residual) {
+                        const uint2 rr = h ? rbb : ra;
+                        const act4 tr = *reinterpret_cast<const act4 *>(&rr);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] + (float)tr[j];
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.f ? 0.f : v[j];
+                    }
+                    const act4 ob = {(TAct)v[0], (TAct)v[1], (TAct)v[2], (TAct)v[3]};
+                    o[h] = *reinterpret_cast<const uint2 *>(&ob);
+                }
+                auto t0 = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
+                auto t1 = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);
+                if (live)
+                    *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(y) + (size_t)r * (C * 2) + kp * 64 + poff) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+            }
+        }
+    }
+}
+
+constexpr int kLds64 = 2 * 64 * 8 * 16 + (G64::WIN + G64::OVF + 1) * G64::ROWB + kK * G64::TILE * 2 + 16 + G64::OVF * 4;
+static_assert(2 * kLds64 <= 160 * 1024, "two workgroups per CU");
+
+template <typename TAct>
+int launch_tile64(const void *x, long long x_bytes, const void *w, const void *tile_rb, long long rb_bytes, const int *nbr, int nbr_stride,
+                  const int *n_out, int cap, void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s) {
+    auto kern = spconv_tile64_kernel<TAct>;
+    static bool raised = false;   // (idempotent; a race only repeats the call)
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds64) != hipSuccess) return FNP_ERR_HIP;
+        raised = true;
+    }
+    const int tiles = fnp_divup(cap, G64::TILE);
+    const int grid = tiles < 512 ? tiles : 512;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLds64, s, (const TAct *)x, (int)x_bytes, (const TAct *)w, (const unsigned char *)tile_rb, (int)rb_bytes,
+                       nbr, nbr_stride, n_out, cap, (TAct *)y, scale, shift, (const TAct *)residual, relu);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
 template <typename TAct>
 int launch_tile32(const void *x, long long x_bytes, const void *w, const void *tile_rb, long long rb_bytes, const int *nbr, int nbr_stride,
                   const int *n_out, int cap, void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s) {
@@ -524,13 +814,23 @@ extern "C" int fnp_debug_tile_stamps(unsigned long long *out32) {
 }
 #endif
 
-extern "C" long long fnp_tile_rulebook_bytes(int cap_out) { return cap_out > 0 ? (long long)fnp_divup(cap_out, kTile) * kRecBytes : 0; }
+extern "C" long long fnp_tile_rulebook_bytes(int cap_out, int channels) {
+    if (cap_out <= 0) return 0;
+    if (channels == 32) return (long long)fnp_divup(cap_out, G32::TILE) * G32::REC;
+    if (channels == 64) return (long long)fnp_divup(cap_out, G64::TILE) * G64::REC;
+    return 0;
+}
 
-extern "C" int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, void *tile_rb, fnp_stream_t stream) {
-    if (!nbr || !n_out || !tile_rb || K != kK || cap_out <= 0 || nbr_stride < cap_out) return FNP_ERR_ARG;
+extern "C" int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int channels, void *tile_rb,
+                                       fnp_stream_t stream) {
+    if (!nbr || !n_out || !tile_rb || K != kK || cap_out <= 0 || nbr_stride < cap_out || (channels != 32 && channels != 64)) return FNP_ERR_ARG;
     if ((uintptr_t)tile_rb & 15) return FNP_ERR_ARG;
-    hipLaunchKernelGGL(tile_rulebook_kernel, dim3(fnp_divup(cap_out, kTile)), dim3(256), 0, (hipStream_t)stream, nbr, nbr_stride, n_out, cap_out,
-                       (unsigned char *)tile_rb);
+    if (channels == 32)
+        hipLaunchKernelGGL(tile_rulebook_kernel<G32>, dim3(fnp_divup(cap_out, G32::TILE)), dim3(256), 0, (hipStream_t)stream, nbr, nbr_stride, n_out, cap_out,
+                           (unsigned char *)tile_rb);
+    else
+        hipLaunchKernelGGL(tile_rulebook_kernel<G64>, dim3(fnp_divup(cap_out, G64::TILE)), dim3(256), 0, (hipStream_t)stream, nbr, nbr_stride, n_out, cap_out,
+                           (unsigned char *)tile_rb);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
@@ -539,13 +839,18 @@ extern "C" int fnp_spconv_forward_tiled(const void *feat_in, int dtype, int n_in
                                         int nbr_stride, const int *n_out, int cap_out, void *feat_out, const float *scale, const float *shift,
                                         const void *residual, int relu, int Cin, int Cout, fnp_stream_t stream) {
     if (!feat_in || !weight || !tile_rb || !nbr || !n_out || !feat_out || cap_out <= 0 || nbr_stride < cap_out || n_in_rows <= 0) return FNP_ERR_ARG;
-    if ((scale == nullptr) != (shift == nullptr) || Cin != kC || Cout != kC) return FNP_ERR_ARG;
-    const long long xb = (long long)n_in_rows * kC * 2, rbb = fnp_tile_rulebook_bytes(cap_out);
+    if ((scale == nullptr) != (shift == nullptr) || Cin != Cout || (Cin != 32 && Cin != 64)) return FNP_ERR_ARG;
+    const long long xb = (long long)n_in_rows * Cin * 2, rbb = fnp_tile_rulebook_bytes(cap_out, Cin);
     // 32-bit buffer offsets into the features, the int32 table (escape fetches) and the tile rulebook
     if (xb >= 0x7fffffffll || (long long)kK * nbr_stride * 4 >= 0x7fffffffll || rbb >= 0x7fffffffll) return FNP_ERR_ARG;
-    if (((uintptr_t)tile_rb & 15) || ((uintptr_t)feat_in & 15) || ((uintptr_t)feat_out & 15) || ((uintptr_t)weight & 15)) return FNP_ERR_ARG;
+    if (((uintptr_t)tile_rb & 15) || ((uintptr_t)feat_in & 15) || ((uintptr_t)feat_out & 15) || ((uintptr_t)weight & 15) || ((uintptr_t)residual & 15)) return FNP_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == FNP_BF16) return launch_tile32<__bf16>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, feat_out, scale, shift, residual, relu, s);
-    if (dtype == FNP_F16) return launch_tile32<_Float16>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, feat_out, scale, shift, residual, relu, s);
+    if (Cin == 32) {
+        if (dtype == FNP_BF16) return launch_tile32<__bf16>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, feat_out, scale, shift, residual, relu, s);
+        if (dtype == FNP_F16) return launch_tile32<_Float16>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, feat_out, scale, shift, residual, relu, s);
+    } else {
+        if (dtype == FNP_BF16) return launch_tile64<__bf16>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, feat_out, scale, shift, residual, relu, s);
+        if (dtype == FNP_F16) return launch_tile64<_Float16>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, feat_out, scale, shift, residual, relu, s);
+    }
     return FNP_ERR_ARG;
 }

@@ -274,11 +274,13 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
  * K must be 27, Cin == Cout == 32, dtype FNP_BF16 or FNP_F16 (features, weights, residual and output alike);
  * FNP_ERR_ARG otherwise, and for tensors beyond 32-bit byte offsets.
  * ------------------------------------------------------------------------------------------ */
-#define FNP_TILE_ROWS 256
+#define FNP_TILE_ROWS 256            /* 32 channels */
 #define FNP_TILE_RECORD_BYTES 14864
+#define FNP_TILE64_ROWS 128          /* 64 channels */
+#define FNP_TILE64_RECORD_BYTES 7440
 #define FNP_TILE_MIN_ROWS 1048576
-long long fnp_tile_rulebook_bytes(int cap_out);
-int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out,
+long long fnp_tile_rulebook_bytes(int cap_out, int channels);
+int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int channels,
                             void *tile_rb, fnp_stream_t stream);
 int fnp_spconv_forward_tiled(const void *feat_in, int dtype, int n_in_rows, const void *weight,
                              const void *tile_rb, const int *nbr, int nbr_stride,

@@ -495,14 +495,15 @@ def test_window_kernel_equals_gather_kernel(cuda, rng, n):
         assert torch.equal(a[:n], b[:n])
 
 
+@pytest.mark.parametrize("C", [32, 64])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("n,order", [(1, "random"), (200, "random"), (257, "sorted"), (5000, "random"), (5000, "sorted"), (40000, "sorted")])
-def test_tile_kernel_equals_gather_kernel(cuda, rng, n, order, dtype):
-    """The LDS-tile kernel of the ranked 32 -> 32 layers (spconv_tile.hip: window, overflow rows and escape fetches prepared
-    by producer waves) against spconv_mfma_kernel: same products, same order, bit-identical output.  Rows in random
-    order put almost every neighbour outside the window (overflow slots run out: the escape path carries the layer);
-    rows sorted by cell put most of them inside."""
-    B, shape, C = 2, [9, 40, 41] if n <= 5000 else [21, 80, 80], 32
+def test_tile_kernel_equals_gather_kernel(cuda, rng, n, order, dtype, C):
+    """The tile-rulebook kernels of the ranked 32 -> 32 and 64 -> 64 layers (spconv_tile.hip: the rulebook restated per
+    tile as LDS addresses of a window, deduplicated far rows and escapes) against spconv_mfma_kernel: same products, same
+    order, bit-identical output.  Rows in random order put almost every neighbour outside the window (the overflow rows
+    run out: the escape path carries the layer); rows sorted by cell put most of them inside."""
+    B, shape = 2, [9, 40, 41] if n <= 5000 else [21, 80, 80]
     feats, idx = _random_sparse(rng, B, shape, n, C)
     if order == "sorted":
         idx = idx[np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))]
@@ -524,9 +525,9 @@ def test_tile_kernel_equals_gather_kernel(cuda, rng, n, order, dtype):
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 def test_tile_kernel_in_the_backbone(cuda, mode):
-    """Full-size grid, 3 real-shaped scenes: the backbone with the LDS-tile kernel forced on its ranked 32 -> 32 layers
-    (rows in rank-grid order: the window carries most neighbours, the overflow rows the rest) equals the backbone
-    without it bit for bit, at every stage."""
+    """Full-size grid, 3 real-shaped scenes: the backbone with the tile-rulebook kernels forced on its ranked 32 -> 32 and
+    64 -> 64 layers (rows in rank-grid order: the window carries most neighbours, the overflow rows the rest) equals the
+    backbone without them bit for bit, at every stage."""
     from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
     grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
     net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 0).to(cuda).eval()

@@ -83,14 +83,14 @@ for tag, rb, n_dev in log:
         for _ in range(args.reps): S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True, ranked=ranked, valu=args.valu, tile=TILE)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
-        if TILE and (cin, cout, K) == (32, 32, 27):   # the one-off restatement of the rulebook
-            L = S._l.load(); tb = torch.empty_like(rb._tile_rb)
+        if TILE and (cin, cout, K) in ((32, 32, 27), (64, 64, 27)):   # the one-off restatement of the rulebook
+            L = S._l.load(); tb = torch.empty_like(rb._tile_rb[cin]); REC, TR, OV = (14864, 256, 256) if cin == 32 else (7440, 128, 128)
             torch.cuda.synchronize(); e0.record()
-            for _ in range(args.reps): L.fnp_tile_rulebook_build(S._l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, S._l.ptr(n_dev), rb.cap_out, S._l.ptr(tb), S._l.stream())
+            for _ in range(args.reps): L.fnp_tile_rulebook_build(S._l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, S._l.ptr(n_dev), rb.cap_out, cin, S._l.ptr(tb), S._l.stream())
             e1.record(); torch.cuda.synchronize()
-            esc = tb.view(-1, 14864)[: (n + 255) // 256, 14848:14856]
+            nt_ = (n + TR - 1) // TR; esc = tb.view(-1, REC)[:nt_, REC - 16:REC - 16 + TR // 32]
             print(json.dumps({"tile_rulebook_build_ms": round(e0.elapsed_time(e1) / args.reps, 4), "wave_tiles_with_escape": round(esc.float().mean().item(), 5),
-                              "far_rows_per_tile": round((tb.view(-1, 14864)[: (n + 255) // 256, 13824:14848].contiguous().view(torch.int32) >= 0).float().sum(1).mean().item(), 1)}))
+                              "far_rows_per_tile": round((tb.view(-1, REC)[:nt_, 27 * TR * 2:27 * TR * 2 + OV * 4].contiguous().view(torch.int32) >= 0).float().sum(1).mean().item(), 1)}))
         if os.environ.get("FNP_LIB_PATH", "").find("stamp") >= 0 and (cin, cout) == (32, 32):
             import ctypes
             raw = ctypes.CDLL(os.environ["FNP_LIB_PATH"])
