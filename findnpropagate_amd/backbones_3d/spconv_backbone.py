@@ -510,8 +510,11 @@ class FusedResBackbone:
             rbs = S.rulebook_strided(idx_prev, n_prev, g_prev, dconv.kernel_size, dconv.stride, dconv.padding,
                                      caps[li + 1], out_grid=grids[li + 1], want_nbr=not fused)
             x = conv(x_prev, P[down_key], rbs, rbs.out_n)
-            rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3)
-            # stages 2-4: rows are in rank-grid order on both sides of the SubM convolutions
+            # stages 2-4: rows are in rank-grid order on both sides of the SubM convolutions; where they run on the tile
+            # rulebook (stage 2, 32 channels), the rulebook kernel writes it in the same pass
+            ch = int(P[blk_key][0][0][0].shape[1])
+            rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3,
+                                 tile_channels=ch if S.tiled_by_default(ch, act, caps[li + 1]) else None)
             x = blocks(x, rb, rbs.out_n, P[blk_key], ranked=True)
             stage.append((x, rbs.out_indices, rbs.out_n, rbs.out_grid))
             x_prev, idx_prev, n_prev, g_prev = x, rbs.out_indices, rbs.out_n, rbs.out_grid

@@ -13,6 +13,7 @@
 //              is emitted in rank order — a deterministic, spatially blocked row order (spconv
 //              leaves the output order implementation-defined).
 #include "rankgrid.cuh"
+#include "tilerb.cuh"
 
 namespace {
 
@@ -239,6 +240,52 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_kernel(const int *__res
     }
 }
 
+// subm_nbr_row_kernel<3, 3, 3> that also writes the TILE RULEBOOK of the table (tilerb.cuh; same records as
+// fnp_tile_rulebook_build makes from the table afterwards, without reading the table back): the 256 rows a workgroup
+// resolves per pass are one 256-row tile or two 128-row tiles, and the entries are restated from the LDS strips the int32
+// rows are flushed from.
+template <typename G>
+__global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows, int cap,
+                                                                     RG g, int *__restrict__ nbr, unsigned char *__restrict__ tile_rb) {
+    constexpr int K = tilerb::kK, TPP = kThreads / G::TILE;   // tiles per pass
+    static_assert(kThreads % G::TILE == 0 && TPP * G::OVF == kThreads, "one table slot per thread");
+    __shared__ __attribute__((aligned(16))) int strips[kThreads / 64][K * 64];
+    __shared__ int table[TPP][G::OVF];
+    __shared__ int esc[kThreads / 32];
+    int *strip_wave = strips[threadIdx.x >> 6];
+    const int n = min(*n_rows, cap), tid = threadIdx.x, lane = fnp_lane();
+    for (int base = blockIdx.x * kThreads; base < n; base += gridDim.x * kThreads) {   // (whole workgroups stay in the loop)
+        const int o = base + tid;
+        (&table[0][0])[tid] = -1;
+        if (tid < kThreads / 32) esc[tid] = 0;
+        if (o < n) {
+            const int4 c = reinterpret_cast<const int4 *>(coords)[o];
+            nbr_row<3, 3, 3>(g, c.x, c.y - 1, c.z - 1, c.w - 1, strip_wave + lane, 64);
+        }
+        nbr_flush<K>(strip_wave, base + (tid & ~63), n, cap, nbr);
+        __syncthreads();   // empty tables
+        const int tl = tid / G::TILE, r = tid % G::TILE, tile = base / G::TILE + tl;
+        const int wlo = max(0, tile * G::TILE - G::HALO);
+        unsigned char *rec = tile_rb + (size_t)tile * G::REC;
+        if (tile * G::TILE < n) {
+            bool any_esc = false;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const unsigned code = tilerb::entry_of<G>(o < n ? strip_wave[k * 64 + lane] : -1, wlo, table[tl]);
+                any_esc |= code == tilerb::kEscape;
+                reinterpret_cast<unsigned short *>(rec)[k * G::TILE + r] = (unsigned short)code;
+            }
+            if (any_esc) esc[tid >> 5] = 1;
+        }
+        __syncthreads();   // every far row has its slot
+        if (tile * G::TILE < n) {
+            reinterpret_cast<int *>(rec + G::REC_FAR)[tid % G::OVF] = (&table[0][0])[tid];
+            if (r < 16) rec[G::REC_ESC + r] = r < G::TILE / 32 ? (unsigned char)esc[tl * (G::TILE / 32) + r] : 0;
+        }
+        __syncthreads();   // (the next pass clears the tables and rewrites the strips)
+    }
+}
+
 template <int KZ, int KY, int KX>
 __global__ __launch_bounds__(kThreads) void strided_nbr_row_kernel(const int *__restrict__ out_coords,
                                                                    const int *__restrict__ n_out, int cap_out, RG gi, Geom ge,
@@ -296,6 +343,22 @@ extern "C" int fnp_rulebook_subm(const int *coords, const int *n_rows, int cap, 
         hipLaunchKernelGGL(subm_nbr_kernel, blocks, dim3(kThreads), 0, (hipStream_t)stream, coords, n_rows, cap,
                            fnp_rg_view(grid), to_geom(geom), nbr);
     }
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+extern "C" int fnp_rulebook_subm_tiled(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom, const fnp_rankgrid *grid,
+                                       int *nbr, int channels, void *tile_rb, fnp_stream_t stream) {
+    if (!coords || !n_rows || cap <= 0 || !nbr || !tile_rb || !geom_ok(geom) || !fnp_rg_valid(grid)) return FNP_ERR_ARG;
+    if (!shape_is(grid, geom->in_shape) || ((uintptr_t)tile_rb & 15) || (channels != 32 && channels != 64)) return FNP_ERR_ARG;
+    for (int d = 0; d < 3; ++d)
+        if (geom->ksize[d] != 3) return FNP_ERR_ARG;
+    if (channels == 32)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G32>), dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0,
+                           (hipStream_t)stream, coords, n_rows, cap, fnp_rg_view(grid), nbr, (unsigned char *)tile_rb);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G64>), dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0,
+                           (hipStream_t)stream, coords, n_rows, cap, fnp_rg_view(grid), nbr, (unsigned char *)tile_rb);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }

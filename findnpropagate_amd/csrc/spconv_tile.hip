@@ -22,7 +22,7 @@
 // they are handed over through counters in LDS, not workgroup barriers (see below).
 // Products, their order (offsets ascending, one 32-wide MFMA step per offset) and the epilogue arithmetic are those of
 // spconv_mfma_kernel: the output is bit-identical (tests/test_gpu_spconv.py::test_tile_kernel_equals_gather_kernel).
-#include "common.h"
+#include "tilerb.cuh"
 #include <type_traits>
 
 namespace {
@@ -36,49 +36,24 @@ template <typename T> struct V16 {
 __device__ __forceinline__ f32x4 tmfma(V16<__bf16>::v8 a, V16<__bf16>::v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 tmfma(V16<_Float16>::v8 a, V16<_Float16>::v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-constexpr int kK = 27, kC = 32, kCH = 4, kRowB = 64;   // offsets, channels, 16-byte chunks and bytes per row
-constexpr int kTile = FNP_TILE_ROWS;                    // rows per tile
-constexpr int kHalo = 32;                               // window rows on either side of the tile (64 holds 20 % fewer far rows, for 8 KB of LDS)
-constexpr int kWin = kTile + 2 * kHalo;
-constexpr int kOvf = 256;                               // overflow rows of a tile image
-constexpr int kZeroRow = kWin + kOvf;
-constexpr unsigned kEscape = 0xFFFFu;
+using tilerb::G32;
+using tilerb::G64;
+using tilerb::kEscape;
+constexpr int kK = tilerb::kK, kC = 32, kCH = 4, kRowB = G32::ROWB;   // offsets; 32-channel kernel: channels, 16-byte chunks and bytes per row
+constexpr int kTile = G32::TILE, kHalo = G32::HALO, kWin = G32::WIN, kOvf = G32::OVF, kZeroRow = G32::ZERO;
 constexpr int kSlab = kC * kCH;                         // chunks per weight slab
 constexpr int kWBytes = kK * kSlab * 16;                // 55,296: all 27 slabs resident
 constexpr int kXBytes = (kWin + kOvf + 1) * kRowB;      // window + overflow + zero row
 constexpr int kRbBytes = kK * kTile * 2;                // the entries of a tile
 constexpr int kImgBytes = kXBytes + kRbBytes;           // one tile image
 constexpr int kLds = kWBytes + 2 * kImgBytes + 64 + 64; // + escape flags + hand-over counters
-// tile record of the tile rulebook
-constexpr int kRecFar = kRbBytes, kRecEsc = kRecFar + kOvf * 4, kRecBytes = kRecEsc + 16;
-static_assert(kRecBytes == FNP_TILE_RECORD_BYTES && kRecBytes % 16 == 0, "include/fnp.h states the record size");
+constexpr int kRecFar = G32::REC_FAR, kRecEsc = G32::REC_ESC, kRecBytes = G32::REC;
 static_assert(kLds <= 160 * 1024, "LDS budget");
-static_assert(kZeroRow * kRowB + 48 < 0xFFFF, "16-bit LDS row addresses");
-static_assert(kTile == 256 && kHalo % 32 == 0 && (kWin / 2) % 4 == 0, "shape");
-
-// Entry of the feature row stored at row slot `rs` of an image: its LDS byte address with its swizzle in bits 4-5 — the
-// row stores logical 16-byte chunk c at chunk c ^ (-(rs >> 2) & 3); lane (l15, q) of a fragment read takes chunk q at
-// entry ^ (q << 4).  Window rows: even rows first, then odd rows (see the consumer geometry below).
-__host__ __device__ constexpr unsigned row_code(unsigned rs) { return rs * kRowB + (((0u - (rs >> 2)) & 3u) << 4); }
-__host__ __device__ constexpr unsigned win_slot(unsigned d) { return (d & 1u) * (kWin / 2) + (d >> 1); }
+static_assert(kTile == 256, "shape");
+__host__ __device__ constexpr unsigned row_code(unsigned rs) { return G32::code(rs); }
+__host__ __device__ constexpr unsigned win_slot(unsigned d) { return tilerb::win_slot<G32>(d); }
 
 // ------------------------------------------------------------------------------------------ tile rulebook
-// Geometry of a tile image, per channel count.  32 channels: 256-row tiles, window +-32 rows, 256 overflow rows, 64-byte
-// rows.  64 channels (spconv_tile64_kernel below): 128-row tiles, window +-32, 128 overflow rows, 128-byte rows.
-struct G32 {
-    static constexpr int TILE = kTile, HALO = kHalo, WIN = kWin, OVF = kOvf, ZERO = kZeroRow;
-    static constexpr int REC_FAR = kRecFar, REC_ESC = kRecEsc, REC = kRecBytes;
-    __host__ __device__ static constexpr unsigned code(unsigned rs) { return row_code(rs); }
-};
-struct G64 {
-    static constexpr int TILE = 128, HALO = 32, WIN = TILE + 2 * HALO, OVF = 128, ZERO = WIN + OVF, ROWB = 128;
-    static constexpr int REC_FAR = kK * TILE * 2, REC_ESC = REC_FAR + OVF * 4, REC = REC_ESC + 16;
-    // the row at slot rs stores logical 16-byte chunk c (0..7) at chunk c ^ ((rs >> 1) & 7); a lane reads chunk c at entry ^ (c << 4)
-    __host__ __device__ static constexpr unsigned code(unsigned rs) { return rs * ROWB + (((rs >> 1) & 7u) << 4); }
-};
-static_assert(G64::REC == FNP_TILE64_RECORD_BYTES && G64::REC % 16 == 0 && G64::ZERO * G64::ROWB + 112 < 0xFFFF, "64-channel tile record");
-template <typename G> __host__ __device__ constexpr unsigned g_win_slot(unsigned d) { return (d & 1u) * (G::WIN / 2) + (d >> 1); }
-
 // One 256-thread workgroup per tile; a thread restates 4 consecutive rows of the offsets kq, kq + NG, ... (16-byte loads
 // of the int32 table, 8-byte stores of the entries).  Far rows go through an LDS open-addressing table (compare-and-
 // swap, linear probing): which slot a row gets depends on the order the threads arrive in, the BYTES the convolution
@@ -117,26 +92,8 @@ __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restric
         unsigned code[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int v = row0 + u < n ? ids[u] : -1;
-            const unsigned d = (unsigned)(v - wlo);
-            code[u] = G::code(G::ZERO);
-            if (v >= 0) {
-                if (d < (unsigned)G::WIN) {
-                    code[u] = G::code(g_win_slot<G>(d));
-                } else {
-                    unsigned h = (unsigned)v & (unsigned)(G::OVF - 1);
-                    code[u] = kEscape;
-                    for (int probe = 0; probe < 64; ++probe) {
-                        const int old = atomicCAS(&table[h], -1, v);
-                        if (old == -1 || old == v) {
-                            code[u] = G::code((unsigned)G::WIN + h);
-                            break;
-                        }
-                        h = (h + 1) & (unsigned)(G::OVF - 1);
-                    }
-                    if (code[u] == kEscape) esc[(r0 + u) >> 5] = 1;
-                }
-            }
+            code[u] = tilerb::entry_of<G>(row0 + u < n ? ids[u] : -1, wlo, table);
+            if (code[u] == kEscape) esc[(r0 + u) >> 5] = 1;
         }
         *reinterpret_cast<uint2 *>(rec + ((size_t)k * G::TILE + r0) * 2) = make_uint2(code[0] | (code[1] << 16), code[2] | (code[3] << 16));
     }
@@ -147,7 +104,7 @@ __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restric
 
 // Development-only timing probes (results are wrong; the shipped library has 0): 1 = escape entries are taken as absent,
 // 2 = consumers skip the offset sweep, 4 = producers write the first two tiles only, 16 / 32 = consumers skip weight / fragment reads,
-// 64 = no MFMA
+// 64 = no MFMA; 64-channel kernel: 128 = the weight slabs are not streamed, 256 = no barrier per offset
 #ifndef FNP_TILE_ABLATE
 #define FNP_TILE_ABLATE 0
 #endif
@@ -570,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
 #pragma unroll
     for (int j = 0; j < NWL; ++j) {
         const unsigned p = (unsigned)tid + j * NT;
-        win_dst[j] = G::code(g_win_slot<G>(p / CH)) ^ ((p % CH) << 4);
+        win_dst[j] = G::code(tilerb::win_slot<G>(p / CH)) ^ ((p % CH) << 4);
     }
 #pragma unroll
     for (int j = 0; j < NOL; ++j) {
@@ -618,16 +575,23 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
     req_far_ids(t_begin + 1);
     for (int t = t_begin; t < t_end; ++t) {
         const int tile_base = t * G::TILE, row_end = min(n, tile_base + G::TILE);
-        // slabs 0 and 1 requested before the image is written: they land meanwhile
-        u32x4 wreg[NSL], wslab[2][NSL];   // wslab[k & 1]: slab k + 1 on its way to LDS, requested an offset before it is stored
+        // Weight slabs: slab k lives in ring slot k & 1.  The A fragments of offset k + 1 are read (slot (k + 1) & 1) during
+        // offset k, so a wave leaves the barrier with everything its next 16 MFMAs need in registers; slab k + 2 is stored
+        // (slot k & 1, whose fragments were read an offset ago) during offset k, requested from L2 an offset before that.
+        // Slabs 0 - 2 are requested before the image is written: they land meanwhile.
+        u32x4 wreg[2][NSL], wslab[2][NSL];   // wslab[k & 1]: slab k + 2 on its way to LDS
 #pragma unroll
-        for (int j = 0; j < NSL; ++j) wreg[j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, 0, 0);
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int j = 0; j < NSL; ++j) wslab[0][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)(C * C * 2), 0);
+            for (int j = 0; j < NSL; ++j) wreg[h][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)h * (C * C * 2), 0);
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) wslab[0][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, 2u * (C * C * 2), 0);
         __syncthreads();   // every wave has left the previous tile's image and slabs
         put_tile();
 #pragma unroll
-        for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[st_pos + j * NT]) = wreg[j];
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[h * SLABC + st_pos + j * NT]) = wreg[h][j];
         __syncthreads();
         req_tile(t + 1);        // (one more barrier inside: the ids' pass through LDS)
         req_far_ids(t + 2);
@@ -638,6 +602,19 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
             for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const unsigned *rb32 = reinterpret_cast<const unsigned *>(img + XB) + wave * 16 + l15;   // both blocks' entries
         auto entry = [&](int k) -> unsigned { return rb32[(k < kK ? k : kK - 1) * (G::TILE / 2)]; };
+        uint4 rv[MB][NB / 2];   // residual rows: requested a few offsets before the sweep ends
+        auto req_residual = [&]() {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int kp = 0; kp < NB / 2; ++kp) {
+                    const int r = tile_base + rloc + mb;
+                    rv[mb][kp] = make_uint4(0u, 0u, 0u, 0u);
+                    if (residual && r < row_end)
+                        rv[mb][kp] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(residual) + (size_t)r * (C * 2) + kp * 64 + poff);
+                }
+        };
+        if (FNP_TILE_ABLATE & 2) req_residual();
         auto sweep = [&](auto esc_tag) {
             constexpr bool ESC = decltype(esc_tag)::value;
             // fragments of one offset: [ks][mb]; lane (l15, q) takes chunk 4 ks + q of its row
@@ -665,43 +642,52 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
                     for (int ks = 0; ks < KS; ++ks) xv[ks][mb] = *reinterpret_cast<const u32x4 *>(img + (em ^ ((unsigned)(ks * 4 + q) << 4)));
                 }
             };
-            unsigned en[2];
-            u32x4 xf[2][KS][MB];
-            fragments(entry(0), 0, xf[0]);
-            en[1] = entry(1);
-            en[0] = entry(2);
-#pragma unroll
-            for (int k = 0; k < ((FNP_TILE_ABLATE & 2) ? 0 : kK); ++k) {
+            auto weights = [&](int k, frag8 (&wa)[KS][NB]) {
                 const uint4 *wk = wl + (k & 1) * SLABC;
-                // slab k + 2: requested now, stored to LDS behind the NEXT offset's matrix work (an L2 round trip is longer
-                // than one offset's)
-                if (k + 2 < kK) {
 #pragma unroll
-                    for (int j = 0; j < NSL; ++j)
-                        wslab[(k + 1) & 1][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)(k + 2) * (C * C * 2), 0);
-                }
-                const unsigned e_new = entry(k + 3);
-                if (k + 1 < kK) fragments(en[(k + 1) & 1], k + 1, xf[(k + 1) & 1]);
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    frag8 wa[NB];
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const uint4 tw = wk[aoff[ks] + nb * 16 * CH];
-                        wa[nb] = *reinterpret_cast<const frag8 *>(&tw);
+                        wa[ks][nb] = *reinterpret_cast<const frag8 *>(&tw);
                     }
+            };
+            unsigned en[2];
+            u32x4 xf[2][KS][MB];
+            frag8 wa[2][KS][NB];
+            fragments(entry(0), 0, xf[0]);
+            weights(0, wa[0]);
+            en[1] = entry(1);
+            en[0] = entry(2);
+            __syncthreads();   // slab 0's fragments are read: offset 0 may store slab 2 over it
+#pragma unroll
+            for (int k = 0; k < ((FNP_TILE_ABLATE & 2) ? 0 : kK); ++k) {
+                if (k + 3 < kK && !(FNP_TILE_ABLATE & 128)) {
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j)
+                        wslab[(k + 1) & 1][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)(k + 3) * (C * C * 2), 0);
+                }
+                if (k == kK - 6) req_residual();
+                const unsigned e_new = entry(k + 3);
+                if (k + 1 < kK) {
+                    fragments(en[(k + 1) & 1], k + 1, xf[(k + 1) & 1]);
+                    weights(k + 1, wa[(k + 1) & 1]);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) {
                         const frag8 xv = *reinterpret_cast<const frag8 *>(&xf[k & 1][ks][mb]);
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = tmfma(wa[nb], xv, acc[nb][mb]);
+                        for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = tmfma(wa[k & 1][ks][nb], xv, acc[nb][mb]);
                     }
-                }
                 en[(k + 1) & 1] = e_new;
                 if (k + 1 < kK) {
+                    if (k + 2 < kK && !(FNP_TILE_ABLATE & 128)) {
 #pragma unroll
-                    for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[((k + 1) & 1) * SLABC + st_pos + j * NT]) = wslab[k & 1][j];
-                    __syncthreads();
+                        for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[(k & 1) * SLABC + st_pos + j * NT]) = wslab[k & 1][j];
+                    }
+                    if (!(FNP_TILE_ABLATE & 256)) __syncthreads();
                 }
             }
         };
@@ -709,16 +695,6 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
         else sweep(std::false_type{});
 
         // epilogue: the arithmetic of spconv_mfma_kernel (scale / shift, residual, ReLU, one rounding), 16 bytes per lane
-        uint4 rv[MB][NB / 2];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int kp = 0; kp < NB / 2; ++kp) {
-                const int r = tile_base + rloc + mb;
-                rv[mb][kp] = make_uint4(0u, 0u, 0u, 0u);
-                if (residual && r < row_end)
-                    rv[mb][kp] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(residual) + (size_t)r * (C * 2) + kp * 64 + poff);
-            }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int r = tile_base + rloc + mb;

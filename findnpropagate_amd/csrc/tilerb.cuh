@@ -1,0 +1,50 @@
+// Geometry of the tile rulebook (include/fnp.h: fnp_tile_rulebook_build) shared by its two writers — the stand-alone
+// restatement of an int32 table (spconv_tile.hip) and the SubM rulebook kernel that emits both forms at once
+// (rulebook.hip) — and by the convolutions that read it (spconv_tile.hip).
+#pragma once
+#include "common.h"
+
+namespace tilerb {
+
+constexpr int kK = 27;                  // 3x3x3 kernels only
+constexpr unsigned kEscape = 0xFFFFu;   // entry: not in the tile image — fetch through the int32 table
+
+// An entry is the LDS byte address, inside the tile image, of a feature row with the row's swizzle in its low bits: a
+// lane reads logical 16-byte chunk c at entry ^ (c << 4).  Image rows: the window (rows [tile - HALO, tile + TILE + HALO)
+// of the input, even rows first, then odd rows: the neighbours of a consumer wave's 16 columns — every other row — are then
+// 16 consecutive image rows), OVF overflow rows (far neighbours, one slot per distinct row), one row of zeros.
+struct G32 {   // 32 channels: 64-byte rows
+    static constexpr int TILE = FNP_TILE_ROWS, HALO = 32, WIN = TILE + 2 * HALO, OVF = 256, ZERO = WIN + OVF, ROWB = 64;
+    static constexpr int REC_FAR = kK * TILE * 2, REC_ESC = REC_FAR + OVF * 4, REC = REC_ESC + 16;
+    // the row at slot rs stores logical chunk c (0..3) at chunk c ^ (-(rs >> 2) & 3)
+    __host__ __device__ static constexpr unsigned code(unsigned rs) { return rs * ROWB + (((0u - (rs >> 2)) & 3u) << 4); }
+};
+struct G64 {   // 64 channels: 128-byte rows
+    static constexpr int TILE = FNP_TILE64_ROWS, HALO = 32, WIN = TILE + 2 * HALO, OVF = 128, ZERO = WIN + OVF, ROWB = 128;
+    static constexpr int REC_FAR = kK * TILE * 2, REC_ESC = REC_FAR + OVF * 4, REC = REC_ESC + 16;
+    // the row at slot rs stores logical chunk c (0..7) at chunk c ^ ((rs >> 1) & 7)
+    __host__ __device__ static constexpr unsigned code(unsigned rs) { return rs * ROWB + (((rs >> 1) & 7u) << 4); }
+};
+static_assert(G32::REC == FNP_TILE_RECORD_BYTES && G32::REC % 16 == 0 && G32::ZERO * G32::ROWB + 48 < 0xFFFF, "32-channel tile record");
+static_assert(G64::REC == FNP_TILE64_RECORD_BYTES && G64::REC % 16 == 0 && G64::ZERO * G64::ROWB + 112 < 0xFFFF, "64-channel tile record");
+static_assert(G32::HALO % 32 == 0 && (G32::WIN / 2) % 4 == 0 && G64::HALO % 32 == 0 && (G64::WIN / 2) % 8 == 0, "window halves keep the swizzle period");
+template <typename G> __host__ __device__ constexpr unsigned win_slot(unsigned d) { return (d & 1u) * (G::WIN / 2) + (d >> 1); }
+
+// The entry of neighbour row `id` (-1: none) of a row of the tile whose window starts at row wlo.  Far rows take a slot
+// of `table` (G::OVF ints, -1 = free, shared by the threads working on the tile): compare-and-swap with linear probing —
+// which slot a row gets depends on the order the threads arrive in, the BYTES the convolution reads through it do not.
+template <typename G>
+__device__ __forceinline__ unsigned entry_of(int id, int wlo, int *table) {
+    if (id < 0) return G::code(G::ZERO);
+    const unsigned d = (unsigned)(id - wlo);
+    if (d < (unsigned)G::WIN) return G::code(win_slot<G>(d));
+    unsigned h = (unsigned)id & (unsigned)(G::OVF - 1);
+    for (int probe = 0; probe < 64; ++probe) {
+        const int old = atomicCAS(&table[h], -1, id);
+        if (old == -1 || old == id) return G::code((unsigned)G::WIN + h);
+        h = (h + 1) & (unsigned)(G::OVF - 1);
+    }
+    return kEscape;
+}
+
+}  // namespace tilerb

@@ -118,6 +118,7 @@ SIGNATURES = {
                                            P, P, c_int, c_int, c_int, P]),
     "fnp_tile_rulebook_bytes": (c_int64, [c_int, c_int]),
     "fnp_tile_rulebook_build": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P]),
+    "fnp_rulebook_subm_tiled": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, P]),
     "fnp_spconv_forward_tiled": (c_int, [P, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     "fnp_boxseeker_workspace_bytes": (c_int64, [c_int, c_int]),
     "fnp_host_enumerate_frustums": (c_int, [P, P, P, P, P, c_int, c_int, POINTER(c_int), c_int, c_float, c_float, P, c_int]),

@@ -192,15 +192,32 @@ def clear_grids(jobs):
 
 
 # --------------------------------------------------------------------------------- rulebooks
-def rulebook_subm(indices, n_dev, grid, ksize):
+def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None):
+    """tile_channels (32 or 64, 3x3x3 only): also write the tile rulebook the `tile_channels`-channel layers of this rulebook
+    run on (conv_forward's tiled path finds it with the rulebook), in the same pass."""
     L = _l.load()
     cap = max(indices.shape[0], 1)
     geom, _ = make_geom(ksize, 1, [k // 2 for k in _triple(ksize)], grid.shape, grid.shape)
     K = geom.ksize[0] * geom.ksize[1] * geom.ksize[2]
     nbr = torch.empty((K, cap), dtype=torch.int32, device=indices.device)
+    if tile_channels and K == 27 and os.environ.get("FNP_TILE_FUSED", "1") != "0":   # (0: development A/B — the stand-alone build on first use)
+        t = torch.empty((L.fnp_tile_rulebook_bytes(cap, tile_channels),), dtype=torch.uint8, device=indices.device)
+        rc = L.fnp_rulebook_subm_tiled(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), tile_channels, _l.ptr(t), _l.stream())
+        _l.check(rc, "fnp_rulebook_subm_tiled")
+        rb = Rulebook(nbr=nbr, K=K, cap_out=cap, geom=geom)
+        rb._tile_rb = {tile_channels: t}
+        return rb
     rc = L.fnp_rulebook_subm(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), _l.stream())
     _l.check(rc, "fnp_rulebook_subm")
     return Rulebook(nbr=nbr, K=K, cap_out=cap, geom=geom)
+
+
+def tiled_by_default(channels, dtype, cap):
+    """Does conv_forward take the tile-rulebook kernel by itself for a ranked `channels` -> `channels` 3x3x3 layer of this
+    dtype and row capacity?  (What a caller that builds the rulebook asks, to have the tile rulebook written with it.)"""
+    if TILE_MODE is not None:
+        return bool(TILE_MODE) and channels in TILED_CHANNELS and dtype in (torch.bfloat16, torch.float16)
+    return channels in TILED_AUTO and dtype in (torch.bfloat16, torch.float16) and cap >= TILE_MIN_ROWS
 
 
 def rulebook_strided(indices, n_dev, grid, ksize, stride, padding, cap_out, out_grid=None, want_nbr=True):
@@ -273,9 +290,9 @@ def tile_rulebook(rb, n_out_dev, channels):
 
 
 TILED_CHANNELS = (32, 64)   # channel counts fnp_spconv_forward_tiled covers
-# ... and the ones that take it by themselves: at 64 channels the tiled kernel is 10 % faster per layer (0.39 vs 0.44 ms at 64
-# scenes), which its tile-rulebook build (0.14 ms per forward) gives back
-TILED_AUTO = (32,)
+# ... and the ones that take it by themselves (measured at 64 scenes, per layer: 32 channels 0.305 -> 0.18 ms; 64 channels
+# 0.43 -> 0.385 ms, +1 % end to end)
+TILED_AUTO = (32, 64)
 
 
 def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, shift=None, residual=None, relu=False,
@@ -301,7 +318,7 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
     if scale is not None:
         assert scale.dtype == torch.float32 and shift.dtype == torch.float32
     if (K == 27 and Cin == Cout and Cin in TILED_CHANNELS and feat_in.dtype in (torch.bfloat16, torch.float16) and out.dtype == feat_in.dtype
-            and (tile or (tile is None and ranked and Cin in TILED_AUTO and cap_out >= TILE_MIN_ROWS))):
+            and (tile or (tile is None and ranked and tiled_by_default(Cin, feat_in.dtype, cap_out)))):
         rc = L.fnp_spconv_forward_tiled(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
                                         _l.ptr(tile_rulebook(rb, n_out_dev, Cin)), _l.ptr(rb.nbr), rb.nbr.shape[1], _l.ptr(n_out_dev), cap_out,
                                         _l.ptr(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual), int(bool(relu)), Cin, Cout, _l.stream())

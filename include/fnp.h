@@ -282,6 +282,10 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
 long long fnp_tile_rulebook_bytes(int cap_out, int channels);
 int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int channels,
                             void *tile_rb, fnp_stream_t stream);
+/* fnp_rulebook_subm for a 3x3x3 kernel that writes the tile rulebook (for `channels` = 32 or 64) in the same pass: what
+ * fnp_rulebook_subm followed by fnp_tile_rulebook_build leaves, without reading the table back. */
+int fnp_rulebook_subm_tiled(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom,
+                            const fnp_rankgrid *grid, int *nbr, int channels, void *tile_rb, fnp_stream_t stream);
 int fnp_spconv_forward_tiled(const void *feat_in, int dtype, int n_in_rows, const void *weight,
                              const void *tile_rb, const int *nbr, int nbr_stride,
                              const int *n_out, int cap_out, void *feat_out,
