@@ -252,8 +252,10 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *
     __shared__ __attribute__((aligned(16))) int strips[kThreads / 64][K * 64];
     __shared__ int table[TPP][G::OVF];
     __shared__ int esc[kThreads / 32];
+    __shared__ unsigned short lut[G::WIN + 2];
     int *strip_wave = strips[threadIdx.x >> 6];
     const int n = min(*n_rows, cap), tid = threadIdx.x, lane = fnp_lane();
+    tilerb::fill_lut<G>(lut, tid, kThreads);
     for (int base = blockIdx.x * kThreads; base < n; base += gridDim.x * kThreads) {   // (whole workgroups stay in the loop)
         const int o = base + tid;
         (&table[0][0])[tid] = -1;
@@ -268,16 +270,38 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *
         const int wlo = max(0, tile * G::TILE - G::HALO);
         unsigned char *rec = tile_rb + (size_t)tile * G::REC;
         if (tile * G::TILE < n) {
-            bool any_esc = false;
+            int id[K];
+            unsigned code[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const unsigned code = tilerb::entry_of<G>(o < n ? strip_wave[k * 64 + lane] : -1, wlo, table[tl]);
-                any_esc |= code == tilerb::kEscape;
-                reinterpret_cast<unsigned short *>(rec)[k * G::TILE + r] = (unsigned short)code;
-            }
+            for (int k = 0; k < K; ++k) id[k] = o < n ? strip_wave[k * 64 + lane] : -1;
+#ifdef FNP_RBT_ABLATE
+            bool any_esc = false;
+            if (FNP_RBT_ABLATE & 1) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) code[k] = (unsigned)id[k];
+            } else any_esc = tilerb::entries_of_row<G>(id, wlo, table[tl], lut, code);
+#else
+            const bool any_esc = tilerb::entries_of_row<G>(id, wlo, table[tl], lut, code);
+#endif
+            // the entries take the place of the wave's int32 strip (flushed above, read into id[]): [offset][row of the wave]
+            unsigned short *cw = reinterpret_cast<unsigned short *>(strip_wave);
+#pragma unroll
+            for (int k = 0; k < K; ++k) cw[k * 64 + lane] = (unsigned short)code[k];
             if (any_esc) esc[tid >> 5] = 1;
         }
-        __syncthreads();   // every far row has its slot
+        __syncthreads();   // every far row has its slot, every entry is in the strips
+        // the entries leave 16 bytes (8 rows of one offset) per lane
+        constexpr int CPK = G::TILE / 8, CPT = K * CPK;   // chunks per offset, per tile
+        for (int c = tid; c < TPP * CPT; c += kThreads) {
+            const int tlc = c / CPT, cc = c % CPT, k = cc / CPK, r8 = tlc * G::TILE + (cc % CPK) * 8;   // r8: first row, inside the pass
+            const int tc = base / G::TILE + tlc;
+#ifdef FNP_RBT_ABLATE
+            if (FNP_RBT_ABLATE & 2) continue;
+#endif
+            if (tc * G::TILE < n)
+                reinterpret_cast<uint4 *>(tile_rb + (size_t)tc * G::REC)[cc] =
+                    *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned short *>(strips[r8 >> 6]) + k * 64 + (r8 & 63));
+        }
         if (tile * G::TILE < n) {
             reinterpret_cast<int *>(rec + G::REC_FAR)[tid % G::OVF] = (&table[0][0])[tid];
             if (r < 16) rec[G::REC_ESC + r] = r < G::TILE / 32 ? (unsigned char)esc[tl * (G::TILE / 32) + r] : 0;

@@ -29,6 +29,12 @@ static_assert(G32::REC == FNP_TILE_RECORD_BYTES && G32::REC % 16 == 0 && G32::ZE
 static_assert(G64::REC == FNP_TILE64_RECORD_BYTES && G64::REC % 16 == 0 && G64::ZERO * G64::ROWB + 112 < 0xFFFF, "64-channel tile record");
 static_assert(G32::HALO % 32 == 0 && (G32::WIN / 2) % 4 == 0 && G64::HALO % 32 == 0 && (G64::WIN / 2) % 8 == 0, "window halves keep the swizzle period");
 template <typename G> __host__ __device__ constexpr unsigned win_slot(unsigned d) { return (d & 1u) * (G::WIN / 2) + (d >> 1); }
+// first slot a far row probes: multiplicative, so that the runs of consecutive row ids far neighbours come in do not pile up
+// into one long cluster of the linear-probing table (with id & (OVF - 1) the 64-channel build spent 0.12 ms in probes)
+template <typename G> __host__ __device__ constexpr unsigned far_hash(int id) {
+    return ((unsigned)id * 0x9E3779B1u) >> (32 - (G::OVF == 256 ? 8 : G::OVF == 128 ? 7 : 6));
+}
+static_assert(G32::OVF == 256 && G64::OVF == 128, "far_hash knows these table sizes");
 
 // The entry of neighbour row `id` (-1: none) of a row of the tile whose window starts at row wlo.  Far rows take a slot
 // of `table` (G::OVF ints, -1 = free, shared by the threads working on the tile): compare-and-swap with linear probing —
@@ -38,13 +44,56 @@ __device__ __forceinline__ unsigned entry_of(int id, int wlo, int *table) {
     if (id < 0) return G::code(G::ZERO);
     const unsigned d = (unsigned)(id - wlo);
     if (d < (unsigned)G::WIN) return G::code(win_slot<G>(d));
-    unsigned h = (unsigned)id & (unsigned)(G::OVF - 1);
+    unsigned h = far_hash<G>(id);
     for (int probe = 0; probe < 64; ++probe) {
         const int old = atomicCAS(&table[h], -1, id);
         if (old == -1 || old == id) return G::code((unsigned)G::WIN + h);
         h = (h + 1) & (unsigned)(G::OVF - 1);
     }
     return kEscape;
+}
+
+// The 27 entries of one row at once, for the kernels that restate whole rows: window rows and absent neighbours through a
+// table (lut[min(id - wlo, WIN)], G::WIN + 1 entries made by fill_lut), the first probes of all far rows issued back to
+// back (one LDS round trip for the row instead of one per far entry), stragglers one by one.  Returns whether any entry
+// escaped.
+template <typename G>
+__device__ __forceinline__ void fill_lut(unsigned short *lut, int tid, int nthreads) {
+    for (int d = tid; d <= G::WIN; d += nthreads) lut[d] = (unsigned short)(d < G::WIN ? G::code(win_slot<G>((unsigned)d)) : G::code(G::ZERO));
+}
+template <typename G>
+__device__ __forceinline__ bool entries_of_row(const int (&id)[kK], int wlo, int *table, const unsigned short *lut, unsigned (&code)[kK]) {
+    int old[kK];
+    unsigned far = 0;
+#pragma unroll
+    for (int k = 0; k < kK; ++k) {
+        const unsigned d = (unsigned)(id[k] - wlo);
+        code[k] = lut[min(d, (unsigned)G::WIN)];
+        old[k] = 0;
+        if (d >= (unsigned)G::WIN && id[k] != -1) {
+            far |= 1u << k;
+            old[k] = atomicCAS(&table[far_hash<G>(id[k])], -1, id[k]);
+        }
+    }
+    bool esc = false;
+    if (far) {
+#pragma unroll
+        for (int k = 0; k < kK; ++k) {
+            if (far & (1u << k)) {
+                unsigned h = far_hash<G>(id[k]);
+                bool ok = old[k] == -1 || old[k] == id[k];
+#pragma unroll 1
+                for (int probe = 1; probe < 64 && !ok; ++probe) {
+                    h = (h + 1) & (unsigned)(G::OVF - 1);
+                    const int o2 = atomicCAS(&table[h], -1, id[k]);
+                    ok = o2 == -1 || o2 == id[k];
+                }
+                code[k] = ok ? G::code((unsigned)G::WIN + h) : kEscape;
+                esc |= !ok;
+            }
+        }
+    }
+    return esc;
 }
 
 }  // namespace tilerb

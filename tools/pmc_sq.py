@@ -18,7 +18,7 @@ out = {"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WA
                "per-launch averages; mfma_util = MFMA busy cycles / (avg launch ns x 2.4 x 1024 SIMDs); wait/active/issue-stall "
                "fractions of SQ_WAVE_CYCLES", "batch": int(sys.argv[3]), "kernels": {}}
 for k, cs in acc.items():
-    if 'spconv' not in k:
+    if 'spconv' not in k and 'tile' not in k:
         continue
     a = {c: sum(v) / len(v) for c, v in cs.items()}
     e = {"launches": len(next(iter(cs.values()))), **{c: round(v) for c, v in a.items()}}

@@ -31,6 +31,9 @@ def short(k):
     m = re.search(r'spconv_mfma_f32_kernel<(\d+), (\d+), (\d+), (true|false)>', k)
     if m:
         return "spconv_mfma_f32_kernel<%s,%s,%s>" % m.groups()[:3]
+    m = re.search(r'(spconv_tile\d+_kernel)I(DF16b|DF16_)E', k) or re.search(r'(spconv_tile\d+_kernel)<(__bf16|_Float16)>', k)
+    if m:
+        return "%s<%s>" % (m.group(1), "bf16" if m.group(2) in ("DF16b", "__bf16") else "f16")
     return re.sub(r'\(.*', '', k)[:80]
 
 
