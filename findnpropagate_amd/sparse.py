@@ -217,7 +217,7 @@ def tiled_by_default(channels, dtype, cap):
     dtype and row capacity?  (What a caller that builds the rulebook asks, to have the tile rulebook written with it.)"""
     if TILE_MODE is not None:
         return bool(TILE_MODE) and channels in TILED_CHANNELS and dtype in (torch.bfloat16, torch.float16)
-    return channels in TILED_AUTO and dtype in (torch.bfloat16, torch.float16) and cap >= TILE_MIN_ROWS
+    return channels in TILED_AUTO and dtype in (torch.bfloat16, torch.float16)   # (measured ahead from 1 to 64 scenes per step)
 
 
 def rulebook_strided(indices, n_dev, grid, ksize, stride, padding, cap_out, out_grid=None, want_nbr=True):
@@ -270,7 +270,6 @@ def pack_weight(weight, dtype, mfma_f32=False):
 HINT_ROWS_RANKED = 1   # fnp.h FNP_HINT_ROWS_RANKED
 HINT_VALU = 2          # fnp.h FNP_HINT_VALU
 HINT_W_PERMUTED = 4    # fnp.h FNP_HINT_W_PERMUTED
-TILE_MIN_ROWS = 1048576  # fnp.h FNP_TILE_MIN_ROWS
 # development / tests: force (True) or forbid (False) the tile-rulebook kernel wherever a caller leaves `tile` unset (FNP_TILE=1 / 0)
 TILE_MODE = {"0": False, "1": True}.get(os.environ.get("FNP_TILE", ""))
 
@@ -301,7 +300,7 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
     ranked: input and output rows are both in rank-grid order (performance hint only).
     valu: f32 only — the thread-per-element chain instead of the f32 MFMA kernel (same bits).
     tile: 16-bit 32 -> 32 and 64 -> 64 layers of 3x3x3 kernels — True / False forces / forbids the tile-rulebook kernel
-    (None: ranked 32-channel tensors of at least TILE_MIN_ROWS rows of capacity take it; same bits either way)."""
+    (None: ranked tensors take it; same bits either way)."""
     L = _l.load()
     _l.require_device(feat_in, w_packed, rb.nbr, n_out_dev)
     if tile is None:

@@ -266,9 +266,9 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
  * around the tile + up to 256 far rows, deduplicated) — FNP_TILE_RECORD_BYTES per tile, 58 bytes per row instead of 108 —
  * and fnp_spconv_forward_tiled sweeps the offsets from LDS alone.  Bit-identical to fnp_spconv_forward on the int32
  * table for ANY row order; the tiled form is the faster one when rows are in rank-grid order (FNP_HINT_ROWS_RANKED's
- * condition) and the tensor's capacity is at least FNP_TILE_MIN_ROWS rows (measured break-even of four tiled convolutions +
- * one fnp_tile_rulebook_build against four gather convolutions: ~300k live rows, i.e. 8-16 scenes of the backbone's stage 2).
- *   tile_rb  fnp_tile_rulebook_bytes(cap_out) bytes, 16-byte aligned; valid for the (nbr, n_out) it was built from
+ * condition): with the tile rulebook written by fnp_rulebook_subm_tiled, four tiled convolutions + that rulebook were ahead
+ * of four gather convolutions + fnp_rulebook_subm from 1 to 64 scenes of the backbone (1-4 % at 1-3 scenes, 10 % at 32-64).
+ *   tile_rb  fnp_tile_rulebook_bytes(cap_out, channels) bytes, 16-byte aligned; valid for the (nbr, n_out) it was built from
  *   nbr      the int32 table itself: read only for entries the tile record could not hold (more than 256 distinct far
  *            rows in a tile: arbitrary row orders)
  * K must be 27, Cin == Cout == 32, dtype FNP_BF16 or FNP_F16 (features, weights, residual and output alike);
@@ -278,7 +278,6 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
 #define FNP_TILE_RECORD_BYTES 14864
 #define FNP_TILE64_ROWS 128          /* 64 channels */
 #define FNP_TILE64_RECORD_BYTES 7440
-#define FNP_TILE_MIN_ROWS 1048576
 long long fnp_tile_rulebook_bytes(int cap_out, int channels);
 int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int channels,
                             void *tile_rb, fnp_stream_t stream);
