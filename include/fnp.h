@@ -259,19 +259,20 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
                        int hints, int Cin, int Cout, fnp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * The same convolution on a TILE RULEBOOK, for the ranked 16-bit 32 -> 32 layers of 3x3x3 kernels (the four SubM
- * convolutions of stage 2 of VoxelResBackBone8x, spconv_backbone.py:210-212: one rulebook, indice_key 'subm2' / 'res2',
- * used four times per forward).  fnp_tile_rulebook_build restates the (27, cap) int32 table once, per tile of
- * FNP_TILE_ROWS output rows, as 16-bit addresses into an LDS image of the tile's neighbourhood (a window of input rows
- * around the tile + up to 256 far rows, deduplicated) — FNP_TILE_RECORD_BYTES per tile, 58 bytes per row instead of 108 —
- * and fnp_spconv_forward_tiled sweeps the offsets from LDS alone.  Bit-identical to fnp_spconv_forward on the int32
+ * The same convolution on a TILE RULEBOOK, for the ranked 16-bit 32 -> 32 and 64 -> 64 layers of 3x3x3 kernels (the SubM
+ * convolutions of stages 2 and 3 of VoxelResBackBone8x, spconv_backbone.py:210-219: one rulebook per stage, indice_keys
+ * 'subm2' / 'subm3', each used four times per forward).  fnp_tile_rulebook_build restates the (27, cap) int32 table once,
+ * per tile of FNP_TILE_ROWS (32 channels) / FNP_TILE64_ROWS (64 channels) output rows, as 16-bit addresses into an LDS
+ * image of the tile's neighbourhood (a window of input rows around the tile + up to 256 / 128 far rows, deduplicated) —
+ * FNP_TILE_RECORD_BYTES / FNP_TILE64_RECORD_BYTES per tile, 58 bytes per row instead of 108 — and
+ * fnp_spconv_forward_tiled sweeps the offsets from LDS alone (64 channels: with the weight slabs streamed).  Bit-identical to fnp_spconv_forward on the int32
  * table for ANY row order; the tiled form is the faster one when rows are in rank-grid order (FNP_HINT_ROWS_RANKED's
  * condition): with the tile rulebook written by fnp_rulebook_subm_tiled, four tiled convolutions + that rulebook were ahead
  * of four gather convolutions + fnp_rulebook_subm from 1 to 64 scenes of the backbone (1-4 % at 1-3 scenes, 10 % at 32-64).
  *   tile_rb  fnp_tile_rulebook_bytes(cap_out, channels) bytes, 16-byte aligned; valid for the (nbr, n_out) it was built from
- *   nbr      the int32 table itself: read only for entries the tile record could not hold (more than 256 distinct far
- *            rows in a tile: arbitrary row orders)
- * K must be 27, Cin == Cout == 32, dtype FNP_BF16 or FNP_F16 (features, weights, residual and output alike);
+ *   nbr      the int32 table itself: read only for entries the tile record could not hold (more distinct far rows in a tile than its
+ *            image has overflow rows: arbitrary row orders)
+ * K must be 27, Cin == Cout == 32 or 64 (the channel count the tile rulebook was built for), dtype FNP_BF16 or FNP_F16 (features, weights, residual and output alike);
  * FNP_ERR_ARG otherwise, and for tensors beyond 32-bit byte offsets.
  * ------------------------------------------------------------------------------------------ */
 #define FNP_TILE_ROWS 256            /* 32 channels */
