@@ -27,11 +27,11 @@ class SparseConvFunction(torch.autograd.Function):
     fp16), weight gradient accumulated in f32 and returned in the parameter's dtype."""
 
     @staticmethod
-    def forward(ctx, feats, weight, rb, n_out_dev, n_in_dev):
+    def forward(ctx, feats, weight, rb, n_out_dev, n_in_dev, ranked=False):
         w = S.pack_weight(weight, feats.dtype)
-        out = S.conv_forward(feats, w, rb, n_out_dev)
+        out = S.conv_forward(feats, w, rb, n_out_dev, ranked=ranked)
         ctx.save_for_backward(feats, weight)
-        ctx.rb, ctx.n_out_dev, ctx.n_in_dev = rb, n_out_dev, n_in_dev
+        ctx.rb, ctx.n_out_dev, ctx.n_in_dev, ctx.ranked = rb, n_out_dev, n_in_dev, ranked
         return out
 
     @staticmethod
@@ -46,7 +46,11 @@ class SparseConvFunction(torch.autograd.Function):
             if rb.out_indices is None and rb.cap_out == feats.shape[0]:
                 # SubM: the rulebook is its own transpose up to the mirror of the offsets (input i feeds output o through
                 # offset k  <=>  o is the neighbour of i at offset K-1-k): same table, weight slabs in mirrored order
-                dx = S.conv_dgrad(grad_out, wp.flip(0), rb.nbr, n_in_dev, feats.shape[0])
+                if ctx.ranked and Cin == Cout and S.tiled_by_default(Cin, feats.dtype, rb.cap_out):
+                    # ... and on the tile rulebook where the forward ran on it: the forward kernel on (K, Cin, Cout) slabs
+                    dx = S.conv_forward(grad_out, wp.flip(0).transpose(1, 2).contiguous(), rb, n_in_dev, ranked=True)
+                else:
+                    dx = S.conv_dgrad(grad_out, wp.flip(0), rb.nbr, n_in_dev, feats.shape[0])
             else:
                 if getattr(rb, "_nbr_t", None) is None or rb._nbr_t.shape[1] != feats.shape[0]:
                     rb._nbr_t = S.rulebook_transpose(rb, n_out_dev, feats.shape[0])   # (kept with the rulebook: one per layer)
@@ -54,7 +58,7 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dwp = S.conv_wgrad(feats, grad_out, rb, n_out_dev, Cin, Cout)               # (K, Cout, Cin) f32
             dw = dwp.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 class SparseConvolution(SparseModule):
@@ -117,15 +121,20 @@ class SparseConvolution(SparseModule):
         w = None if with_grad else self.packed_weight(feats.dtype)
         n_dev = input.n_dev()
 
+        # rows in rank-grid order on both sides of a SubM layer behind a strided one: the window / tile-rulebook kernels
+        ranked = bool(self.subm and input.rows_ranked)
+
         def run(rb, n_out_dev):
             if with_grad:
-                return SparseConvFunction.apply(feats, self.weight, rb, n_out_dev, n_dev)
-            return S.conv_forward(feats, w, rb, n_out_dev)
+                return SparseConvFunction.apply(feats, self.weight, rb, n_out_dev, n_dev, ranked)
+            return S.conv_forward(feats, w, rb, n_out_dev, ranked=ranked)
 
         if self.subm:
             rb = input.find_indice_pair(self.indice_key)
             if rb is None or rb.K != self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]:
-                rb = S.rulebook_subm(input.indices, n_dev, input.rank_grid(), self.kernel_size)
+                ch = self.in_channels if self.in_channels == self.out_channels else 0
+                rb = S.rulebook_subm(input.indices, n_dev, input.rank_grid(), self.kernel_size,
+                                     tile_channels=ch if ranked and ch and S.tiled_by_default(ch, feats.dtype, feats.shape[0]) else None)
                 if self.indice_key is not None:
                     input.indice_dict[self.indice_key] = rb
             out_feats = run(rb, n_dev)

@@ -47,6 +47,12 @@ class SparseConvTensor:
         return out
 
     # ---- device-side bookkeeping ----------------------------------------------------------
+    @property
+    def rows_ranked(self):
+        """Are the rows in rank-grid order (the output of a strided convolution, and whatever SubM layers make of it)?  Such a
+        tensor carries a rank grid without a row permutation."""
+        return self._rank_grid is not None and self._rank_grid.perm is None
+
     def n_dev(self):
         if self._n_dev is None:
             self._n_dev = S.device_scalar(self.features.shape[0], self.features.device)
