@@ -156,6 +156,8 @@ __device__ unsigned long long g_tile_stamps[4][8];   // [role][phase] sums, [2 +
 #endif
 
 // ------------------------------------------------------------------------------------------ convolution
+__device__ unsigned g_tile_aborts;   // hand-over waits that timed out, since the library was loaded (never, unless the protocol is broken)
+
 // Geometry: 8 consumer waves x 32 rows.  Consumer wave w owns tile rows [32 w, 32 w + 32); its MFMA column l15 of block mb
 // is row 32 w + 2 l15 + mb, so the two entries of a lane sit in one 32-bit word of the natural [offset][row] table.
 // Neighbours of such a column set are rows of ONE parity, so the window image keeps even and odd rows in separate halves:
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
     // counts WAVES that completed an event and only grows; i = tile number inside the workgroup's run, image i & 1:
     //   READY[i & 1]  producer waves that finished writing the image     consumers of tile i wait for 8 (i / 2 + 1)
     //   FREED[i & 1]  consumer waves that finished reading the image     producers of tile i wait for 8 (i / 2)
-    // A wait that outlasts kSpinLimit polls raises ABORT, which ends every wave (wrong output instead of a hung GPU).
+    // A wait that outlasts kSpinLimit polls (~0.3 s; a hand-over takes microseconds) raises ABORT, which ends every wave of
+    // the workgroup — wrong output instead of a hung GPU — and counts in g_tile_aborts (fnp_spconv_tiled_aborts()).
     int *const cnt = esc_flags + 16;
     enum { READY = 0, FREED = 2, ABORT = 8 };
     constexpr int kSpinLimit = 1 << 20;
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
         int spins = 0;
         while (__atomic_load_n(&cnt[which], __ATOMIC_RELAXED) < need) {
             if (++spins > kSpinLimit || __atomic_load_n(&cnt[ABORT], __ATOMIC_RELAXED)) {
+                if (spins > kSpinLimit && (threadIdx.x & 63) == 0) atomicAdd(&g_tile_aborts, 1u);
                 __atomic_store_n(&cnt[ABORT], 1, __ATOMIC_RELAXED);
                 return false;
             }
@@ -789,6 +793,12 @@ extern "C" int fnp_debug_tile_stamps(unsigned long long *out32) {
     return FNP_OK;
 }
 #endif
+
+extern "C" int fnp_spconv_tiled_aborts(void) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_tile_aborts), sizeof(v)) != hipSuccess) return FNP_ERR_HIP;
+    return (int)v;
+}
 
 extern "C" long long fnp_tile_rulebook_bytes(int cap_out, int channels) {
     if (cap_out <= 0) return 0;

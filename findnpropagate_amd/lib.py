@@ -116,6 +116,7 @@ SIGNATURES = {
                                    P, P, P, c_int, c_int, c_int, c_int, P]),
     "fnp_spconv_forward_strided": (c_int, [P, c_int, c_int, P, POINTER(RankGridC), POINTER(ConvGeom), P, P, c_int, P, c_int,
                                            P, P, c_int, c_int, c_int, P]),
+    "fnp_spconv_tiled_aborts": (c_int, []),
     "fnp_tile_rulebook_bytes": (c_int64, [c_int, c_int]),
     "fnp_tile_rulebook_build": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P]),
     "fnp_rulebook_subm_tiled": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, P]),

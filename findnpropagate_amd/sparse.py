@@ -321,8 +321,9 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
         rc = L.fnp_spconv_forward_tiled(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
                                         _l.ptr(tile_rulebook(rb, n_out_dev, Cin)), _l.ptr(rb.nbr), rb.nbr.shape[1], _l.ptr(n_out_dev), cap_out,
                                         _l.ptr(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual), int(bool(relu)), Cin, Cout, _l.stream())
-        _l.check(rc, "fnp_spconv_forward_tiled")
-        return out
+        if rc != -1:   # (FNP_ERR_ARG: a tensor beyond the tiled kernels' 32-bit offsets — the gather kernel below takes it)
+            _l.check(rc, "fnp_spconv_forward_tiled")
+            return out
     rc = L.fnp_spconv_forward(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
                               _l.ptr(rb.nbr), rb.nbr.shape[1], K, _l.ptr(n_out_dev), cap_out,
                               _l.ptr(out), _l.dtype_code(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual),

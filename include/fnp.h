@@ -279,6 +279,10 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
 #define FNP_TILE_RECORD_BYTES 14864
 #define FNP_TILE64_ROWS 128          /* 64 channels */
 #define FNP_TILE64_RECORD_BYTES 7440
+/* Diagnostic: the 32-channel kernel hands tile images between its producer and consumer waves through counters in LDS; a
+ * wait that times out (~0.3 s; never, unless that protocol is broken) ends the workgroup with wrong output and counts
+ * here.  Synchronises the device; >= 0, or a negative error code. */
+int fnp_spconv_tiled_aborts(void);
 long long fnp_tile_rulebook_bytes(int cap_out, int channels);
 int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int channels,
                             void *tile_rb, fnp_stream_t stream);

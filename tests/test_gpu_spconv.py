@@ -547,6 +547,8 @@ def test_tile_kernel_in_the_backbone(cuda, mode):
     for k in outs[0]:
         assert torch.equal(outs[0][k][1], outs[1][k][1]), k
         assert torch.equal(outs[0][k][0], outs[1][k][0]), k
+    from findnpropagate_amd import lib as _lib
+    assert _lib.load().fnp_spconv_tiled_aborts() == 0   # no hand-over wait of the tiled kernels ever timed out
 
 
 def test_forward_points_edge_batches(cuda):
