@@ -20,7 +20,7 @@ struct G32 {   // 32 channels: 64-byte rows
     __host__ __device__ static constexpr unsigned code(unsigned rs) { return rs * ROWB + (((0u - (rs >> 2)) & 3u) << 4); }
 };
 struct G64 {   // 64 channels: 128-byte rows
-    static constexpr int TILE = FNP_TILE64_ROWS, HALO = 32, WIN = TILE + 2 * HALO, OVF = 128, ZERO = WIN + OVF, ROWB = 128;
+    static constexpr int TILE = FNP_TILE64_ROWS, HALO = 64, WIN = TILE + 2 * HALO, OVF = 128, ZERO = WIN + OVF, ROWB = 128;
     static constexpr int REC_FAR = kK * TILE * 2, REC_ESC = REC_FAR + OVF * 4, REC = REC_ESC + 16;
     // the row at slot rs stores logical chunk c (0..7) at chunk c ^ ((rs >> 1) & 7)
     __host__ __device__ static constexpr unsigned code(unsigned rs) { return rs * ROWB + (((rs >> 1) & 7u) << 4); }
