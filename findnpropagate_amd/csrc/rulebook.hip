@@ -248,7 +248,7 @@ template <typename G>
 __global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows, int cap,
                                                                      RG g, int *__restrict__ nbr, unsigned char *__restrict__ tile_rb) {
     constexpr int K = tilerb::kK, TPP = kThreads / G::TILE;   // tiles per pass
-    static_assert(kThreads % G::TILE == 0 && TPP * G::OVF == kThreads, "one table slot per thread");
+    static_assert(kThreads % G::TILE == 0 && TPP * G::OVF <= kThreads, "at most one table slot per thread");
     __shared__ __attribute__((aligned(16))) int strips[kThreads / 64][K * 64];
     __shared__ int table[TPP][G::OVF];
     __shared__ int esc[kThreads / 32];
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *
     tilerb::fill_lut<G>(lut, tid, kThreads);
     for (int base = blockIdx.x * kThreads; base < n; base += gridDim.x * kThreads) {   // (whole workgroups stay in the loop)
         const int o = base + tid;
-        (&table[0][0])[tid] = -1;
+        if (tid < TPP * G::OVF) (&table[0][0])[tid] = -1;
         if (tid < kThreads / 32) esc[tid] = 0;
         if (o < n) {
             const int4 c = reinterpret_cast<const int4 *>(coords)[o];
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *
                     *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned short *>(strips[r8 >> 6]) + k * 64 + (r8 & 63));
         }
         if (tile * G::TILE < n) {
-            reinterpret_cast<int *>(rec + G::REC_FAR)[tid % G::OVF] = (&table[0][0])[tid];
+            if (r < G::OVF) reinterpret_cast<int *>(rec + G::REC_FAR)[r] = table[tl][r];
             if (r < 16) rec[G::REC_ESC + r] = r < G::TILE / 32 ? (unsigned char)esc[tl * (G::TILE / 32) + r] : 0;
         }
         __syncthreads();   // (the next pass clears the tables and rewrites the strips)

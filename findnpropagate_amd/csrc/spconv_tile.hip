@@ -175,7 +175,8 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
     constexpr int NWL = (kWin * kCH + PT - 1) / PT;          // window chunks per producer thread
     constexpr int NCL = (kRbBytes / 16 + PT - 1) / PT;       // entry-table chunks per producer thread
     constexpr int NGL = kOvf / NPW / 16;                     // overflow-row loads per producer thread (4 lanes per row)
-    static_assert(NB == 2 && kTile == NCW * MB * 16 && kOvf == NPW * 32, "shape");
+    constexpr int OPW = kOvf / NPW;                          // overflow rows a producer wave fetches
+    static_assert(NB == 2 && kTile == NCW * MB * 16 && OPW == NGL * 16 && OPW <= 64, "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *wl = reinterpret_cast<uint4 *>(smem);
     unsigned char *const img0 = smem + kWBytes;
@@ -251,10 +252,10 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
             win_dst[j] = row_code(win_slot(p / kCH)) ^ ((p % kCH) << 4);
         }
 #pragma unroll
-        for (int i = 0; i < NGL; ++i) ovf_dst[i] = row_code((unsigned)(kWin + pw * 32 + i * 16 + (lane >> 2))) ^ ((unsigned)(lane & 3) << 4);
+        for (int i = 0; i < NGL; ++i) ovf_dst[i] = row_code((unsigned)(kWin + pw * OPW + i * 16 + (lane >> 2))) ^ ((unsigned)(lane & 3) << 4);
         auto rec_off = [&](int t) -> unsigned { return t < t_end ? (unsigned)t * (unsigned)kRecBytes : 0x80000000u; };
         auto req_far_ids = [&](int t) {
-            far_id = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane < 32 ? rec_off(t) + (unsigned)(kRecFar + (pw * 32 + lane) * 4) : 0x80000000u, 0, 0);
+            far_id = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane < OPW ? rec_off(t) + (unsigned)(kRecFar + (pw * OPW + lane) * 4) : 0x80000000u, 0, 0);
         };
         auto req_tile = [&](int t) {   // everything of tile t but its far-row ids, which must be in far_id already
             const unsigned ro = rec_off(t);
