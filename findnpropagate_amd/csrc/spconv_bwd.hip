@@ -89,6 +89,57 @@ __global__ __launch_bounds__(kThreads) void wgrad_partial_kernel(const TX *__res
     }
 }
 
+// The same sum for layers with few (Cin x Cout <= 128) pairs — conv_input, 5 -> 16 — where the kernel above leaves two thirds
+// of its threads idle and meets three barriers per 16 rows: 128-row tiles, and the 256 threads form G = 256 / pairs groups
+// that each take every G-th row of a tile; the groups' sums are added in group order at the end (fixed order).
+template <typename TX, typename TY>
+__global__ __launch_bounds__(kThreads) void wgrad_small_kernel(const TX *__restrict__ x, const TY *__restrict__ dy,
+                                                               const int *__restrict__ nbr, int nbr_stride,
+                                                               const int *__restrict__ n_out, int cap_out,
+                                                               int Cin, int Cout, float *__restrict__ partial) {
+    constexpr int TR = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fnp_wg_smem[];
+    float *sy = reinterpret_cast<float *>(fnp_wg_smem);   // [TR][Cout]
+    float *sx = sy + TR * Cout;                           // [TR][Cin]
+    __shared__ int sidx[TR];
+    __shared__ float sred[kThreads];
+    const int n = min(*n_out, cap_out);
+    const int k = blockIdx.y, chunk = blockIdx.x, K = gridDim.y;
+    const int rows_per_chunk = ((n + (int)gridDim.x - 1) / (int)gridDim.x + 127) / 128 * 128;
+    const int r0 = min(n, chunk * rows_per_chunk), r1 = min(n, r0 + rows_per_chunk);
+    const int pairs = Cin * Cout, G = kThreads / pairs;
+    const int g = threadIdx.x / pairs, p = threadIdx.x % pairs, co = p / Cin, ci = p % Cin;
+    float acc = 0.f;
+    for (int t0 = r0; t0 < r1; t0 += TR) {
+        __syncthreads();
+        if (threadIdx.x < TR) {
+            const int r = t0 + threadIdx.x;
+            sidx[threadIdx.x] = r < r1 ? nbr[(size_t)k * nbr_stride + r] : -1;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < TR * Cout; e += kThreads) {
+            const int rr = e / Cout, c = e % Cout, r = t0 + rr;
+            sy[e] = (r < r1 && sidx[rr] >= 0) ? ld_f32(dy + (size_t)r * Cout + c) : 0.f;
+        }
+        for (int e = threadIdx.x; e < TR * Cin; e += kThreads) {
+            const int rr = e / Cin, c = e % Cin, id = sidx[rr];
+            sx[e] = id >= 0 ? ld_f32(x + (size_t)id * Cin + c) : 0.f;
+        }
+        __syncthreads();
+        if (g < G) {
+            for (int rr = g; rr < TR; rr += G) acc = fmaf(sy[rr * Cout + co], sx[rr * Cin + ci], acc);
+        }
+    }
+    __syncthreads();
+    sred[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < pairs) {
+        float a = 0.f;
+        for (int gg = 0; gg < G; ++gg) a += sred[gg * pairs + threadIdx.x];
+        partial[((size_t)chunk * K + k) * pairs + threadIdx.x] = a;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float *__restrict__ partial, int chunks, long long total,
                                                                 float *__restrict__ dw) {
     for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kThreads) {
@@ -313,6 +364,15 @@ int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int
             FNP_LAUNCH_CHECK();
             return FNP_OK;
         }
+    }
+    if (pairs <= 128) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_small_kernel<TX, TY>), grid, dim3(kThreads), (size_t)128 * (Cin + Cout) * 4, s, (const TX *)x,
+                           (const TY *)dy, nbr, nbr_stride, n_out, cap_out, Cin, Cout, partial);
+        FNP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fnp_grid_for(total, kThreads)), dim3(kThreads), 0, s, (const float *)partial, chunks,
+                           total, dw);
+        FNP_LAUNCH_CHECK();
+        return FNP_OK;
     }
 #define FNP_WG(P)                                                                                                          \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_partial_kernel<TX, TY, P>), grid, dim3(kThreads), lds, s, (const TX *)x,         \

@@ -97,12 +97,12 @@ def test_backbone_training_step_runs_and_matches_torch_reference_ops(cuda, rng):
 
     class RefFn:   # same signature as SparseConvFunction.apply, torch ops only
         @staticmethod
-        def apply(f, weight, rb, n_out_dev, n_in_dev, ranked=False):
+        def apply(f, weight, rb, n_out_dev, n_in_dev, ranked=False, rows=None):
             n_out = int(n_out_dev.item())
             Cout, Cin = weight.shape[0], weight.shape[-1]
             wk = weight.reshape(Cout, rb.K, Cin)
             fz = torch.cat([f.float(), f.new_zeros((1, Cin), dtype=torch.float32)], 0)
-            out = f.new_zeros((rb.cap_out, Cout), dtype=torch.float32)
+            out = f.new_zeros((rb.cap_out if rows is None else rows, Cout), dtype=torch.float32)
             for k in range(rb.K):
                 nb = rb.nbr[k, :n_out].long()
                 nb = torch.where(nb < 0, torch.full_like(nb, f.shape[0]), nb)
