@@ -372,6 +372,11 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     int *const fstrip = reinterpret_cast<int *>(fnp_smem + Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN) +
                                                 Cfg::epi_bytes(MfmaWg<CIN, COUT>::NW, WIN, sizeof(TOut) == 2)) + wave * (27 * SR);
     int frow0 = 0;                // first row of the wave's current tile (set by the tile body)
+    // BatchNorm scale and shift in LDS (behind every other region): an epilogue reads them per tile, and from L2 that is a
+    // ~800-cycle round trip at the end of a sweep that takes 3-6 k cycles on the narrow layers
+    float *const ss_lds = reinterpret_cast<float *>(fnp_smem + Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN) +
+                                                    Cfg::epi_bytes(MfmaWg<CIN, COUT>::NW, WIN, sizeof(TOut) == 2) +
+                                                    (FUSED ? MfmaWg<CIN, COUT>::NW * 27 * MB * 16 * 4 : 0));
     auto nbr_at = [&](int k, int r, int r_end) -> int {
         const int rc = r < r_end ? r : r_end - 1;
         const int kr = PAIR ? 2 * k + qk : k, KR = PAIR ? KVOL : K;
@@ -426,6 +431,8 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     const int row_begin = (int)((nblk16 * range) / G) << 4;
     const int row_end = min(n, (int)((nblk16 * (range + 1)) / G) << 4);
     if (row_begin >= row_end) return;  // before any barrier: safe early exit
+    for (int c = tid; c < 2 * COUT; c += MfmaWg<CIN, COUT>::NW * 64)   // (a barrier — weight staging or the first slab — lies before any epilogue)
+        ss_lds[c] = scale ? (c < COUT ? scale[c] : shift[c - COUT]) : (c < COUT ? 1.f : 0.f);
 
 #define FNP_LDS_POS(row, chunk) ((row) * CH + ((chunk) ^ (((row) >> SW) & (CH - 1))))
     // LDS addressing with compile-time immediates: the swizzle term of row nb*16 + l15 depends on
@@ -750,8 +757,8 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = acc[nb][mb][j];
                         if (scale) {
-                            const float4 s4 = *reinterpret_cast<const float4 *>(scale + c0);
-                            const float4 h4 = *reinterpret_cast<const float4 *>(shift + c0);
+                            const float4 s4 = *reinterpret_cast<const float4 *>(ss_lds + c0);
+                            const float4 h4 = *reinterpret_cast<const float4 *>(ss_lds + COUT + c0);
                             v[0] = v[0] * s4.x + h4.x; v[1] = v[1] * s4.y + h4.y; v[2] = v[2] * s4.z + h4.z; v[3] = v[3] * s4.w + h4.w;
                         }
                         if (mine) {
@@ -806,8 +813,8 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = acc[nb][mb][j];
                         if (scale) {
-                            const float4 s4 = *reinterpret_cast<const float4 *>(scale + c0);
-                            const float4 h4 = *reinterpret_cast<const float4 *>(shift + c0);
+                            const float4 s4 = *reinterpret_cast<const float4 *>(ss_lds + c0);
+                            const float4 h4 = *reinterpret_cast<const float4 *>(ss_lds + COUT + c0);
                             v[0] = v[0] * s4.x + h4.x; v[1] = v[1] * s4.y + h4.y; v[2] = v[2] * s4.z + h4.z; v[3] = v[3] * s4.w + h4.w;
                         }
                         if (residual && !(FNP_ABLATE & 256)) {
@@ -836,8 +843,8 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
             const int c0 = nb * 16 + q * 4;
             float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
             if (scale) {
-                const float4 s4 = *reinterpret_cast<const float4 *>(scale + c0);
-                const float4 h4 = *reinterpret_cast<const float4 *>(shift + c0);
+                const float4 s4 = *reinterpret_cast<const float4 *>(ss_lds + c0);
+                const float4 h4 = *reinterpret_cast<const float4 *>(ss_lds + COUT + c0);
                 sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
                 sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
             }
@@ -902,7 +909,7 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
     auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut, FUSED, TAct>;
     constexpr int lds = Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN) + Cfg::epi_bytes(MfmaWg<CIN, COUT>::NW, WIN, sizeof(TOut) == 2) +
-                        (FUSED ? MfmaWg<CIN, COUT>::NW * 27 * MB * 16 * 4 : 0);
+                        (FUSED ? MfmaWg<CIN, COUT>::NW * 27 * MB * 16 * 4 : 0) + COUT * 8;   // (+ BatchNorm scale / shift)
     FusedRb frb{};
     if (FUSED) {
         if (!frb_in) return FNP_ERR_ARG;

@@ -544,6 +544,8 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
         far_id = __builtin_amdgcn_raw_buffer_load_b32(trsrc, tid < G::OVF ? rec_off(t) + (unsigned)(G::REC_FAR + tid * 4) : 0x80000000u, 0, 0);
     };
     int *const id_lds = reinterpret_cast<int *>(img + XB + EB + 16);   // [OVF] far-row ids of the tile being requested
+    float *const ss_lds = reinterpret_cast<float *>(img + XB + EB + 16 + G::OVF * 4);   // [2][C] BatchNorm scale, shift (read per tile from LDS, not L2)
+    if (tid < 2 * C) ss_lds[tid] = scale ? (tid < C ? scale[tid] : shift[tid - C]) : (tid < C ? 1.f : 0.f);
     auto req_tile = [&](int t) {   // (far_id holds tile t's ids; they pass through LDS to the lanes that fetch the rows)
         const unsigned ro = rec_off(t);
         const unsigned wbase = t < t_end ? (unsigned)max(0, t * G::TILE - G::HALO) * G::ROWB + (unsigned)tid * 16u : 0x80000000u;
@@ -578,6 +580,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
     req_far_ids(t_begin);
     req_tile(t_begin);
     req_far_ids(t_begin + 1);
+    FNP_STAMP_DECL;
     for (int t = t_begin; t < t_end; ++t) {
         const int tile_base = t * G::TILE, row_end = min(n, tile_base + G::TILE);
         // Weight slabs: slab k lives in ring slot k & 1.  The A fragments of offset k + 1 are read (slot (k + 1) & 1) during
@@ -591,15 +594,19 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
             for (int j = 0; j < NSL; ++j) wreg[h][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)h * (C * C * 2), 0);
 #pragma unroll
         for (int j = 0; j < NSL; ++j) wslab[0][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, 2u * (C * C * 2), 0);
+        FNP_STAMP(0);   // (slab requests)
         __syncthreads();   // every wave has left the previous tile's image and slabs
+        FNP_STAMP(1);   // (barrier: the slowest wave's epilogue)
         put_tile();
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[h * SLABC + st_pos + j * NT]) = wreg[h][j];
         __syncthreads();
+        FNP_STAMP(2);   // (image + slabs 0, 1 -> LDS, barrier)
         req_tile(t + 1);        // (one more barrier inside: the ids' pass through LDS)
         req_far_ids(t + 2);
+        FNP_STAMP(3);   // (next tile requested)
         f32x4 acc[NB][MB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
@@ -698,6 +705,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
         };
         if (esc_flags[wave]) sweep(std::true_type{});
         else sweep(std::false_type{});
+        FNP_STAMP(4);   // (sweep)
 
         // epilogue: the arithmetic of spconv_mfma_kernel (scale / shift, residual, ReLU, one rounding), 16 bytes per lane
 #pragma unroll
@@ -721,8 +729,8 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = acc[nb][mb][j];
                     if (scale) {
-                        const float4 s4 = *reinterpret_cast<const float4 *>(scale + c0);
-                        const float4 h4 = *reinterpret_cast<const float4 *>(shift + c0);
+                        const float4 s4 = *reinterpret_cast<const float4 *>(ss_lds + c0);
+                        const float4 h4 = *reinterpret_cast<const float4 *>(ss_lds + C + c0);
                         v[0] = v[0] * s4.x + h4.x; v[1] = v[1] * s4.y + h4.y; v[2] = v[2] * s4.z + h4.z; v[3] = v[3] * s4.w + h4.w;
                     }
                     if (residual) {
@@ -744,10 +752,12 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
                     *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(y) + (size_t)r * (C * 2) + kp * 64 + poff) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
             }
         }
+        FNP_STAMP(5);   // (epilogue)
     }
+    FNP_STAMP_FLUSH(0);
 }
 
-constexpr int kLds64 = 2 * 64 * 8 * 16 + (G64::WIN + G64::OVF + 1) * G64::ROWB + kK * G64::TILE * 2 + 16 + G64::OVF * 4;
+constexpr int kLds64 = 2 * 64 * 8 * 16 + (G64::WIN + G64::OVF + 1) * G64::ROWB + kK * G64::TILE * 2 + 16 + G64::OVF * 4 + 2 * 64 * 4;
 static_assert(2 * kLds64 <= 160 * 1024, "two workgroups per CU");
 
 template <typename TAct>

@@ -91,7 +91,7 @@ for tag, rb, n_dev in log:
             nt_ = (n + TR - 1) // TR; esc = tb.view(-1, REC)[:nt_, REC - 16:REC - 16 + TR // 32]
             print(json.dumps({"tile_rulebook_build_ms": round(e0.elapsed_time(e1) / args.reps, 4), "wave_tiles_with_escape": round(esc.float().mean().item(), 5),
                               "far_rows_per_tile": round((tb.view(-1, REC)[:nt_, 27 * TR * 2:27 * TR * 2 + OV * 4].contiguous().view(torch.int32) >= 0).float().sum(1).mean().item(), 1)}))
-        if os.environ.get("FNP_LIB_PATH", "").find("stamp") >= 0 and (cin, cout) == (32, 32):
+        if os.environ.get("FNP_LIB_PATH", "").find("stamp") >= 0 and (cin, cout) in ((32, 32), (64, 64)):
             import ctypes
             raw = ctypes.CDLL(os.environ["FNP_LIB_PATH"])
             buf = (ctypes.c_ulonglong * 32)()
@@ -99,7 +99,9 @@ for tag, rb, n_dev in log:
             S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True, ranked=ranked, valu=args.valu, tile=TILE)
             torch.cuda.synchronize()
             raw.fnp_debug_tile_stamps(buf)
-            tiles = (n + 255) // 256
+            tiles = (n + 255) // 256 if cin == 32 else (n + 127) // 128
+            if cin == 64:
+                print(json.dumps({"stamp64_cycles_per_tile[slab_req,barrier,put,req_next,sweep,epilogue]": [round(buf[i] / (tiles * 4)) for i in range(6)], "slowest": [round(buf[16 + i] / (tiles / 512)) for i in range(6)]}))
             # s_memtime ticks (shader cycles) summed over the waves of a role: per tile and wave
             print(json.dumps({"stamp_cycles_per_tile": {"consumer[sweep,epilogue,barrier]": [round(buf[i] / (tiles * 8)) for i in range(3)],
                                                      "producer[codes,requests,translate,rows,overflow_req,barrier]": [round(buf[8 + i] / (tiles * 8)) for i in range(6)]},
