@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restric
 
 // Development-only timing probes (results are wrong; the shipped library has 0): 1 = escape entries are taken as absent,
 // 2 = consumers skip the offset sweep, 4 = producers write the first two tiles only, 16 / 32 = consumers skip weight / fragment reads,
-// 64 = no MFMA; 64-channel kernel: 128 = the weight slabs are not streamed, 256 = no barrier per offset
+// 64 = no MFMA, 512 = no output stores; 64-channel kernel: 128 = the weight slabs are not streamed, 256 = no barrier per offset
 #ifndef FNP_TILE_ABLATE
 #define FNP_TILE_ABLATE 0
 #endif
@@ -465,8 +465,9 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
             }
             auto t0 = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
             auto t1 = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);
-            if (live)
+            if (live && !(FNP_TILE_ABLATE & 512))
                 *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(y) + (size_t)r * kRowB + poff) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+            if (FNP_TILE_ABLATE & 512) asm volatile("" ::"v"(t0[0]), "v"(t1[0]), "v"(t0[1]), "v"(t1[1]));
         }
         signal(FREED + image);
         FNP_STAMP(1);

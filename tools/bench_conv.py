@@ -10,7 +10,7 @@ from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--reps", type=int, default=20); ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"]); ap.add_argument("--valu", action="store_true"); ap.add_argument("--identity", action="store_true", help="replace every valid rulebook entry by the output row itself (perfect gather locality, same instruction stream)"); ap.add_argument("--fracs", type=str, default="1.0", help="comma list: time each layer on the first frac*n output rows too (tile staircase)")
 ap.add_argument("--tile", default="auto", choices=["auto", "on", "off"], help="LDS-tile kernel for the ranked 32 -> 32 layers: by size / forced / forbidden")
-ap.add_argument("--only", default="", help="e.g. 32x32: time this layer class only")
+ap.add_argument("--no-residual", action="store_true"); ap.add_argument("--only", default="", help="e.g. 32x32: time this layer class only")
 ap.add_argument("--tile-stats", action="store_true", help="far-neighbour statistics of the ranked 32 -> 32 layer per 256-row tile")
 args = ap.parse_args()
 TILE = {"auto": None, "on": True, "off": False}[args.tile]
@@ -41,7 +41,7 @@ for tag, rb, n_dev in log:
     x = torch.randn((n_in, cin), device=dev).to(TD)
     w = (torch.randn((K, cout, cin), device=dev) * 0.05).to(TD)
     sc = torch.ones(cout, device=dev); sh = torch.zeros(cout, device=dev)
-    resid = torch.randn((rb.cap_out, cout), device=dev).to(TD)
+    resid = None if args.no_residual else torch.randn((rb.cap_out, cout), device=dev).to(TD)
     n_full = n
     if args.tile_stats and ranked and K == 27:
         # far rows of spconv_tile.hip's tiles: per producer wave (32 rows x 27 offsets) the unique far row ids
