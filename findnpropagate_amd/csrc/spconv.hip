@@ -289,6 +289,13 @@ struct FusedRb {
     const int *out_coords;    // (cap, 4) [b, z, y, x] of the output rows
 };
 
+#ifdef FNP_MFMA_STAMP
+__device__ unsigned long long g_mfma_stamps[8];
+#define FNP_MS_NOW(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define FNP_MS(ph) do { if (CIN == 128 && COUT == 128 && KVOL == 27) { unsigned long long n_; FNP_MS_NOW(n_); ms_acc[ph] += n_ - ms_prev; ms_prev = n_; } } while (0)
+#else
+#define FNP_MS(ph)
+#endif
 template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut, bool FUSED = false, typename TAct = __bf16>
 __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const TAct *__restrict__ x, int x_bytes,
                                                              const TAct *__restrict__ w,
@@ -467,6 +474,10 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     // block counts of a range's last, partial tile: a workgroup whose range ends with t blocks runs
     // that tile with ceil(t / 4) blocks per wave instead of MBT, so the matrix work of the tail is
     // proportional to its rows (every wave of the workgroup still passes the same barriers).
+#ifdef FNP_MFMA_STAMP
+    unsigned long long ms_acc[4] = {0, 0, 0, 0}, ms_prev;
+    FNP_MS_NOW(ms_prev);
+#endif
     bool first_tile = true;
     auto run_tile = [&](auto mbt_tag, const int tile_base) __attribute__((always_inline)) {
         constexpr int MBT = decltype(mbt_tag)::value;
@@ -583,6 +594,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
             const uint4 *w1 = reinterpret_cast<const uint4 *>(w + (size_t)(WPAIR ? (K > 2 ? 2 : 0) : (K > 1 ? 1 : 0)) * COUT * CIN);
             wd0 = w1[tid]; wd1 = w1[tid + NT]; wd2 = w1[tid + 2 * NT]; wd3 = w1[tid + 3 * NT];
         }
+        FNP_MS(2);
         for (int k0 = 0; k0 < K; k0 += PFK) {
 #pragma unroll
             for (int u = 0; u < PFK; ++u) {
@@ -710,7 +722,9 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                                 wl[((k + 1) & 1) * SLAB + st_pos0 + c * NT] = (j == 0 ? wreg0 : wreg1);
                         }
                     }
+                    FNP_MS(0);
                     if (!WPAIR || (k & 1) || k == K - 1) __syncthreads();  // plain loads stay in flight across it; only the LDS writes are waited for
+                    FNP_MS(1);
                 }
             }
         }
@@ -732,6 +746,21 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
             static_assert(LPR <= 16 && EH % SPI == 0 && NRD >= 1, "wide epilogue shape");
             unsigned char *const eb = fnp_smem + Cfg::lds_bytes(NW, MB, WIN) + wave * (EH * ES);
             const int wsite = lane / LPR, wchunk = lane % LPR;
+            // the residual rows of ALL the wave's blocks are requested before the first one is used (one memory round trip for
+            // the tile instead of one per 16-site block: the sweep's registers are free here)
+            u32x4 rs_all[MBT][16 / EH][NRD];
+            if (residual && !(FNP_ABLATE & 256)) {
+#pragma unroll
+                for (int mb = 0; mb < MBT; ++mb)
+#pragma unroll
+                    for (int h = 0; h < 16 / EH; ++h)
+#pragma unroll
+                        for (int i = 0; i < NRD; ++i) {
+                            const int r = row0 + mb * 16 + h * EH + i * SPI + wsite;
+                            rs_all[mb][h][i] = u32x4{0u, 0u, 0u, 0u};
+                            if (r < row_end) rs_all[mb][h][i] = *reinterpret_cast<const u32x4 *>(residual + (size_t)r * COUT + wchunk * 8);
+                        }
+            }
 #pragma unroll
             for (int mb = 0; mb < MBT; ++mb) {
 #pragma unroll
@@ -739,16 +768,9 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                     const int rb = row0 + mb * 16 + h * EH;
                     const bool mine = EH == 16 || (l15 / EH) == h;   // this lane's site is in the pass
                     if (residual && !(FNP_ABLATE & 256)) {
-                        u32x4 rs[NRD];
-#pragma unroll
-                        for (int i = 0; i < NRD; ++i) {
-                            const int r = rb + i * SPI + wsite;
-                            rs[i] = u32x4{0u, 0u, 0u, 0u};
-                            if (r < row_end) rs[i] = *reinterpret_cast<const u32x4 *>(residual + (size_t)r * COUT + wchunk * 8);
-                        }
 #pragma unroll
                         for (int i = 0; i < NRD; ++i)
-                            *reinterpret_cast<u32x4 *>(eb + (i * SPI + wsite) * ES + wchunk * 16) = rs[i];
+                            *reinterpret_cast<u32x4 *>(eb + (i * SPI + wsite) * ES + wchunk * 16) = rs_all[mb][h][i];
                     }
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
@@ -875,6 +897,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
             }
         }
         }
+        FNP_MS(3);
         first_tile = false;
     };
     const int nblk_wg = (row_end - row_begin + 15) >> 4;
@@ -886,6 +909,10 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     if constexpr (MB > 1) { if (tper == 1) run_tile(std::integral_constant<int, 1>{}, tail_base); }
     if constexpr (MB > 2) { if (tper == 2) run_tile(std::integral_constant<int, 2>{}, tail_base); }
     if constexpr (MB > 3) { if (tper == 3) run_tile(std::integral_constant<int, 3>{}, tail_base); }
+#ifdef FNP_MFMA_STAMP
+    if (CIN == 128 && COUT == 128 && KVOL == 27 && lane == 0)
+        for (int ph = 0; ph < 4; ++ph) atomicAdd(&g_mfma_stamps[ph], ms_acc[ph]);
+#endif
 }
 
 template <int CIN, int COUT, int KVOL, bool WIN, typename TOut, bool FUSED = false, typename TAct = __bf16>
@@ -1015,6 +1042,15 @@ int dispatch_16(const void *x, long long n_in, const void *w, const int *nbr, in
 }
 
 }  // namespace
+
+#ifdef FNP_MFMA_STAMP
+extern "C" int fnp_debug_mfma_stamps(unsigned long long *out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mfma_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return FNP_ERR_HIP;
+    unsigned long long zero[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mfma_stamps), zero, sizeof(zero)) != hipSuccess) return FNP_ERR_HIP;
+    return FNP_OK;
+}
+#endif
 
 int fnp_spconv_forward_f32_mfma(const void *feat_in, long long n_in_rows, const void *weight, const int *nbr, int nbr_stride,
                                 int K, const int *n_out, int cap_out, void *feat_out, const float *scale, const float *shift,

@@ -83,6 +83,15 @@ for tag, rb, n_dev in log:
         for _ in range(args.reps): S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True, ranked=ranked, valu=args.valu, tile=TILE)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
+        if os.environ.get("FNP_LIB_PATH", "").find("mstamp") >= 0 and (cin, cout, K) == (128, 128, 27):
+            import ctypes
+            raw = ctypes.CDLL(os.environ["FNP_LIB_PATH"]); buf = (ctypes.c_ulonglong * 8)()
+            raw.fnp_debug_mfma_stamps(buf)
+            S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True, ranked=ranked, valu=args.valu, tile=TILE)
+            torch.cuda.synchronize(); raw.fnp_debug_mfma_stamps(buf)
+            tot = sum(buf[i] for i in range(4))
+            print(json.dumps({"mfma128_wave_cycle_share[offset_body,barrier,tile_prologue,epilogue]": [round(buf[i] / tot, 3) for i in range(4)],
+                              "cycles_per_wave": round(tot / (256 * 8))}))
         if TILE and (cin, cout, K) in ((32, 32, 27), (64, 64, 27)):   # the one-off restatement of the rulebook
             L = S._l.load(); tb = torch.empty_like(rb._tile_rb[cin]); REC, TR, OV = (14864, 256, 256) if cin == 32 else (7440, 128, 128)
             torch.cuda.synchronize(); e0.record()
