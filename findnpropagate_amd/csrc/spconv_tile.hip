@@ -478,18 +478,13 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
 
 // ------------------------------------------------------------------------------------------ 64 -> 64 channels
 // The same idea for the ranked 64 -> 64 layers (the four SubM convolutions of stage 3).  Their 27 weight slabs (8 KB each)
-// do not fit LDS next to a tile image, so the slabs stream through a three-slot ring, one offset per slot and workgroup
+// do not fit LDS next to a tile image, so the slabs stream through a two-slot ring, one offset per slot and workgroup
 // barrier, as in spconv_mfma_kernel — what goes is everything else that kernel issues per (site, offset): the int32 entry
-// loads, the row-address arithmetic and the gather instructions, which (not the matrix work) bound it.
-// One 512-thread workgroup per CU, 256-row tiles.  Waves 0-3 are CONSUMERS, one per SIMD, 64 rows each as four 16-column
-// blocks (column l15 of block mb = row 64 w + 4 l15 + mb: a lane's four entries are one 8-byte read, and the blocks'
-// neighbours — every fourth row — are consecutive rows of one window quarter): per offset 32 MFMAs on fragments read an
-// offset ahead, so the per-offset LDS traffic is 4 x 8 KB of weights + 32 KB of features against 512 MFMA cycles per SIMD
-// (four 32-row waves per 128 rows, the first form of this kernel, read 2 x 32 + 2 x 16 KB per 256 rows and were bound by it).
-// Waves 4-7 are PRODUCERS: they stream the slabs (global -> registers -> ring, two offsets ahead) and carry the next tile's
-// image memory -> registers during the sweep, registers -> LDS while the consumers run the epilogue.
+// loads, the row-address arithmetic and the gather instructions, which (not the matrix work) bound it.  128-row tiles,
+// one 256-thread workgroup (4 waves x 32 rows), two workgroups per CU (one fills its image while the other sweeps); the
+// image of the next tile travels memory -> registers during the sweep and registers -> LDS between two sweeps.
 template <typename TAct>
-__global__ __launch_bounds__(512, 2) void spconv_tile64_kernel(const TAct *__restrict__ x, int x_bytes, const TAct *__restrict__ w,
+__global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__restrict__ x, int x_bytes, const TAct *__restrict__ w,
                                                                 const unsigned char *__restrict__ tile_rb, int rb_bytes,
                                                                 const int *__restrict__ nbr, int nbr_stride,
                                                                 const int *__restrict__ n_out, int cap, TAct *__restrict__ y,
@@ -498,18 +493,16 @@ __global__ __launch_bounds__(512, 2) void spconv_tile64_kernel(const TAct *__res
     using G = G64;
     using frag8 = typename V16<TAct>::v8;
     using act4 = typename V16<TAct>::v4;
-    constexpr int C = 64, CH = 8, KS = 2, NB = 4, MB = 4, NCW = 4, PT = 256;
+    constexpr int C = 64, CH = 8, KS = 2, NB = 4, MB = 2, NW = 4, NT = 256;
     constexpr int SLABC = C * CH;                                  // 512 chunks (8 KB) per weight slab
-    constexpr int XB = G::SLOTS * G::ROWB;                         // feature rows of the image (64 KB)
+    constexpr int XB = (G::WIN + G::OVF + 1) * G::ROWB;            // feature rows of the image
     constexpr int EB = kK * G::TILE * 2;                           // entries
-    constexpr int NWL = G::WIN * CH / PT, NEL = (EB / 16 + PT - 1) / PT, NOL = G::OVF * CH / PT, NSL = SLABC / PT;
-    static_assert(G::WIN * CH % PT == 0 && G::OVF * CH % PT == 0 && SLABC % PT == 0 && G::TILE == NCW * MB * 16 && G::OVF <= PT, "shape");
+    constexpr int NWL = G::WIN * CH / NT, NEL = (EB / 16 + NT - 1) / NT, NOL = G::OVF * CH / NT, NSL = SLABC / NT;
+    static_assert(G::WIN * CH % NT == 0 && G::OVF * CH % NT == 0 && SLABC % NT == 0 && G::TILE == NW * MB * 16 && G::OVF <= NT, "shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4 *wl = reinterpret_cast<uint4 *>(smem);                   // [3][SLABC]
-    unsigned char *const img = smem + 3 * SLABC * 16;
-    int *const esc_flags = reinterpret_cast<int *>(img + XB + EB);                     // [TILE / 32]
-    int *const id_lds = esc_flags + 8;                                                 // [OVF] far-row ids of the tile being requested
-    float *const ss_lds = reinterpret_cast<float *>(id_lds + G::OVF);                  // [2][C] BatchNorm scale, shift
+    uint4 *wl = reinterpret_cast<uint4 *>(smem);                   // [2][SLABC]
+    unsigned char *const img = smem + 2 * SLABC * 16;
+    int *const esc_flags = reinterpret_cast<int *>(img + XB + EB);
 
     const int n = min(*n_out, cap);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
@@ -525,125 +518,103 @@ __global__ __launch_bounds__(512, 2) void spconv_tile64_kernel(const TAct *__res
     const int t_begin = (int)(((long long)ntiles * range) / Gd), t_end = (int)(((long long)ntiles * (range + 1)) / Gd);
     if (t_begin >= t_end) return;   // (whole workgroup, before any barrier)
 
-    if (tid < CH) reinterpret_cast<uint4 *>(img + G::code(G::ZERO))[tid] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid < 2 * C) ss_lds[tid] = scale ? (tid < C ? scale[tid] : shift[tid - C]) : (tid < C ? 1.f : 0.f);
-
-    // Barriers (all 8 waves): T (tile top: everybody has left the previous image and slabs), I (image + slabs 0, 1 in LDS),
-    // D (far-row ids of the next tile in LDS), then one per offset k = 0 .. 25 (slab k + 2 stored, fragments of offset k + 1
-    // read).  Ring slot of slab k: k % 3 — read (into registers) during offset k - 1, overwritten by slab k + 3 during
-    // offset k + 1.
-    if (wave >= NCW) {
-        // ------------------------------------------------------------------ producer waves
-        const int ptid = tid - NCW * 64;
-        const int st_pos = (ptid / CH) * CH + ((ptid % CH) ^ (((ptid / CH) >> 1) & 7));   // weight image: row r stores chunk c at c ^ ((r >> 1) & 7)
-        u32x4 pwin[NWL], pent[NEL], povf[NOL], wslab[2][NSL];
-        int far_id = -1;      // producer thread s < OVF: row id of overflow row s, one tile ahead of the image in the registers
-        unsigned pesc = 0;
-        unsigned win_dst[NWL], ovf_dst[NOL];
-#pragma unroll
-        for (int j = 0; j < NWL; ++j) {
-            const unsigned p = (unsigned)ptid + j * PT;
-            win_dst[j] = G::code(G::slot(p / CH)) ^ ((p % CH) << 4);
-        }
-#pragma unroll
-        for (int j = 0; j < NOL; ++j) {
-            const unsigned p = (unsigned)ptid + j * PT;
-            ovf_dst[j] = G::code((unsigned)G::OVF_BASE + p / CH) ^ ((p % CH) << 4);
-        }
-        auto rec_off = [&](int t) -> unsigned { return t < t_end ? (unsigned)t * (unsigned)G::REC : 0x80000000u; };
-        auto req_far_ids = [&](int t) {
-            far_id = __builtin_amdgcn_raw_buffer_load_b32(trsrc, ptid < G::OVF ? rec_off(t) + (unsigned)(G::REC_FAR + ptid * 4) : 0x80000000u, 0, 0);
-        };
-        auto req_image = [&](int t) {   // window, entries, flags of tile t
-            const unsigned ro = rec_off(t);
-            const unsigned wbase = t < t_end ? (unsigned)max(0, t * G::TILE - G::HALO) * G::ROWB + (unsigned)ptid * 16u : 0x80000000u;
-#pragma unroll
-            for (int j = 0; j < NWL; ++j) pwin[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, wbase + j * (PT * 16), 0, 0);
-#pragma unroll
-            for (int j = 0; j < NEL; ++j)
-                pent[j] = __builtin_amdgcn_raw_buffer_load_b128(trsrc, (ptid + j * PT < EB / 16) ? ro + (unsigned)(ptid + j * PT) * 16u : 0x80000000u, 0, 0);
-            pesc = __builtin_amdgcn_raw_buffer_load_b8(trsrc, ptid < G::TILE / 32 ? ro + (unsigned)(G::REC_ESC + ptid) : 0x80000000u, 0, 0);
-        };
-        auto put_far_ids = [&](int t) {
-            if (ptid < G::OVF) id_lds[ptid] = t < t_end ? far_id : -1;   // (a load that was not issued left 0, which is a row)
-        };
-        auto req_overflow = [&]() {   // the rows id_lds names (behind a barrier)
-#pragma unroll
-            for (int j = 0; j < NOL; ++j) {
-                const unsigned p = (unsigned)ptid + j * PT;
-                const int key = id_lds[p / CH];
-                povf[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, key >= 0 ? (unsigned)key * G::ROWB + (p % CH) * 16u : 0x80000000u, 0, 0);
-            }
-        };
-        auto put_image = [&]() {
-#pragma unroll
-            for (int j = 0; j < NEL; ++j)
-                if (ptid + j * PT < EB / 16) *reinterpret_cast<u32x4 *>(img + XB + (ptid + j * PT) * 16) = pent[j];
-#pragma unroll
-            for (int j = 0; j < NOL; ++j) *reinterpret_cast<u32x4 *>(img + ovf_dst[j]) = povf[j];
-#pragma unroll
-            for (int j = 0; j < NWL; ++j) *reinterpret_cast<u32x4 *>(img + win_dst[j]) = pwin[j];
-            if (ptid < G::TILE / 32) esc_flags[ptid] = (FNP_TILE_ABLATE & 1) ? 0 : (int)pesc;
-        };
-        auto req_slab = [&](int k, u32x4 (&r)[NSL]) {
-#pragma unroll
-            for (int j = 0; j < NSL; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(ptid + j * PT) * 16u, (unsigned)k * (C * C * 2), 0);
-        };
-        auto put_slab = [&](int k, const u32x4 (&r)[NSL]) {
-#pragma unroll
-            for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[(k % 3) * SLABC + st_pos + j * PT]) = r[j];
-        };
-        // first tile: ids -> LDS -> overflow rows; image
-        req_far_ids(t_begin);
-        req_image(t_begin);
-        put_far_ids(t_begin);
-        __syncthreads();                       // (P0: ids of the first tile; zero row, scale / shift)
-        req_overflow();
-        req_far_ids(t_begin + 1);
-        for (int t = t_begin; t < t_end; ++t) {
-            req_slab(0, wslab[0]);
-            req_slab(1, wslab[1]);
-            __syncthreads();                   // T
-            put_image();
-            put_slab(0, wslab[0]);
-            put_slab(1, wslab[1]);
-            put_far_ids(t + 1);
-            __syncthreads();                   // I
-            req_slab(2, wslab[0]);
-            req_slab(3, wslab[1]);
-            if (!(FNP_TILE_ABLATE & 1024)) req_image(t + 1);
-            if (!(FNP_TILE_ABLATE & 1024)) req_overflow();                    // (ids of tile t + 1: stored before I)
-            req_far_ids(t + 2);
-            __syncthreads();                   // D (the consumers' first fragments are read: slot 0 may be rewritten from offset 1 on)
-#pragma unroll
-            for (int k = 0; k < kK - 1; ++k) {
-                // offset k: slab k + 2 -> slot (k + 2) % 3 (slab k - 1's fragments were read during offset k - 2); request slab k + 4
-                if (k + 2 < kK && !(FNP_TILE_ABLATE & 128)) put_slab(k + 2, wslab[k & 1]);
-                if (k + 4 < kK && !(FNP_TILE_ABLATE & 128)) req_slab(k + 4, wslab[k & 1]);
-                __syncthreads();
-            }
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- consumer waves
+    // weight slab image: row r (one output channel, 8 chunks) stores logical chunk c at c ^ ((r >> 1) & 7)
+    const int st_pos = (tid / CH) * CH + ((tid % CH) ^ (((tid / CH) >> 1) & 7));   // (+ j * NT: 32 rows further, same swizzle)
     int aoff[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) aoff[ks] = l15 * CH + ((ks * 4 + q) ^ ((l15 >> 1) & 7));
-    const int rloc = wave * 64 + 4 * l15;            // this lane's row of block 0 inside the tile (block mb: + mb)
+    if (tid < CH) reinterpret_cast<uint4 *>(img + G::ZERO * G::ROWB)[tid] = make_uint4(0u, 0u, 0u, 0u);
+
+    // the next tile's image on its way: window, entries, overflow rows (4 lanes... 8 chunks per row), flags; far-row ids one tile further
+    u32x4 pwin[NWL], pent[NEL], povf[NOL];
+    int far_id = -1;      // thread s < OVF: row id of overflow row s
+    unsigned pesc = 0;
+    unsigned win_dst[NWL], ovf_dst[NOL];
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) {
+        const unsigned p = (unsigned)tid + j * NT;
+        win_dst[j] = G::code(tilerb::win_slot<G>(p / CH)) ^ ((p % CH) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NOL; ++j) {
+        const unsigned p = (unsigned)tid + j * NT;
+        ovf_dst[j] = G::code((unsigned)G::WIN + p / CH) ^ ((p % CH) << 4);
+    }
+    auto rec_off = [&](int t) -> unsigned { return t < t_end ? (unsigned)t * (unsigned)G::REC : 0x80000000u; };
+    auto req_far_ids = [&](int t) {
+        far_id = __builtin_amdgcn_raw_buffer_load_b32(trsrc, tid < G::OVF ? rec_off(t) + (unsigned)(G::REC_FAR + tid * 4) : 0x80000000u, 0, 0);
+    };
+    int *const id_lds = reinterpret_cast<int *>(img + XB + EB + 16);   // [OVF] far-row ids of the tile being requested
+    float *const ss_lds = reinterpret_cast<float *>(img + XB + EB + 16 + G::OVF * 4);   // [2][C] BatchNorm scale, shift (read per tile from LDS, not L2)
+    if (tid < 2 * C) ss_lds[tid] = scale ? (tid < C ? scale[tid] : shift[tid - C]) : (tid < C ? 1.f : 0.f);
+    auto req_tile = [&](int t) {   // (far_id holds tile t's ids; they pass through LDS to the lanes that fetch the rows)
+        const unsigned ro = rec_off(t);
+        const unsigned wbase = t < t_end ? (unsigned)max(0, t * G::TILE - G::HALO) * G::ROWB + (unsigned)tid * 16u : 0x80000000u;
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) pwin[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, wbase + j * (NT * 16), 0, 0);
+#pragma unroll
+        for (int j = 0; j < NEL; ++j)
+            pent[j] = __builtin_amdgcn_raw_buffer_load_b128(trsrc, (tid + j * NT < EB / 16) ? ro + (unsigned)(tid + j * NT) * 16u : 0x80000000u, 0, 0);
+        pesc = __builtin_amdgcn_raw_buffer_load_b8(trsrc, tid < NW ? ro + (unsigned)(G::REC_ESC + tid) : 0x80000000u, 0, 0);
+        if (tid < G::OVF) id_lds[tid] = t < t_end ? far_id : -1;   // (a load that was not issued left 0, which is a row)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NOL; ++j) {
+            const unsigned p = (unsigned)tid + j * NT;
+            const int key = id_lds[p / CH];
+            povf[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, key >= 0 ? (unsigned)key * G::ROWB + (p % CH) * 16u : 0x80000000u, 0, 0);
+        }
+    };
+    auto put_tile = [&]() {
+#pragma unroll
+        for (int j = 0; j < NEL; ++j)
+            if (tid + j * NT < EB / 16) *reinterpret_cast<u32x4 *>(img + XB + (tid + j * NT) * 16) = pent[j];
+#pragma unroll
+        for (int j = 0; j < NOL; ++j) *reinterpret_cast<u32x4 *>(img + ovf_dst[j]) = povf[j];
+#pragma unroll
+        for (int j = 0; j < NWL; ++j) *reinterpret_cast<u32x4 *>(img + win_dst[j]) = pwin[j];
+        if (tid < NW) esc_flags[tid] = (FNP_TILE_ABLATE & 1) ? 0 : (int)pesc;
+    };
+
+    const int rloc = wave * 32 + 2 * l15;            // this lane's row of block 0 inside the tile (block 1: the next row)
     const int poff = (q & 1) * 32 + (q >> 1) * 16;   // epilogue: this lane's 16 bytes of a 64-byte channel-block pair
-    __syncthreads();                           // P0
+    req_far_ids(t_begin);
+    req_tile(t_begin);
+    req_far_ids(t_begin + 1);
+    FNP_STAMP_DECL;
     for (int t = t_begin; t < t_end; ++t) {
         const int tile_base = t * G::TILE, row_end = min(n, tile_base + G::TILE);
-        __syncthreads();                       // T
-        __syncthreads();                       // I
+        // Weight slabs: slab k lives in ring slot k & 1.  The A fragments of offset k + 1 are read (slot (k + 1) & 1) during
+        // offset k, so a wave leaves the barrier with everything its next 16 MFMAs need in registers; slab k + 2 is stored
+        // (slot k & 1, whose fragments were read an offset ago) during offset k, requested from L2 an offset before that.
+        // Slabs 0 - 2 are requested before the image is written: they land meanwhile.
+        u32x4 wreg[2][NSL], wslab[2][NSL];   // wslab[k & 1]: slab k + 2 on its way to LDS
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) wreg[h][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)h * (C * C * 2), 0);
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) wslab[0][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, 2u * (C * C * 2), 0);
+        FNP_STAMP(0);   // (slab requests)
+        __syncthreads();   // every wave has left the previous tile's image and slabs
+        FNP_STAMP(1);   // (barrier: the slowest wave's epilogue)
+        put_tile();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[h * SLABC + st_pos + j * NT]) = wreg[h][j];
+        __syncthreads();
+        FNP_STAMP(2);   // (image + slabs 0, 1 -> LDS, barrier)
+        req_tile(t + 1);        // (one more barrier inside: the ids' pass through LDS)
+        req_far_ids(t + 2);
+        FNP_STAMP(3);   // (next tile requested)
         f32x4 acc[NB][MB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const uint2 *rb64 = reinterpret_cast<const uint2 *>(img + XB) + wave * 16 + l15;   // the four blocks' entries of an offset
-        auto entry = [&](int k) -> uint2 { return rb64[(k < kK ? k : kK - 1) * (G::TILE / 4)]; };
+        const unsigned *rb32 = reinterpret_cast<const unsigned *>(img + XB) + wave * 16 + l15;   // both blocks' entries
+        auto entry = [&](int k) -> unsigned { return rb32[(k < kK ? k : kK - 1) * (G::TILE / 2)]; };
         uint4 rv[MB][NB / 2];   // residual rows: requested a few offsets before the sweep ends
         auto req_residual = [&]() {
 #pragma unroll
@@ -656,14 +627,14 @@ __global__ __launch_bounds__(512, 2) void spconv_tile64_kernel(const TAct *__res
                         rv[mb][kp] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(residual) + (size_t)r * (C * 2) + kp * 64 + poff);
                 }
         };
+        if (FNP_TILE_ABLATE & 2) req_residual();
         auto sweep = [&](auto esc_tag) {
             constexpr bool ESC = decltype(esc_tag)::value;
             // fragments of one offset: [ks][mb]; lane (l15, q) takes chunk 4 ks + q of its row
-            auto fragments = [&](uint2 e2, int k, u32x4 (&xv)[KS][MB]) {
+            auto fragments = [&](unsigned e, int k, u32x4 (&xv)[KS][MB]) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    const unsigned ew = mb < 2 ? e2.x : e2.y;
-                    const unsigned em = (mb & 1) ? ew >> 16 : ew & 0xffffu;
+                    const unsigned em = mb ? e >> 16 : e & 0xffffu;
                     if constexpr (ESC) {
                         if (__ballot(em == kEscape) != 0ull) {
                             // more far rows than overflow slots: these fragments come from memory
@@ -685,7 +656,7 @@ __global__ __launch_bounds__(512, 2) void spconv_tile64_kernel(const TAct *__res
                 }
             };
             auto weights = [&](int k, frag8 (&wa)[KS][NB]) {
-                const uint4 *wk = wl + (k % 3) * SLABC;
+                const uint4 *wk = wl + (k & 1) * SLABC;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -694,53 +665,48 @@ __global__ __launch_bounds__(512, 2) void spconv_tile64_kernel(const TAct *__res
                         wa[ks][nb] = *reinterpret_cast<const frag8 *>(&tw);
                     }
             };
-            uint2 en[2];
+            unsigned en[2];
             u32x4 xf[2][KS][MB];
             frag8 wa[2][KS][NB];
             fragments(entry(0), 0, xf[0]);
             weights(0, wa[0]);
             en[1] = entry(1);
             en[0] = entry(2);
-            __syncthreads();                   // D
+            __syncthreads();   // slab 0's fragments are read: offset 0 may store slab 2 over it
 #pragma unroll
-            for (int k = 0; k < kK; ++k) {
+            for (int k = 0; k < ((FNP_TILE_ABLATE & 2) ? 0 : kK); ++k) {
+                if (k + 3 < kK && !(FNP_TILE_ABLATE & 128)) {
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j)
+                        wslab[(k + 1) & 1][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)(k + 3) * (C * C * 2), 0);
+                }
                 if (k == kK - 6) req_residual();
-                const uint2 e_new = entry(k + 3);
-                if (k + 1 < kK && !(FNP_TILE_ABLATE & 32)) {
+                const unsigned e_new = entry(k + 3);
+                if (k + 1 < kK) {
                     fragments(en[(k + 1) & 1], k + 1, xf[(k + 1) & 1]);
                     weights(k + 1, wa[(k + 1) & 1]);
                 }
-                // (the reads of offset k + 1 stay in front of the matrix work of offset k: left to itself the scheduler sinks
-                //  each read to just before its first use and the single consumer wave of a SIMD then waits for LDS eight times
-                //  per offset)
-                if (!(FNP_TILE_ABLATE & 2)) {
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) {
-                            const frag8 xv = *reinterpret_cast<const frag8 *>(&xf[(FNP_TILE_ABLATE & 32) ? 0 : (k & 1)][ks][mb]);
+                    for (int mb = 0; mb < MB; ++mb) {
+                        const frag8 xv = *reinterpret_cast<const frag8 *>(&xf[k & 1][ks][mb]);
 #pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = tmfma(wa[(FNP_TILE_ABLATE & 32) ? 0 : (k & 1)][ks][nb], xv, acc[nb][mb]);
-                        }
-                }
-                if constexpr (!ESC) {
-                    // ... and spread between them: a read issued in an MFMA's shadow costs the wave almost nothing, a burst of 17 in
-                    // front of the 32 MFMAs stalls it on the LDS queue (one consumer wave per SIMD: nobody else fills the gap)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // VALU (fragment addresses)
+                        for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = tmfma(wa[k & 1][ks][nb], xv, acc[nb][mb]);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 en[(k + 1) & 1] = e_new;
-                if (k + 1 < kK) __syncthreads();
+                if (k + 1 < kK) {
+                    if (k + 2 < kK && !(FNP_TILE_ABLATE & 128)) {
+#pragma unroll
+                        for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[(k & 1) * SLABC + st_pos + j * NT]) = wslab[k & 1][j];
+                    }
+                    if (!(FNP_TILE_ABLATE & 256)) __syncthreads();
+                }
             }
         };
-        if (esc_flags[2 * wave] | esc_flags[2 * wave + 1]) sweep(std::true_type{});
+        if (esc_flags[wave]) sweep(std::true_type{});
         else sweep(std::false_type{});
+        FNP_STAMP(4);   // (sweep)
 
         // epilogue: the arithmetic of spconv_mfma_kernel (scale / shift, residual, ReLU, one rounding), 16 bytes per lane
 #pragma unroll
@@ -787,11 +753,13 @@ __global__ __launch_bounds__(512, 2) void spconv_tile64_kernel(const TAct *__res
                     *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(y) + (size_t)r * (C * 2) + kp * 64 + poff) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
             }
         }
+        FNP_STAMP(5);   // (epilogue)
     }
+    FNP_STAMP_FLUSH(0);
 }
 
-constexpr int kLds64 = 3 * 64 * 8 * 16 + G64::SLOTS * G64::ROWB + kK * G64::TILE * 2 + 32 + G64::OVF * 4 + 2 * 64 * 4;
-static_assert(kLds64 <= 160 * 1024, "LDS budget");
+constexpr int kLds64 = 2 * 64 * 8 * 16 + (G64::WIN + G64::OVF + 1) * G64::ROWB + kK * G64::TILE * 2 + 16 + G64::OVF * 4 + 2 * 64 * 4;
+static_assert(2 * kLds64 <= 160 * 1024, "two workgroups per CU");
 
 template <typename TAct>
 int launch_tile64(const void *x, long long x_bytes, const void *w, const void *tile_rb, long long rb_bytes, const int *nbr, int nbr_stride,
@@ -803,8 +771,8 @@ int launch_tile64(const void *x, long long x_bytes, const void *w, const void *t
         raised = true;
     }
     const int tiles = fnp_divup(cap, G64::TILE);
-    const int grid = tiles < 256 ? tiles : 256;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), kLds64, s, (const TAct *)x, (int)x_bytes, (const TAct *)w, (const unsigned char *)tile_rb, (int)rb_bytes,
+    const int grid = tiles < 512 ? tiles : 512;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLds64, s, (const TAct *)x, (int)x_bytes, (const TAct *)w, (const unsigned char *)tile_rb, (int)rb_bytes,
                        nbr, nbr_stride, n_out, cap, (TAct *)y, scale, shift, (const TAct *)residual, relu);
     FNP_LAUNCH_CHECK();
     return FNP_OK;

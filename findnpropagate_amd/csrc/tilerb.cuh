@@ -15,29 +15,21 @@ constexpr unsigned kEscape = 0xFFFFu;   // entry: not in the tile image — fetc
 // 16 consecutive image rows), OVF overflow rows (far neighbours, one slot per distinct row), one row of zeros.
 struct G32 {   // 32 channels: 64-byte rows.  (window +-64 with 128 overflow rows fits LDS too and was slower: 0.20 vs 0.18 ms per
                // layer, rulebook pass 0.27 vs 0.20 ms — 39 distinct far rows crowd a 128-slot table)
-    static constexpr int TILE = FNP_TILE_ROWS, HALO = 32, WIN = TILE + 2 * HALO, OVF = 256, OVF_BASE = WIN, ZERO = WIN + OVF, ROWB = 64;
+    static constexpr int TILE = FNP_TILE_ROWS, HALO = 32, WIN = TILE + 2 * HALO, OVF = 256, ZERO = WIN + OVF, ROWB = 64;
     static constexpr int REC_FAR = kK * TILE * 2, REC_ESC = REC_FAR + OVF * 4, REC = REC_ESC + 16;
     // the row at slot rs stores logical chunk c (0..3) at chunk c ^ (-(rs >> 2) & 3)
     __host__ __device__ static constexpr unsigned code(unsigned rs) { return rs * ROWB + (((0u - (rs >> 2)) & 3u) << 4); }
-    // window position d -> image slot: even rows first, then odd rows (a consumer wave's 16 columns are every other row)
-    __host__ __device__ static constexpr unsigned slot(unsigned d) { return (d & 1u) * (WIN / 2) + (d >> 1); }
 };
-struct G64 {   // 64 channels: 128-byte rows, 256-row tiles, a consumer wave's 16 columns are every FOURTH row: the window is kept
-               // in four quarters (rows d = 0, 1, 2, 3 mod 4) of 96 slots, each starting 8 slots in so that the tile's own rows
-               // begin at a multiple of 16 (the swizzle period); the row of zeros takes the unused slot 0; 512 slots = 64 KB,
-               // the most 16-bit entries reach
-    static constexpr int TILE = FNP_TILE64_ROWS, HALO = 32, WIN = TILE + 2 * HALO, QS = 96, OVF = 128, OVF_BASE = 4 * QS, ZERO = 0, ROWB = 128;
-    static constexpr int SLOTS = OVF_BASE + OVF;
+struct G64 {   // 64 channels: 128-byte rows
+    static constexpr int TILE = FNP_TILE64_ROWS, HALO = 64, WIN = TILE + 2 * HALO, OVF = 128, ZERO = WIN + OVF, ROWB = 128;
     static constexpr int REC_FAR = kK * TILE * 2, REC_ESC = REC_FAR + OVF * 4, REC = REC_ESC + 16;
     // the row at slot rs stores logical chunk c (0..7) at chunk c ^ ((rs >> 1) & 7)
     __host__ __device__ static constexpr unsigned code(unsigned rs) { return rs * ROWB + (((rs >> 1) & 7u) << 4); }
-    __host__ __device__ static constexpr unsigned slot(unsigned d) { return (d & 3u) * QS + 8u + (d >> 2); }
 };
 static_assert(G32::REC == FNP_TILE_RECORD_BYTES && G32::REC % 16 == 0 && G32::ZERO * G32::ROWB + 48 < 0xFFFF, "32-channel tile record");
-static_assert(G64::REC == FNP_TILE64_RECORD_BYTES && G64::REC % 16 == 0 && (G64::SLOTS - 1) * G64::ROWB + 112 < 0xFFFF, "64-channel tile record");
-static_assert(G32::HALO % 32 == 0 && (G32::WIN / 2) % 4 == 0, "32 channels: window halves keep the swizzle period");
-static_assert(G64::TILE == 256 && (G64::HALO / 4 + 8) % 16 == 0 && G64::QS % 16 == 0 && G64::WIN / 4 + 8 <= G64::QS, "64 channels: window quarters");
-template <typename G> __host__ __device__ constexpr unsigned win_slot(unsigned d) { return G::slot(d); }
+static_assert(G64::REC == FNP_TILE64_RECORD_BYTES && G64::REC % 16 == 0 && G64::ZERO * G64::ROWB + 112 < 0xFFFF, "64-channel tile record");
+static_assert(G32::HALO % 32 == 0 && (G32::WIN / 2) % 4 == 0 && G64::HALO % 32 == 0 && (G64::WIN / 2) % 8 == 0, "window halves keep the swizzle period");
+template <typename G> __host__ __device__ constexpr unsigned win_slot(unsigned d) { return (d & 1u) * (G::WIN / 2) + (d >> 1); }
 // first slot a far row probes: multiplicative, so that the runs of consecutive row ids far neighbours come in do not pile up
 // into one long cluster of the linear-probing table (with id & (OVF - 1) the 64-channel build spent 0.12 ms in probes)
 template <typename G> __host__ __device__ constexpr unsigned far_hash(int id) {
@@ -56,7 +48,7 @@ __device__ __forceinline__ unsigned entry_of(int id, int wlo, int *table) {
     unsigned h = far_hash<G>(id);
     for (int probe = 0; probe < 64; ++probe) {
         const int old = atomicCAS(&table[h], -1, id);
-        if (old == -1 || old == id) return G::code((unsigned)G::OVF_BASE + h);
+        if (old == -1 || old == id) return G::code((unsigned)G::WIN + h);
         h = (h + 1) & (unsigned)(G::OVF - 1);
     }
     return kEscape;
@@ -97,7 +89,7 @@ __device__ __forceinline__ bool entries_of_row(const int (&id)[kK], int wlo, int
                     const int o2 = atomicCAS(&table[h], -1, id[k]);
                     ok = o2 == -1 || o2 == id[k];
                 }
-                code[k] = ok ? G::code((unsigned)G::OVF_BASE + h) : kEscape;
+                code[k] = ok ? G::code((unsigned)G::WIN + h) : kEscape;
                 esc |= !ok;
             }
         }

@@ -277,8 +277,8 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
  * ------------------------------------------------------------------------------------------ */
 #define FNP_TILE_ROWS 256            /* 32 channels */
 #define FNP_TILE_RECORD_BYTES 14864
-#define FNP_TILE64_ROWS 256          /* 64 channels */
-#define FNP_TILE64_RECORD_BYTES 14352
+#define FNP_TILE64_ROWS 128          /* 64 channels */
+#define FNP_TILE64_RECORD_BYTES 7440
 /* Diagnostic: the 32-channel kernel hands tile images between its producer and consumer waves through counters in LDS; a
  * wait that times out (~0.3 s; never, unless that protocol is broken) ends the workgroup with wrong output and counts
  * here.  Synchronises the device; >= 0, or a negative error code. */

@@ -10,11 +10,8 @@ K = 27
 ESCAPE = 0xFFFF
 GEOMETRY = {  # channels -> (TILE, HALO, OVF, ROW_BYTES)
     32: (256, 32, 256, 64),
-    64: (256, 32, 128, 128),
+    64: (128, 64, 128, 128),
 }
-# image slots (tilerb.cuh G32 / G64): 32 channels — window rows, even ones first, then odd ones; overflow rows; the row of zeros.
-# 64 channels — four window quarters (row position mod 4) of 96 slots, each starting 8 slots in; overflow rows from slot 384;
-# the row of zeros is slot 0.
 
 
 def record_bytes(channels):
@@ -32,17 +29,7 @@ def swizzle(channels, rs):
 def decode(tile_rb, n, channels):
     """tile_rb: uint8 array; returns (nbr (27, n) int64 with -2 where the entry is an escape, escape flags (tiles, TILE//32))."""
     tile, halo, ovf, rowb = GEOMETRY[channels]
-    win, rec = tile + 2 * halo, record_bytes(channels)
-    if channels == 32:
-        ovf_base, zero, nslots = win, win + ovf, win + ovf + 1
-        win_pos = np.full(nslots, -1, dtype=np.int64)          # slot -> window position
-        d = np.arange(win)
-        win_pos[(d & 1) * (win // 2) + (d >> 1)] = d
-    else:
-        ovf_base, zero, nslots = 384, 0, 512
-        win_pos = np.full(nslots, -1, dtype=np.int64)
-        d = np.arange(win)
-        win_pos[(d & 3) * 96 + 8 + (d >> 2)] = d
+    win, zero, rec = tile + 2 * halo, tile + 2 * halo + ovf, record_bytes(channels)
     ntiles = (n + tile - 1) // tile
     recs = np.asarray(tile_rb[: ntiles * rec], dtype=np.uint8).reshape(ntiles, rec)
     codes = recs[:, : K * tile * 2].copy().view(np.uint16).reshape(ntiles, K, tile).astype(np.int64)
@@ -55,14 +42,12 @@ def decode(tile_rb, n, channels):
         rs = c // rowb
         assert np.all(is_esc | ((c % rowb) == swizzle(channels, rs))), "entry swizzle bits"
         wlo = max(0, t * tile - halo)
-        assert np.all(is_esc | (rs < nslots)), "entry beyond the image"
-        rsc = np.clip(rs, 0, nslots - 1)
-        d = win_pos[rsc]
-        in_ovf = (rsc >= ovf_base) & (rsc < ovf_base + ovf) & ~is_esc
-        assert np.all(is_esc | in_ovf | (rsc == zero) | (d >= 0)), "entry names an unused image slot"
-        ids = np.where(d >= 0, wlo + d, -1)
-        ids = np.where(in_ovf, far[t][np.clip(rsc - ovf_base, 0, ovf - 1)], ids)
-        ids = np.where(rsc == zero, -1, ids)
+        half = win // 2
+        d = np.where(rs < half, 2 * rs, 2 * (rs - half) + 1)                     # window slot -> window position
+        ids = np.where(rs < win, wlo + d, -1)
+        in_ovf = (rs >= win) & (rs < zero) & ~is_esc
+        ids = np.where(in_ovf, far[t][np.clip(rs - win, 0, ovf - 1)], ids)
+        assert np.all(is_esc | (rs <= zero)), "entry beyond the image"
         ids = np.where(is_esc, -2, ids)
         out[:, t * tile:(t + 1) * tile] = ids
     return out[:, :n], esc

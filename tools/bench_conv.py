@@ -93,7 +93,7 @@ for tag, rb, n_dev in log:
             print(json.dumps({"mfma128_wave_cycle_share[offset_body,barrier,tile_prologue,epilogue]": [round(buf[i] / tot, 3) for i in range(4)],
                               "cycles_per_wave": round(tot / (256 * 8))}))
         if TILE and (cin, cout, K) in ((32, 32, 27), (64, 64, 27)):   # the one-off restatement of the rulebook
-            L = S._l.load(); tb = torch.empty_like(rb._tile_rb[cin]); REC, TR, OV = (14864, 256, 256) if cin == 32 else (14352, 256, 128)
+            L = S._l.load(); tb = torch.empty_like(rb._tile_rb[cin]); REC, TR, OV = (14864, 256, 256) if cin == 32 else (7440, 128, 128)
             torch.cuda.synchronize(); e0.record()
             for _ in range(args.reps): L.fnp_tile_rulebook_build(S._l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, S._l.ptr(n_dev), rb.cap_out, cin, S._l.ptr(tb), S._l.stream())
             e1.record(); torch.cuda.synchronize()
