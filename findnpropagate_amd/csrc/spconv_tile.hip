@@ -111,6 +111,9 @@ __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restric
 #ifndef FNP_TILE_SCHED
 #define FNP_TILE_SCHED 1
 #endif
+#ifndef FNP_TILE64_SCHED
+#define FNP_TILE64_SCHED 1
+#endif
 #ifndef FNP_TILE_PSLEEP
 #define FNP_TILE_PSLEEP 8
 #endif
@@ -686,6 +689,8 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
                     fragments(en[(k + 1) & 1], k + 1, xf[(k + 1) & 1]);
                     weights(k + 1, wa[(k + 1) & 1]);
                 }
+                // the 12 LDS reads of offset k + 1 interleaved with the 16 MFMAs of offset k and nothing moved across: left to
+                // itself the scheduler sinks every read to just before its first use and the wave waits for LDS four times an offset
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -694,6 +699,16 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = tmfma(wa[k & 1][ks][nb], xv, acc[nb][mb]);
                     }
+                if constexpr (!ESC && FNP_TILE64_SCHED) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // VALU (fragment addresses)
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 en[(k + 1) & 1] = e_new;
                 if (k + 1 < kK) {
                     if (k + 2 < kK && !(FNP_TILE_ABLATE & 128)) {
