@@ -36,6 +36,7 @@ class SparseConvFunction(torch.autograd.Function):
                              out=None if rows is None else torch.empty((rows, weight.shape[0]), dtype=feats.dtype, device=feats.device))
         ctx.save_for_backward(feats, weight)
         ctx.rb, ctx.n_out_dev, ctx.n_in_dev, ctx.ranked = rb, n_out_dev, n_in_dev, ranked
+        ctx.w_packed = w   # (the data gradient runs on the same packed slabs: no second permute + cast per layer and step)
         return out
 
     @staticmethod
@@ -46,7 +47,7 @@ class SparseConvFunction(torch.autograd.Function):
         K, Cout, Cin = rb.K, weight.shape[0], weight.shape[-1]
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wp = S.pack_weight(weight, feats.dtype)
+            wp = ctx.w_packed
             if rb.out_indices is None and rb.cap_out == feats.shape[0]:
                 # SubM: the rulebook is its own transpose up to the mirror of the offsets (input i feeds output o through
                 # offset k  <=>  o is the neighbour of i at offset K-1-k): same table, weight slabs in mirrored order
