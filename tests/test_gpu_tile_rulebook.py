@@ -59,3 +59,41 @@ def test_tile_rulebook_restates_the_table(cuda, n, order, fused, channels):
         far = np.unique(w[(w >= 0) & ((w < wlo) | (w >= wlo + tile + 2 * halo))])
         assert far.size > ovf // 2
     assert _l.load().fnp_spconv_tiled_aborts() == 0
+
+
+def test_tiled_entry_points_refuse_what_they_do_not_cover(cuda):
+    """fnp_spconv_forward_tiled / fnp_tile_rulebook_build return FNP_ERR_ARG (no launch) for shapes and buffers outside
+    their contract; sparse.conv_forward then takes the gather kernel by itself."""
+    L = _l.load()
+    n, C = 300, 32
+    rng = np.random.default_rng(5)
+    idx = torch.from_numpy(_sites(rng, 1, [5, 20, 21], n, "sorted")).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    rb = S.rulebook_subm(idx, n_dev, S.build_grid(idx, n_dev, 1, [5, 20, 21]), 3)
+    x = torch.randn((n, C), device=cuda).bfloat16()
+    w = torch.randn((27, C, C), device=cuda).bfloat16()
+    y = torch.empty_like(x)
+    t = S.tile_rulebook(rb, n_dev, C)
+    args = lambda **kw: dict(dict(feat=_l.ptr(x), dtype=_l.FNP_BF16, rows=n, w=_l.ptr(w), t=_l.ptr(t), nbr=_l.ptr(rb.nbr), stride=rb.nbr.shape[1],
+                                   n=_l.ptr(n_dev), cap=rb.cap_out, out=_l.ptr(y), cin=C, cout=C), **kw)
+
+    def call(a):
+        return L.fnp_spconv_forward_tiled(a["feat"], a["dtype"], a["rows"], a["w"], a["t"], a["nbr"], a["stride"], a["n"], a["cap"], a["out"],
+                                          None, None, None, 0, a["cin"], a["cout"], _l.stream())
+    assert call(args()) == 0
+    assert call(args(cin=16, cout=16)) == -1            # channels
+    assert call(args(cin=32, cout=64)) == -1
+    assert call(args(dtype=_l.FNP_F32)) == -1           # f32 features
+    assert call(args(t=_l.ptr(t) + 4)) == -1            # misaligned tile rulebook
+    assert call(args(t=None)) == -1
+    assert call(args(stride=rb.cap_out - 1)) == -1      # table narrower than the capacity
+    assert L.fnp_tile_rulebook_bytes(rb.cap_out, 48) == 0
+    assert L.fnp_tile_rulebook_build(_l.ptr(rb.nbr), rb.nbr.shape[1], 27, _l.ptr(n_dev), rb.cap_out, 48, _l.ptr(t), _l.stream()) == -1
+    assert L.fnp_tile_rulebook_build(_l.ptr(rb.nbr), rb.nbr.shape[1], 8, _l.ptr(n_dev), rb.cap_out, 32, _l.ptr(t), _l.stream()) == -1
+    torch.cuda.synchronize()
+    # the Python layer falls back to the gather kernel for a layer the tiled kernels do not cover, whatever `tile` says
+    w16 = torch.randn((27, 16, 16), device=cuda).bfloat16()
+    x16 = torch.randn((n, 16), device=cuda).bfloat16()
+    a = S.conv_forward(x16, w16, rb, n_dev, tile=True)
+    b = S.conv_forward(x16, w16, rb, n_dev, tile=False)
+    assert torch.equal(a[:n], b[:n])
