@@ -309,6 +309,9 @@ class _PointsGraph:
         return vox, res
 
 
+_ABORTS_SEEN = 0   # last value of the library's tiled-kernel time-out counter any engine has read
+
+
 class FusedResBackbone:
     """Sync-free executor of VoxelResBackBone8x in eval mode (see module docstring)."""
 
@@ -328,16 +331,44 @@ class FusedResBackbone:
         self.profile = None
         self.profile_only = None      # optional set of (Cin, Cout, K): bracket only these layer classes
         self.rulebook_log = None
+        # hand-over time-outs of the tiled 32-channel kernel (csrc/spconv_tile.hip g_tile_aborts): the library-wide counter
+        # is copied behind every forward into a device word that travels with the per-stage counts of the one host sync
+
+    def _aborts_word(self, device):
+        """enqueue a copy of the library's time-out counter; returns the (1,) int32 device tensor it lands in"""
+        from .. import lib as _l
+        t = torch.empty((1,), dtype=torch.int32, device=device)
+        _l.check(_l.load().fnp_spconv_tiled_aborts_copy(_l.ptr(t), _l.stream()), "fnp_spconv_tiled_aborts_copy")
+        return t
+
+    def _check_aborts(self, value):
+        """raise when the counter has grown since this engine last looked: a tiled convolution ended a workgroup early and
+        left rows of its output unwritten (never seen; the protocol's time-out exists so that a bug cannot hang the GPU)"""
+        from .. import lib as _l
+        global _ABORTS_SEEN
+        seen, _ABORTS_SEEN = _ABORTS_SEEN, max(_ABORTS_SEEN, int(value))   # (the counter is the library's, not the engine's)
+        if int(value) > seen:
+            raise _l.FnpError(f"spconv_tile32_kernel: {int(value) - seen} hand-over wait(s) timed out during this forward; "
+                              "its features are incomplete")
 
     # ---- weights --------------------------------------------------------------------------
     def _fold(self, conv, bn, dtype):
+        """packed weight + BatchNorm(eval) as per-channel scale / shift.  The fold runs on the HOST in IEEE f32 —
+        inv = 1 / sqrt(var + eps), scale = gamma * inv, shift = beta - mean * scale, each operation rounded once — i.e. the
+        arithmetic of the CPU oracle's bn_fold, so that the fp32 engine equals the oracle bit for bit through the whole
+        backbone (a device rsqrt differs from 1 / sqrt in the last place); it is cached with the packed weights."""
+        import numpy as np
         w = conv.packed_weight(dtype)
-        inv = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
-        scale = (bn.weight.detach().float() * inv).contiguous()
-        shift = (bn.bias.detach().float() - bn.running_mean.detach().float() * scale)
+        dev = bn.running_var.device
+        f32 = lambda t: t.detach().float().cpu().numpy()
+        var, mean, gamma, beta = f32(bn.running_var), f32(bn.running_mean), f32(bn.weight), f32(bn.bias)
+        inv = np.float32(1.0) / np.sqrt(var + np.float32(bn.eps))     # (numpy f32: IEEE sqrt and divide, as the oracle's C)
+        scale = gamma * inv
+        shift = beta - mean * scale
         if conv.bias is not None:
-            shift = shift + conv.bias.detach().float() * scale
-        return w, scale, shift.contiguous()
+            shift = shift + f32(conv.bias) * scale
+        scale, shift = torch.from_numpy(np.ascontiguousarray(scale, np.float32)), torch.from_numpy(np.ascontiguousarray(shift, np.float32))
+        return w, scale.contiguous().to(dev), shift.contiguous().to(dev)
 
     def prepare(self):
         m = self.m
@@ -416,7 +447,8 @@ class FusedResBackbone:
             g.off.copy_(batch_offsets)
             g.graph.replay()
             stage, caps, shapes = g.res['stages'], g.res['caps'], g.res['shapes']
-            counts = torch.cat([s[2] for s in stage]).cpu().tolist()   # the one host sync
+            counts = torch.cat([s[2] for s in stage] + [g.res['aborts']]).cpu().tolist()   # the one host sync
+            self._check_aborts(counts.pop())
             overflow = False
             for l in range(1, 5):
                 if counts[l] > caps[l]:
@@ -513,8 +545,11 @@ class FusedResBackbone:
             # stages 2-4: rows are in rank-grid order on both sides of the SubM convolutions; where they run on the tile
             # rulebook (stage 2, 32 channels), the rulebook kernel writes it in the same pass
             ch = int(P[blk_key][0][0][0].shape[1])
+            srt = S.sorted_by_default(ch, ch, act, caps[li + 1])
             rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3,
-                                 tile_channels=ch if S.tiled_by_default(ch, act, caps[li + 1]) else None)
+                                 tile_channels=ch if S.tiled_by_default(ch, act, caps[li + 1]) else None, masks=srt)
+            if srt:
+                S.classsort(rb, rbs.out_n, ch)   # stage 4: the 128-channel layers sweep their rows class by class
             x = blocks(x, rb, rbs.out_n, P[blk_key], ranked=True)
             stage.append((x, rbs.out_indices, rbs.out_n, rbs.out_grid))
             x_prev, idx_prev, n_prev, g_prev = x, rbs.out_indices, rbs.out_n, rbs.out_grid
@@ -527,11 +562,13 @@ class FusedResBackbone:
         # leave every persistent grid zeroed for the next call (O(rows) sparse clear, all five grids in one launch)
         S.clear_grids([(g, idx, n_cells if (l == 0 and n_cells is not None) else n) for l, (_, idx, n, g) in enumerate(stage)])
         self._dirty = False
+        aborts = self._aborts_word(dev)
 
         shapes = self._stage_shapes()
         if not sync:
-            return {'stages': stage, 'shapes': shapes, 'caps': caps, 'batch_size': batch_size}
-        counts = torch.cat([s[2] for s in stage]).cpu().tolist()   # the one host sync
+            return {'stages': stage, 'shapes': shapes, 'caps': caps, 'batch_size': batch_size, 'aborts': aborts}
+        counts = torch.cat([s[2] for s in stage] + [aborts]).cpu().tolist()   # the one host sync
+        self._check_aborts(counts.pop())
         overflow = False
         for l in range(1, 5):
             if counts[l] > caps[l]:

@@ -120,8 +120,10 @@ __device__ __forceinline__ int rg_lookup(const RG &g, int b, int z, int y, int x
 // The K entries of a row go to a wave-private LDS strip ([k][sstride]); rulebook.hip's nbr_flush then writes the strip out 16 bytes
 // per lane, four offsets (4 x 256 contiguous bytes) per wave instruction instead of one: the 4-byte form was
 // bound by the number of store instructions, not by bytes.
+// mask_out (optional): bit k = the row has a neighbour at offset k (K <= 32).
 template <int KZ, int KY, int KX>
-__device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, int lox, int *strip, int sstride) {   // (strip: LDS shared by the lanes of a wave - no __restrict__)
+__device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, int lox, int *strip, int sstride, unsigned *mask_out = nullptr) {   // (strip: LDS shared by the lanes of a wave - no __restrict__)
+    unsigned msk = 0u;
     const int bz0 = loz >> 2, by0 = loy >> 2, bx0 = lox >> 2;   // (arithmetic shift: -1 -> block -1, outside)
     unsigned long long w[2][2][2];
     unsigned base[2][2][2];
@@ -180,9 +182,11 @@ __device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, in
                     if (g.perm) r = g.perm[r];
                 }
                 strip[((jz * KY + jy) * KX + jx) * sstride] = r;
+                if (mask_out && r >= 0) msk |= 1u << (((jz * KY + jy) * KX + jx) & 31);
             }
         }
     }
+    if (mask_out) *mask_out = msk;
 }
 
 

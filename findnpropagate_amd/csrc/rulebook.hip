@@ -223,9 +223,10 @@ __device__ __forceinline__ void nbr_flush(const int *__restrict__ strip_wave, in
     }
 }
 
-template <int KZ, int KY, int KX>
+// MASKS: also write rowmask[o] = which of the K offsets row o has a neighbour at (the class sort of the 128-channel layers)
+template <int KZ, int KY, int KX, bool MASKS = false>
 __global__ __launch_bounds__(kThreads) void subm_nbr_row_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows,
-                                                                int cap, RG g, int *__restrict__ nbr) {
+                                                                int cap, RG g, int *__restrict__ nbr, unsigned *__restrict__ rowmask = nullptr) {
     constexpr int K = KZ * KY * KX;
     __shared__ __attribute__((aligned(16))) int strips[kThreads / 64][K * 64];
     int *strip_wave = strips[threadIdx.x >> 6];
@@ -234,6 +235,11 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_kernel(const int *__res
         const int o = base + threadIdx.x;
         if (o < n) {
             const int4 c = reinterpret_cast<const int4 *>(coords)[o];
+            if constexpr (MASKS) {
+                unsigned msk;
+                nbr_row<KZ, KY, KX>(g, c.x, c.y - KZ / 2, c.z - KY / 2, c.w - KX / 2, strip_wave + fnp_lane(), 64, &msk);
+                rowmask[o] = msk;
+            } else
             nbr_row<KZ, KY, KX>(g, c.x, c.y - KZ / 2, c.z - KY / 2, c.w - KX / 2, strip_wave + fnp_lane(), 64);
         }
         nbr_flush<K>(strip_wave, base + (threadIdx.x & ~63), n, cap, nbr);
@@ -367,6 +373,18 @@ extern "C" int fnp_rulebook_subm(const int *coords, const int *n_rows, int cap, 
         hipLaunchKernelGGL(subm_nbr_kernel, blocks, dim3(kThreads), 0, (hipStream_t)stream, coords, n_rows, cap,
                            fnp_rg_view(grid), to_geom(geom), nbr);
     }
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+extern "C" int fnp_rulebook_subm_masked(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom, const fnp_rankgrid *grid,
+                                        int *nbr, unsigned *rowmask, fnp_stream_t stream) {
+    if (!coords || !n_rows || cap <= 0 || !nbr || !rowmask || !geom_ok(geom) || !fnp_rg_valid(grid)) return FNP_ERR_ARG;
+    if (!shape_is(grid, geom->in_shape)) return FNP_ERR_ARG;
+    for (int d = 0; d < 3; ++d)
+        if (geom->ksize[d] != 3 || geom->in_shape[d] != geom->out_shape[d]) return FNP_ERR_ARG;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_kernel<3, 3, 3, true>), dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, coords,
+                       n_rows, cap, fnp_rg_view(grid), nbr, rowmask);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }

@@ -20,6 +20,7 @@
 // No atomics anywhere: every output row is written once, results are run-to-run identical.
 #include "rankgrid.cuh"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -289,6 +290,56 @@ struct FusedRb {
     const int *out_coords;    // (cap, 4) [b, z, y, x] of the output rows
 };
 
+// SORTED (the 128 -> 128 SubM layers of stage 4): the rows a workgroup owns are processed in an order sorted by
+// neighbourhood class (fnp_rulebook_classsort: no neighbour below / above / both / neither in z), so that most tiles hold
+// rows of one class and the tile sweeps only the kernel offsets at least one of its rows has a neighbour at — the
+// offset's slab load, barrier, gathers and matrix work all go (20 % of the (tile, offset) pairs on lidar scenes;
+// unsorted, every tile needs every offset).  `perm` maps a processing position to its row (rulebook entries, residual
+// and output rows are addressed through it), `blockmask` holds the union of the 27-bit neighbour masks of each 16
+// positions.  Every row still sums its own neighbours in ascending offset order: same values as the unsorted sweep.
+struct SortedRb {
+    const int *perm;
+    const unsigned *blockmask;
+};
+
+// rows [row_begin, row_end) of workgroup range `range` of `G` when n rows are cut at 16-row blocks: the split of
+// spconv_mfma_kernel, shared with the class-sort pass (which must sort exactly the rows a workgroup will own)
+__device__ __forceinline__ void fnp_range_rows(int n, int range, int G, int &row_begin, int &row_end) {
+    const long long nblk16 = (n + 15) >> 4;
+    row_begin = (int)((nblk16 * range) / G) << 4;
+    row_end = min(n, (int)((nblk16 * (range + 1)) / G) << 4);
+}
+
+// SORTED work split.  Blocks b and b + 8 share an XCD (and its L2); the slots of one such group own ONE contiguous run of rows
+// [X0, X1) together and take its tiles round-robin: round j = positions [X0 + j S T, X0 + (j + 1) S T), slot s its s-th
+// tile of T rows.  At any time the S workgroups of a group sweep S consecutive tiles — one contiguous region of the
+// feature map, about the XCD's L2 in size — and the class sort orders the rows of each ROUND: of its S tiles all but the
+// two or three at the class boundaries hold rows of one class.  (Sorting the rows of a private per-workgroup range
+// instead made every tile gather from the whole range: L2 misses + 31 %, and most of the skipped offsets' time went back
+// into gather latency.)  The last, partial round is cut into S tiles of fewer blocks per wave, so that the matrix work of
+// the tail stays proportional to its rows.  Placement only affects speed, never results.
+struct XcdRows {
+    int X0, X1, S;   // rows of the group, number of slots
+};
+__device__ __forceinline__ XcdRows fnp_xcd_rows(int n, int G, int xcd) {
+    const int per = G >> 3, rem = G & 7;
+    XcdRows x;
+    x.S = per + (xcd < rem ? 1 : 0);
+    x.X0 = x.X1 = 0;
+    if (x.S > 0) {
+        const int first = xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per;
+        int t;
+        fnp_range_rows(n, first, G, x.X0, t);
+        fnp_range_rows(n, first + x.S - 1, G, t, x.X1);
+    }
+    return x;
+}
+// blocks per wave (0 = no tile) of the partial last round of `rows_left` rows cut into S tiles of NW waves
+__device__ __forceinline__ int fnp_tail_blocks(int rows_left, int S, int NW) {
+    const int nb = (rows_left + 15) >> 4;
+    return ((nb + S - 1) / S + NW - 1) / NW;
+}
+
 #ifdef FNP_MFMA_STAMP
 __device__ unsigned long long g_mfma_stamps[8];
 #define FNP_MS_NOW(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -296,15 +347,16 @@ __device__ unsigned long long g_mfma_stamps[8];
 #else
 #define FNP_MS(ph)
 #endif
-template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut, bool FUSED = false, typename TAct = __bf16>
+template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut, bool FUSED = false, typename TAct = __bf16, bool SORTED = false>
 __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const TAct *__restrict__ x, int x_bytes,
                                                              const TAct *__restrict__ w,
                                                              const int *__restrict__ nbr, int nbr_stride, int Krt,
                                                              const int *__restrict__ n_out, int cap,
                                                              TOut *__restrict__ y, const float *__restrict__ scale,
                                                              const float *__restrict__ shift,
-                                                             const TOut *__restrict__ residual, int relu, int hints, FusedRb frb) {
+                                                             const TOut *__restrict__ residual, int relu, int hints, FusedRb frb, SortedRb srb) {
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
+    static_assert(!SORTED || (KVOL == 27 && !WIN && !FUSED && !Cfg::PAIR && !Cfg::ALLK && sizeof(TOut) == 2), "sorted sweep: wide double-buffered 3x3x3 layers");
     using bf16x8 = typename Vec16<TAct>::v8;   // (named after the default activation type)
     using bf16x4 = typename Vec16<TAct>::v4;
     static_assert(sizeof(TOut) == 4 || std::is_same<TOut, TAct>::value, "16-bit outputs have the activation type");
@@ -434,9 +486,16 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int per = G >> 3, rem = G & 7;
     const int range = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;  // bijective
-    const long long nblk16 = (n + 15) >> 4;
-    const int row_begin = (int)((nblk16 * range) / G) << 4;
-    const int row_end = min(n, (int)((nblk16 * (range + 1)) / G) << 4);
+    int row_begin, row_end;
+    int xslots = 1;   // SORTED: slots of this workgroup's XCD group
+    if constexpr (SORTED) {
+        const XcdRows xr = fnp_xcd_rows(n, G, xcd);   // (row_begin .. row_end: the rows of the whole group)
+        row_begin = xr.X0;
+        row_end = xr.X1;
+        xslots = xr.S;
+    } else {
+        fnp_range_rows(n, range, G, row_begin, row_end);
+    }
     if (row_begin >= row_end) return;  // before any barrier: safe early exit
     for (int c = tid; c < 2 * COUT; c += MfmaWg<CIN, COUT>::NW * 64)   // (a barrier — weight staging or the first slab — lies before any epilogue)
         ss_lds[c] = scale ? (c < COUT ? scale[c] : shift[c - COUT]) : (c < COUT ? 1.f : 0.f);
@@ -482,6 +541,52 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     auto run_tile = [&](auto mbt_tag, const int tile_base) __attribute__((always_inline)) {
         constexpr int MBT = decltype(mbt_tag)::value;
         const int row0 = tile_base + wave * (MBT * 16);
+        // SORTED: the offsets this tile sweeps.  Every wave forms the union of the tile's block masks itself (no LDS, no
+        // barrier: the value is the same in all of them); lane l then holds the l-th live offset, read back with readlane.
+        int Kt = K;           // offsets swept by this tile
+        int kl = 0;           // SORTED: lane l: the l-th live offset (lanes >= Kt: the last one)
+        int prow[MBT];        // SORTED: row of this lane's position in block mb
+        if constexpr (SORTED) {
+            const int nbt = min(NW * MBT, (row_end - tile_base + 15) >> 4);
+            unsigned m = lane < nbt ? srb.blockmask[(tile_base >> 4) + lane] : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) m |= (unsigned)__shfl_xor((int)m, d);
+            m = (unsigned)__builtin_amdgcn_readfirstlane((int)m) & 0x7ffffffu;
+            if (m == 0u) m = 1u << 13;   // (cannot happen for a tile with rows: a row is its own neighbour at offset 13)
+            Kt = __popc(m);
+            int cnt = 0;
+#pragma unroll
+            for (int pbit = 0; pbit < 27; ++pbit) {
+                if ((m >> pbit) & 1u) {   // (uniform)
+                    if (lane >= cnt) kl = pbit;
+                    ++cnt;
+                }
+            }
+#pragma unroll
+            for (int mb = 0; mb < MBT; ++mb) prow[mb] = srb.perm[min(row0 + mb * 16 + l15, row_end - 1)];
+        }
+        // offset of sweep step i (clamped to the last step); rulebook entries of (step, block mb) for this lane's row
+        auto koff = [&](int i) -> int {
+            if constexpr (SORTED) return __builtin_amdgcn_readlane(kl, i < Kt ? i : Kt - 1);
+            else return i;
+        };
+        auto ent_raw = [&](int k, int mb) -> int {
+            if constexpr (SORTED) return nbr[(size_t)koff(k) * nbr_stride + prow[mb]];
+            else return nbr_raw(k, row0 + mb * 16 + l15, row_end);
+        };
+        auto ent_at = [&](int k, int mb) -> int {
+            if constexpr (SORTED) {
+                const int v = ent_raw(k, mb);
+                return (row0 + mb * 16 + l15 < row_end && k < Kt) ? v : -1;
+            } else return nbr_at(k, row0 + mb * 16 + l15, row_end);
+        };
+        auto live = [&](int k) -> bool {
+            if constexpr (SORTED) return k < Kt;
+            else return k_live(k);
+        };
+        auto wslab = [&](int i) -> const uint4 * {   // weight slab of sweep step i (past the end: the last step's, never used)
+            return reinterpret_cast<const uint4 *>(w + (size_t)koff(i < Kt ? i : Kt - 1) * COUT * CIN);
+        };
         if constexpr (FUSED) {
             // rulebook rows of this wave's tile: lane j resolves the 27 input cells of row row0 + j.  The strip is
             // written by lane j and read by every lane of the wave (and overwritten by the next tile): wave-level
@@ -541,13 +646,13 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
         for (int u = 0; u < PFK; ++u)
 #pragma unroll
             for (int mb = 0; mb < MBT; ++mb) {
-                const int id0 = nbr_at(u, row0 + mb * 16 + l15, row_end);
+                const int id0 = ent_at(u, mb);
                 const unsigned ro = WIN ? row_off_w(id0, wlo) : row_off(id0);
                 if (WIN) loff[u][mb] = win_off(id0, wlo);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) xb[u][ks][mb] = gather(ro, ks);
-                rawq[u][mb] = nbr_raw(PFK + u, row0 + mb * 16 + l15, row_end);
-                rawr[u][mb] = nbr_raw(2 * PFK + u, row0 + mb * 16 + l15, row_end);
+                rawq[u][mb] = ent_raw(PFK + u, mb);
+                rawr[u][mb] = ent_raw(2 * PFK + u, mb);
             }
         // L2 line touch (ranked rows): the input rows just above this tile — the next tile's own rows, first
         // reached by the upper-neighbour offsets of this one — are requested one dword per 128-byte line now,
@@ -567,8 +672,8 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
                     const int p = tid + j * NT;
-                    if (SLAB % NT == 0 || p < SLAB) wl[st_pos0 + j * NT] = reinterpret_cast<const uint4 *>(w)[p];
-                    if (WPAIR) wl[SLAB + st_pos0 + j * NT] = reinterpret_cast<const uint4 *>(w + (size_t)(K > 1 ? 1 : 0) * COUT * CIN)[p];
+                    if (SLAB % NT == 0 || p < SLAB) wl[st_pos0 + j * NT] = wslab(0)[p];
+                    if (WPAIR) wl[SLAB + st_pos0 + j * NT] = wslab(1)[p];
                 }
             }
             __syncthreads();
@@ -584,36 +689,36 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
         // (named scalars, not an array: a conditionally written array lands in scratch memory)
         uint4 wcur0 = make_uint4(0u, 0u, 0u, 0u), wcur1 = make_uint4(0u, 0u, 0u, 0u);
         if (WDEEP && !(FNP_ABLATE & 2)) {
-            const uint4 *w1 = reinterpret_cast<const uint4 *>(w + (size_t)(K > 1 ? 1 : 0) * COUT * CIN);
+            const uint4 *w1 = wslab(1);
             wcur0 = w1[tid < SLAB ? tid : 0];
             if (NCH > 1) wcur1 = w1[tid + NT];
         }
 
         uint4 wd0 = make_uint4(0u, 0u, 0u, 0u), wd1 = wd0, wd2 = wd0, wd3 = wd0;   // (named: see wcur0)
         if (WD4 && !(FNP_ABLATE & 2)) {
-            const uint4 *w1 = reinterpret_cast<const uint4 *>(w + (size_t)(WPAIR ? (K > 2 ? 2 : 0) : (K > 1 ? 1 : 0)) * COUT * CIN);
+            const uint4 *w1 = wslab(WPAIR ? 2 : 1);
             wd0 = w1[tid]; wd1 = w1[tid + NT]; wd2 = w1[tid + 2 * NT]; wd3 = w1[tid + 3 * NT];
         }
         FNP_MS(2);
-        for (int k0 = 0; k0 < K; k0 += PFK) {
+        for (int k0 = 0; k0 < Kt; k0 += PFK) {
 #pragma unroll
             for (int u = 0; u < PFK; ++u) {
                 const int k = k0 + u;
-                if (k >= K) break;  // wave-uniform
+                if (k >= Kt) break;  // wave-uniform
                 u32x4 xl_nx[WIN ? KS : 1][WIN ? MBT : 1];
                 const uint4 *wk = wl + (ALLK ? k : WPAIR ? (k & 3) : (k & 1)) * SLAB;
-                const uint4 *wsrc = reinterpret_cast<const uint4 *>(w + (size_t)(k + 1 < K ? k + 1 : k) * COUT * CIN);
+                const uint4 *wsrc = wslab(k + 1);
                 // rulebook entries for offset k + 3*PFK: requested FIRST in the round, so that they are
                 // older than this round's gathers (VMEM returns in order: a young index load in
                 // front of the next round's first MFMA would stall it)
                 int rawn[MBT];
 #pragma unroll
-                for (int mb = 0; mb < MBT; ++mb) rawn[mb] = nbr_raw(k + 3 * PFK, row0 + mb * 16 + l15, row_end);
+                for (int mb = 0; mb < MBT; ++mb) rawn[mb] = ent_raw(k + 3 * PFK, mb);
                 unsigned lnew[WIN ? MBT : 1];  // window addresses of offset k + PFK
                 if constexpr (WIN) {
 #pragma unroll
                     for (int mb = 0; mb < MBT; ++mb) {
-                        const bool ok = k_live(k + PFK) && (row0 + mb * 16 + l15 < row_end);
+                        const bool ok = live(k + PFK) && (row0 + mb * 16 + l15 < row_end);
                         lnew[mb] = win_off(ok ? rawq[u][mb] : -1, wlo);
                     }
                 }
@@ -621,7 +726,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                 uint4 wreg0 = make_uint4(0u, 0u, 0u, 0u), wreg1 = make_uint4(0u, 0u, 0u, 0u);  // (named: see wcur0)
                 uint4 wnext0 = make_uint4(0u, 0u, 0u, 0u), wnext1 = make_uint4(0u, 0u, 0u, 0u);
                 if (WDEEP && !(FNP_ABLATE & 2)) {
-                    const uint4 *w2 = reinterpret_cast<const uint4 *>(w + (size_t)(k + 2 < K ? k + 2 : k) * COUT * CIN);
+                    const uint4 *w2 = wslab(k + 2);
                     wnext0 = w2[tid < SLAB ? tid : 0];
                     if (NCH > 1) wnext1 = w2[tid + NT];
                 }
@@ -632,7 +737,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                         // chunk ks of W_{k+1} (WPAIR: of W_{k+2}, into the ring slot nobody has read since the last barrier)
                         wl[(WPAIR ? ((k + 2) & 3) : ((k + 1) & 1)) * SLAB + st_pos0 + ks * NT] = wd;
                         constexpr int AH = WPAIR ? 3 : 2;
-                        const uint4 *w2 = reinterpret_cast<const uint4 *>(w + (size_t)(k + AH < K ? k + AH : k) * COUT * CIN);
+                        const uint4 *w2 = wslab(k + AH);
                         wd = w2[tid + ks * NT];                                               // chunk ks of W_{k+2} (WPAIR: W_{k+3})
                     }
                     // (1) previous step's weight chunks -> other LDS buffer; (2) request this step's
@@ -696,7 +801,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                     //     rulebook entry was loaded two rounds ago; validity is decided here)
 #pragma unroll
                     for (int mb = 0; mb < MBT; ++mb) {
-                        const bool ok = k_live(k + PFK) && (row0 + mb * 16 + l15 < row_end);
+                        const bool ok = live(k + PFK) && (row0 + mb * 16 + l15 < row_end);
                         xb[u][ks][mb] = gather(WIN ? row_off_w(ok ? rawq[u][mb] : -1, wlo) : row_off(ok ? rawq[u][mb] : -1), ks);
                     }
                     __builtin_amdgcn_sched_barrier(0);  // keep the steps in program order
@@ -723,7 +828,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                         }
                     }
                     FNP_MS(0);
-                    if (!WPAIR || (k & 1) || k == K - 1) __syncthreads();  // plain loads stay in flight across it; only the LDS writes are waited for
+                    if (!WPAIR || (k & 1) || k == Kt - 1) __syncthreads();  // plain loads stay in flight across it; only the LDS writes are waited for
                     FNP_MS(1);
                 }
             }
@@ -737,6 +842,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
         // epilogue: lane holds out[site = row0 + mb*16 + l15][c0 .. c0+3], c0 = nb*16 + q*4
         // (window kernel: measured slower with either strip placement — 194 -> 200 / 214 us — and keeps the narrow form)
         constexpr bool WIDE = Cfg::WIDE && sizeof(TOut) == 2 && !WIN;
+        static_assert(!SORTED || WIDE, "sorted sweep: the wide epilogue addresses rows through perm");
         if constexpr (WIDE) {
             constexpr int EH = Cfg::epi_sites(WIN);   // sites per strip pass
             constexpr int LPR = COUT / 8;        // 16-byte chunks (lanes) per row
@@ -749,6 +855,19 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
             // the residual rows of ALL the wave's blocks are requested before the first one is used (one memory round trip for
             // the tile instead of one per 16-site block: the sweep's registers are free here)
             u32x4 rs_all[MBT][16 / EH][NRD];
+            // SORTED: the rows behind the positions this lane reads the residual of and stores (one dependent load per tile)
+            int orow[SORTED ? MBT : 1][SORTED ? 16 / EH : 1][SORTED ? NRD : 1];
+            if constexpr (SORTED) {
+#pragma unroll
+                for (int mb = 0; mb < MBT; ++mb)
+#pragma unroll
+                    for (int h = 0; h < 16 / EH; ++h)
+#pragma unroll
+                        for (int i = 0; i < NRD; ++i) {
+                            const int r = row0 + mb * 16 + h * EH + i * SPI + wsite;
+                            orow[mb][h][i] = srb.perm[r < row_end ? r : row_end - 1];
+                        }
+            }
             if (residual && !(FNP_ABLATE & 256)) {
 #pragma unroll
                 for (int mb = 0; mb < MBT; ++mb)
@@ -757,8 +876,10 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
 #pragma unroll
                         for (int i = 0; i < NRD; ++i) {
                             const int r = row0 + mb * 16 + h * EH + i * SPI + wsite;
+                            int ro = r;
+                            if constexpr (SORTED) ro = orow[mb][h][i];
                             rs_all[mb][h][i] = u32x4{0u, 0u, 0u, 0u};
-                            if (r < row_end) rs_all[mb][h][i] = *reinterpret_cast<const u32x4 *>(residual + (size_t)r * COUT + wchunk * 8);
+                            if (r < row_end) rs_all[mb][h][i] = *reinterpret_cast<const u32x4 *>(residual + (size_t)ro * COUT + wchunk * 8);
                         }
             }
 #pragma unroll
@@ -800,8 +921,10 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
 #pragma unroll
                     for (int i = 0; i < NRD; ++i) {
                         const int r = rb + i * SPI + wsite;
+                        int ro = r;
+                        if constexpr (SORTED) ro = orow[mb][h][i];
                         const u32x4 t = *reinterpret_cast<const u32x4 *>(eb + (i * SPI + wsite) * ES + wchunk * 16);
-                        if (r < row_end && !(FNP_ABLATE & 128)) *reinterpret_cast<u32x4 *>(y + (size_t)r * COUT + wchunk * 8) = t;
+                        if (r < row_end && !(FNP_ABLATE & 128)) *reinterpret_cast<u32x4 *>(y + (size_t)ro * COUT + wchunk * 8) = t;
                     }
                 }
             }
@@ -900,11 +1023,32 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
         FNP_MS(3);
         first_tile = false;
     };
-    const int nblk_wg = (row_end - row_begin + 15) >> 4;
-    const int full = nblk_wg / (NW * MB);
-    for (int t = 0; t < full; ++t) run_tile(std::integral_constant<int, MB>{}, row_begin + t * ROWS_PER_WG);
-    const int tper = (nblk_wg - full * NW * MB + NW - 1) / NW;  // blocks per wave in the partial tile (0 = none)
-    const int tail_base = row_begin + full * ROWS_PER_WG;
+    int full, tper, tail_base, tstride = ROWS_PER_WG, tfirst = row_begin;
+    if constexpr (SORTED) {
+        // rounds of the XCD group (see XcdRows): this slot's tile of every full round, then its share of the partial round
+        const int round_rows = xslots * ROWS_PER_WG;
+        full = (row_end - row_begin) / round_rows;
+        tstride = round_rows;
+        tfirst = row_begin + slot * ROWS_PER_WG;
+        const int left0 = row_begin + full * round_rows;
+        tper = fnp_tail_blocks(row_end - left0, xslots, NW);
+        tail_base = left0 + slot * (NW * tper * 16);
+        if (tail_base >= row_end) tper = 0;
+    } else {
+        const int nblk_wg = (row_end - row_begin + 15) >> 4;
+        full = nblk_wg / (NW * MB);
+        tper = (nblk_wg - full * NW * MB + NW - 1) / NW;  // blocks per wave in the partial tile (0 = none)
+        tail_base = row_begin + full * ROWS_PER_WG;
+    }
+    if constexpr (SORTED) {
+        // the tiles of a round are sorted by class, and a class has its own number of live offsets: slot s takes tile
+        // (s + j ROT) mod S of round j, so that every workgroup meets every class in turn (with tile s in every round the
+        // slots of the middle class sweep all 27 offsets in every round and set the launch's length)
+        const int rot = (xslots * 3 + 4) >> 3;
+        for (int t = 0; t < full; ++t) run_tile(std::integral_constant<int, MB>{}, row_begin + t * tstride + ((slot + t * rot) % xslots) * ROWS_PER_WG);
+    } else {
+        for (int t = 0; t < full; ++t) run_tile(std::integral_constant<int, MB>{}, tfirst + t * tstride);
+    }
     if (tper == MB) run_tile(std::integral_constant<int, MB>{}, tail_base);
     if constexpr (MB > 1) { if (tper == 1) run_tile(std::integral_constant<int, 1>{}, tail_base); }
     if constexpr (MB > 2) { if (tper == 2) run_tile(std::integral_constant<int, 2>{}, tail_base); }
@@ -915,10 +1059,12 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
 #endif
 }
 
-template <int CIN, int COUT, int KVOL, bool WIN, typename TOut, bool FUSED = false, typename TAct = __bf16>
+// grid_only: write the workgroup count the launch would use for this capacity and return without launching (the class-sort
+// pass sorts the rows of exactly those ranges)
+template <int CIN, int COUT, int KVOL, bool WIN, typename TOut, bool FUSED = false, typename TAct = __bf16, bool SORTED = false>
 int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
                   void *y, const float *scale, const float *shift, const void *residual, int relu, int hints, hipStream_t s,
-                  const FusedRb *frb_in = nullptr) {
+                  const FusedRb *frb_in = nullptr, const SortedRb *srb_in = nullptr, int *grid_only = nullptr) {
     // 16-site blocks per wave: 4 (64 sites); 3 for 128 output channels (accumulators = COUT/16 * MB * 4
     // registers; 4 spills heavily, 3 spills ~16 registers outside the offset loop and measured 13 %
     // faster than 2 on MI355X: fewer weight-slab sweeps per site); 2 for the 16 -> 16 layers
@@ -934,7 +1080,7 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
 #endif
     constexpr int MB = COUT >= 128 ? FNP_MB128 : (CIN == 16 && COUT <= 32) ? 2 : (CIN == 32 && COUT == 32) ? FNP_MB3232 : (CIN == 64 && COUT == 64) ? FNP_MB6464 : 4;
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
-    auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut, FUSED, TAct>;
+    auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut, FUSED, TAct, SORTED>;
     constexpr int lds = Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN) + Cfg::epi_bytes(MfmaWg<CIN, COUT>::NW, WIN, sizeof(TOut) == 2) +
                         (FUSED ? MfmaWg<CIN, COUT>::NW * 27 * MB * 16 * 4 : 0) + COUT * 8;   // (+ BatchNorm scale / shift)
     FusedRb frb{};
@@ -942,11 +1088,16 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
         if (!frb_in) return FNP_ERR_ARG;
         frb = *frb_in;
     }
+    SortedRb srb{nullptr, nullptr};
+    if (SORTED && !grid_only) {
+        if (!srb_in || !srb_in->perm || !srb_in->blockmask) return FNP_ERR_ARG;
+        srb = *srb_in;
+    }
     // workgroups a CU holds: by the register budget (launch bounds), and for the fused-rulebook form by its larger LDS
     constexpr int wg_regs = MfmaOcc<CIN, COUT>::WAVES * 4 / MfmaWg<CIN, COUT>::NW;
     constexpr int wg_per_cu = FUSED && lds * wg_regs > 160 * 1024 ? 160 * 1024 / lds : wg_regs;
     static_assert(wg_per_cu >= 1 && lds * wg_per_cu <= 160 * 1024, "LDS budget of the resident workgroups");
-    if (lds > 64 * 1024) {
+    if (lds > 64 * 1024 && !grid_only) {
         static bool raised = false;  // (idempotent; a race only repeats the call)
         if (!raised) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -968,8 +1119,12 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
 #else
     const int grid = tiles >= resident ? resident : (fine < resident ? fine : resident);
 #endif
+    if (grid_only) {
+        *grid_only = grid;
+        return FNP_OK;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MfmaWg<CIN, COUT>::NW * 64), lds, s, (const TAct *)x, x_bytes, (const TAct *)w,
-                       nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu, hints, frb);
+                       nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu, hints, frb, srb);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
@@ -1014,6 +1169,92 @@ int launch_valu(const void *x, const void *w, const int *nbr, int nbr_stride, in
                        relu, Cin, Cout);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Class sort (see SortedRb).  One workgroup per range of the convolution's grid: pass 1 forms the 27-bit neighbour mask of
+// every row of the range from the table (kept in `rowmask`) and counts the four z classes — no neighbour in either
+// adjacent plane, above only (offsets 18..26), both, below only (offsets 0..8): in that order a tile of one class, or of
+// two adjacent ones, still drops a whole plane of offsets; pass 2 gives every row its position — class by class, rows of
+// a class in their original (rank) order, so the gathers keep their locality — writes perm[position] = row and ORs the
+// row's mask into blockmask[position / 16].  Deterministic: positions depend on the masks only.
+// ------------------------------------------------------------------------------------------
+constexpr int kSortThreads = 1024, kSortQ = 16;   // a thread places at most kSortQ consecutive rows of a round
+__device__ __forceinline__ int fnp_zclass(unsigned m) {
+    const bool lo = (m & 0x1ffu) != 0u, hi = (m & (0x1ffu << 18)) != 0u;
+    return lo ? (hi ? 2 : 3) : (hi ? 1 : 0);
+}
+// per-row masks from the table (for a rulebook that was built without them)
+__global__ __launch_bounds__(256) void rowmask_kernel(const int *__restrict__ nbr, int nbr_stride, const int *__restrict__ n_out, int cap,
+                                                      unsigned *__restrict__ rowmask) {
+    const int n = min(*n_out, cap);
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+        unsigned m = 0u;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) m |= (nbr[(size_t)k * nbr_stride + r] >= 0 ? 1u : 0u) << k;
+        rowmask[r] = m;
+    }
+}
+// grid (rounds, 8 XCD groups): one workgroup per round; thread t owns rows [t q, (t + 1) q) of the round (q <= kSortQ), counts
+// their classes, a workgroup-wide exclusive scan of the four counts (packed 4 x 16 bits: a round has < 65,536 rows) gives
+// each thread its first position per class, and it places its rows in order.  Stable: rows of a class keep their order.
+__global__ __launch_bounds__(kSortThreads) void classsort_place_kernel(const unsigned *__restrict__ rowmask, const int *__restrict__ n_out, int cap,
+                                                                        int G, int tile_rows, int NW, int *__restrict__ perm,
+                                                                        unsigned *__restrict__ blockmask) {
+    constexpr int NWV = kSortThreads / 64;
+    __shared__ unsigned long long wtot[NWV];
+    const int n = min(*n_out, cap), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const XcdRows xr = fnp_xcd_rows(n, G, blockIdx.y);
+    if (xr.S == 0 || xr.X0 >= xr.X1) return;   // (whole workgroup)
+    const int round_rows = xr.S * tile_rows, full = (xr.X1 - xr.X0) / round_rows;
+    for (int i = blockIdx.x; i <= full; i += gridDim.x) {   // (whole workgroups stay in the loop)
+        const int b = xr.X0 + i * round_rows, e = min(xr.X1, b + round_rows);
+        if (b >= e) break;
+        const int q = (e - b + kSortThreads - 1) / kSortThreads, r0 = b + tid * q;
+        for (int j = (b >> 4) + tid; j < ((e + 15) >> 4); j += kSortThreads) blockmask[j] = 0u;
+        unsigned m[kSortQ];
+        unsigned long long cnt = 0ull;
+#pragma unroll
+        for (int u = 0; u < kSortQ; ++u) {
+            m[u] = 0u;
+            if (u < q && r0 + u < e) {
+                m[u] = rowmask[r0 + u];
+                cnt += 1ull << (16 * fnp_zclass(m[u]));
+            }
+        }
+        unsigned long long v = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = __shfl_up(v, d);
+            if (lane >= d) v += t;
+        }
+        if (lane == 63) wtot[wave] = v;
+        __syncthreads();   // (also orders the zeroing of blockmask before the atomics below)
+        unsigned long long woff = 0ull, grand = 0ull;
+#pragma unroll
+        for (int wv = 0; wv < NWV; ++wv) {
+            const unsigned long long t = wtot[wv];
+            if (wv < wave) woff += t;
+            grand += t;
+        }
+        const unsigned long long excl = v - cnt + woff;
+        int run[4];
+        const int t0 = (int)(grand & 0xffffu), t1 = (int)((grand >> 16) & 0xffffu), t2 = (int)((grand >> 32) & 0xffffu);
+        run[0] = (int)(excl & 0xffffu);
+        run[1] = t0 + (int)((excl >> 16) & 0xffffu);
+        run[2] = t0 + t1 + (int)((excl >> 32) & 0xffffu);
+        run[3] = t0 + t1 + t2 + (int)((excl >> 48) & 0xffffu);
+#pragma unroll
+        for (int u = 0; u < kSortQ; ++u) {
+            if (u < q && r0 + u < e) {
+                const int c = fnp_zclass(m[u]);
+                const int pos = b + (c == 0 ? run[0]++ : c == 1 ? run[1]++ : c == 2 ? run[2]++ : run[3]++);
+                perm[pos] = r0 + u;
+                atomicOr(&blockmask[pos >> 4], m[u]);
+            }
+        }
+        __syncthreads();   // (wtot is rewritten by the next round of this workgroup)
+    }
 }
 
 template <typename TAct, typename TOut>
@@ -1158,3 +1399,59 @@ extern "C" int fnp_spconv_forward_strided(const void *feat_in, int in_dtype, int
     return FNP_ERR_ARG;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Class-sorted sweep of the 128 -> 128 SubM layers (SortedRb).  fnp_rulebook_classsort restates the processing order of a
+// 3x3x3 rulebook once per forward (its four convolutions share it); fnp_spconv_forward_sorted is fnp_spconv_forward for
+// (Cin, Cout) = (128, 128), 16-bit features in and out, on that order.  Same values as fnp_spconv_forward.
+// ------------------------------------------------------------------------------------------
+extern "C" long long fnp_classsort_workspace_bytes(int cap_out) {
+    if (cap_out <= 0) return 0;
+    return (long long)cap_out * 4;   // the row masks, when the caller has none
+}
+
+extern "C" int fnp_rulebook_classsort(const int *nbr, int nbr_stride, int K, const unsigned *rowmask, const int *n_out, int cap_out, int Cin,
+                                      int Cout, int *perm, unsigned *blockmask, void *workspace, long long workspace_bytes,
+                                      fnp_stream_t stream) {
+    if (!n_out || !perm || !blockmask || K != 27 || cap_out <= 0) return FNP_ERR_ARG;
+    if (Cin != 128 || Cout != 128) return FNP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (!rowmask) {
+        if (!nbr || nbr_stride < cap_out || !workspace) return FNP_ERR_ARG;
+        if (workspace_bytes < fnp_classsort_workspace_bytes(cap_out)) return FNP_ERR_WORKSPACE;
+        hipLaunchKernelGGL(rowmask_kernel, dim3(fnp_grid_for(cap_out, 256)), dim3(256), 0, s, nbr, nbr_stride, n_out, cap_out, (unsigned *)workspace);
+        FNP_LAUNCH_CHECK();
+        rowmask = (const unsigned *)workspace;
+    }
+    int grid = 0;
+    const int rc = launch_mfma_k<128, 128, 27, false, __bf16, false, __bf16, true>(nullptr, 0, nullptr, nullptr, cap_out, 27, n_out, cap_out, nullptr, nullptr,
+                                                                                    nullptr, nullptr, 0, 0, s, nullptr, nullptr, &grid);
+    if (rc != FNP_OK) return rc;
+    constexpr int NW = MfmaWg<128, 128>::NW, TILE = NW * FNP_MB128 * 16;
+    const int slots = (grid >> 3) + ((grid & 7) ? 1 : 0);
+    if ((long long)slots * TILE > (long long)kSortThreads * kSortQ) return FNP_ERR_ARG;   // (a round is placed by one workgroup)
+    const int rounds = fnp_divup(fnp_divup(cap_out, 8) + 16 * (slots + 1), (long long)((grid >> 3) > 0 ? (grid >> 3) : 1) * TILE) + 1;
+    hipLaunchKernelGGL(classsort_place_kernel, dim3(rounds < 1024 ? rounds : 1024, 8), dim3(kSortThreads), 0, s, rowmask, n_out, cap_out, grid, TILE, NW, perm,
+                       blockmask);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+extern "C" int fnp_spconv_forward_sorted(const void *feat_in, int dtype, int n_in_rows, const void *weight, const int *nbr, int nbr_stride,
+                                         const int *perm, const unsigned *blockmask, const int *n_out, int cap_out, void *feat_out,
+                                         const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
+                                         fnp_stream_t stream) {
+    if (!feat_in || !weight || !nbr || !perm || !blockmask || !n_out || !feat_out || cap_out <= 0 || nbr_stride < cap_out || n_in_rows <= 0)
+        return FNP_ERR_ARG;
+    if ((scale == nullptr) != (shift == nullptr) || Cin != 128 || Cout != 128) return FNP_ERR_ARG;
+    const long long xb = (long long)n_in_rows * Cin * 2;
+    if (xb >= 0x7fffffffll) return FNP_ERR_ARG;
+    const SortedRb srb{perm, blockmask};
+    if (dtype == FNP_BF16)
+        return launch_mfma_k<128, 128, 27, false, __bf16, false, __bf16, true>(feat_in, (int)xb, weight, nbr, nbr_stride, 27, n_out, cap_out, feat_out, scale,
+                                                                                shift, residual, relu, 0, (hipStream_t)stream, nullptr, &srb);
+    if (dtype == FNP_F16)
+        return launch_mfma_k<128, 128, 27, false, _Float16, false, _Float16, true>(feat_in, (int)xb, weight, nbr, nbr_stride, 27, n_out, cap_out, feat_out,
+                                                                                    scale, shift, residual, relu, 0, (hipStream_t)stream, nullptr, &srb);
+    return FNP_ERR_ARG;
+}

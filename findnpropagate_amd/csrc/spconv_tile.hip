@@ -160,6 +160,7 @@ __device__ unsigned long long g_tile_stamps[4][8];   // [role][phase] sums, [2 +
 
 // ------------------------------------------------------------------------------------------ convolution
 __device__ unsigned g_tile_aborts;   // hand-over waits that timed out, since the library was loaded (never, unless the protocol is broken)
+__device__ int g_tile_hold;          // test hook (fnp_debug_tile_hold): producers never publish an image, so every consumer wait times out
 
 // Geometry: 8 consumer waves x 32 rows.  Consumer wave w owns tile rows [32 w, 32 w + 32); its MFMA column l15 of block mb
 // is row 32 w + 2 l15 + mb, so the two entries of a lane sit in one 32-bit word of the natural [offset][row] table.
@@ -189,8 +190,9 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
     // counts WAVES that completed an event and only grows; i = tile number inside the workgroup's run, image i & 1:
     //   READY[i & 1]  producer waves that finished writing the image     consumers of tile i wait for 8 (i / 2 + 1)
     //   FREED[i & 1]  consumer waves that finished reading the image     producers of tile i wait for 8 (i / 2)
-    // A wait that outlasts kSpinLimit polls (~0.3 s; a hand-over takes microseconds) raises ABORT, which ends every wave of
-    // the workgroup — wrong output instead of a hung GPU — and counts in g_tile_aborts (fnp_spconv_tiled_aborts()).
+    // A wait that outlasts kSpinLimit polls (tens of milliseconds; a hand-over takes microseconds) raises ABORT, which ends
+    // every wave of the workgroup — wrong output instead of a hung GPU — and counts in g_tile_aborts, which the host layer
+    // reads with its per-forward counts (fnp_spconv_tiled_aborts_copy) and turns into an error.
     int *const cnt = esc_flags + 16;
     enum { READY = 0, FREED = 2, ABORT = 8 };
     constexpr int kSpinLimit = 1 << 20;
@@ -292,6 +294,7 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
         req_far_ids(t_begin);
         req_tile(t_begin);
         req_far_ids(t_begin + 1);
+        const bool hold = __atomic_load_n(&g_tile_hold, __ATOMIC_RELAXED) != 0;
         __syncthreads();   // weights, zero rows, counters
         FNP_STAMP_DECL;
         for (int i = -1; i + 1 < nt; ++i) {
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
             if (!wait_for(FREED + p, 8 * ((i + 1) / 2))) break;
             FNP_STAMP(5);
             if (!(FNP_TILE_ABLATE & 4) || i < 1) put_tile(img0 + p * kImgBytes, p);
-            signal(READY + p);
+            if (!hold) signal(READY + p);
             FNP_STAMP(0);
             if (!(FNP_TILE_ABLATE & 4)) {
                 req_tile(t + 2);
@@ -825,6 +828,18 @@ extern "C" int fnp_spconv_tiled_aborts(void) {
     unsigned v = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_tile_aborts), sizeof(v)) != hipSuccess) return FNP_ERR_HIP;
     return (int)v;
+}
+
+extern "C" int fnp_spconv_tiled_aborts_copy(int *dst, fnp_stream_t stream) {
+    if (!dst) return FNP_ERR_ARG;
+    if (hipMemcpyFromSymbolAsync(dst, HIP_SYMBOL(g_tile_aborts), sizeof(unsigned), 0, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FNP_ERR_HIP;
+    return FNP_OK;
+}
+
+extern "C" int fnp_debug_tile_hold(int on) {
+    const int v = on ? 1 : 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_hold), &v, sizeof(v)) != hipSuccess) return FNP_ERR_HIP;
+    return FNP_OK;
 }
 
 extern "C" long long fnp_tile_rulebook_bytes(int cap_out, int channels) {

@@ -117,10 +117,16 @@ SIGNATURES = {
     "fnp_spconv_forward_strided": (c_int, [P, c_int, c_int, P, POINTER(RankGridC), POINTER(ConvGeom), P, P, c_int, P, c_int,
                                            P, P, c_int, c_int, c_int, P]),
     "fnp_spconv_tiled_aborts": (c_int, []),
+    "fnp_spconv_tiled_aborts_copy": (c_int, [P, P]),
+    "fnp_debug_tile_hold": (c_int, [c_int]),
     "fnp_tile_rulebook_bytes": (c_int64, [c_int, c_int]),
     "fnp_tile_rulebook_build": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P]),
     "fnp_rulebook_subm_tiled": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, P]),
     "fnp_spconv_forward_tiled": (c_int, [P, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
+    "fnp_classsort_workspace_bytes": (c_int64, [c_int]),
+    "fnp_rulebook_subm_masked": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, P, P]),
+    "fnp_rulebook_classsort": (c_int, [P, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P, c_int64, P]),
+    "fnp_spconv_forward_sorted": (c_int, [P, c_int, c_int, P, P, c_int, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     "fnp_boxseeker_workspace_bytes": (c_int64, [c_int, c_int]),
     "fnp_host_enumerate_frustums": (c_int, [P, P, P, P, P, c_int, c_int, POINTER(c_int), c_int, c_float, c_float, P, c_int]),
     "fnp_boxseeker": (c_int, [P, P, c_int, c_int, POINTER(SeekerParams), P, P, P, c_int, P, P, P, P, c_int64,

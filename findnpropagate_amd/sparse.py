@@ -192,9 +192,10 @@ def clear_grids(jobs):
 
 
 # --------------------------------------------------------------------------------- rulebooks
-def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None):
+def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None, masks=False):
     """tile_channels (32 or 64, 3x3x3 only): also write the tile rulebook the `tile_channels`-channel layers of this rulebook
-    run on (conv_forward's tiled path finds it with the rulebook), in the same pass."""
+    run on (conv_forward's tiled path finds it with the rulebook), in the same pass.
+    masks (3x3x3 only): also write the per-row neighbour masks (`rb._rowmask`) the class sort of the 128-channel layers starts from."""
     L = _l.load()
     cap = max(indices.shape[0], 1)
     geom, _ = make_geom(ksize, 1, [k // 2 for k in _triple(ksize)], grid.shape, grid.shape)
@@ -206,6 +207,13 @@ def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None):
         _l.check(rc, "fnp_rulebook_subm_tiled")
         rb = Rulebook(nbr=nbr, K=K, cap_out=cap, geom=geom)
         rb._tile_rb = {tile_channels: t}
+        return rb
+    if masks and K == 27:
+        rowmask = torch.empty((cap,), dtype=torch.int32, device=indices.device)
+        rc = L.fnp_rulebook_subm_masked(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), _l.ptr(rowmask), _l.stream())
+        _l.check(rc, "fnp_rulebook_subm_masked")
+        rb = Rulebook(nbr=nbr, K=K, cap_out=cap, geom=geom)
+        rb._rowmask = rowmask
         return rb
     rc = L.fnp_rulebook_subm(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), _l.stream())
     _l.check(rc, "fnp_rulebook_subm")
@@ -289,9 +297,51 @@ def tile_rulebook(rb, n_out_dev, channels):
 
 
 TILED_CHANNELS = (32, 64)   # channel counts fnp_spconv_forward_tiled covers
+
+
+def tiled_fits(n_in_rows, channels, nbr_stride, cap_out):
+    """fnp_spconv_forward_tiled's documented size limit (fnp.h): the feature tensor, the int32 table and the tile rulebook are
+    addressed with 32-bit byte offsets."""
+    rb_bytes = int(_l.load().fnp_tile_rulebook_bytes(cap_out, channels))
+    return n_in_rows * channels * 2 < 0x7fffffff and 27 * nbr_stride * 4 < 0x7fffffff and rb_bytes < 0x7fffffff
+
 # ... and the ones that take it by themselves (measured at 64 scenes, per layer: 32 channels 0.305 -> 0.18 ms; 64 channels
 # 0.43 -> 0.385 ms, +1 % end to end)
 TILED_AUTO = (32, 64)
+
+
+SORTED_SHAPES = {(128, 128)}   # (Cin, Cout) fnp_spconv_forward_sorted covers
+# the class-sorted sweep pays from a few scenes on (one more small kernel per forward against ~20 % of four sweeps); 0 / 1 force it
+SORT_MODE = {"0": False, "1": True}.get(os.environ.get("FNP_SORT", ""))
+SORT_MIN_ROWS = 65536
+
+
+def sorted_by_default(cin, cout, dtype, cap):
+    if (cin, cout) not in SORTED_SHAPES or dtype not in (torch.bfloat16, torch.float16):
+        return False
+    return bool(SORT_MODE) if SORT_MODE is not None else cap >= SORT_MIN_ROWS
+
+
+def classsort(rb, n_out_dev, channels=128):
+    """Processing order of a 3x3x3 SubM rulebook for the class-sorted 128-channel sweep (fnp_rulebook_classsort): kept with
+    the rulebook (`rb._sorted` = (perm, blockmask)), valid as long as rb.nbr and the row count are.  Starts from the row masks
+    the rulebook kernel wrote (rulebook_subm(masks=True)) or derives them from the table.  No host sync."""
+    L = _l.load()
+    assert rb.K == 27
+    dev = rb.nbr.device
+    perm = torch.empty((rb.cap_out,), dtype=torch.int32, device=dev)
+    blockmask = torch.empty((rb.cap_out // 16 + 1,), dtype=torch.int32, device=dev)
+    rowmask = getattr(rb, "_rowmask", None)
+    ws = None
+    if rowmask is None:
+        ws = torch.empty((int(L.fnp_classsort_workspace_bytes(rb.cap_out)),), dtype=torch.uint8, device=dev)
+    rc = L.fnp_rulebook_classsort(_l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, _l.ptr(rowmask), _l.ptr(n_out_dev), rb.cap_out, channels, channels,
+                                  _l.ptr(perm), _l.ptr(blockmask), _l.ptr(ws), 0 if ws is None else ws.numel(), _l.stream())
+    _l.check(rc, "fnp_rulebook_classsort")
+    rb._sorted = (perm, blockmask)
+    if rowmask is None:
+        rb._rowmask = ws.view(torch.int32)
+    return rb
 
 
 def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, shift=None, residual=None, relu=False,
@@ -317,13 +367,27 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
     if scale is not None:
         assert scale.dtype == torch.float32 and shift.dtype == torch.float32
     if (K == 27 and Cin == Cout and Cin in TILED_CHANNELS and feat_in.dtype in (torch.bfloat16, torch.float16) and out.dtype == feat_in.dtype
-            and (tile or (tile is None and ranked and tiled_by_default(Cin, feat_in.dtype, cap_out)))):
+            and (tile or (tile is None and ranked and tiled_by_default(Cin, feat_in.dtype, cap_out)))
+            and tiled_fits(feat_in.shape[0], Cin, rb.nbr.shape[1], cap_out)):
+        # (a tensor beyond the tiled kernels' 32-bit offsets takes the gather kernel below: decided HERE from the documented
+        #  condition, so that any error code of the call is an error and not a silent change of kernel)
         rc = L.fnp_spconv_forward_tiled(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
                                         _l.ptr(tile_rulebook(rb, n_out_dev, Cin)), _l.ptr(rb.nbr), rb.nbr.shape[1], _l.ptr(n_out_dev), cap_out,
                                         _l.ptr(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual), int(bool(relu)), Cin, Cout, _l.stream())
-        if rc != -1:   # (FNP_ERR_ARG: a tensor beyond the tiled kernels' 32-bit offsets — the gather kernel below takes it)
-            _l.check(rc, "fnp_spconv_forward_tiled")
-            return out
+        _l.check(rc, "fnp_spconv_forward_tiled")
+        return out
+    srt = getattr(rb, "_sorted", None)
+    if (srt is not None and K == 27 and (Cin, Cout) in SORTED_SHAPES and feat_in.dtype in (torch.bfloat16, torch.float16)
+            and out.dtype == feat_in.dtype and feat_in.shape[0] * Cin * 2 < 0x7fffffff):
+        rc = L.fnp_spconv_forward_sorted(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed), _l.ptr(rb.nbr),
+                                         rb.nbr.shape[1], _l.ptr(srt[0]), _l.ptr(srt[1]), _l.ptr(n_out_dev), cap_out, _l.ptr(out),
+                                         _l.ptr(scale), _l.ptr(shift), _l.ptr(residual), int(bool(relu)), Cin, Cout, _l.stream())
+        _l.check(rc, "fnp_spconv_forward_sorted")
+        return out
+    if isinstance(w_packed, PermutedWeight) and feat_in.shape[0] * Cin * 4 >= 0x7fffffff:
+        # the f32 MFMA kernel addresses the features with 32-bit offsets; beyond them the thread-per-element chain runs,
+        # and it reads the plain (K, Cout, Cin) layout: undo the 4 x 4 transposition of the 16-channel groups
+        w_packed = w_packed.as_subclass(torch.Tensor).view(K, Cout, Cin // 16, 4, 4).transpose(3, 4).contiguous().view(K, Cout, Cin)
     rc = L.fnp_spconv_forward(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
                               _l.ptr(rb.nbr), rb.nbr.shape[1], K, _l.ptr(n_out_dev), cap_out,
                               _l.ptr(out), _l.dtype_code(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual),

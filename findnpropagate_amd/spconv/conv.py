@@ -48,9 +48,11 @@ class SparseConvFunction(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             wp = ctx.w_packed
-            if rb.out_indices is None and rb.cap_out == feats.shape[0]:
+            odd = all(int(v) & 1 for v in rb.geom.ksize)
+            if rb.out_indices is None and rb.cap_out == feats.shape[0] and odd:
                 # SubM: the rulebook is its own transpose up to the mirror of the offsets (input i feeds output o through
-                # offset k  <=>  o is the neighbour of i at offset K-1-k): same table, weight slabs in mirrored order
+                # offset k  <=>  o is the neighbour of i at offset K-1-k): same table, weight slabs in mirrored order.
+                # That identity needs a centred kernel (every size odd); an even size takes the transposed table below.
                 if ctx.ranked and Cin == Cout and S.tiled_by_default(Cin, feats.dtype, rb.cap_out):
                     # ... and on the tile rulebook where the forward ran on it: the forward kernel on (K, Cin, Cout) slabs
                     dx = S.conv_forward(grad_out, wp.flip(0).transpose(1, 2).contiguous(), rb, n_in_dev, ranked=True)

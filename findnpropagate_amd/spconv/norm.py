@@ -29,6 +29,10 @@ class _BNActFunction(torch.autograd.Function):
                                     _l.ptr(running_mean), _l.ptr(running_var), float(momentum), float(eps), _l.ptr(residual),
                                     int(bool(relu)), _l.ptr(y), _l.ptr(mean), _l.ptr(invstd), _l.ptr(ws), ws.numel(), _l.stream())
         _l.check(rc, "fnp_bn_train_forward")
+        # the kernel wrote the running statistics through raw pointers: tell torch (FusedResBackbone.prepare() keys its
+        # folded BatchNorm constants on the buffers' versions)
+        torch.autograd.graph.increment_version(running_mean)
+        torch.autograd.graph.increment_version(running_var)
         ctx.save_for_backward(x, y, g32, mean, invstd, n_dev)
         ctx.relu, ctx.has_res, ctx.param_dtype = bool(relu), residual is not None, gamma.dtype
         return y

@@ -280,9 +280,14 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
 #define FNP_TILE64_ROWS 128          /* 64 channels */
 #define FNP_TILE64_RECORD_BYTES 7440
 /* Diagnostic: the 32-channel kernel hands tile images between its producer and consumer waves through counters in LDS; a
- * wait that times out (~0.3 s; never, unless that protocol is broken) ends the workgroup with wrong output and counts
- * here.  Synchronises the device; >= 0, or a negative error code. */
+ * wait that times out (2^20 polls, tens of milliseconds; never, unless that protocol is broken) ends the workgroup with
+ * wrong output and counts here.  fnp_spconv_tiled_aborts synchronises the device (>= 0, or a negative error code);
+ * fnp_spconv_tiled_aborts_copy enqueues a device-to-device copy of the counter (one int32) on `stream`, for a caller that
+ * reads it with its other per-forward counts (the host layer raises when it has grown); fnp_debug_tile_hold(1) is the
+ * test hook that makes every hand-over time out (producers stop publishing), fnp_debug_tile_hold(0) restores them. */
 int fnp_spconv_tiled_aborts(void);
+int fnp_spconv_tiled_aborts_copy(int *dst, fnp_stream_t stream);
+int fnp_debug_tile_hold(int on);
 long long fnp_tile_rulebook_bytes(int cap_out, int channels);
 int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int channels,
                             void *tile_rb, fnp_stream_t stream);
@@ -295,6 +300,34 @@ int fnp_spconv_forward_tiled(const void *feat_in, int dtype, int n_in_rows, cons
                              const int *n_out, int cap_out, void *feat_out,
                              const float *scale, const float *shift, const void *residual, int relu,
                              int Cin, int Cout, fnp_stream_t stream);
+
+/* CLASS-SORTED sweep of the 128 -> 128 SubM layers (the four 3x3x3 convolutions of stage 4, spconv_backbone.py:219-224).
+ * After three stride-2 layers a lidar surface is two cells thick: ~36 % of the stage-4 sites have neighbours only in the
+ * plane above, ~36 % only in the plane below.  fnp_rulebook_classsort orders the rows each persistent workgroup of the
+ * convolution sweeps concurrently by that class (once per forward; the four convolutions share it): perm[position] = row, and
+ * blockmask[position / 16] = union of the 27-bit neighbour masks of 16 consecutive positions.  fnp_spconv_forward_sorted
+ * then sweeps, per tile, only the kernel offsets some row of the tile has a neighbour at (on lidar scenes 20 % of the
+ * (tile, offset) pairs go, with their slab loads, barriers, gathers and matrix work); every row still sums its own
+ * neighbours in ascending offset order, so the values equal fnp_spconv_forward's.
+ * The convolution's workgroups that share an XCD (blocks b, b + 8, ...) own one contiguous run of rows together and take
+ * its tiles round-robin; the sort orders the rows of each ROUND of tiles, so that the tiles in flight on an XCD cover one
+ * contiguous region of the feature map (its L2) and all but the two or three tiles at the class boundaries are of one class.
+ *   rowmask    (cap_out) uint32, bit k = row has a neighbour at offset k: written by fnp_rulebook_subm_masked (the SubM
+ *              rulebook kernel with that one extra store per row); NULL: classsort derives it from nbr into `workspace`
+ *              (fnp_classsort_workspace_bytes(cap_out) bytes)
+ *   perm       (cap_out) int32, blockmask (cap_out / 16 + 1) uint32: written by classsort, read by the convolution; valid
+ *              for the (nbr, n_out, cap_out) they were built from
+ * K must be 27, (Cin, Cout) = (128, 128), dtype FNP_BF16 or FNP_F16 for features, weights, residual and output alike;
+ * FNP_ERR_ARG otherwise. */
+long long fnp_classsort_workspace_bytes(int cap_out);
+int fnp_rulebook_subm_masked(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom,
+                             const fnp_rankgrid *grid, int *nbr, unsigned *rowmask, fnp_stream_t stream);
+int fnp_rulebook_classsort(const int *nbr, int nbr_stride, int K, const unsigned *rowmask, const int *n_out, int cap_out, int Cin, int Cout,
+                           int *perm, unsigned *blockmask, void *workspace, long long workspace_bytes, fnp_stream_t stream);
+int fnp_spconv_forward_sorted(const void *feat_in, int dtype, int n_in_rows, const void *weight, const int *nbr, int nbr_stride,
+                              const int *perm, const unsigned *blockmask, const int *n_out, int cap_out, void *feat_out,
+                              const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
+                              fnp_stream_t stream);
 
 /* The same convolution for a STRIDED 3x3x3 layer whose rulebook has no other user (the three down-sampling
  * layers of VoxelResBackBone8x, spconv_backbone.py:207,214,221): the kernel computes the rulebook rows of its

@@ -241,6 +241,49 @@ def test_fused_backbone_f32_within_1e4(cuda, oracle, rng):
     _check_stage(out2["encoded_spconv_tensor"], want["out"], 1e-4, 1e-4)
 
 
+def test_fused_backbone_f32_is_the_oracle_bit_for_bit(cuda, oracle, rng):
+    """The fp32 engine (BASELINE.json's 1e-4 mode) is not merely within 1e-4 of the CPU oracle: every convolution is the
+    oracle's k-ascending fmaf chain on v_mfma_f32_16x16x4_f32, the BatchNorm fold runs in the oracle's IEEE arithmetic on
+    the host, the epilogue is one multiply, one add (+ residual add) and a compare — so all five stage outputs are EQUAL."""
+    net = _small_net(cuda, "fp32")
+    shape = net.sparse_shape
+    feats, idx = _random_sparse(rng, 2, shape, 6000, 5)
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    want = oracle.backbone_forward(sd, feats, idx, 2, shape)
+    with torch.no_grad():
+        out = net({"voxel_features": torch.from_numpy(feats).to(cuda), "voxel_coords": torch.from_numpy(idx).to(cuda), "batch_size": 2})
+    stages = dict(out["multi_scale_3d_features"], out=out["encoded_spconv_tensor"])
+    for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out"):
+        gf, gi = _by_coord(stages[k].features.cpu().numpy(), stages[k].indices.cpu().numpy(), stages[k].spatial_shape)
+        wf, wi = _by_coord(want[k].features, want[k].indices, want[k].spatial_shape)
+        assert np.array_equal(gi, wi), k
+        assert np.array_equal(gf, wf), (k, float(np.abs(gf - wf).max()))
+
+
+def test_tile_timeout_is_an_error_not_wrong_features(cuda, rng):
+    """A hand-over wait of the tiled 32-channel kernel that times out ends its workgroup with rows unwritten.  The engine
+    reads the library's time-out counter with the per-stage counts of its one host sync and raises; the next forward,
+    with the protocol intact again, is clean.  (fnp_debug_tile_hold makes the producers stop publishing images.)"""
+    from findnpropagate_amd import lib as _lib
+    net = _small_net(cuda, "bf16")
+    shape = net.sparse_shape
+    feats, idx = _random_sparse(rng, 1, shape, 3000, 5)
+    bd = lambda: {"voxel_features": torch.from_numpy(feats).to(cuda), "voxel_coords": torch.from_numpy(idx).to(cuda), "batch_size": 1}
+    L = _lib.load()
+    with torch.no_grad():
+        ref = net(bd())["encoded_spconv_tensor"].features.clone()
+        before = L.fnp_spconv_tiled_aborts()
+        assert L.fnp_debug_tile_hold(1) == 0
+        try:
+            with pytest.raises(_lib.FnpError, match="timed out"):
+                net(bd())
+        finally:
+            assert L.fnp_debug_tile_hold(0) == 0
+        assert L.fnp_spconv_tiled_aborts() > before
+        again = net(bd())["encoded_spconv_tensor"].features
+    assert torch.equal(ref, again)
+
+
 def test_fused_backbone_bf16(cuda, oracle, rng):
     net = _small_net(cuda, "bf16")
     shape = net.sparse_shape
@@ -521,6 +564,69 @@ def test_tile_kernel_equals_gather_kernel(cuda, rng, n, order, dtype, C):
         b = S.conv_forward(x, wp, rb, n_dev, scale=scale, shift=shift, residual=residual, relu=relu, ranked=True, tile=True)
         c = S.conv_forward(x, wp, rb, n_dev, scale=scale, shift=shift, residual=residual, relu=relu, ranked=True, tile=False)
         assert torch.equal(a[:n], b[:n]) and torch.equal(a[:n], c[:n])
+
+
+def _surface_sites(rng, B, shape, n):
+    """sites on a two-cell-thick wavy sheet: like a lidar surface after stride-2 layers, most sites have neighbours in only
+    one of the two adjacent z planes (what the class sort separates)."""
+    D, H, W = shape
+    out = []
+    for b in range(B):
+        yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        z0 = ((D - 2) * 0.5 * (1 + np.sin(yy / 7.0 + b) * np.cos(xx / 9.0))).astype(np.int64).clip(0, D - 2)
+        for dz in (0, 1):
+            keep = rng.random((H, W)) < 0.8
+            out.append(np.stack([np.full(keep.sum(), b), (z0 + dz)[keep], yy[keep], xx[keep]], 1))
+    idx = np.concatenate(out).astype(np.int32)
+    idx = idx[rng.permutation(idx.shape[0])[:n]]
+    return idx
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,order", [(1, "random"), (17, "random"), (400, "sorted"), (5000, "random"), (5000, "sorted"), (60000, "sorted")])
+def test_class_sorted_sweep_equals_plain_sweep(cuda, rng, n, order, dtype):
+    """fnp_rulebook_classsort + fnp_spconv_forward_sorted (128 -> 128: rows processed class by class, tiles sweep only the
+    offsets their rows use) against fnp_spconv_forward: perm is a permutation of each workgroup range with the z classes
+    in order, blockmask is the union of the masks of 16 positions, and the convolution gives the same values."""
+    C = 128
+    B, shape = 2, [5, 60, 64] if n <= 5000 else [5, 200, 200]
+    idx = _surface_sites(rng, B, shape, n)
+    n = idx.shape[0]
+    if order == "sorted":
+        idx = idx[np.lexsort((idx[:, 1], idx[:, 3], idx[:, 2], idx[:, 0]))]
+    feats = rng.standard_normal((n, C)).astype(np.float32)
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    rb = S.rulebook_subm(d_idx, n_dev, S.build_grid(d_idx, n_dev, B, shape), 3)
+    wp = S.pack_weight(torch.from_numpy((rng.standard_normal((C, 3, 3, 3, C)) * 0.05).astype(np.float32)).to(cuda), dtype)
+    x = torch.from_numpy(feats).to(cuda).to(dtype)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)).to(cuda)
+    sh = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).to(cuda)
+    res = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32)).to(cuda).to(dtype)
+    plain = [S.conv_forward(x, wp, rb, n_dev, scale=a, shift=b, residual=r, relu=relu, ranked=True)
+             for r, a, b, relu in ((None, sc, sh, True), (res, sc, sh, True), (res, None, None, False))]
+    S.classsort(rb, n_dev, C)
+    perm, bm = rb._sorted[0][:n].cpu().numpy(), rb._sorted[1].cpu().numpy().view(np.uint32)
+    nbr = rb.nbr[:, :n].cpu().numpy()
+    masks = ((nbr >= 0).astype(np.uint32) << np.arange(27, dtype=np.uint32)[:, None]).sum(0).astype(np.uint32)
+    assert np.array_equal(rb._rowmask[:n].cpu().numpy().view(np.uint32), masks)
+    assert np.array_equal(np.sort(perm), np.arange(n)), "perm is a permutation of the rows"
+    for blk in range((n + 15) // 16):
+        assert bm[blk] == np.bitwise_or.reduce(masks[perm[blk * 16:(blk + 1) * 16]]), blk
+    lo, hi = (masks & 0x1ff) != 0, (masks >> 18) != 0
+    cls = np.where(lo, np.where(hi, 2, 3), np.where(hi, 1, 0))[perm]
+    # inside a workgroup range classes ascend and rows of a class keep their order; a drop marks the next range
+    drops = np.nonzero(np.diff(cls) < 0)[0]
+    assert len(drops) < 2048
+    same = np.diff(cls) == 0
+    assert np.all(np.diff(perm)[same] > 0)
+    srt = [S.conv_forward(x, wp, rb, n_dev, scale=a, shift=b, residual=r, relu=relu, ranked=True)
+           for r, a, b, relu in ((None, sc, sh, True), (res, sc, sh, True), (res, None, None, False))]
+    for a, b in zip(plain, srt):
+        assert torch.equal(a[:n], b[:n])
+    if n >= 5000 and order == "sorted":
+        skipped = 1.0 - np.mean([bin(int(v)).count("1") for v in bm[:(n + 15) // 16]]) / 27.0
+        assert skipped > 0.2, "a two-cell sheet leaves at least a plane of offsets empty for most blocks"
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])

@@ -11,6 +11,7 @@ from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=16); ap.add_argument("--reps", type=int, default=20); ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16"]); ap.add_argument("--valu", action="store_true"); ap.add_argument("--identity", action="store_true", help="replace every valid rulebook entry by the output row itself (perfect gather locality, same instruction stream)"); ap.add_argument("--fracs", type=str, default="1.0", help="comma list: time each layer on the first frac*n output rows too (tile staircase)")
 ap.add_argument("--tile", default="auto", choices=["auto", "on", "off"], help="LDS-tile kernel for the ranked 32 -> 32 layers: by size / forced / forbidden")
 ap.add_argument("--no-residual", action="store_true"); ap.add_argument("--only", default="", help="e.g. 32x32: time this layer class only")
+ap.add_argument("--sort", default="auto", choices=["auto", "on", "off", "identity", "fake18", "fakemix"], help="class-sorted sweep of the 128 -> 128 layers (identity: the sorted kernel on the natural order with every offset live = the mechanism's overhead)")
 ap.add_argument("--tile-stats", action="store_true", help="far-neighbour statistics of the ranked 32 -> 32 layer per 256-row tile")
 args = ap.parse_args()
 TILE = {"auto": None, "on": True, "off": False}[args.tile]
@@ -43,6 +44,37 @@ for tag, rb, n_dev in log:
     sc = torch.ones(cout, device=dev); sh = torch.zeros(cout, device=dev)
     resid = None if args.no_residual else torch.randn((rb.cap_out, cout), device=dev).to(TD)
     n_full = n
+    if (cin, cout, K) == (128, 128, 27) and args.sort != "auto":
+        rb.__dict__.pop("_sorted", None)
+        if args.sort == "identity":
+            rb._sorted = (torch.arange(rb.cap_out, dtype=torch.int32, device=dev), torch.full((rb.cap_out // 16 + 1,), (1 << 27) - 1, dtype=torch.int32, device=dev))
+        if args.sort == "fake18":   # timing probe (wrong results): natural order, every tile sweeps offsets 9..26 only
+            rb._sorted = (torch.arange(rb.cap_out, dtype=torch.int32, device=dev), torch.full((rb.cap_out // 16 + 1,), ((1 << 27) - 1) & ~0x1ff, dtype=torch.int32, device=dev))
+        if args.sort == "fakemix":  # timing probe (wrong results): natural order, blocks alternate per 384 rows between 18 and 27 live offsets
+            bmk = torch.full((rb.cap_out // 16 + 1,), (1 << 27) - 1, dtype=torch.int32, device=dev)
+            blk = torch.arange(rb.cap_out // 16 + 1, device=dev)
+            bmk[(blk // 24) % 3 != 1] = ((1 << 27) - 1) & ~0x1ff
+            rb._sorted = (torch.arange(rb.cap_out, dtype=torch.int32, device=dev), bmk)
+        if args.sort == "on":
+            for _ in range(3): S.classsort(rb, n_dev, 128)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(args.reps): S.classsort(rb, n_dev, 128)
+            e1.record(); torch.cuda.synchronize()
+            bm = rb._sorted[1][: (n + 15) // 16].cpu().numpy().view(np.uint32)
+            # tile masks: the 8 XCD groups of the 256-workgroup grid, tiles of 24 blocks from each group's first row
+            Gr = 256; nb16 = (n + 15) // 16; live = []; rows = []
+            for xg in range(8):
+                b0, b1 = nb16 * (xg * 32) // Gr, nb16 * (xg * 32 + 32) // Gr
+                for t0 in range(b0, b1, 24):
+                    t1 = min(b1, t0 + 24)
+                    live.append(bin(int(np.bitwise_or.reduce(bm[t0:t1]))).count("1")); rows.append(t1 - t0)
+            print(json.dumps({"tile_offsets_live(weighted by rows; the partial last round counted as full tiles)": round(float(np.average(live, weights=rows)) / 27, 3)}))
+            nt24 = len(bm) // 24
+            tm = np.bitwise_or.reduce(bm[: nt24 * 24].reshape(nt24, 24), axis=1)
+            print(json.dumps({"classsort_ms": round(e0.elapsed_time(e1) / args.reps, 4), "seg": os.environ.get("FNP_SORT_SEG", "3"),
+                              "block_offsets_live": round(float(np.mean([bin(int(v)).count("1") for v in bm])) / 27, 3),
+                              "tile24_offsets_live(approx)": round(float(np.mean([bin(int(v)).count("1") for v in tm])) / 27, 3)}))
     if args.tile_stats and ranked and K == 27:
         # far rows of spconv_tile.hip's tiles: per producer wave (32 rows x 27 offsets) the unique far row ids
         T, HALO, WR = 256, 64, 32
