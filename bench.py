@@ -35,8 +35,11 @@ def parse():
                                                           "are launch-bound); per-kernel events are not recorded")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-scenes", type=int, default=8, help="scenes timed through the CPU oracle on ONE thread (0 = skip the CPU baseline)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU leg (0 = min(physical cores, 16): "
-                                                              "a one-GPU box grants 16 cores)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU leg (0 = every core this job may use: "
+                                                              "min(physical cores, sched_getaffinity, cgroup cpu.max))")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step region; `value` is the median one, the list is reported")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (fp32 engine, Box Seeker, extraction, training "
+                                                                "step: each a fresh child process)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket conv launches with events")
     ap.add_argument("--no-sweep", action="store_true", help="skip the extra small-batch measurements (1 and 8 scenes per step)")
     return ap.parse_args()
@@ -51,6 +54,24 @@ def algorithmic_bytes(tag, P, n_out, b):
     return v
 
 
+def cgroup_cpus():
+    """cores the cgroup's CPU quota allows (cpu.max = "<quota> <period>" | "max <period>"), None when unlimited / unknown"""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] == "max":
+                    return None
+                return max(1, int(int(txt[0]) / int(txt[1])))
+            q = int(txt[0])
+            if q <= 0:
+                return None
+            return max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))
+        except Exception:
+            continue
+    return None
+
+
 def host_cpu():
     """CPU model, physical cores (sockets x cores per socket) and the cores this process may use."""
     import subprocess
@@ -63,14 +84,19 @@ def host_cpu():
     except Exception:
         pass
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cgroup_cpus()
+    if quota is not None:
+        usable = min(usable, quota)
     return model, phys or usable, usable
 
 
 def cpu_baseline(args, net, syn):
     """oracle/ (the CPU restatement: sequential voxeliser, hash rulebooks, gather-GEMM-scatter f32 — spconv's native CPU
     algorithm) timed on this host: (i) ONE thread, what a dataloader worker running spconv's CPU voxeliser + a CPU model
-    would use; (ii) all cores granted to this job, one scene per thread (scenes are independent; the conv kernel
-    releases the GIL).  Scenes are synthesised BEFORE the clocks start.  BASELINE.md section 3."""
+    would use; (ii) every core this job may use (physical cores, capped by sched_getaffinity and the cgroup's cpu.max), in
+    the two forms a CPU deployment has: one scene per thread (scenes are independent; the conv kernel releases the GIL),
+    and one scene at a time with OpenMP over the output tiles of each convolution — `value` is the
+    faster of the two, both are reported.  Scenes are synthesised BEFORE the clocks start; each leg is bounded to ~10-20 s."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import oracle as O
@@ -78,9 +104,8 @@ def cpu_baseline(args, net, syn):
     sd = {k: t.detach().cpu().numpy() for k, t in net.state_dict().items()}
     O.lib()
     model, phys, usable = host_cpu()
-    threads = args.cpu_threads if args.cpu_threads > 0 else max(1, min(phys, usable, 16))
-    n_multi = max(args.cpu_scenes, 2 * threads)
-    scenes = [syn.make_scene(s) for s in range(n_multi)]
+    threads = args.cpu_threads if args.cpu_threads > 0 else max(1, min(phys, usable))
+    distinct = [syn.make_scene(s) for s in range(max(args.cpu_scenes, min(32, 2 * threads)))]
 
     def one(p):
         v, c, n = O.voxelize(p, syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, syn.MAX_POINTS_PER_VOXEL, syn.MAX_VOXELS_TEST)
@@ -89,24 +114,58 @@ def cpu_baseline(args, net, syn):
         O.backbone_forward(sd, f, idx, 1, net.sparse_shape)
 
     O.set_threads(1)
-    one(scenes[0])                                         # warm-up (page faults, lazy loads)
+    one(distinct[0])                                       # warm-up (page faults, lazy loads)
     t0 = time.perf_counter()
-    for p in scenes[:args.cpu_scenes]:
+    for p in distinct[:args.cpu_scenes]:
         one(p)
     t1 = time.perf_counter() - t0
     single = args.cpu_scenes / t1
+    # (ii-a) one scene per thread: 2 scenes per thread (the distinct scenes cycled), ~2 / single seconds
+    n_multi = 2 * threads
+    scenes = [distinct[i % len(distinct)] for i in range(n_multi)]
     with ThreadPoolExecutor(max_workers=threads) as pool:
         list(pool.map(one, scenes[:threads]))              # warm-up of the pool
         t0 = time.perf_counter()
         list(pool.map(one, scenes))
         tm = time.perf_counter() - t0
     multi = n_multi / tm
-    return {"value": multi, "unit": "scenes/s", "cores": threads, "kind": "port",
-            "sample": f"{n_multi} of the same synthetic scenes, batch 1, f32, voxelize + MeanVFE + VoxelResBackBone8x "
-                      f"through oracle/ (sequential voxeliser, hash rulebook, gather-GEMM-scatter), one scene per thread "
-                      f"on {threads} threads, {tm:.1f} s; single-thread leg: {args.cpu_scenes} scenes in {t1:.1f} s",
+    # (ii-b) OpenMP over the output tiles of each convolution, scenes one after the other
+    omp_threads = min(threads, int(O.lib().orc_max_threads()))
+    O.set_threads(omp_threads)
+    one(distinct[0])
+    n_omp = max(2, min(len(distinct), int(10.0 * single * min(omp_threads, 8))))
+    t0 = time.perf_counter()
+    for p in distinct[:n_omp]:
+        one(p)
+    to = time.perf_counter() - t0
+    O.set_threads(1)
+    omp = n_omp / to
+    return {"value": max(multi, omp), "unit": "scenes/s", "cores": threads, "kind": "port",
+            "sample": f"the same synthetic scenes, batch 1, f32, voxelize + MeanVFE + VoxelResBackBone8x through oracle/ (sequential voxeliser, hash "
+                      f"rulebook, gather-GEMM-scatter): {n_multi} scenes one per thread on {threads} threads in {tm:.1f} s = {multi:.2f} scenes/s; "
+                      f"{n_omp} scenes with OpenMP over output tiles on {omp_threads} threads in {to:.1f} s = {omp:.2f} scenes/s; "
+                      f"single-thread leg: {args.cpu_scenes} scenes in {t1:.1f} s",
+            "scene_per_thread": {"value": multi, "threads": threads, "scenes": n_multi, "seconds": tm},
+            "openmp_over_tiles": {"value": omp, "threads": omp_threads, "scenes": n_omp, "seconds": to},
             "single_thread": {"value": single, "cores": 1, "seconds": t1, "scenes": args.cpu_scenes},
             "host_cores": phys, "host_cores_usable": usable, "cpu_model": model}
+
+
+def min_traffic_bytes(tag, n_out, b, tile_record_per_row=58):
+    """what a launch of a TILED kernel has to move at least: features in and out once (+ residual), the tile rulebook, the weights"""
+    cin, cout, K, res = tag[:4]
+    return n_out * (cin * b + cout * b * (2 if res else 1) + tile_record_per_row) + K * cin * cout * b
+
+
+def child_json(cmd, timeout):
+    """last JSON line a child process prints (secondary measurements run in fresh processes: their own allocator history,
+    hipGraph capture without this process's event-timed launches before it)"""
+    import subprocess
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if not lines:
+        raise RuntimeError((r.stderr or r.stdout)[-300:])
+    return json.loads(lines[-1])
 
 
 def main():
@@ -200,18 +259,31 @@ def main():
         tied = [k for k, v in per_class_ms.items() if v >= 0.85 * top]
         eng.profile_only = {min(tied, key=rate)}
         eng.profile = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    prof, eng.profile, eng.profile_only = eng.profile, None, None
+    # The timed region (EXACTLY --steps steps between two barrier + synchronize pairs, MAX over ranks) is repeated --reps
+    # times back to back; `value` / `ms_per_step` are those of the MEDIAN repetition and the whole list is reported (one
+    # 0.12 s region is a single draw: boxes of the pool differ by +-8 %, and so do repetitions on one box by 1-2 %).
+    rep_elapsed, rep_prof = [], []
+    for _ in range(max(1, args.reps)):
+        if eng.profile is not None:
+            eng.profile = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        e = t1 - t0
+        if dist is not None:
+            t = torch.tensor([e], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        rep_elapsed.append(e)
+        rep_prof.append(eng.profile)
+    order = sorted(range(len(rep_elapsed)), key=lambda i: rep_elapsed[i])
+    mid = order[(len(order) - 1) // 2]
+    elapsed = rep_elapsed[mid]
+    prof = rep_prof[mid]
+    eng.profile, eng.profile_only = None, None
 
     out = {
         "metric": "NuScenes scenes/s (30k pts, Transfusion voxel backbone)",
@@ -221,6 +293,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "repetitions": {"count": len(rep_elapsed), "steps_each": args.steps, "reported": "median",
+                        "scenes_per_s": [world * B * args.steps / e for e in rep_elapsed]},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -252,37 +326,68 @@ def main():
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
         cin, cout, K = cls
         flops = 2.0 * float(np.mean([stats[("tags", tag)][0][0] for _, tag in per[cls]])) * cin * cout
+        dense_flops = 2.0 * float(np.mean([stats[("tags", tag)][0][1] for _, tag in per[cls]])) * K * cin * cout
         win = "true" if (per[cls][0][1][4] and K == 27 and (cin, cout) == (64, 64)) else "false"
         mb = 3 if cout >= 128 else 2 if (cin, cout) in ((16, 16), (16, 32), (32, 32), (64, 64)) else 4   # launch_mfma_k
         mb32 = 4 if cout <= 64 else 3                                                                    # launch_f32
-        kname = (f"spconv_mfma_kernel<{cin},{cout},{mb},{K if K == 27 else 0},{win},bf16>"
+        srt = ",sorted" if (args.dtype == "bf16" and K == 27 and S.sorted_by_default(cin, cout, torch.bfloat16, int(pts.shape[0] * eng.cap_factor[2]))) else ""
+        kname = (f"spconv_mfma_kernel<{cin},{cout},{mb},{K if K == 27 else 0},{win},bf16{srt}>"
                  if args.dtype == "bf16" else f"spconv_mfma_f32_kernel<{cin},{cout},{mb32}>")
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-        # WRITE_SIZE in separate runs of this same command, gfx950 FETCH_SIZE x2 correction applied:
-        # profiles/r0N_pmc_traffic_<dtype>_b<B>.json); only quoted when a profile of this batch size is committed, else null
-        traffic = None
-        for name in (f"r02_pmc_traffic_{args.dtype}_b{B}.json", f"r01_pmc_traffic_b{B}.json" if args.dtype == "bf16" else ""):
+        # HBM bytes per launch of that kernel: NOT measured in this run (PMC counters need rocprofv3 around the process) but
+        # read from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in separate runs,
+        # gfx950 FETCH_SIZE x2 correction applied: profiles/r0N_pmc_traffic_<dtype>_b<B>.json); null when no profile of
+        # this kernel at this batch size is committed
+        traffic, traffic_src = None, None
+        for name in (f"r03_pmc_traffic_{args.dtype}_b{B}.json", f"r02_pmc_traffic_{args.dtype}_b{B}.json",
+                     f"r01_pmc_traffic_b{B}.json" if args.dtype == "bf16" else ""):
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pj.get("batch") == B and kname in pj["kernels"]:
-                    traffic = pj["kernels"][kname]["hbm_bytes_corrected"]
+                    traffic, traffic_src = pj["kernels"][kname]["hbm_bytes_corrected"], f"profiles/{name} (committed rocprofv3 --pmc passes of this command; not measured in this run)"
                     break
             except Exception:
                 continue
+        # every conv class of the step against ITS roofs (medians of the bracketed probe steps): SURVEY 8(d) gather-equivalent
+        # bytes (an upper bound on useful traffic, NOT a roof for the tiled kernels, where a row enters LDS once per tile:
+        # those are quoted against their minimum traffic), and the matrix pipe in dense-equivalent flops (the absent-
+        # neighbour zeros an output-stationary sweep multiplies included) against the dense peak of the dtype
+        mfma_peak = 2500.0 if args.dtype == "bf16" else 157.3
+        table = {}
+        for key, ms_step in (per_class_ms or {}).items():
+            tags = [t[1] for t in stats if isinstance(t, tuple) and t[0] == "tags" and t[1][:3] == key]
+            items = [(tag, P, n) for tag in tags for (P, n) in stats[("tags", tag)]]
+            if not items:
+                continue
+            ci, co, kk = key
+            alg = sum(algorithmic_bytes(tag, P, n, b) for tag, P, n in items)
+            fl_alg = sum(2.0 * P * ci * co for _, P, _ in items)
+            fl_dense = sum(2.0 * n * kk * ci * co for _, _, n in items)
+            row = {"launches_per_step": len(items), "ms_per_step": ms_step,
+                   "gather_equivalent_GBps": alg / ms_step / 1e6, "frac_hbm_gather_equivalent": alg / ms_step / 1e6 / 8000.0,
+                   "mfma_TFLOPs_algorithmic": fl_alg / ms_step / 1e9, "mfma_TFLOPs_dense_equivalent": fl_dense / ms_step / 1e9,
+                   "frac_mfma_dense_equivalent": fl_dense / ms_step / 1e9 / mfma_peak}
+            if args.dtype == "bf16" and kk == 27 and ci == co and ci in S.TILED_CHANNELS and all(tag[4] for tag, _, _ in items):
+                mt = sum(min_traffic_bytes(tag, n, b) for tag, _, n in items)
+                row.update({"kernel": f"spconv_tile{ci}_kernel", "min_traffic_GBps": mt / ms_step / 1e6, "frac_hbm_min_traffic": mt / ms_step / 1e6 / 8000.0,
+                            "note": "tiled kernel: gather-equivalent bytes exceed what it moves; min traffic = rows in/out once + residual + tile rulebook + weights"})
+            table[f"{ci}x{co}k{kk}"] = row
         common = {
-            "traffic": traffic,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "hbm_frac_from_traffic": (traffic / (avg_ms * 1e-3) / 1e9 / 8000.0) if traffic else None,
             "kernel": kname,
             "avg_launch_ms": avg_ms, "launches_timed": len(ms), "algorithmic_bytes_per_launch": avg_bytes,
-            "algorithmic_flops_per_launch": flops,
+            "algorithmic_flops_per_launch": flops, "dense_equivalent_flops_per_launch": dense_flops,
             "time_share_of_step": sum(ms) / (1e3 * elapsed),
             "all_conv_classes_ms_per_step": {f"{k[0]}x{k[1]}k{k[2]}": v for k, v in (per_class_ms or {}).items()},
             "all_conv_classes_note": "median of 5 untimed steps with every conv launch bracketed; the timed region brackets the dominant class only",
+            "per_class": table,
         }
         tflops = flops / (avg_ms * 1e-3) / 1e12
         if args.dtype == "bf16":
-            # the bf16 layers are bound by the gather path (HBM/L2 bytes), far from the 2.5 PFLOP/s matrix peak
+            # `achieved` = SURVEY 8(d) algorithmic (gather-equivalent) bytes / launch time: most of those bytes are served by L2 / MALL
+            # (`traffic` is what reaches HBM), so `frac` says how fast the gather path runs in HBM-peak units, not HBM utilisation
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                               "mfma_tflops_algorithmic": tflops, **common}
+                               "mfma_tflops_algorithmic": tflops, "mfma_frac_dense_equivalent": dense_flops / (avg_ms * 1e-3) / 1e12 / 2500.0, **common}
         else:
             # f32 runs on v_mfma_f32_16x16x4_f32 at the f32 vector rate (157.3 TFLOP/s dense): that pipe, not memory, bounds it
             out["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s", "frac": tflops / 157.3,
@@ -290,10 +395,10 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_sweep and not args.graph:
         # Extra fields (the headline stays `value` at --batch): the same path at 1 and 8 scenes per step — batch size 1 is
-        # what the reference's extraction script and configs[0] run — as stream launches (measured here) and replayed
-        # from a hipGraph (measured by a child process running this script with --graph: on ROCm 7.2 a graph captured
-        # in a process that has timed launches with events before faulted in replay; a fresh process does not).
-        import subprocess
+        # what the reference's extraction script and configs[0] run — as stream launches and replayed from a hipGraph, both
+        # measured HERE, in this process, after the event-timed launches above (round 2 had to move the graph leg into a
+        # child process: a replay after eager forwards faulted.  Cause, fixed in round 3: the voxeliser's captured
+        # hipMemsetAsync replayed with the fill value of a later eager memset — DESIGN.md section 2).
         sweep = {}
         for b in (1, 8):
             if b == B:
@@ -302,24 +407,47 @@ def main():
             p_b, o_b = torch.from_numpy(p_np).to(dev), torch.from_numpy(o_np).to(dev)
             row = {}
             with torch.no_grad():
-                for _ in range(5):
-                    net.forward_points(p_b, o_b, b, cfg)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(50):
-                    net.forward_points(p_b, o_b, b, cfg)
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t0) / 50
-            row["ms_per_step_stream"], row["scenes_per_s_stream"] = 1e3 * dt, b / dt
-            try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--batch", str(b), "--graph", "--no-sweep", "--cpu-scenes", "0",
-                                    "--steps", "50", "--warmup", "5", "--dtype", args.dtype], capture_output=True, text=True, timeout=180)
-                child = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-                row["ms_per_step_graph"], row["scenes_per_s_graph"] = child["ms_per_step"], child["value"]
-            except Exception as e:   # the extra field is best effort: never lose the headline over it
-                row["graph_error"] = repr(e)[:200]
+                for mode, fwd in (("stream", net.forward_points), ("graph", net.forward_points_graphed)):
+                    try:
+                        for _ in range(5):
+                            fwd(p_b, o_b, b, cfg)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(50):
+                            r_b = fwd(p_b, o_b, b, cfg)
+                        torch.cuda.synchronize()
+                        dt = (time.perf_counter() - t0) / 50
+                        row[f"ms_per_step_{mode}"], row[f"scenes_per_s_{mode}"] = 1e3 * dt, b / dt
+                        row[f"site_counts_{mode}"] = [int(c) for c in r_b["counts"]]
+                    except Exception as e:   # the extra field is best effort: never lose the headline over it
+                        row[f"{mode}_error"] = repr(e)[:200]
+            row["graph_equals_stream"] = row.get("site_counts_graph") == row.get("site_counts_stream")
             sweep[str(b)] = row
         out["batch_sweep"] = sweep
+
+    if rank == 0 and world == 1 and not args.no_secondary and not args.graph and args.dtype == "bf16":
+        # SURVEY 8(d)'s secondary metrics, each from a fresh child process (best effort: never lose the headline over one)
+        py, T = sys.executable, os.path.join(ROOT, "tools")
+        sec = {}
+        jobs = {
+            "fp32_engine": ([py, os.path.abspath(__file__), "--batch", str(B), "--dtype", "fp32", "--no-sweep", "--no-secondary", "--cpu-scenes", "0",
+                             "--steps", "5", "--warmup", "2", "--reps", "3"], 240),
+            "box_seeker": ([py, os.path.join(T, "bench_seeker.py"), "--batch", "64", "--cpu-scenes", "0"], 180),
+            "extraction": ([py, os.path.join(T, "bench_extract.py"), "--scenes", "256", "--force-collective"], 240),
+            "train_step": ([py, os.path.join(T, "bench_train.py"), "--batch", "16"], 240),
+        }
+        for name, (cmd, to) in jobs.items():
+            try:
+                j = child_json(cmd, to)
+                if name == "fp32_engine":
+                    j = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "scenes_per_step": B,
+                         "repetitions": j.get("repetitions"), "note": "FNP_DTYPE fp32: v_mfma_f32_16x16x4_f32, bit-identical to the CPU oracle (the 1e-4 mode)",
+                         "roofline": {k: j["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms",
+                                                                    "time_share_of_step", "algorithmic_flops_per_launch") if k in j.get("roofline", {})}}
+                sec[name] = j
+            except Exception as e:
+                sec[name] = {"error": repr(e)[:300]}
+        out["secondary"] = sec
 
     if rank == 0 and world == 1 and args.cpu_scenes > 0:   # (baseline leg: N = 1 only)
         out["cpu_baseline"] = cpu_baseline(args, net, syn)

@@ -31,3 +31,27 @@ static inline int fnp_grid_for(long long capacity_items, int items_per_block, in
 }
 
 __device__ __forceinline__ int fnp_lane() { return threadIdx.x & 63; }
+
+
+// Fill `count` 32-bit words at a 4-byte aligned address with `value`.  The library never issues hipMemsetAsync on a path a
+// caller may capture into a hipGraph: a memset node captured by torch.cuda.graph (ROCm 7.2, torch 2.10) was seen to replay
+// with the fill value of the last memset issued OUTSIDE the graph (a tensor.zero_()) once an eager forward had run between
+// two replays — tools/dbg_graph.py shows it on the voxeliser's slot lists; a kernel node keeps its arguments.
+static __global__ __launch_bounds__(256) void fnp_fill_words_kernel(unsigned *__restrict__ p, long long count, unsigned value) {
+    const long long head = (((16 - ((uintptr_t)p & 15)) & 15) >> 2) < (unsigned long long)count ? (((16 - ((uintptr_t)p & 15)) & 15) >> 2) : count;
+    uint4 *body = reinterpret_cast<uint4 *>(p + head);
+    const long long n4 = (count - head) >> 2, tail0 = head + (n4 << 2);
+    const uint4 v = make_uint4(value, value, value, value);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) body[i] = v;
+    if (blockIdx.x == 0) {
+        if ((long long)threadIdx.x < head) p[threadIdx.x] = value;
+        if ((long long)threadIdx.x < count - tail0) p[tail0 + threadIdx.x] = value;
+    }
+}
+static inline int fnp_fill_words(void *p, long long count, unsigned value, hipStream_t s) {
+    if (count <= 0) return FNP_OK;
+    if (!p || ((uintptr_t)p & 3)) return FNP_ERR_ARG;
+    hipLaunchKernelGGL(fnp_fill_words_kernel, dim3(fnp_grid_for(count / 4 + 1, 256, 2048)), dim3(256), 0, s, (unsigned *)p, count, value);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}

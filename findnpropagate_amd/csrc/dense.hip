@@ -168,7 +168,15 @@ int run_dense(const void *feats, const int *coords, const int *n_rows, int cap, 
     const int row_bytes = C * (int)sizeof(T);
     const bool tiled = ws != nullptr && row_bytes % 4 == 0 && 64 * (row_bytes + 4) <= 64 * 1024;
     if (!tiled) {
-        if (ws) FNP_HIP_TRY(hipMemsetAsync(out, 0, (size_t)cells * C * sizeof(T), s));   // (workspace given: out may be dirty)
+        if (ws) {   // (workspace given: out may be dirty)
+            const long long bytes = cells * C * (long long)sizeof(T);
+            if (bytes % 4 == 0 && ((uintptr_t)out & 3) == 0) {
+                const int frc = fnp_fill_words(out, bytes / 4, 0u, s);
+                if (frc) return frc;
+            } else {
+                FNP_HIP_TRY(hipMemsetAsync(out, 0, (size_t)bytes, s));   // (odd sizes only: not a shape of the backbone)
+            }
+        }
         const int grid = fnp_grid_for((long long)cap * C, kThreads, 256 * 16);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(dense_scatter_kernel<T>), dim3(grid), dim3(kThreads), 0, s, (const T *)feats, coords,
                            n_rows, cap, C, D, H, W, (T *)out);
@@ -177,7 +185,10 @@ int run_dense(const void *feats, const int *coords, const int *n_rows, int cap, 
     }
     if (ws_bytes < cells * 4) return FNP_ERR_WORKSPACE;
     int *index = (int *)ws;
-    FNP_HIP_TRY(hipMemsetAsync(index, 0xff, (size_t)cells * 4, s));
+    {
+        const int frc = fnp_fill_words(index, cells, 0xffffffffu, s);
+        if (frc) return frc;
+    }
     hipLaunchKernelGGL(dense_index_kernel, dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0, s, coords, n_rows, cap, B, D, H,
                        W, index);
     FNP_LAUNCH_CHECK();

@@ -94,8 +94,7 @@ template <class L, class TOut>
 int run_scan(L load, long long n, TOut *out, int *total, void *ws, hipStream_t s) {
     if (n < 0 || !total) return FNP_ERR_ARG;
     if (n == 0) {
-        FNP_HIP_TRY(hipMemsetAsync(total, 0, sizeof(int), s));
-        return FNP_OK;
+        return fnp_fill_words(total, 1, 0u, s);
     }
     if (!out || !ws) return FNP_ERR_ARG;
     const int tiles = fnp_divup(n, fnp_scan::kTile);

@@ -394,7 +394,10 @@ extern "C" int fnp_rulebook_transpose(const int *nbr, int nbr_stride, int K, con
                                       int cap_in, fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!nbr || !n_out || !nbr_t || K <= 0 || cap_out <= 0 || cap_in <= 0 || nbr_stride < cap_out) return FNP_ERR_ARG;
-    FNP_HIP_TRY(hipMemsetAsync(nbr_t, 0xff, sizeof(int) * (size_t)K * cap_in, s));
+    {
+        const int frc = fnp_fill_words(nbr_t, (long long)K * cap_in, 0xffffffffu, s);
+        if (frc) return frc;
+    }
     hipLaunchKernelGGL(transpose_rulebook_kernel, dim3(fnp_grid_for(cap_out, kThreads, 1024), K), dim3(kThreads), 0, s, nbr,
                        nbr_stride, K, n_out, cap_out, nbr_t, cap_in);
     FNP_LAUNCH_CHECK();

@@ -830,9 +830,12 @@ extern "C" int fnp_spconv_tiled_aborts(void) {
     return (int)v;
 }
 
+__global__ void tile_aborts_copy_kernel(int *dst) { *dst = (int)g_tile_aborts; }   // (a kernel, not a memcpy from the symbol: capturable in a hipGraph)
+
 extern "C" int fnp_spconv_tiled_aborts_copy(int *dst, fnp_stream_t stream) {
     if (!dst) return FNP_ERR_ARG;
-    if (hipMemcpyFromSymbolAsync(dst, HIP_SYMBOL(g_tile_aborts), sizeof(unsigned), 0, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) return FNP_ERR_HIP;
+    hipLaunchKernelGGL(tile_aborts_copy_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst);
+    FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
 

@@ -321,9 +321,9 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
         return FNP_ERR_ARG;
     if (cfg->num_features < 3 || cfg->max_points <= 0 || cfg->max_points > 64 || cfg->max_voxels <= 0) return FNP_ERR_ARG;
     if (n == 0) {
-        FNP_HIP_TRY(hipMemsetAsync(n_voxels, 0, sizeof(int), s));
-        if (n_cells) FNP_HIP_TRY(hipMemsetAsync(n_cells, 0, sizeof(int), s));
-        return FNP_OK;
+        int frc = fnp_fill_words(n_voxels, 1, 0u, s);
+        if (!frc && n_cells) frc = fnp_fill_words(n_cells, 1, 0u, s);
+        return frc;
     }
     if (!points || !batch_offsets || !workspace || !coords || !num_points || !mean_feats) return FNP_ERR_ARG;
     if (cap < n) return FNP_ERR_ARG;  // every point could open a voxel
@@ -335,7 +335,10 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
     const int maxp = cfg->max_points, C = cfg->num_features;
     const int pgrid = fnp_divup(n, kThreads);
 
-    FNP_HIP_TRY(hipMemsetAsync(w.top, 0x7f, sizeof(int) * (size_t)n * maxp, s));
+    {   // (a fill kernel, never hipMemsetAsync on a capturable path: common.h fnp_fill_words)
+        const int frc = fnp_fill_words(w.top, (long long)n * maxp, (unsigned)kSentinel, s);
+        if (frc) return frc;
+    }
     hipLaunchKernelGGL(vox_mark_kernel, dim3(pgrid), dim3(kThreads), 0, s, points, n, C, batch_offsets, B, *cfg, g, w.code);
     FNP_LAUNCH_CHECK();
     int rc = fnp_scan::rank_grid(g, w.n_sorted, w.scan_ws, s);
@@ -371,7 +374,10 @@ extern "C" int fnp_rankgrid_build(const int *coords, const int *n_rows, int cap,
     int rc = fnp_scan::rank_grid(g, total, scan_ws, s);
     if (rc) return rc;
     if (g.perm) {
-        FNP_HIP_TRY(hipMemsetAsync(g.perm, 0xff, sizeof(int) * (size_t)cap, s));
+        {
+            const int frc = fnp_fill_words(g.perm, cap, 0xffffffffu, s);
+            if (frc) return frc;
+        }
         hipLaunchKernelGGL(rg_perm_kernel, dim3(blocks), dim3(kThreads), 0, s, coords, n_rows, cap, g);
         FNP_LAUNCH_CHECK();
     }

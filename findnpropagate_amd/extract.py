@@ -71,9 +71,12 @@ def unpack_record(rec):
             "pred_labels": body[:, 8].to(torch.int32)}, index
 
 
-def all_gather_records(rec, dist=None, async_op=False):
-    """The step's one collective.  rec (S, K_MAX + 1, 9) -> (W, S, K_MAX + 1, 9) [, work handle]."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def all_gather_records(rec, dist=None, async_op=False, force_collective=False):
+    """The step's one collective.  rec (S, K_MAX + 1, 9) -> (W, S, K_MAX + 1, 9) [, work handle].
+    A process group of one rank has nothing to exchange and skips it — unless force_collective: the collective is then
+    issued all the same (RCCL with backend "nccl"), so that the path a multi-GPU run takes — communicator set-up, the
+    collective on the side stream, the consumer one step later — executes on a single GPU too."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         out = rec[None]
         return (out, None) if async_op else out
     W = dist.get_world_size()
@@ -210,7 +213,8 @@ class _Writer:
 
 
 def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank0", resume=True, progress=None,
-                          recall=None, recall_fn=None, scenes_per_step=1, pipeline=None, collate=None):
+                          recall=None, recall_fn=None, scenes_per_step=1, pipeline=None, collate=None, force_collective=False,
+                          trace=None):
     """Run `head` (a FrustumProposerOG-like module: forward(batch_dict) -> batch_dict with
     'final_box_dicts') over `dataset` sharded across the process group.
 
@@ -227,6 +231,9 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
              duplicates are counted once); `recall` then holds the totals plus 'recall_<thr>' = rcnn_<thr> / gt.
              recall_fn: the record function (default Detector3DTemplate.generate_recall_record; the CPU tests
              inject a counter); a custom one runs on host pred_dicts, i.e. outside the pipeline.
+    force_collective: issue the step's all-gather even in a process group of one rank (see all_gather_records).
+    trace:   optional list; the pipeline appends ("launch", step), ("collective", step) and ("consume", step) as it goes — the
+             order a test reads the one-step-late consumption from.
     Returns the number of frames this rank wrote.
     """
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
@@ -258,8 +265,10 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
         raise ValueError(write)
 
     def drain(p):
-        host, ev = p
+        host, ev, st = p
         ev.synchronize()                              # the only host wait of the pipeline: previous step's copy
+        if trace is not None:
+            trace.append(("consume", st))
         writer.submit(host)
 
     with torch.no_grad():
@@ -279,6 +288,8 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
                 if scenes:
                     batch = collate(scenes)
                     r = head.launch(batch)
+                    if trace is not None:
+                        trace.append(("launch", step))
                     rec = _records_from_launch(r, slot_tags, device)
                     if recall is not None and "gt_boxes_list" in batch:
                         from .detectors import Detector3DTemplate
@@ -292,7 +303,9 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
                 cur = torch.cuda.current_stream(device)
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    recs_w, work = all_gather_records(rec, dist, async_op=True)
+                    recs_w, work = all_gather_records(rec, dist, async_op=True, force_collective=force_collective)
+                    if trace is not None:
+                        trace.append(("collective", step))
                     if work is not None:
                         work.wait()                   # stream-level wait (side stream), not a host wait
                     mine_w = writes_for(recs_w)
@@ -304,7 +317,7 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
                 recs_w.record_stream(side)
                 if pending is not None:
                     drain(pending)
-                pending = (host, ev)
+                pending = (host, ev, step)
             else:
                 recs = []
                 if scenes:
@@ -322,7 +335,7 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
                 empty = {"pred_boxes": torch.zeros((0, 7)), "pred_scores": torch.zeros((0,)), "pred_labels": torch.zeros((0,), dtype=torch.int32)}
                 while len(recs) < S:
                     recs.append(pack_record(empty, -1, device))   # tells the writers to leave an existing file alone
-                recs_w = all_gather_records(torch.stack(recs), dist)
+                recs_w = all_gather_records(torch.stack(recs), dist, force_collective=force_collective)
                 writer.submit(writes_for(recs_w).cpu())
             if progress is not None:
                 progress(step, len(steps))

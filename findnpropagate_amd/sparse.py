@@ -418,7 +418,7 @@ def conv_forward_strided(feat_in, w_packed, rb, scale=None, shift=None, relu=Fal
 
 # layers the fused backbone runs this way (16 -> 32 is built and tested too, but measured 2.5 % slower end to end than its table
 # path: its input grid carries the voxeliser's permutation and its LDS strip costs a resident workgroup)
-FUSED_STRIDED_SHAPES = {(32, 64), (64, 128)}
+FUSED_STRIDED_SHAPES = {(32, 64), (64, 128)} | ({(16, 32)} if os.environ.get("FNP_FUSED1632") == "1" else set())   # (development switch)
 
 
 # --------------------------------------------------------------------------------- backward

@@ -103,8 +103,10 @@ def test_matches_reference_golden(cuda, seed):
         k += 1
     assert k == len(d["iou_out_off"]) - 1
     # chosen boxes: the candidate-set rule of tests/seeker_parity.py (full 7-vector, 1e-4)
-    n_unique = check_choices(d, boxes.cpu().numpy(), _chosen(dbg), extra_tol=2e-3 * float(pv[0].get("dst_w", 0.0)))
-    assert n_unique >= 0.5 * boxes.shape[0]
+    n_unique, n_tied_ref, n_loose = check_choices(d, boxes.cpu().numpy(), _chosen(dbg), extra_tol=2e-3 * float(pv[0].get("dst_w", 0.0)))
+    # the bound comes from the fixture: every frustum whose reference scores are NOT tied (beyond 1e-4) was compared with the
+    # reference's output box, except the few decided only through a face-grazing point count (<= 2 points, < 1 % of candidates)
+    assert n_unique == boxes.shape[0] - n_tied_ref - n_loose and n_loose <= max(1, boxes.shape[0] // 10)
     if "lone_point" in sc["variant"]:
         npts = dbg["npts"].cpu().numpy()
         assert ((npts == 1) & dbg["has_box"].numpy()).any(), "the single-return frustum yields a box"

@@ -111,6 +111,44 @@ def test_pipeline_issues_one_collective_per_step_and_no_sync(cuda, nccl_world1):
     assert calls == [] or calls == [(2 * (E.K_MAX + 1), 9)] * 4
 
 
+def test_rccl_collective_runs_on_one_gpu_and_is_consumed_a_step_late(cuda, nccl_world1):
+    """force_collective: the nccl (= RCCL) all_gather_into_tensor of the packed record is really issued every step in the
+    world-size-1 group — on the side stream, shape (S (K_MAX + 1), 9) in and out — its result is consumed one step later
+    (step k's records reach the writer after step k + 1 has been launched), and the files equal those of the path that
+    skips the collective."""
+    data = syn.SeekerScenes(8, 4, cuda, seed0=60, variants=[(), ("aug",), ("no_dets",), ("lone_point",)])
+    head = _head()
+    calls = []
+    orig = nccl_world1.all_gather_into_tensor
+
+    def spy(out, inp, **kw):
+        calls.append((tuple(out.shape), tuple(inp.shape), torch.cuda.current_stream(cuda) != torch.cuda.default_stream(cuda), kw.get("async_op", False)))
+        return orig(out, inp, **kw)
+    nccl_world1.all_gather_into_tensor = spy
+    trace = []
+    try:
+        with tempfile.TemporaryDirectory() as d_f, tempfile.TemporaryDirectory() as d_s:
+            assert E.extract_pseudo_labels(data, head, d_f, cuda, dist=nccl_world1, scenes_per_step=2, force_collective=True, trace=trace) == 8
+            n_calls = len(calls)
+            assert E.extract_pseudo_labels(data, head, d_s, cuda, dist=nccl_world1, scenes_per_step=2) == 8
+            assert len(calls) == n_calls, "without the switch a one-rank group skips the collective"
+            a, b = _load(d_f), _load(d_s)
+            assert sorted(a) == sorted(b) and len(a) == 8
+            for f in a:
+                for k in a[f]:
+                    assert torch.equal(a[f][k], b[f][k]), (f, k)
+    finally:
+        nccl_world1.all_gather_into_tensor = orig
+    rows = 2 * (E.K_MAX + 1)
+    assert calls[:4] == [((rows, 9), (rows, 9), True, True)] * 4 and n_calls == 4
+    # order: launch k, collective k, then (for k >= 1) consume k - 1; the last step is consumed after the loop
+    want = []
+    for k in range(4):
+        want += [("launch", k), ("collective", k)] + ([("consume", k - 1)] if k else [])
+    want.append(("consume", 3))
+    assert trace == want, trace
+
+
 def test_collate_scenes_batches_like_single_scenes(cuda):
     data = syn.SeekerScenes(3, 3, cuda, seed0=50, variants=[(), ("aug",), ("lone_point",)])
     head = _head()

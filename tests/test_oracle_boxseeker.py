@@ -96,10 +96,12 @@ def test_get_proposals_matches_reference(bs, seed):
         dcount = np.abs(t["counts"].astype(np.int64) - ref).max()
         np.testing.assert_allclose(t["scores"], ws[:, 0], rtol=0, atol=1e-4 + dst_tol + 2.0 * dcount / max(ref.max(), 1))
     chosen = [(t["idx_final"], t["best"], t["counts"]) for t in trace if "scores" in t]
-    n_unique = check_choices(d, boxes, chosen, extra_tol=dst_tol)
+    n_unique, n_tied_ref, n_loose = check_choices(d, boxes, chosen, extra_tol=dst_tol)
     if "lone_point" in sc["variant"]:
         assert any(t["n_points"] == 1 and "scores" in t for t in trace), "the single-return frustum reaches the scoring stage"
-    assert n_unique >= 0.5 * boxes.shape[0]
+    # the bound comes from the fixture: every frustum whose reference scores are NOT tied (beyond 1e-4) was compared with the
+    # reference's output box, except the few decided only through a face-grazing point count (<= 2 points, < 1 % of candidates)
+    assert n_unique == boxes.shape[0] - n_tied_ref - n_loose and n_loose <= max(1, boxes.shape[0] // 10)
 
 
 def test_quantile_matches_torch(bs):
