@@ -54,7 +54,9 @@ constexpr int kSlots = 64;
 template <typename T, int VEC>
 __global__ __launch_bounds__(kThreads) void dense_write_kernel(const T *__restrict__ feats, const int *__restrict__ index, int C,
                                                                int B, int D, long long plane, int tiles_per_plane,
-                                                               T *__restrict__ out) {
+                                                               T *__restrict__ out, const float *__restrict__ fill) {
+    // fill (optional, per channel): the value of a cell without a row instead of 0 — the BEV map behind a convolution whose
+    // epilogue (BatchNorm shift, ReLU) gives cells with no input in reach a constant per channel
     extern __shared__ __attribute__((aligned(16))) unsigned char fnp_dense_smem[];
     typedef int IVec __attribute__((ext_vector_type(VEC)));
     typedef T TVec __attribute__((ext_vector_type(VEC)));
@@ -107,10 +109,13 @@ __global__ __launch_bounds__(kThreads) void dense_write_kernel(const T *__restri
 
     if (total == 0) {
         if (!in) return;
-        TVec v;
+        for (int c = wave; c < C; c += 4) {
+            const T bg = fill ? (T)fill[c] : (T)0;
+            TVec v;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) v[j] = (T)0;
-        for (int c = wave; c < C; c += 4) *reinterpret_cast<TVec *>(o + c * cstep) = v;
+            for (int j = 0; j < VEC; ++j) v[j] = bg;
+            *reinterpret_cast<TVec *>(o + c * cstep) = v;
+        }
     } else if (total <= kSlots) {
         int first = 0, myslot[VEC];
 #pragma unroll
@@ -121,10 +126,11 @@ __global__ __launch_bounds__(kThreads) void dense_write_kernel(const T *__restri
         __syncthreads();
         if (!in) return;
         for (int c = wave; c < C; c += 4) {
+            const T bg = fill ? (T)fill[c] : (T)0;
             TVec v;
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
-                v[j] = ((occ[j] >> lane) & 1ull) ? reinterpret_cast<const T *>(fnp_dense_smem + myslot[j] * stride)[c] : (T)0;
+                v[j] = ((occ[j] >> lane) & 1ull) ? reinterpret_cast<const T *>(fnp_dense_smem + myslot[j] * stride)[c] : bg;
             *reinterpret_cast<TVec *>(o + c * cstep) = v;
         }
     } else {
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void dense_write_kernel(const T *__restri
             if (in) {
                 const bool has = (occ[j] >> lane) & 1ull;
                 const T *mine = reinterpret_cast<const T *>(fnp_dense_smem + __popcll(occ[j] & below) * stride);
-                for (int c = wave; c < C; c += 4) o[c * cstep + j] = has ? mine[c] : (T)0;
+                for (int c = wave; c < C; c += 4) o[c * cstep + j] = has ? mine[c] : (fill ? (T)fill[c] : (T)0);
             }
             __syncthreads();
         }
@@ -150,24 +156,25 @@ __global__ __launch_bounds__(kThreads) void dense_write_kernel(const T *__restri
 #endif
 
 template <typename T, int VEC>
-int launch_dense_write(const void *feats, const int *index, int C, int B, int D, long long plane, void *out, hipStream_t s) {
+int launch_dense_write(const void *feats, const int *index, int C, int B, int D, long long plane, void *out, const float *fill, hipStream_t s) {
     const int row_bytes = C * (int)sizeof(T);
     const int tiles_per_plane = (int)((plane + 64 * VEC - 1) / (64 * VEC));
     const long long tiles = (long long)B * D * tiles_per_plane;
     if (tiles > 0x7fffffffll) return FNP_ERR_ARG;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(dense_write_kernel<T, VEC>), dim3((unsigned)tiles), dim3(kThreads), kSlots * (row_bytes + 4), s,
-                       (const T *)feats, index, C, B, D, plane, tiles_per_plane, (T *)out);
+                       (const T *)feats, index, C, B, D, plane, tiles_per_plane, (T *)out, fill);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
 
 template <typename T>
 int run_dense(const void *feats, const int *coords, const int *n_rows, int cap, int C, int B, int D, int H, int W, void *out,
-              void *ws, int64_t ws_bytes, hipStream_t s) {
+              void *ws, int64_t ws_bytes, hipStream_t s, const float *fill = nullptr) {
     const long long plane = (long long)H * W, cells = (long long)B * D * plane;
     const int row_bytes = C * (int)sizeof(T);
     const bool tiled = ws != nullptr && row_bytes % 4 == 0 && 64 * (row_bytes + 4) <= 64 * 1024;
     if (!tiled) {
+        if (fill) return FNP_ERR_ARG;   // (a per-channel background needs the single-pass writer: workspace + a row size it takes)
         if (ws) {   // (workspace given: out may be dirty)
             const long long bytes = cells * C * (long long)sizeof(T);
             if (bytes % 4 == 0 && ((uintptr_t)out & 3) == 0) {
@@ -196,15 +203,15 @@ int run_dense(const void *feats, const int *coords, const int *n_rows, int cap, 
     const bool al = ((uintptr_t)out % 16 == 0) && ((uintptr_t)ws % 16 == 0);
     constexpr int kMaxVec = 16 / (int)sizeof(T) < FNP_DENSE_VEC ? 16 / (int)sizeof(T) : FNP_DENSE_VEC;
     if constexpr (kMaxVec >= 8) {
-        if (al && plane % 8 == 0) return launch_dense_write<T, 8>(feats, index, C, B, D, plane, out, s);
+        if (al && plane % 8 == 0) return launch_dense_write<T, 8>(feats, index, C, B, D, plane, out, fill, s);
     }
     if constexpr (kMaxVec >= 4) {
-        if (al && plane % 4 == 0) return launch_dense_write<T, 4>(feats, index, C, B, D, plane, out, s);
+        if (al && plane % 4 == 0) return launch_dense_write<T, 4>(feats, index, C, B, D, plane, out, fill, s);
     }
     if constexpr (kMaxVec >= 2) {
-        if (al && plane % 2 == 0) return launch_dense_write<T, 2>(feats, index, C, B, D, plane, out, s);
+        if (al && plane % 2 == 0) return launch_dense_write<T, 2>(feats, index, C, B, D, plane, out, fill, s);
     }
-    return launch_dense_write<T, 1>(feats, index, C, B, D, plane, out, s);
+    return launch_dense_write<T, 1>(feats, index, C, B, D, plane, out, fill, s);
 }
 
 }  // namespace
@@ -223,5 +230,19 @@ extern "C" int fnp_sparse_to_dense(const void *feats, int dtype, const int *coor
         return run_dense<float>(feats, coords, n_rows, cap, C, B, D, H, W, out, workspace, workspace_bytes, (hipStream_t)stream);
     if (dtype == FNP_BF16)
         return run_dense<__bf16>(feats, coords, n_rows, cap, C, B, D, H, W, out, workspace, workspace_bytes, (hipStream_t)stream);
+    return FNP_ERR_ARG;
+}
+
+// fnp_sparse_to_dense with a per-channel value for the cells without a row (fill: C floats in device memory).  Needs the
+// workspace (the single-pass writer).  The first BaseBEVBackbone block evaluated on sparse rows ends with it.
+extern "C" int fnp_sparse_to_dense_fill(const void *feats, int dtype, const int *coords, const int *n_rows, int cap, int C,
+                                        int B, int D, int H, int W, void *out, const float *fill, void *workspace,
+                                        int64_t workspace_bytes, fnp_stream_t stream) {
+    if (!feats || !coords || !n_rows || !out || !fill || !workspace || cap <= 0 || C <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0)
+        return FNP_ERR_ARG;
+    if (dtype == FNP_F32)
+        return run_dense<float>(feats, coords, n_rows, cap, C, B, D, H, W, out, workspace, workspace_bytes, (hipStream_t)stream, fill);
+    if (dtype == FNP_BF16)
+        return run_dense<__bf16>(feats, coords, n_rows, cap, C, B, D, H, W, out, workspace, workspace_bytes, (hipStream_t)stream, fill);
     return FNP_ERR_ARG;
 }

@@ -141,6 +141,7 @@ SIGNATURES = {
     "fnp_clipcrop_sample": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, P, P]),
     "fnp_sparse_to_dense_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "fnp_sparse_to_dense": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64, P]),
+    "fnp_sparse_to_dense_fill": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int64, P]),
 }
 
 

@@ -462,9 +462,10 @@ def conv_wgrad(feat_in, grad_out, rb, n_out_dev, Cin, Cout):
     return dw
 
 
-def to_dense(features, indices, n_dev, batch_size, shape, workspace=None, out=None):
+def to_dense(features, indices, n_dev, batch_size, shape, workspace=None, out=None, fill=None):
     """SparseConvTensor.dense(): (B, C, D, H, W), written once (zeros included) through a cell -> row map.
-    workspace / out: optional persistent buffers of a caller that densifies every step."""
+    workspace / out: optional persistent buffers of a caller that densifies every step.
+    fill: optional (C,) f32 device tensor — the value of cells without a row, per channel, instead of 0."""
     L = _l.load()
     C = features.shape[1]
     need = int(L.fnp_sparse_to_dense_workspace_bytes(batch_size, *shape))
@@ -473,6 +474,13 @@ def to_dense(features, indices, n_dev, batch_size, shape, workspace=None, out=No
     if out is None:
         out = torch.empty((batch_size, C, *shape), dtype=features.dtype, device=features.device)
     assert out.is_contiguous() and out.dtype == features.dtype and tuple(out.shape) == (batch_size, C, *shape)
+    if fill is not None:
+        assert fill.dtype == torch.float32 and fill.numel() == C and fill.is_contiguous()
+        rc = L.fnp_sparse_to_dense_fill(_l.ptr(features), _l.dtype_code(features), _l.ptr(indices), _l.ptr(n_dev),
+                                        max(indices.shape[0], 1), C, batch_size, *shape, _l.ptr(out), _l.ptr(fill), _l.ptr(workspace),
+                                        workspace.numel(), _l.stream())
+        _l.check(rc, "fnp_sparse_to_dense_fill")
+        return out
     rc = L.fnp_sparse_to_dense(_l.ptr(features), _l.dtype_code(features), _l.ptr(indices), _l.ptr(n_dev),
                                max(indices.shape[0], 1), C, batch_size, *shape, _l.ptr(out), _l.ptr(workspace),
                                workspace.numel(), _l.stream())

@@ -410,6 +410,12 @@ int64_t fnp_sparse_to_dense_workspace_bytes(int B, int D, int H, int W);
 int fnp_sparse_to_dense(const void *feats, int dtype, const int *coords, const int *n_rows, int cap,
                         int C, int B, int D, int H, int W, void *out,
                         void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
+/* The same with a per-channel value (fill: C floats, device) for the cells WITHOUT a row instead of 0: the dense map behind
+ * a convolution whose epilogue gives unreached cells a constant — relu(BatchNorm shift) — i.e. the output of the first
+ * BaseBEVBackbone block (base_bev_backbone.py:31-40) evaluated on the sparse rows.  Needs the workspace. */
+int fnp_sparse_to_dense_fill(const void *feats, int dtype, const int *coords, const int *n_rows, int cap, int C,
+                             int B, int D, int H, int W, void *out, const float *fill, void *workspace,
+                             int64_t workspace_bytes, fnp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Greedy Box Seeker — replaces hot loops 2-4 of FrustumProposerOG.get_proposals
