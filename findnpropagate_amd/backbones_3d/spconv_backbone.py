@@ -289,7 +289,7 @@ class _PointsGraph:
         self.pts = torch.full((capacity, n_feat), self.FAR, dtype=torch.float32, device=device)
         self.off = torch.zeros((batch_size + 1,), dtype=torch.int32, device=device)
         self.n_prev = 0
-        self.cap_factor = list(engine.cap_factor)
+        self.cap_factor = list(engine.cap_factor) + list(engine.ell_pool)
         self.prep_key = engine._prep_key
         # warm-up on a side stream (allocations of persistent grids/workspaces, lazy kernel attributes), then capture
         self._body(voxel_cfg)
@@ -323,6 +323,9 @@ class FusedResBackbone:
         self._grids = {}
         # capacity of stage l (l = 2..5) as a multiple of the stage-1 capacity; grown on overflow
         self.cap_factor = [3.0, 2.0, 1.0, 1.0]
+        # extension-record pools of the compact rulebooks (stage 1, the 16 -> 32 layer) in records per row capacity; measured
+        # need on lidar scenes 0.10 / 0.01; grown on overflow like the capacities
+        self.ell_pool = [0.25, 0.0625]
         self._vox_ws = None
         self._graphs = {}
         self._dirty = False      # a forward is in flight or died before its sparse clear: grids may hold stale bits
@@ -350,6 +353,17 @@ class FusedResBackbone:
         if int(value) > seen:
             raise _l.FnpError(f"spconv_tile32_kernel: {int(value) - seen} hand-over wait(s) timed out during this forward; "
                               "its features are incomplete")
+
+    def _ell_overflow(self, counts, ell_used, cap1):
+        """pops the pool counters of the compact rulebooks off `counts`; True when a pool was too small (its factor is grown:
+        the caller reruns, as for a row capacity)"""
+        over = False
+        for used_t, pool, which in reversed(ell_used):
+            used = counts.pop()
+            if used > pool:
+                self.ell_pool[which] = max(self.ell_pool[which] * 2.0, used * 1.25 / max(cap1 * (self.cap_factor[0] if which else 1.0), 1))
+                over = True
+        return over
 
     # ---- weights --------------------------------------------------------------------------
     def _fold(self, conv, bn, dtype):
@@ -437,7 +451,7 @@ class FusedResBackbone:
         key = (batch_size, capacity, C, str(points.device))
         while True:
             g = self._graphs.get(key)
-            if g is None or g.cap_factor != self.cap_factor or g.prep_key != self._prep_key:
+            if g is None or g.cap_factor != list(self.cap_factor) + list(self.ell_pool) or g.prep_key != self._prep_key:
                 g = _PointsGraph(self, capacity, C, batch_size, voxel_cfg, points.device)
                 self._graphs[key] = g
             g.pts[:n].copy_(points)
@@ -447,9 +461,9 @@ class FusedResBackbone:
             g.off.copy_(batch_offsets)
             g.graph.replay()
             stage, caps, shapes = g.res['stages'], g.res['caps'], g.res['shapes']
-            counts = torch.cat([s[2] for s in stage] + [g.res['aborts']]).cpu().tolist()   # the one host sync
+            counts = torch.cat([s[2] for s in stage] + [g.res['aborts']] + [u for u, _, _ in g.res['ell_used']]).cpu().tolist()   # the one host sync
+            overflow = self._ell_overflow(counts, g.res['ell_used'], caps[0])
             self._check_aborts(counts.pop())
-            overflow = False
             for l in range(1, 5):
                 if counts[l] > caps[l]:
                     self.cap_factor[l - 1] = max(self.cap_factor[l - 1] * 2.0, counts[l] * 1.25 / caps[0])
@@ -499,6 +513,15 @@ class FusedResBackbone:
             tag = (int(w.shape[2]), int(w.shape[1]), int(w.shape[0]), residual is not None, ranked)  # Cin, Cout, K, res
             if self.rulebook_log is not None:
                 self.rulebook_log.append((tag, rb, n))
+            if getattr(rb, "_ell", None) is not None and (rb.nbr is None or int(w.shape[2]) <= 8):   # on the compact rulebook
+                if self.profile is None or (self.profile_only is not None and tag[:3] not in self.profile_only):
+                    return S.conv_forward_ell(x, w, rb, n, out_dtype=out_dtype, scale=sc, shift=sh, residual=residual, relu=True)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                y = S.conv_forward_ell(x, w, rb, n, out_dtype=out_dtype, scale=sc, shift=sh, residual=residual, relu=True)
+                e1.record()
+                self.profile.append((tag, e0, e1))
+                return y
             if rb.nbr is None:   # fused strided layer
                 if self.profile is None or (self.profile_only is not None and tag[:3] not in self.profile_only):
                     return S.conv_forward_strided(x, w, rb, scale=sc, shift=sh, relu=True)
@@ -525,8 +548,20 @@ class FusedResBackbone:
                 x = conv(t, p2, rb, n, residual=x, ranked=ranked)
             return x
 
-        # stage 1 (conv_input + conv1): one SubM rulebook serves indice_keys 'subm1' and 'res1'
-        rb1 = S.rulebook_subm(indices, n1, grid1, 3)
+        # stage 1 (conv_input + conv1): one SubM rulebook serves indice_keys 'subm1' and 'res1'.  16-bit engines: the rulebook
+        # kernel writes the compact form (32 bytes per row, neighbours that exist only) beside the (27, cap) table: conv_input
+        # (5 input channels: 2.3x faster on the records) reads the records, the four 16 -> 16 layers stay on the matrix
+        # kernels and the table (16-channel rows are v_dot2c work on the VALU: 30 % slower there; FNP_ELL=1 runs them and the
+        # 16 -> 32 layer on records all the same, without any table).  f32, and while rulebooks are logged: tables only.
+        ell = (act in (torch.bfloat16, torch.float16) and self.rulebook_log is None and S.ELL_MODE is not False
+               and (int(P['in'][0].shape[2]), 16) in S.ELL_SHAPES and not isinstance(P['in'][0], S.PermutedWeight))
+        ell_used = []
+        ell_all = ell and S.ELL_MODE is True
+        if ell:
+            rb1 = S.rulebook_subm_ell(indices, n1, grid1, int(cap1 * self.ell_pool[0]) + 64, with_table=not ell_all)
+            ell_used.append((rb1._ell[2], rb1._ell[1], 0))
+        else:
+            rb1 = S.rulebook_subm(indices, n1, grid1, 3)
         x = conv(feats, P['in'], rb1, n1)
         x1 = blocks(x, rb1, n1, P['blocks1'])
         stage = [(x1, indices, n1, grid1)]
@@ -539,8 +574,12 @@ class FusedResBackbone:
             wd = P[down_key][0]
             fused = (act in (torch.bfloat16, torch.float16) and self.rulebook_log is None and tuple(dconv.kernel_size) == (3, 3, 3)
                      and (int(wd.shape[2]), int(wd.shape[1])) in S.FUSED_STRIDED_SHAPES)
+            ell_down = ell_all and li == 0 and tuple(dconv.kernel_size) == (3, 3, 3) and (int(wd.shape[2]), int(wd.shape[1])) in S.ELL_SHAPES
             rbs = S.rulebook_strided(idx_prev, n_prev, g_prev, dconv.kernel_size, dconv.stride, dconv.padding,
-                                     caps[li + 1], out_grid=grids[li + 1], want_nbr=not fused)
+                                     caps[li + 1], out_grid=grids[li + 1], want_nbr=not (fused or ell_down))
+            if ell_down:
+                S.ell_for_strided(rbs, int(caps[li + 1] * self.ell_pool[1]) + 64)
+                ell_used.append((rbs._ell[2], rbs._ell[1], 1))
             x = conv(x_prev, P[down_key], rbs, rbs.out_n)
             # stages 2-4: rows are in rank-grid order on both sides of the SubM convolutions; where they run on the tile
             # rulebook (stage 2, 32 channels), the rulebook kernel writes it in the same pass
@@ -566,10 +605,10 @@ class FusedResBackbone:
 
         shapes = self._stage_shapes()
         if not sync:
-            return {'stages': stage, 'shapes': shapes, 'caps': caps, 'batch_size': batch_size, 'aborts': aborts}
-        counts = torch.cat([s[2] for s in stage] + [aborts]).cpu().tolist()   # the one host sync
+            return {'stages': stage, 'shapes': shapes, 'caps': caps, 'batch_size': batch_size, 'aborts': aborts, 'ell_used': ell_used}
+        counts = torch.cat([s[2] for s in stage] + [aborts] + [u for u, _, _ in ell_used]).cpu().tolist()   # the one host sync
+        overflow = self._ell_overflow(counts, ell_used, cap1)
         self._check_aborts(counts.pop())
-        overflow = False
         for l in range(1, 5):
             if counts[l] > caps[l]:
                 self.cap_factor[l - 1] = max(self.cap_factor[l - 1] * 2.0, counts[l] * 1.25 / cap1)

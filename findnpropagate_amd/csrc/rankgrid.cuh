@@ -190,6 +190,33 @@ __device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, in
 }
 
 
+// strip -> nbr[k][o0 .. o0 + 63] for the K offsets (table stride `cap`); rows >= n are never written
+template <int K>
+__device__ __forceinline__ void nbr_flush(const int *__restrict__ strip_wave, int o0, int n, int cap, int *__restrict__ nbr) {
+    const int lane = fnp_lane();
+    if ((cap & 3) == 0) {   // 16-byte aligned rows of the table (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < (K * 16 + 63) / 64; ++j) {
+            const int e = j * 64 + lane, k = e >> 4, c = e & 15;
+            if (k < K) {
+                const int4 v = *reinterpret_cast<const int4 *>(strip_wave + k * 64 + c * 4);
+                const int o = o0 + c * 4;
+                if (o + 3 < n) *reinterpret_cast<int4 *>(nbr + (size_t)k * cap + o) = v;
+                else {
+                    if (o < n) nbr[(size_t)k * cap + o] = v.x;
+                    if (o + 1 < n) nbr[(size_t)k * cap + o + 1] = v.y;
+                    if (o + 2 < n) nbr[(size_t)k * cap + o + 2] = v.z;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (o0 + lane < n) nbr[(size_t)k * cap + o0 + lane] = strip_wave[k * 64 + lane];
+    }
+}
+
+
 // Device-wide exclusive scans (scan.hip).
 namespace fnp_scan {
 constexpr int kTile = 4096;  // elements per workgroup (256 threads x 16)

@@ -310,6 +310,61 @@ def tiled_fits(n_in_rows, channels, nbr_stride, cap_out):
 TILED_AUTO = (32, 64)
 
 
+# --------------------------------------------------------------------------------- compact rulebook (sparse-neighbourhood layers)
+ELL_SHAPES = {(4, 16), (5, 16), (16, 16), (16, 32)}   # (Cin, Cout) fnp_spconv_forward_ell covers (the first: f32 point features in)
+ELL_MODE = {"0": False, "1": True}.get(os.environ.get("FNP_ELL", ""))   # (development / tests: forbid or force)
+
+
+def ell_rulebook(coords, n_dev, cap, geom, in_grid, pool_records, nbr=None):
+    """Compact rulebook (fnp_rulebook_ell) of the rows whose cells are `coords`: returns (records, pool_records, pool_used).
+    nbr: optional (27, cap) int32 tensor that receives the table of the same rows in the same pass.
+    No host sync: the caller reads pool_used with its other counts and discards the result when it exceeds the pool."""
+    L = _l.load()
+    dev = coords.device
+    pool_records = max(int(pool_records), 0)
+    rec = torch.empty((int(L.fnp_ell_bytes(cap, pool_records)) // 4,), dtype=torch.int32, device=dev)
+    used = torch.empty((1,), dtype=torch.int32, device=dev)
+    rc = L.fnp_rulebook_ell(_l.ptr(coords), _l.ptr(n_dev), cap, geom, in_grid.c(), _l.ptr(rec), pool_records, _l.ptr(used), _l.ptr(nbr), _l.stream())
+    _l.check(rc, "fnp_rulebook_ell")
+    return rec, pool_records, used
+
+
+def rulebook_subm_ell(indices, n_dev, grid, pool_records, with_table=False):
+    """SubM 3x3x3 rulebook in the compact form (`_ell` set); with_table: the (27, cap) table too, from the same pass (else
+    Rulebook.nbr is None)."""
+    cap = max(indices.shape[0], 1)
+    geom, _ = make_geom(3, 1, 1, grid.shape, grid.shape)
+    nbr = torch.empty((27, cap), dtype=torch.int32, device=indices.device) if with_table else None
+    rb = Rulebook(nbr=nbr, K=27, cap_out=cap, geom=geom)
+    rb._ell = ell_rulebook(indices, n_dev, cap, geom, grid, pool_records, nbr=nbr)
+    return rb
+
+
+def ell_for_strided(rb, pool_records):
+    """Compact rulebook of a strided 3x3x3 layer built with want_nbr=False (its output coordinates + the input grid)."""
+    assert rb.nbr is None and rb.in_grid is not None and rb.K == 27
+    rb._ell = ell_rulebook(rb.out_indices, rb.out_n, rb.cap_out, rb.geom, rb.in_grid, pool_records)
+    return rb
+
+
+def conv_forward_ell(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, shift=None, residual=None, relu=False):
+    """conv_forward on the compact rulebook (`rb._ell`): the sparse-neighbourhood layers.  No host sync."""
+    L = _l.load()
+    rec, pool, _ = rb._ell
+    K, Cout, Cin = w_packed.shape
+    assert K == 27 and (Cin, Cout) in ELL_SHAPES and feat_in.shape[1] == Cin and feat_in.dtype == w_packed.dtype
+    assert feat_in.is_contiguous() and w_packed.is_contiguous() and not isinstance(w_packed, PermutedWeight)
+    out_dtype = out_dtype or feat_in.dtype
+    out = torch.empty((rb.cap_out, Cout), dtype=out_dtype, device=feat_in.device)
+    if residual is not None:
+        assert residual.dtype == out.dtype and residual.shape[1] == Cout and residual.is_contiguous()
+    rc = L.fnp_spconv_forward_ell(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed), _l.ptr(rec), rb.cap_out, pool,
+                                  _l.ptr(n_out_dev), _l.ptr(out), _l.dtype_code(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual),
+                                  int(bool(relu)), Cin, Cout, _l.stream())
+    _l.check(rc, "fnp_spconv_forward_ell")
+    return out
+
+
 SORTED_SHAPES = {(128, 128)}   # (Cin, Cout) fnp_spconv_forward_sorted covers
 # the class-sorted sweep pays from a few scenes on (one more small kernel per forward against ~20 % of four sweeps); 0 / 1 force it
 SORT_MODE = {"0": False, "1": True}.get(os.environ.get("FNP_SORT", ""))

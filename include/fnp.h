@@ -301,6 +301,34 @@ int fnp_spconv_forward_tiled(const void *feat_in, int dtype, int n_in_rows, cons
                              const float *scale, const float *shift, const void *residual, int relu,
                              int Cin, int Cout, fnp_stream_t stream);
 
+/* COMPACT RULEBOOK for the sparse-neighbourhood layers (conv_input 5 -> 16, the four 16 -> 16 SubM layers, the strided
+ * 16 -> 32 layer: spconv_backbone.py:193-210).  A stage-1 voxel has 3.6 of its 27 neighbours, an output site of the first
+ * strided layer 2.1 of 27 inputs: the (27, cap) int32 table spends 108 bytes per row on that and the matrix kernel a gather
+ * and a matrix step per (16-row block, offset).  fnp_rulebook_ell writes 32 bytes per row instead —
+ *     record = 8 x uint32: (k << 27) | input row, ascending k; 0xFFFFFFFF = empty; slot 7 may be (31 << 27) | e = link to
+ *     extension record e of a pool behind the cap_rows row records (rows with more than 8 neighbours)
+ * — and fnp_spconv_forward_ell sums sum_k W_k^T x over the entries that exist, on the VALU (v_dot2c_f32_bf16 /
+ * v_dot2_f32_f16 for 16-bit rows; the oracle's fmaf chain, bit for bit, for the f32 point features of conv_input), with the
+ * BatchNorm(eval) scale / shift, residual and ReLU epilogue of fnp_spconv_forward.
+ *   records    fnp_ell_bytes(cap_rows, pool_records) bytes, 16-byte aligned
+ *   coords     the rows' cells: the tensor's own coordinates (SubM: geom with in_shape == out_shape, stride 1, padding 1) or
+ *              the output coordinates of fnp_rulebook_strided(nbr = NULL) (strided 3x3x3: geom as given there)
+ *   pool_used  one int32 (device): ends as the number of extension records the rows asked for; above pool_records the
+ *              chains were cut and the caller must discard the result and come back with a larger pool
+ *   nbr        optional (27, cap) int32 table of the same rows (fnp_rulebook_subm's / fnp_rulebook_strided's), written in the
+ *              same pass: measured on MI355X the VALU convolution wins 2.3x on conv_input (5 input channels) and loses 30 %
+ *              on the 16-channel layers (256 products per pair are v_dot2c work at a quarter of the FMA rate), so the
+ *              backbone reads the records in conv_input and keeps the table for the four 16 -> 16 layers
+ * fnp_spconv_forward_ell: K = 27; (in_dtype FNP_F32, Cin 4 or 5, Cout 16, any out_dtype) or (in_dtype = out_dtype = FNP_BF16
+ * / FNP_F16, Cin 16, Cout 16 or 32); FNP_ERR_ARG otherwise.  weight: packed (27, Cout, Cin) in in_dtype. */
+long long fnp_ell_bytes(int cap_rows, int pool_records);
+int fnp_rulebook_ell(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom, const fnp_rankgrid *in_grid,
+                     void *records, int pool_records, int *pool_used, int *nbr, fnp_stream_t stream);
+int fnp_spconv_forward_ell(const void *feat_in, int in_dtype, int n_in_rows, const void *weight, const void *records,
+                           int cap_rows, int pool_records, const int *n_out, void *feat_out, int out_dtype,
+                           const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
+                           fnp_stream_t stream);
+
 /* CLASS-SORTED sweep of the 128 -> 128 SubM layers (the four 3x3x3 convolutions of stage 4, spconv_backbone.py:219-224).
  * After three stride-2 layers a lidar surface is two cells thick: ~36 % of the stage-4 sites have neighbours only in the
  * plane above, ~36 % only in the plane below.  fnp_rulebook_classsort orders the rows each persistent workgroup of the
