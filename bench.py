@@ -435,6 +435,7 @@ def main():
             "box_seeker": ([py, os.path.join(T, "bench_seeker.py"), "--batch", "64", "--cpu-scenes", "0"], 180),
             "extraction": ([py, os.path.join(T, "bench_extract.py"), "--scenes", "256", "--force-collective"], 240),
             "train_step": ([py, os.path.join(T, "bench_train.py"), "--batch", "16"], 240),
+            "first_bev_block": ([py, os.path.join(T, "bench_bev.py"), "--batch", "16"], 240),
         }
         for name, (cmd, to) in jobs.items():
             try:
