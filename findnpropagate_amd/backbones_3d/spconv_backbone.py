@@ -585,8 +585,9 @@ class FusedResBackbone:
             # rulebook (stage 2, 32 channels), the rulebook kernel writes it in the same pass
             ch = int(P[blk_key][0][0][0].shape[1])
             srt = S.sorted_by_default(ch, ch, act, caps[li + 1])
-            rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3,
-                                 tile_channels=ch if S.tiled_by_default(ch, act, caps[li + 1]) else None, masks=srt)
+            tiled = S.tiled_by_default(ch, act, caps[li + 1]) and S.tiled_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
+            rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3, tile_channels=ch if tiled else None, masks=srt,
+                                 lean_table=tiled and self.rulebook_log is None)   # (all four layers of the stage run tiled)
             if srt:
                 S.classsort(rb, rbs.out_n, ch)   # stage 4: the 128-channel layers sweep their rows class by class
             x = blocks(x, rb, rbs.out_n, P[blk_key], ranked=True)

@@ -224,7 +224,10 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_kernel(const int *__res
 // fnp_tile_rulebook_build makes from the table afterwards, without reading the table back): the 256 rows a workgroup
 // resolves per pass are one 256-row tile or two 128-row tiles, and the entries are restated from the LDS strips the int32
 // rows are flushed from.
-template <typename G>
+// LEAN: the int32 table is written only for the rows of tiles that hold an ESCAPE entry — the only rows the tiled
+// convolutions ever look up in it (rank-ordered inputs: ~1e-5 of the tiles; the 108 bytes per row of the full table were
+// two thirds of this kernel's stores).  For a caller whose every consumer of the table is fnp_spconv_forward_tiled.
+template <typename G, bool LEAN = false>
 __global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows, int cap,
                                                                      RG g, int *__restrict__ nbr, unsigned char *__restrict__ tile_rb) {
     constexpr int K = tilerb::kK, TPP = kThreads / G::TILE;   // tiles per pass
@@ -244,9 +247,10 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *
             const int4 c = reinterpret_cast<const int4 *>(coords)[o];
             nbr_row<3, 3, 3>(g, c.x, c.y - 1, c.z - 1, c.w - 1, strip_wave + lane, 64);
         }
-        nbr_flush<K>(strip_wave, base + (tid & ~63), n, cap, nbr);
+        if constexpr (!LEAN) nbr_flush<K>(strip_wave, base + (tid & ~63), n, cap, nbr);
         __syncthreads();   // empty tables
         const int tl = tid / G::TILE, r = tid % G::TILE, tile = base / G::TILE + tl;
+        int id_keep[LEAN ? K : 1];   // (LEAN: the row's int32 entries, kept for the rare tile that needs them in the table)
         const int wlo = max(0, tile * G::TILE - G::HALO);
         unsigned char *rec = tile_rb + (size_t)tile * G::REC;
         if (tile * G::TILE < n) {
@@ -254,6 +258,10 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *
             unsigned code[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) id[k] = o < n ? strip_wave[k * 64 + lane] : -1;
+            if constexpr (LEAN) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) id_keep[k] = id[k];
+            }
 #ifdef FNP_RBT_ABLATE
             bool any_esc = false;
             if (FNP_RBT_ABLATE & 1) {
@@ -285,6 +293,15 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *
         if (tile * G::TILE < n) {
             if (r < G::OVF) reinterpret_cast<int *>(rec + G::REC_FAR)[r] = table[tl][r];
             if (r < 16) rec[G::REC_ESC + r] = r < G::TILE / 32 ? (unsigned char)esc[tl * (G::TILE / 32) + r] : 0;
+            if constexpr (LEAN) {
+                int any = 0;
+#pragma unroll
+                for (int q = 0; q < G::TILE / 32; ++q) any |= esc[tl * (G::TILE / 32) + q];
+                if (any && o < n) {   // (uniform per tile) this tile's rows go to the table after all
+#pragma unroll
+                    for (int k = 0; k < K; ++k) nbr[(size_t)k * cap + o] = id_keep[k];
+                }
+            }
         }
         __syncthreads();   // (the next pass clears the tables and rewrites the strips)
     }
@@ -359,6 +376,22 @@ extern "C" int fnp_rulebook_subm_masked(const int *coords, const int *n_rows, in
         if (geom->ksize[d] != 3 || geom->in_shape[d] != geom->out_shape[d]) return FNP_ERR_ARG;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_kernel<3, 3, 3, true>), dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, coords,
                        n_rows, cap, fnp_rg_view(grid), nbr, rowmask);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+extern "C" int fnp_rulebook_subm_tiled_lean(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom, const fnp_rankgrid *grid,
+                                            int *nbr, int channels, void *tile_rb, fnp_stream_t stream) {
+    if (!coords || !n_rows || cap <= 0 || !nbr || !tile_rb || !geom_ok(geom) || !fnp_rg_valid(grid)) return FNP_ERR_ARG;
+    if (!shape_is(grid, geom->in_shape) || ((uintptr_t)tile_rb & 15) || (channels != 32 && channels != 64)) return FNP_ERR_ARG;
+    for (int d = 0; d < 3; ++d)
+        if (geom->ksize[d] != 3) return FNP_ERR_ARG;
+    if (channels == 32)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G32, true>), dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0,
+                           (hipStream_t)stream, coords, n_rows, cap, fnp_rg_view(grid), nbr, (unsigned char *)tile_rb);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G64, true>), dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0,
+                           (hipStream_t)stream, coords, n_rows, cap, fnp_rg_view(grid), nbr, (unsigned char *)tile_rb);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }

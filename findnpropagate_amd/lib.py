@@ -122,6 +122,7 @@ SIGNATURES = {
     "fnp_tile_rulebook_bytes": (c_int64, [c_int, c_int]),
     "fnp_tile_rulebook_build": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P]),
     "fnp_rulebook_subm_tiled": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, P]),
+    "fnp_rulebook_subm_tiled_lean": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, P]),
     "fnp_spconv_forward_tiled": (c_int, [P, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     "fnp_ell_bytes": (c_int64, [c_int, c_int]),
     "fnp_rulebook_ell": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, P, P]),

@@ -192,10 +192,13 @@ def clear_grids(jobs):
 
 
 # --------------------------------------------------------------------------------- rulebooks
-def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None, masks=False):
+def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None, masks=False, lean_table=False):
     """tile_channels (32 or 64, 3x3x3 only): also write the tile rulebook the `tile_channels`-channel layers of this rulebook
     run on (conv_forward's tiled path finds it with the rulebook), in the same pass.
-    masks (3x3x3 only): also write the per-row neighbour masks (`rb._rowmask`) the class sort of the 128-channel layers starts from."""
+    masks (3x3x3 only): also write the per-row neighbour masks (`rb._rowmask`) the class sort of the 128-channel layers starts from.
+    lean_table (with tile_channels): the int32 table gets only the rows the tiled convolutions can ask it for (tiles with escape
+    entries) — for a caller that runs nothing but conv_forward's tiled path on this rulebook (`rb._lean` is set: conv_forward
+    refuses any other kernel on it)."""
     L = _l.load()
     cap = max(indices.shape[0], 1)
     geom, _ = make_geom(ksize, 1, [k // 2 for k in _triple(ksize)], grid.shape, grid.shape)
@@ -203,10 +206,12 @@ def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None, masks=False):
     nbr = torch.empty((K, cap), dtype=torch.int32, device=indices.device)
     if tile_channels and K == 27 and os.environ.get("FNP_TILE_FUSED", "1") != "0":   # (0: development A/B — the stand-alone build on first use)
         t = torch.empty((L.fnp_tile_rulebook_bytes(cap, tile_channels),), dtype=torch.uint8, device=indices.device)
-        rc = L.fnp_rulebook_subm_tiled(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), tile_channels, _l.ptr(t), _l.stream())
+        fn = L.fnp_rulebook_subm_tiled_lean if lean_table else L.fnp_rulebook_subm_tiled
+        rc = fn(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), tile_channels, _l.ptr(t), _l.stream())
         _l.check(rc, "fnp_rulebook_subm_tiled")
         rb = Rulebook(nbr=nbr, K=K, cap_out=cap, geom=geom)
         rb._tile_rb = {tile_channels: t}
+        rb._lean = bool(lean_table)
         return rb
     if masks and K == 27:
         rowmask = torch.empty((cap,), dtype=torch.int32, device=indices.device)
@@ -431,6 +436,9 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
                                         _l.ptr(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual), int(bool(relu)), Cin, Cout, _l.stream())
         _l.check(rc, "fnp_spconv_forward_tiled")
         return out
+    if getattr(rb, "_lean", False):
+        raise _l.FnpError("this rulebook's int32 table holds the rows of escape tiles only (rulebook_subm(lean_table=True)): "
+                          "only the tiled convolution of its channel count may run on it")
     srt = getattr(rb, "_sorted", None)
     if (srt is not None and K == 27 and (Cin, Cout) in SORTED_SHAPES and feat_in.dtype in (torch.bfloat16, torch.float16)
             and out.dtype == feat_in.dtype and feat_in.shape[0] * Cin * 2 < 0x7fffffff):

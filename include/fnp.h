@@ -295,6 +295,12 @@ int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_
  * fnp_rulebook_subm followed by fnp_tile_rulebook_build leaves, without reading the table back. */
 int fnp_rulebook_subm_tiled(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom,
                             const fnp_rankgrid *grid, int *nbr, int channels, void *tile_rb, fnp_stream_t stream);
+/* The same, but the int32 table receives only the rows of tiles whose record holds an escape entry (the only rows
+ * fnp_spconv_forward_tiled ever looks up in it; ~1e-5 of the tiles of a rank-ordered tensor): for a caller whose every
+ * consumer of this rulebook is fnp_spconv_forward_tiled — the fused inference backbone; the int32 table was 108 of the 166
+ * bytes per row this kernel stores.  nbr must still be a (27, cap) buffer; rows outside such tiles stay unwritten. */
+int fnp_rulebook_subm_tiled_lean(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom,
+                                 const fnp_rankgrid *grid, int *nbr, int channels, void *tile_rb, fnp_stream_t stream);
 int fnp_spconv_forward_tiled(const void *feat_in, int dtype, int n_in_rows, const void *weight,
                              const void *tile_rb, const int *nbr, int nbr_stride,
                              const int *n_out, int cap_out, void *feat_out,

@@ -564,6 +564,15 @@ def test_tile_kernel_equals_gather_kernel(cuda, rng, n, order, dtype, C):
         b = S.conv_forward(x, wp, rb, n_dev, scale=scale, shift=shift, residual=residual, relu=relu, ranked=True, tile=True)
         c = S.conv_forward(x, wp, rb, n_dev, scale=scale, shift=shift, residual=residual, relu=relu, ranked=True, tile=False)
         assert torch.equal(a[:n], b[:n]) and torch.equal(a[:n], c[:n])
+    # the rulebook kernel that writes the tile rulebook itself, with the full table and with the lean one (int32 rows of escape
+    # tiles only: everything the tiled kernel may ask for): same output; any other kernel on the lean rulebook is refused
+    grid2 = S.build_grid(d_idx, n_dev, B, shape)
+    for lean in (False, True):
+        rb2 = S.rulebook_subm(d_idx, n_dev, grid2, 3, tile_channels=C, lean_table=lean)
+        d = S.conv_forward(x, wp, rb2, n_dev, scale=sc, shift=sh, residual=res, relu=True, ranked=True, tile=True)
+        assert torch.equal(d[:n], S.conv_forward(x, wp, rb, n_dev, scale=sc, shift=sh, residual=res, relu=True, ranked=False)[:n]), lean
+    with pytest.raises(S._l.FnpError, match="escape tiles only"):
+        S.conv_forward(x, wp, rb2, n_dev, ranked=True, tile=False)
 
 
 def _surface_sites(rng, B, shape, n):
