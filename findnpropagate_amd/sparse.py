@@ -373,7 +373,7 @@ def conv_forward_ell(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=Non
 SORTED_SHAPES = {(128, 128)}   # (Cin, Cout) fnp_spconv_forward_sorted covers
 # the class-sorted sweep pays from a few scenes on (one more small kernel per forward against ~20 % of four sweeps); 0 / 1 force it
 SORT_MODE = {"0": False, "1": True}.get(os.environ.get("FNP_SORT", ""))
-SORT_MIN_ROWS = 65536
+SORT_MIN_ROWS = 131072   # (row CAPACITY of the stage: a one-scene hipGraph has 65,536; from ~4 scenes on the sort pays)
 
 
 def sorted_by_default(cin, cout, dtype, cap):

@@ -40,6 +40,6 @@ def test_switches_and_size_limits():
     assert S.tiled_fits(1 << 20, 64, 1 << 20, 1 << 20)
     assert not S.tiled_fits(1 << 25, 64, 1 << 20, 1 << 20)          # 2^25 rows x 128 bytes = 4 GiB of features
     assert not S.tiled_fits(1 << 20, 64, 1 << 25, 1 << 20)          # the int32 table beyond 32-bit offsets
-    assert S.sorted_by_default(128, 128, torch.bfloat16, 1 << 20) and not S.sorted_by_default(128, 128, torch.bfloat16, 1000)
+    assert S.sorted_by_default(128, 128, torch.bfloat16, 1 << 20) and not S.sorted_by_default(128, 128, torch.bfloat16, 65536)
     assert not S.sorted_by_default(64, 64, torch.bfloat16, 1 << 20) and not S.sorted_by_default(128, 128, torch.float32, 1 << 20)
     assert (5, 16) in S.ELL_SHAPES and (16, 32) in S.ELL_SHAPES and (32, 32) not in S.ELL_SHAPES
