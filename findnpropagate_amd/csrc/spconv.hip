@@ -347,8 +347,13 @@ __device__ unsigned long long g_mfma_stamps[8];
 #else
 #define FNP_MS(ph)
 #endif
-template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut, bool FUSED = false, typename TAct = __bf16, bool SORTED = false>
-__global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const TAct *__restrict__ x, int x_bytes,
+// NWO: waves per workgroup when not the layer class's own (MfmaWg): the SMALL-INPUT form of the 128 -> 128 layers.  With a few
+// thousand rows (one scene: the reference's extraction runs batch size 1) every workgroup holds one 16-row block per wave, and an
+// offset then costs what eight waves need to read the whole 32 KB slab as A fragments — 256 KB of LDS reads for 128 rows;
+// four waves read half of that per row and the rows spread over twice the workgroups.
+template <int CIN, int COUT, int NWO> struct NwOf { static constexpr int value = NWO ? NWO : MfmaWg<CIN, COUT>::NW; };
+template <int CIN, int COUT, int MB, int KVOL, bool WIN, typename TOut, bool FUSED = false, typename TAct = __bf16, bool SORTED = false, int NWO = 0>
+__global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, COUT>::WAVES)) void spconv_mfma_kernel(const TAct *__restrict__ x, int x_bytes,
                                                              const TAct *__restrict__ w,
                                                              const int *__restrict__ nbr, int nbr_stride, int Krt,
                                                              const int *__restrict__ n_out, int cap,
@@ -356,6 +361,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                                                              const float *__restrict__ shift,
                                                              const TOut *__restrict__ residual, int relu, int hints, FusedRb frb, SortedRb srb) {
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
+    constexpr int NWX = NwOf<CIN, COUT, NWO>::value;
     static_assert(!SORTED || (KVOL == 27 && !WIN && !FUSED && !Cfg::PAIR && !Cfg::ALLK && sizeof(TOut) == 2), "sorted sweep: wide double-buffered 3x3x3 layers");
     using bf16x8 = typename Vec16<TAct>::v8;   // (named after the default activation type)
     using bf16x4 = typename Vec16<TAct>::v4;
@@ -363,12 +369,12 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     static_assert(!FUSED || (KVOL == 27 && !WIN), "fused rulebook: 3x3x3 strided layers");
     constexpr int CH = Cfg::CH, SLAB = Cfg::SLAB, SW = Cfg::SW, KS = Cfg::KS, PFK = Cfg::PFK;
     constexpr bool ALLK = Cfg::ALLK;
-    constexpr int XLB = Cfg::XLB, WROWS = Cfg::win_rows(MfmaWg<CIN, COUT>::NW, MB), WH = Cfg::WH;
+    constexpr int XLB = Cfg::XLB, WROWS = Cfg::win_rows(NWX, MB), WH = Cfg::WH;
     static_assert(!WIN || ((CH == 4 || CH == 8) && XLB <= PFK && PFK % XLB == 0), "window path: 32/64 input channels");
     constexpr int NB = COUT / 16;         // 16-channel output blocks
     constexpr int NBH = NB < 4 ? NB : 4;  // A fragments held at once
     constexpr int ROWS_PER_WAVE = MB * 16;
-    constexpr int NW = MfmaWg<CIN, COUT>::NW, NT = NW * 64;   // waves / threads per workgroup
+    constexpr int NW = NWX, NT = NW * 64;   // waves / threads per workgroup
     constexpr int ROWS_PER_WG = NW * ROWS_PER_WAVE;
     // weight staging of the double-buffered path: NCH chunks per thread per slab, WST per MFMA step
     constexpr int NCH = (SLAB + NT - 1) / NT;
@@ -383,7 +389,8 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
 #ifndef FNP_WD4
 #define FNP_WD4 1
 #endif
-    constexpr bool WD4 = FNP_WD4 && !ALLK && NW == 8 && NCH == KS && NCH == 4;
+    constexpr bool WD4 = FNP_WD4 && !ALLK && ((NW == 8 && NCH == KS && NCH == 4) || (NWO == 4 && NCH == 2 * KS && KS == 4));
+    constexpr int WDN = WD4 ? NCH / KS : 1;   // chunks per thread and MFMA step (2 in the four-wave small-input form)
     constexpr bool WPAIR = Cfg::WPAIR && WD4;
     static_assert(CIN % 16 == 0 && COUT % 16 == 0, "channel counts must be multiples of 16");
     static_assert(ALLK || SLAB % NT == 0 || SLAB < NT, "unsupported slab size");
@@ -428,14 +435,14 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
     // (FUSED: the entries of the wave's tile rows sit in its LDS strip [offset][row of the tile], -1 for rows past
     //  the range)
     constexpr int SR = MB * 16;   // rows of a wave tile
-    int *const fstrip = reinterpret_cast<int *>(fnp_smem + Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN) +
-                                                Cfg::epi_bytes(MfmaWg<CIN, COUT>::NW, WIN, sizeof(TOut) == 2)) + wave * (27 * SR);
+    int *const fstrip = reinterpret_cast<int *>(fnp_smem + Cfg::lds_bytes(NWX, MB, WIN) +
+                                                Cfg::epi_bytes(NWX, WIN, sizeof(TOut) == 2)) + wave * (27 * SR);
     int frow0 = 0;                // first row of the wave's current tile (set by the tile body)
     // BatchNorm scale and shift in LDS (behind every other region): an epilogue reads them per tile, and from L2 that is a
     // ~800-cycle round trip at the end of a sweep that takes 3-6 k cycles on the narrow layers
-    float *const ss_lds = reinterpret_cast<float *>(fnp_smem + Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN) +
-                                                    Cfg::epi_bytes(MfmaWg<CIN, COUT>::NW, WIN, sizeof(TOut) == 2) +
-                                                    (FUSED ? MfmaWg<CIN, COUT>::NW * 27 * MB * 16 * 4 : 0));
+    float *const ss_lds = reinterpret_cast<float *>(fnp_smem + Cfg::lds_bytes(NWX, MB, WIN) +
+                                                    Cfg::epi_bytes(NWX, WIN, sizeof(TOut) == 2) +
+                                                    (FUSED ? NWX * 27 * MB * 16 * 4 : 0));
     auto nbr_at = [&](int k, int r, int r_end) -> int {
         const int rc = r < r_end ? r : r_end - 1;
         const int kr = PAIR ? 2 * k + qk : k, KR = PAIR ? KVOL : K;
@@ -497,7 +504,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
         fnp_range_rows(n, range, G, row_begin, row_end);
     }
     if (row_begin >= row_end) return;  // before any barrier: safe early exit
-    for (int c = tid; c < 2 * COUT; c += MfmaWg<CIN, COUT>::NW * 64)   // (a barrier — weight staging or the first slab — lies before any epilogue)
+    for (int c = tid; c < 2 * COUT; c += NWX * 64)   // (a barrier — weight staging or the first slab — lies before any epilogue)
         ss_lds[c] = scale ? (c < COUT ? scale[c] : shift[c - COUT]) : (c < COUT ? 1.f : 0.f);
 
 #define FNP_LDS_POS(row, chunk) ((row) * CH + ((chunk) ^ (((row) >> SW) & (CH - 1))))
@@ -695,9 +702,11 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
         }
 
         uint4 wd0 = make_uint4(0u, 0u, 0u, 0u), wd1 = wd0, wd2 = wd0, wd3 = wd0;   // (named: see wcur0)
+        uint4 we0 = wd0, we1 = wd0, we2 = wd0, we3 = wd0;                          // (WDN == 2: the second chunk of a step)
         if (WD4 && !(FNP_ABLATE & 2)) {
             const uint4 *w1 = wslab(WPAIR ? 2 : 1);
-            wd0 = w1[tid]; wd1 = w1[tid + NT]; wd2 = w1[tid + 2 * NT]; wd3 = w1[tid + 3 * NT];
+            wd0 = w1[tid]; wd1 = w1[tid + WDN * NT]; wd2 = w1[tid + 2 * WDN * NT]; wd3 = w1[tid + 3 * WDN * NT];
+            if constexpr (WDN == 2) { we0 = w1[tid + NT]; we1 = w1[tid + 3 * NT]; we2 = w1[tid + 5 * NT]; we3 = w1[tid + 7 * NT]; }
         }
         FNP_MS(2);
         for (int k0 = 0; k0 < Kt; k0 += PFK) {
@@ -735,10 +744,15 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
                     if (WD4 && !(FNP_ABLATE & 2)) {
                         uint4 &wd = ks == 0 ? wd0 : ks == 1 ? wd1 : ks == 2 ? wd2 : wd3;
                         // chunk ks of W_{k+1} (WPAIR: of W_{k+2}, into the ring slot nobody has read since the last barrier)
-                        wl[(WPAIR ? ((k + 2) & 3) : ((k + 1) & 1)) * SLAB + st_pos0 + ks * NT] = wd;
+                        wl[(WPAIR ? ((k + 2) & 3) : ((k + 1) & 1)) * SLAB + st_pos0 + ks * WDN * NT] = wd;
                         constexpr int AH = WPAIR ? 3 : 2;
                         const uint4 *w2 = wslab(k + AH);
-                        wd = w2[tid + ks * NT];                                               // chunk ks of W_{k+2} (WPAIR: W_{k+3})
+                        wd = w2[tid + ks * WDN * NT];                                         // chunk ks of W_{k+2} (WPAIR: W_{k+3})
+                        if constexpr (WDN == 2) {
+                            uint4 &we = ks == 0 ? we0 : ks == 1 ? we1 : ks == 2 ? we2 : we3;
+                            wl[((k + 1) & 1) * SLAB + st_pos0 + (ks * 2 + 1) * NT] = we;
+                            we = w2[tid + (ks * 2 + 1) * NT];
+                        }
                     }
                     // (1) previous step's weight chunks -> other LDS buffer; (2) request this step's
                     if (!ALLK && !WDEEP && !WD4 && !(FNP_ABLATE & 2)) {
@@ -1061,7 +1075,7 @@ __global__ __launch_bounds__((MfmaWg<CIN, COUT>::NW * 64), (MfmaOcc<CIN, COUT>::
 
 // grid_only: write the workgroup count the launch would use for this capacity and return without launching (the class-sort
 // pass sorts the rows of exactly those ranges)
-template <int CIN, int COUT, int KVOL, bool WIN, typename TOut, bool FUSED = false, typename TAct = __bf16, bool SORTED = false>
+template <int CIN, int COUT, int KVOL, bool WIN, typename TOut, bool FUSED = false, typename TAct = __bf16, bool SORTED = false, int NWO = 0>
 int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
                   void *y, const float *scale, const float *shift, const void *residual, int relu, int hints, hipStream_t s,
                   const FusedRb *frb_in = nullptr, const SortedRb *srb_in = nullptr, int *grid_only = nullptr) {
@@ -1078,11 +1092,12 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
 #ifndef FNP_MB6464
 #define FNP_MB6464 2
 #endif
-    constexpr int MB = COUT >= 128 ? FNP_MB128 : (CIN == 16 && COUT <= 32) ? 2 : (CIN == 32 && COUT == 32) ? FNP_MB3232 : (CIN == 64 && COUT == 64) ? FNP_MB6464 : 4;
+    constexpr int NWX = NwOf<CIN, COUT, NWO>::value;
+    constexpr int MB = NWO ? 2 : COUT >= 128 ? FNP_MB128 : (CIN == 16 && COUT <= 32) ? 2 : (CIN == 32 && COUT == 32) ? FNP_MB3232 : (CIN == 64 && COUT == 64) ? FNP_MB6464 : 4;
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
-    auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut, FUSED, TAct, SORTED>;
-    constexpr int lds = Cfg::lds_bytes(MfmaWg<CIN, COUT>::NW, MB, WIN) + Cfg::epi_bytes(MfmaWg<CIN, COUT>::NW, WIN, sizeof(TOut) == 2) +
-                        (FUSED ? MfmaWg<CIN, COUT>::NW * 27 * MB * 16 * 4 : 0) + COUT * 8;   // (+ BatchNorm scale / shift)
+    auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut, FUSED, TAct, SORTED, NWO>;
+    constexpr int lds = Cfg::lds_bytes(NWX, MB, WIN) + Cfg::epi_bytes(NWX, WIN, sizeof(TOut) == 2) +
+                        (FUSED ? NWX * 27 * MB * 16 * 4 : 0) + COUT * 8;   // (+ BatchNorm scale / shift)
     FusedRb frb{};
     if (FUSED) {
         if (!frb_in) return FNP_ERR_ARG;
@@ -1094,8 +1109,8 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
         srb = *srb_in;
     }
     // workgroups a CU holds: by the register budget (launch bounds), and for the fused-rulebook form by its larger LDS
-    constexpr int wg_regs = MfmaOcc<CIN, COUT>::WAVES * 4 / MfmaWg<CIN, COUT>::NW;
-    constexpr int wg_per_cu = FUSED && lds * wg_regs > 160 * 1024 ? 160 * 1024 / lds : wg_regs;
+    constexpr int wg_regs = MfmaOcc<CIN, COUT>::WAVES * 4 / NWX;
+    constexpr int wg_per_cu = lds * wg_regs > 160 * 1024 ? 160 * 1024 / lds : wg_regs;
     static_assert(wg_per_cu >= 1 && lds * wg_per_cu <= 160 * 1024, "LDS budget of the resident workgroups");
     if (lds > 64 * 1024 && !grid_only) {
         static bool raised = false;  // (idempotent; a race only repeats the call)
@@ -1105,7 +1120,7 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
             raised = true;
         }
     }
-    const int tiles = fnp_divup(cap, MfmaWg<CIN, COUT>::NW * MB * 16);
+    const int tiles = fnp_divup(cap, NWX * MB * 16);
     // persistent grid: two workgroups per CU are resident (register / LDS budget of the wide
     // layers); the narrow ALLK layers stage all weights once per workgroup, so keep them few too.
     // The kernel splits the rows evenly over whatever grid it gets.
@@ -1113,7 +1128,7 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
     // Small inputs (a single scene: the reference's extraction runs batch size 1): with fewer full tiles than resident
     // workgroups most CUs would idle while a few sweep MB blocks per wave — split finer instead, down to one 16-site
     // block per wave (the kernel runs such a range as a partial tile).  The split never changes results.
-    const int fine = fnp_divup(cap, MfmaWg<CIN, COUT>::NW * 16);
+    const int fine = fnp_divup(cap, NWX * 16);
 #ifdef FNP_NO_FINE   // (development switch)
     const int grid = tiles < resident ? tiles : resident;
 #else
@@ -1123,7 +1138,7 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
         *grid_only = grid;
         return FNP_OK;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MfmaWg<CIN, COUT>::NW * 64), lds, s, (const TAct *)x, x_bytes, (const TAct *)w,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWX * 64), lds, s, (const TAct *)x, x_bytes, (const TAct *)w,
                        nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu, hints, frb, srb);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
@@ -1140,6 +1155,10 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
 #ifndef FNP_WIN64
 #define FNP_WIN64 1
 #endif
+#ifndef FNP_SMALL128
+#define FNP_SMALL128 1
+#endif
+#define FNP_MB128_DEFAULT 3
 template <int CIN, int COUT> struct HasWindow { static constexpr bool value = (FNP_WIN64 && CIN == 64 && COUT == 64) || (FNP_WIN32 && CIN == 32 && COUT == 32); };
 
 template <int CIN, int COUT, typename TOut, typename TAct>
@@ -1151,6 +1170,12 @@ int launch_mfma(const void *x, int x_bytes, const void *w, const int *nbr, int n
             if (hints & FNP_HINT_ROWS_RANKED)
                 return launch_mfma_k<CIN, COUT, 27, true, TOut, false, TAct>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale,
                                                                 shift, residual, relu, hints, s);
+        }
+        if constexpr (CIN == 128 && COUT == 128 && sizeof(TOut) == 2) {
+            // fewer rows than the persistent grid has 384-row tiles: the four-wave form (see NwOf)
+            if (cap < 256 * MfmaWg<CIN, COUT>::NW * FNP_MB128_DEFAULT * 16 && FNP_SMALL128)
+                return launch_mfma_k<CIN, COUT, 27, false, TOut, false, TAct, false, 4>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift,
+                                                                                        residual, relu, hints, s);
         }
         return launch_mfma_k<CIN, COUT, 27, false, TOut, false, TAct>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift,
                                                          residual, relu, hints, s);
