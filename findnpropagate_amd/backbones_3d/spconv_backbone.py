@@ -566,6 +566,8 @@ class FusedResBackbone:
         x1 = blocks(x, rb1, n1, P['blocks1'])
         stage = [(x1, indices, n1, grid1)]
         x_prev, idx_prev, n_prev, g_prev = x1, indices, n1, grid1
+        down_convs = (m.conv2[0][0], m.conv3[0][0], m.conv4[0][0], m.conv_out[0])
+        premarked = False     # did the previous stage's rulebook kernel mark this strided layer's output sites already?
         for li, (down_key, blk_key, dconv) in enumerate((('down2', 'blocks2', m.conv2[0][0]),
                                                           ('down3', 'blocks3', m.conv3[0][0]),
                                                           ('down4', 'blocks4', m.conv4[0][0]))):
@@ -576,7 +578,7 @@ class FusedResBackbone:
                      and (int(wd.shape[2]), int(wd.shape[1])) in S.FUSED_STRIDED_SHAPES)
             ell_down = ell_all and li == 0 and tuple(dconv.kernel_size) == (3, 3, 3) and (int(wd.shape[2]), int(wd.shape[1])) in S.ELL_SHAPES
             rbs = S.rulebook_strided(idx_prev, n_prev, g_prev, dconv.kernel_size, dconv.stride, dconv.padding,
-                                     caps[li + 1], out_grid=grids[li + 1], want_nbr=not (fused or ell_down))
+                                     caps[li + 1], out_grid=grids[li + 1], want_nbr=not (fused or ell_down), premarked=premarked)
             if ell_down:
                 S.ell_for_strided(rbs, int(caps[li + 1] * self.ell_pool[1]) + 64)
                 ell_used.append((rbs._ell[2], rbs._ell[1], 1))
@@ -586,8 +588,14 @@ class FusedResBackbone:
             ch = int(P[blk_key][0][0][0].shape[1])
             srt = S.sorted_by_default(ch, ch, act, caps[li + 1])
             tiled = S.tiled_by_default(ch, act, caps[li + 1]) and S.tiled_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
+            # the SubM rulebook kernel of this stage also marks the output sites of the NEXT strided layer (the coordinates are
+            # in its registers): that layer's own marking launch goes
+            nxt = down_convs[li + 1]
+            lean = tiled and self.rulebook_log is None   # (all four layers of the stage run tiled)
+            mark_next = (grids[li + 2], nxt.kernel_size, nxt.stride, nxt.padding) if (lean or srt) and S.MARK_FUSED else None
             rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3, tile_channels=ch if tiled else None, masks=srt,
-                                 lean_table=tiled and self.rulebook_log is None)   # (all four layers of the stage run tiled)
+                                 lean_table=lean, mark_next=mark_next)
+            premarked = bool(getattr(rb, "_marked_next", False))
             if srt:
                 S.classsort(rb, rbs.out_n, ch)   # stage 4: the 128-channel layers sweep their rows class by class
             x = blocks(x, rb, rbs.out_n, P[blk_key], ranked=True)
@@ -595,7 +603,7 @@ class FusedResBackbone:
             x_prev, idx_prev, n_prev, g_prev = x, rbs.out_indices, rbs.out_n, rbs.out_grid
         oconv = m.conv_out[0]
         rbo = S.rulebook_strided(idx_prev, n_prev, g_prev, oconv.kernel_size, oconv.stride, oconv.padding, caps[4],
-                                 out_grid=grids[4])
+                                 out_grid=grids[4], premarked=premarked)
         xo = conv(x_prev, P['out'], rbo, rbo.out_n, out_dtype=final_dtype or act)
         stage.append((xo, rbo.out_indices, rbo.out_n, rbo.out_grid))
 

@@ -107,9 +107,72 @@ __device__ __forceinline__ unsigned long long spread16(unsigned s) {
     return (unsigned long long)(s & 1u) | ((unsigned long long)(s & 2u) << 15) | ((unsigned long long)(s & 4u) << 30) |
            ((unsigned long long)(s & 8u) << 45);
 }
+// The output cells one input row (cell c of scene c.x; !valid: none) feeds, marked in the output grid `go`.  Every lane of the
+// wave must call it (wave-level merging: inputs in rank-grid order reach one output block from ~30 consecutive rows; the bits
+// of equal blocks are OR-ed along the wave — a lane may take in any earlier lane's bits of the same block — and the last lane
+// of each run issues the one atomic: same-address atomics serialise in L2).
+template <int SZ, int SY, int SX>
+__device__ __forceinline__ void mark2_row(bool valid, const int4 c, const RG &go, const Geom &ge, int lane) {
+    long long blk0 = -1;          // block of the first outputs (corner 0,0,0) and its bits
+    unsigned long long m0 = 0ull;
+    if (valid) {
+        const AxisOut az = axis_outputs<SZ>(c.y, ge.k[0], ge.s[0], ge.p[0], go.d.D);
+        const AxisOut ay = axis_outputs<SY>(c.z, ge.k[1], ge.s[1], ge.p[1], go.d.H);
+        const AxisOut ax = axis_outputs<SX>(c.w, ge.k[2], ge.s[2], ge.p[2], go.d.W);
+        if (az.any && ay.any && ax.any) {
+#pragma unroll
+            for (int cz = 0; cz < 2; ++cz) {
+                const unsigned sz = cz ? az.s1 : az.s0;
+                if (!sz) continue;
+#pragma unroll
+                for (int cy = 0; cy < 2; ++cy) {
+                    const unsigned sy = cy ? ay.s1 : ay.s0;
+                    if (!sy) continue;
+#pragma unroll
+                    for (int cx = 0; cx < 2; ++cx) {
+                        const unsigned sx = cx ? ax.s1 : ax.s0;
+                        if (!sx) continue;
+                        const unsigned long long m = (unsigned long long)(sx * spread4(sy)) * spread16(sz);
+                        const long long blk = rg_block_of(go.d, c.x, (az.b0 + cz) << 2, (ay.b0 + cy) << 2, (ax.b0 + cx) << 2);
+                        if (cz + cy + cx == 0) {
+                            blk0 = blk;
+                            m0 = m;
+                        } else {
+                            rg_mark_mask(go, blk, m);   // outputs across a block border: rare
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long nb = __shfl_up(blk0, d);
+        const unsigned long long nm = __shfl_up(m0, d);
+        if (lane >= d && nb == blk0) m0 |= nm;
+    }
+    const long long nxt = __shfl_down(blk0, 1);
+    if (blk0 >= 0 && (lane == 63 || nxt != blk0)) rg_mark_mask(go, blk0, m0);
+}
+
+// A marking job a rulebook kernel carries along (round 3): while it resolves the neighbours of the rows of stage l it also
+// marks, for the same rows (their coordinates are in its registers), the output sites of the strided convolution that
+// consumes stage l — the separate marking launch (a chain of dependent loads and atomics per wave) and its second read of
+// the coordinates go.  on == 0: nothing to mark.
+struct MarkJob {
+    RG go;
+    Geom ge;
+    int on;   // 0 none, 1 stride (2,2,2), 2 stride (2,1,1), 3 any stride with at most two outputs per cell and axis
+};
+__device__ __forceinline__ void mark_job_row(const MarkJob &mk, bool valid, const int4 c, int lane) {
+    if (mk.on == 1) mark2_row<2, 2, 2>(valid, c, mk.go, mk.ge, lane);
+    else if (mk.on == 2) mark2_row<2, 1, 1>(valid, c, mk.go, mk.ge, lane);
+    else if (mk.on == 3) mark2_row<0, 0, 0>(valid, c, mk.go, mk.ge, lane);
+}
+
 template <int SZ, int SY, int SX>
 // order: optional rank -> row map of the input grid (stage 1, whose rows are in the voxeliser's first-come
-// order): the inputs are then visited in rank order, which is what makes the wave-level merging below bite.
+// order): the inputs are then visited in rank order, which is what makes the wave-level merging bite.
 __global__ __launch_bounds__(kThreads) void strided_mark2_kernel(const int *__restrict__ in_coords,
                                                                  const int *__restrict__ n_in, int cap_in, RG go, Geom ge,
                                                                  const int *__restrict__ order) {
@@ -130,53 +193,11 @@ __global__ __launch_bounds__(kThreads) void strided_mark2_kernel(const int *__re
     int row_n;
     int4 c_n;
     fetch(0, row_n, c_n);
-    for (int it = 0; it < nround; ++it) {   // (whole waves stay in the loop: the shuffles below need them)
-        long long blk0 = -1;          // block of the first outputs (corner 0,0,0) and its bits
-        unsigned long long m0 = 0ull;
+    for (int it = 0; it < nround; ++it) {   // (whole waves stay in the loop: the shuffles need them)
         const int row = row_n;
         const int4 c = c_n;
         fetch(it + 1, row_n, c_n);
-        if (row >= 0) {
-            const AxisOut az = axis_outputs<SZ>(c.y, ge.k[0], ge.s[0], ge.p[0], go.d.D);
-            const AxisOut ay = axis_outputs<SY>(c.z, ge.k[1], ge.s[1], ge.p[1], go.d.H);
-            const AxisOut ax = axis_outputs<SX>(c.w, ge.k[2], ge.s[2], ge.p[2], go.d.W);
-            if (az.any && ay.any && ax.any) {
-#pragma unroll
-                for (int cz = 0; cz < 2; ++cz) {
-                    const unsigned sz = cz ? az.s1 : az.s0;
-                    if (!sz) continue;
-#pragma unroll
-                    for (int cy = 0; cy < 2; ++cy) {
-                        const unsigned sy = cy ? ay.s1 : ay.s0;
-                        if (!sy) continue;
-#pragma unroll
-                        for (int cx = 0; cx < 2; ++cx) {
-                            const unsigned sx = cx ? ax.s1 : ax.s0;
-                            if (!sx) continue;
-                            const unsigned long long m = (unsigned long long)(sx * spread4(sy)) * spread16(sz);
-                            const long long blk = rg_block_of(go.d, c.x, (az.b0 + cz) << 2, (ay.b0 + cy) << 2, (ax.b0 + cx) << 2);
-                            if (cz + cy + cx == 0) {
-                                blk0 = blk;
-                                m0 = m;
-                            } else {
-                                rg_mark_mask(go, blk, m);   // outputs across a block border: rare
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        // Inputs in rank-grid order reach one output block from ~30 consecutive rows.  OR the bits of
-        // equal blocks along the wave (a lane may take in any earlier lane's bits of the same block)
-        // and let the last lane of each run issue the one atomic: same-address atomics serialise in L2.
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const long long nb = __shfl_up(blk0, d);
-            const unsigned long long nm = __shfl_up(m0, d);
-            if (lane >= d && nb == blk0) m0 |= nm;
-        }
-        const long long nxt = __shfl_down(blk0, 1);
-        if (blk0 >= 0 && (lane == 63 || nxt != blk0)) rg_mark_mask(go, blk0, m0);
+        mark2_row<SZ, SY, SX>(row >= 0, c, go, ge, lane);
     }
 }
 
@@ -200,15 +221,19 @@ __global__ __launch_bounds__(kThreads) void strided_nbr_kernel(const int *__rest
 // MASKS: also write rowmask[o] = which of the K offsets row o has a neighbour at (the class sort of the 128-channel layers)
 template <int KZ, int KY, int KX, bool MASKS = false>
 __global__ __launch_bounds__(kThreads) void subm_nbr_row_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows,
-                                                                int cap, RG g, int *__restrict__ nbr, unsigned *__restrict__ rowmask = nullptr) {
+                                                                int cap, RG g, int *__restrict__ nbr, unsigned *__restrict__ rowmask = nullptr,
+                                                                MarkJob mk = MarkJob{}) {
     constexpr int K = KZ * KY * KX;
     __shared__ __attribute__((aligned(16))) int strips[kThreads / 64][K * 64];
     int *strip_wave = strips[threadIdx.x >> 6];
     const int n = min(*n_rows, cap);
     for (int base = blockIdx.x * kThreads; base < n; base += gridDim.x * kThreads) {   // (whole waves stay in the loop)
         const int o = base + threadIdx.x;
+        int4 cm = make_int4(0, 0, 0, 0);
+        if (o < n) cm = reinterpret_cast<const int4 *>(coords)[o];
+        if (mk.on) mark_job_row(mk, o < n, cm, fnp_lane());
         if (o < n) {
-            const int4 c = reinterpret_cast<const int4 *>(coords)[o];
+            const int4 c = cm;
             if constexpr (MASKS) {
                 unsigned msk;
                 nbr_row<KZ, KY, KX>(g, c.x, c.y - KZ / 2, c.z - KY / 2, c.w - KX / 2, strip_wave + fnp_lane(), 64, &msk);
@@ -229,7 +254,8 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_kernel(const int *__res
 // two thirds of this kernel's stores).  For a caller whose every consumer of the table is fnp_spconv_forward_tiled.
 template <typename G, bool LEAN = false>
 __global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows, int cap,
-                                                                     RG g, int *__restrict__ nbr, unsigned char *__restrict__ tile_rb) {
+                                                                     RG g, int *__restrict__ nbr, unsigned char *__restrict__ tile_rb,
+                                                                     MarkJob mk = MarkJob{}) {
     constexpr int K = tilerb::kK, TPP = kThreads / G::TILE;   // tiles per pass
     static_assert(kThreads % G::TILE == 0 && TPP * G::OVF <= kThreads, "at most one table slot per thread");
     __shared__ __attribute__((aligned(16))) int strips[kThreads / 64][K * 64];
@@ -243,8 +269,11 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *
         const int o = base + tid;
         if (tid < TPP * G::OVF) (&table[0][0])[tid] = -1;
         if (tid < kThreads / 32) esc[tid] = 0;
+        int4 cm = make_int4(0, 0, 0, 0);
+        if (o < n) cm = reinterpret_cast<const int4 *>(coords)[o];
+        if (mk.on) mark_job_row(mk, o < n, cm, lane);
         if (o < n) {
-            const int4 c = reinterpret_cast<const int4 *>(coords)[o];
+            const int4 c = cm;
             nbr_row<3, 3, 3>(g, c.x, c.y - 1, c.z - 1, c.w - 1, strip_wave + lane, 64);
         }
         if constexpr (!LEAN) nbr_flush<K>(strip_wave, base + (tid & ~63), n, cap, nbr);
@@ -349,6 +378,26 @@ static bool shape_is(const fnp_rankgrid *g, const int *shape) {
     return g->D == shape[0] && g->H == shape[1] && g->W == shape[2];
 }
 
+// mark_grid / mark_geom of a rulebook entry point -> the job its kernel carries (both NULL: none).  The rows whose rulebook is
+// being built are the INPUT sites of the strided convolution `mark_geom` (in_shape = their grid), `mark_grid` its output grid
+// (all zero, as fnp_rulebook_strided expects it).  Returns false for a geometry the closed-form marking does not cover.
+static bool make_mark_job(const fnp_rankgrid *rows_grid, const fnp_rankgrid *mark_grid, const fnp_conv_geom *mark_geom, MarkJob &mk) {
+    mk = MarkJob{};
+    if (!mark_grid && !mark_geom) return true;
+    if (!mark_grid || !geom_ok(mark_geom) || !fnp_rg_valid(mark_grid)) return false;
+    if (mark_grid->B != rows_grid->B || !shape_is(rows_grid, mark_geom->in_shape) || !shape_is(mark_grid, mark_geom->out_shape)) return false;
+    for (int d = 0; d < 3; ++d) {
+        const int expect = (mark_geom->in_shape[d] + 2 * mark_geom->padding[d] - mark_geom->ksize[d]) / mark_geom->stride[d] + 1;
+        if (expect != mark_geom->out_shape[d] || (mark_geom->ksize[d] + mark_geom->stride[d] - 1) / mark_geom->stride[d] > 2) return false;
+    }
+    mk.go = fnp_rg_view(mark_grid);
+    mk.go.perm = nullptr;
+    mk.ge = to_geom(mark_geom);
+    const int *st = mark_geom->stride;
+    mk.on = (st[0] == 2 && st[1] == 2 && st[2] == 2) ? 1 : (st[0] == 2 && st[1] == 1 && st[2] == 1) ? 2 : 3;
+    return true;
+}
+
 extern "C" int fnp_rulebook_subm(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom,
                                  const fnp_rankgrid *grid, int *nbr, fnp_stream_t stream) {
     if (!coords || !n_rows || cap <= 0 || !geom_ok(geom) || !fnp_rg_valid(grid) || !nbr) return FNP_ERR_ARG;
@@ -369,29 +418,35 @@ extern "C" int fnp_rulebook_subm(const int *coords, const int *n_rows, int cap, 
 }
 
 extern "C" int fnp_rulebook_subm_masked(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom, const fnp_rankgrid *grid,
-                                        int *nbr, unsigned *rowmask, fnp_stream_t stream) {
+                                        int *nbr, unsigned *rowmask, const fnp_rankgrid *mark_grid, const fnp_conv_geom *mark_geom,
+                                        fnp_stream_t stream) {
     if (!coords || !n_rows || cap <= 0 || !nbr || !rowmask || !geom_ok(geom) || !fnp_rg_valid(grid)) return FNP_ERR_ARG;
     if (!shape_is(grid, geom->in_shape)) return FNP_ERR_ARG;
     for (int d = 0; d < 3; ++d)
         if (geom->ksize[d] != 3 || geom->in_shape[d] != geom->out_shape[d]) return FNP_ERR_ARG;
+    MarkJob mk;
+    if (!make_mark_job(grid, mark_grid, mark_geom, mk)) return FNP_ERR_ARG;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_kernel<3, 3, 3, true>), dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0, (hipStream_t)stream, coords,
-                       n_rows, cap, fnp_rg_view(grid), nbr, rowmask);
+                       n_rows, cap, fnp_rg_view(grid), nbr, rowmask, mk);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
 
 extern "C" int fnp_rulebook_subm_tiled_lean(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom, const fnp_rankgrid *grid,
-                                            int *nbr, int channels, void *tile_rb, fnp_stream_t stream) {
+                                            int *nbr, int channels, void *tile_rb, const fnp_rankgrid *mark_grid,
+                                            const fnp_conv_geom *mark_geom, fnp_stream_t stream) {
     if (!coords || !n_rows || cap <= 0 || !nbr || !tile_rb || !geom_ok(geom) || !fnp_rg_valid(grid)) return FNP_ERR_ARG;
     if (!shape_is(grid, geom->in_shape) || ((uintptr_t)tile_rb & 15) || (channels != 32 && channels != 64)) return FNP_ERR_ARG;
     for (int d = 0; d < 3; ++d)
         if (geom->ksize[d] != 3) return FNP_ERR_ARG;
+    MarkJob mk;
+    if (!make_mark_job(grid, mark_grid, mark_geom, mk)) return FNP_ERR_ARG;
     if (channels == 32)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G32, true>), dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0,
-                           (hipStream_t)stream, coords, n_rows, cap, fnp_rg_view(grid), nbr, (unsigned char *)tile_rb);
+                           (hipStream_t)stream, coords, n_rows, cap, fnp_rg_view(grid), nbr, (unsigned char *)tile_rb, mk);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G64, true>), dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0,
-                           (hipStream_t)stream, coords, n_rows, cap, fnp_rg_view(grid), nbr, (unsigned char *)tile_rb);
+                           (hipStream_t)stream, coords, n_rows, cap, fnp_rg_view(grid), nbr, (unsigned char *)tile_rb, mk);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
@@ -412,10 +467,29 @@ extern "C" int fnp_rulebook_subm_tiled(const int *coords, const int *n_rows, int
     return FNP_OK;
 }
 
+static int rulebook_strided_impl(const int *in_coords, const int *n_in, int cap_in, const fnp_conv_geom *geom,
+                                 const fnp_rankgrid *in_grid, const fnp_rankgrid *out_grid, int *out_coords,
+                                 int *n_out, int cap_out, int *nbr, void *workspace, int64_t workspace_bytes,
+                                 fnp_stream_t stream, bool premarked);
+
 extern "C" int fnp_rulebook_strided(const int *in_coords, const int *n_in, int cap_in, const fnp_conv_geom *geom,
                                     const fnp_rankgrid *in_grid, const fnp_rankgrid *out_grid, int *out_coords,
                                     int *n_out, int cap_out, int *nbr, void *workspace, int64_t workspace_bytes,
                                     fnp_stream_t stream) {
+    return rulebook_strided_impl(in_coords, n_in, cap_in, geom, in_grid, out_grid, out_coords, n_out, cap_out, nbr, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int fnp_rulebook_strided_premarked(const int *in_coords, const int *n_in, int cap_in, const fnp_conv_geom *geom,
+                                              const fnp_rankgrid *in_grid, const fnp_rankgrid *out_grid, int *out_coords,
+                                              int *n_out, int cap_out, int *nbr, void *workspace, int64_t workspace_bytes,
+                                              fnp_stream_t stream) {
+    return rulebook_strided_impl(in_coords, n_in, cap_in, geom, in_grid, out_grid, out_coords, n_out, cap_out, nbr, workspace, workspace_bytes, stream, true);
+}
+
+static int rulebook_strided_impl(const int *in_coords, const int *n_in, int cap_in, const fnp_conv_geom *geom,
+                                 const fnp_rankgrid *in_grid, const fnp_rankgrid *out_grid, int *out_coords,
+                                 int *n_out, int cap_out, int *nbr, void *workspace, int64_t workspace_bytes,
+                                 fnp_stream_t stream, bool premarked) {
     hipStream_t s = (hipStream_t)stream;
     if (!in_coords || !n_in || cap_in <= 0 || cap_out <= 0 || !geom_ok(geom) || !fnp_rg_valid(in_grid) ||
         !fnp_rg_valid(out_grid) || !out_coords || !n_out || !workspace)
@@ -436,7 +510,10 @@ extern "C" int fnp_rulebook_strided(const int *in_coords, const int *n_in, int c
     bool two = true;   // at most two outputs per input cell and axis
     for (int d = 0; d < 3; ++d) two = two && (ge.k[d] + ge.s[d] - 1) / ge.s[d] <= 2;
     const dim3 mgrid(fnp_grid_for(cap_in, kThreads));
-    if (two && ge.s[0] == 2 && ge.s[1] == 2 && ge.s[2] == 2)
+    if (premarked) {
+        // (the output sites were marked by the kernel that built the rulebook of the input rows: fnp_rulebook_subm_masked /
+        //  fnp_rulebook_subm_tiled_lean with mark_grid = out_grid, mark_geom = geom)
+    } else if (two && ge.s[0] == 2 && ge.s[1] == 2 && ge.s[2] == 2)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_mark2_kernel<2, 2, 2>), mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge, (const int *)gi.perm);
     else if (two && ge.s[0] == 2 && ge.s[1] == 1 && ge.s[2] == 1)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(strided_mark2_kernel<2, 1, 1>), mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge, (const int *)gi.perm);

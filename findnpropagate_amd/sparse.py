@@ -192,33 +192,49 @@ def clear_grids(jobs):
 
 
 # --------------------------------------------------------------------------------- rulebooks
-def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None, masks=False, lean_table=False):
+def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None, masks=False, lean_table=False, mark_next=None):
     """tile_channels (32 or 64, 3x3x3 only): also write the tile rulebook the `tile_channels`-channel layers of this rulebook
     run on (conv_forward's tiled path finds it with the rulebook), in the same pass.
     masks (3x3x3 only): also write the per-row neighbour masks (`rb._rowmask`) the class sort of the 128-channel layers starts from.
     lean_table (with tile_channels): the int32 table gets only the rows the tiled convolutions can ask it for (tiles with escape
     entries) — for a caller that runs nothing but conv_forward's tiled path on this rulebook (`rb._lean` is set: conv_forward
-    refuses any other kernel on it)."""
+    refuses any other kernel on it).
+    mark_next (with lean_table or masks): (out_grid, ksize, stride, padding) of the strided convolution that consumes these rows —
+    the kernel marks its output sites in out_grid (all zero) on the way; rulebook_strided(..., premarked=True) then skips its
+    own marking launch.  `rb._marked_next` says whether it was done."""
     L = _l.load()
     cap = max(indices.shape[0], 1)
     geom, _ = make_geom(ksize, 1, [k // 2 for k in _triple(ksize)], grid.shape, grid.shape)
     K = geom.ksize[0] * geom.ksize[1] * geom.ksize[2]
     nbr = torch.empty((K, cap), dtype=torch.int32, device=indices.device)
+    mg, mgeom = None, None
+    if mark_next is not None:
+        out_grid, mk, ms, mp = mark_next
+        mgeom, _ = make_geom(mk, ms, mp, grid.shape)
+        if all((mgeom.ksize[d] + mgeom.stride[d] - 1) // mgeom.stride[d] <= 2 for d in range(3)):
+            mg = out_grid.c(with_perm=False)
+        else:
+            mgeom = None
     if tile_channels and K == 27 and os.environ.get("FNP_TILE_FUSED", "1") != "0":   # (0: development A/B — the stand-alone build on first use)
         t = torch.empty((L.fnp_tile_rulebook_bytes(cap, tile_channels),), dtype=torch.uint8, device=indices.device)
-        fn = L.fnp_rulebook_subm_tiled_lean if lean_table else L.fnp_rulebook_subm_tiled
-        rc = fn(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), tile_channels, _l.ptr(t), _l.stream())
+        if lean_table:
+            rc = L.fnp_rulebook_subm_tiled_lean(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), tile_channels, _l.ptr(t), mg, mgeom,
+                                                _l.stream())
+        else:
+            rc = L.fnp_rulebook_subm_tiled(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), tile_channels, _l.ptr(t), _l.stream())
         _l.check(rc, "fnp_rulebook_subm_tiled")
         rb = Rulebook(nbr=nbr, K=K, cap_out=cap, geom=geom)
         rb._tile_rb = {tile_channels: t}
         rb._lean = bool(lean_table)
+        rb._marked_next = bool(lean_table and mg is not None)
         return rb
     if masks and K == 27:
         rowmask = torch.empty((cap,), dtype=torch.int32, device=indices.device)
-        rc = L.fnp_rulebook_subm_masked(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), _l.ptr(rowmask), _l.stream())
+        rc = L.fnp_rulebook_subm_masked(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), _l.ptr(rowmask), mg, mgeom, _l.stream())
         _l.check(rc, "fnp_rulebook_subm_masked")
         rb = Rulebook(nbr=nbr, K=K, cap_out=cap, geom=geom)
         rb._rowmask = rowmask
+        rb._marked_next = mg is not None
         return rb
     rc = L.fnp_rulebook_subm(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), _l.stream())
     _l.check(rc, "fnp_rulebook_subm")
@@ -233,11 +249,12 @@ def tiled_by_default(channels, dtype, cap):
     return channels in TILED_AUTO and dtype in (torch.bfloat16, torch.float16)   # (measured ahead from 1 to 64 scenes per step)
 
 
-def rulebook_strided(indices, n_dev, grid, ksize, stride, padding, cap_out, out_grid=None, want_nbr=True):
+def rulebook_strided(indices, n_dev, grid, ksize, stride, padding, cap_out, out_grid=None, want_nbr=True, premarked=False):
     """Builds out grid + out indices (rank order) + nbr.  out_n is the TRUE count (may exceed
     cap_out: the caller checks it when it synchronises).  want_nbr=False: grid and coordinates only, for a layer
     that resolves its neighbours inside the convolution (conv_forward_strided); Rulebook.nbr is then None and
-    Rulebook.in_grid the input grid."""
+    Rulebook.in_grid the input grid.  premarked: out_grid already holds the output sites (rulebook_subm(mark_next=...) of the
+    input rows): the marking launch is skipped."""
     L = _l.load()
     dev = indices.device
     cap_in = max(indices.shape[0], 1)
@@ -250,9 +267,9 @@ def rulebook_strided(indices, n_dev, grid, ksize, stride, padding, cap_out, out_
     out_n = torch.empty((1,), dtype=torch.int32, device=dev)    # always written by fnp_rulebook_strided
     nbr = torch.empty((K, cap_out), dtype=torch.int32, device=dev) if want_nbr else None
     ws = torch.empty((int(L.fnp_rankgrid_workspace_bytes(grid.batch_size, *out_shape)),), dtype=torch.uint8, device=dev)
-    rc = L.fnp_rulebook_strided(_l.ptr(indices), _l.ptr(n_dev), cap_in, geom, grid.c(), out_grid.c(with_perm=False),
-                                _l.ptr(out_idx), _l.ptr(out_n), cap_out, _l.ptr(nbr), _l.ptr(ws), ws.numel(),
-                                _l.stream())
+    fn = L.fnp_rulebook_strided_premarked if premarked else L.fnp_rulebook_strided
+    rc = fn(_l.ptr(indices), _l.ptr(n_dev), cap_in, geom, grid.c(), out_grid.c(with_perm=False),
+            _l.ptr(out_idx), _l.ptr(out_n), cap_out, _l.ptr(nbr), _l.ptr(ws), ws.numel(), _l.stream())
     _l.check(rc, "fnp_rulebook_strided")
     return Rulebook(nbr=nbr, K=K, cap_out=cap_out, geom=geom, out_indices=out_idx, out_n=out_n, out_grid=out_grid,
                     out_shape=out_shape, in_grid=None if want_nbr else grid)
@@ -370,6 +387,10 @@ def conv_forward_ell(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=Non
     return out
 
 
+# the next stage's output sites marked by this stage's rulebook kernel (rulebook_subm(mark_next=...)): built and tested, OFF by
+# default — measured -1.1 % end to end at 64 scenes (the atomics' dependent chain lengthens every pass of the rulebook kernels,
+# which the stand-alone marking launch hides behind a grid of its own with the next row's coordinates prefetched)
+MARK_FUSED = os.environ.get("FNP_MARK_FUSED", "0") == "1"
 SORTED_SHAPES = {(128, 128)}   # (Cin, Cout) fnp_spconv_forward_sorted covers
 # the class-sorted sweep pays from a few scenes on (one more small kernel per forward against ~20 % of four sweeps); 0 / 1 force it
 SORT_MODE = {"0": False, "1": True}.get(os.environ.get("FNP_SORT", ""))

@@ -300,7 +300,17 @@ int fnp_rulebook_subm_tiled(const int *coords, const int *n_rows, int cap, const
  * consumer of this rulebook is fnp_spconv_forward_tiled — the fused inference backbone; the int32 table was 108 of the 166
  * bytes per row this kernel stores.  nbr must still be a (27, cap) buffer; rows outside such tiles stay unwritten. */
 int fnp_rulebook_subm_tiled_lean(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom,
-                                 const fnp_rankgrid *grid, int *nbr, int channels, void *tile_rb, fnp_stream_t stream);
+                                 const fnp_rankgrid *grid, int *nbr, int channels, void *tile_rb,
+                                 const fnp_rankgrid *mark_grid, const fnp_conv_geom *mark_geom, fnp_stream_t stream);
+/* mark_grid / mark_geom (both NULL: none; also on fnp_rulebook_subm_masked): the rows whose rulebook is built are the input
+ * sites of the NEXT strided convolution (mark_geom, in_shape = their grid); while the kernel has their coordinates in its
+ * registers it also marks that convolution's output sites in mark_grid (all zero on entry), so that
+ * fnp_rulebook_strided_premarked — fnp_rulebook_strided without its marking launch — can follow: the separate pass over the
+ * coordinates, a chain of dependent loads and atomics per wave, goes.  Geometries with at most two outputs per input cell and
+ * axis (ceil(k / s) <= 2); FNP_ERR_ARG otherwise. */
+int fnp_rulebook_strided_premarked(const int *in_coords, const int *n_in, int cap_in, const fnp_conv_geom *geom,
+                                   const fnp_rankgrid *in_grid, const fnp_rankgrid *out_grid, int *out_coords, int *n_out,
+                                   int cap_out, int *nbr, void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
 int fnp_spconv_forward_tiled(const void *feat_in, int dtype, int n_in_rows, const void *weight,
                              const void *tile_rb, const int *nbr, int nbr_stride,
                              const int *n_out, int cap_out, void *feat_out,
@@ -355,7 +365,8 @@ int fnp_spconv_forward_ell(const void *feat_in, int in_dtype, int n_in_rows, con
  * FNP_ERR_ARG otherwise. */
 long long fnp_classsort_workspace_bytes(int cap_out);
 int fnp_rulebook_subm_masked(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom,
-                             const fnp_rankgrid *grid, int *nbr, unsigned *rowmask, fnp_stream_t stream);
+                             const fnp_rankgrid *grid, int *nbr, unsigned *rowmask,
+                             const fnp_rankgrid *mark_grid, const fnp_conv_geom *mark_geom, fnp_stream_t stream);
 int fnp_rulebook_classsort(const int *nbr, int nbr_stride, int K, const unsigned *rowmask, const int *n_out, int cap_out, int Cin, int Cout,
                            int *perm, unsigned *blockmask, void *workspace, long long workspace_bytes, fnp_stream_t stream);
 int fnp_spconv_forward_sorted(const void *feat_in, int dtype, int n_in_rows, const void *weight, const int *nbr, int nbr_stride,

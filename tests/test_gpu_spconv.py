@@ -76,6 +76,32 @@ def test_strided_rulebook_bit_exact(cuda, oracle, rng, k, s, p):
     assert mine == want
 
 
+@pytest.mark.parametrize("k,s,p", [(3, 2, 1), (3, 2, (0, 1, 1)), ((3, 1, 1), (2, 1, 1), 0)])
+@pytest.mark.parametrize("how", ["masked", "lean32", "lean64"])
+def test_next_stage_sites_marked_by_the_rulebook_kernel(cuda, rng, k, s, p, how):
+    """rulebook_subm(mark_next=...) marks the output sites of the strided layer that consumes its rows while it resolves their
+    neighbours; rulebook_strided(premarked=True) then skips its own marking launch: same output sites, same order, same
+    table as the plain two-launch form (all three down-sampling geometries of the backbone, all three carrier kernels)."""
+    B, shape, n = 2, [21, 40, 44], 5000
+    _, idx = _random_sparse(rng, B, shape, n, 1)
+    idx = idx[np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))]
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    grid = S.build_grid(d_idx, n_dev, B, shape)
+    plain = S.rulebook_strided(d_idx, n_dev, grid, k, s, p, cap_out=n * 8)
+    out_grid = S.alloc_grid(B, plain.out_shape, cuda)
+    kw = {"masked": dict(masks=True), "lean32": dict(tile_channels=32, lean_table=True), "lean64": dict(tile_channels=64, lean_table=True)}[how]
+    rb = S.rulebook_subm(d_idx, n_dev, grid, 3, mark_next=(out_grid, k, s, p), **kw)
+    assert rb._marked_next
+    fused = S.rulebook_strided(d_idx, n_dev, grid, k, s, p, cap_out=n * 8, out_grid=out_grid, premarked=True)
+    m = int(plain.out_n.item())
+    assert int(fused.out_n.item()) == m
+    assert torch.equal(fused.out_indices[:m], plain.out_indices[:m])
+    assert torch.equal(fused.nbr[:, :m], plain.nbr[:, :m])
+    # and the rulebook the carrier built is its usual self
+    assert torch.equal(S.rulebook_subm(d_idx, n_dev, grid, 3).nbr[:, :n], rb.nbr[:, :n]) or how != "masked"
+
+
 @pytest.mark.parametrize("n", [1, 63, 1500])
 @pytest.mark.parametrize("Cin,Cout", [(5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (24, 40),
                                       (32, 16), (64, 32), (128, 64)])
