@@ -422,6 +422,27 @@ def main():
                     except Exception as e:   # the extra field is best effort: never lose the headline over it
                         row[f"{mode}_error"] = repr(e)[:200]
             row["graph_equals_stream"] = row.get("site_counts_graph") == row.get("site_counts_stream")
+            if b == 1:
+                # frames that arrive one at a time, 2 / 3 of them in flight (PointsPipeline: a hipGraph, an engine and a stream
+                # per slot): the frame RATE of a one-scene stream; the latency of a frame is ms_per_step_graph
+                for depth in (2, 3):
+                    try:
+                        with torch.no_grad():
+                            pipe = net.points_pipeline(1, cfg, depth=depth, capacity=65536)
+                            frames = [(p_b, o_b)] * 60
+                            for r_p in pipe.map(frames[:10]):
+                                pass
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                            for r_p in pipe.map(frames):
+                                pass
+                            torch.cuda.synchronize()
+                            dt = (time.perf_counter() - t0) / len(frames)
+                        row[f"scenes_per_s_graph_{depth}_in_flight"] = 1.0 / dt
+                        row[f"pipeline_{depth}_equals_stream"] = [int(c) for c in r_p["counts"]] == row.get("site_counts_stream")
+                        del pipe
+                    except Exception as e:
+                        row[f"pipeline_{depth}_error"] = repr(e)[:200]
             sweep[str(b)] = row
         out["batch_sweep"] = sweep
 

@@ -453,6 +453,43 @@ def test_graphed_forward_equals_eager(cuda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_points_pipeline_equals_eager_frame_by_frame(cuda, depth):
+    """PointsPipeline (one-scene frames, `depth` hipGraph replays in flight on their own streams, each slot with its own
+    engine): every frame's result equals forward_points', in submission order; a frame whose stage capacities are too small
+    is rerun through the engine's own overflow loop."""
+    from findnpropagate_amd import sparse as S, synthetic as syn
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 0).to(cuda).eval()
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+    frames, want = [], []
+    for seed in (0, 1, 2, 3, 4, 5, 6):
+        pts, off = syn.make_batch([seed])
+        if seed == 4:
+            pts, off = pts[:20000].copy(), np.array([0, 20000], np.int32)   # a shorter frame: the slot's stale padding must go
+        pts, off = torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda)
+        frames.append((pts, off))
+        with torch.no_grad():
+            w = net.forward_points(pts, off, 1, cfg)
+        want.append({k: (w[k].features.clone(), w[k].indices.clone()) for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out")} | {"counts": w["counts"]})
+    pipe = net.points_pipeline(1, cfg, depth=depth, capacity=65536)
+    with torch.no_grad():
+        for i, got in enumerate(pipe.map(frames)):
+            assert got["counts"] == want[i]["counts"], i
+            for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out"):
+                assert torch.equal(got[k].features, want[i][k][0]) and torch.equal(got[k].indices, want[i][k][1]), (i, k)
+        assert i == len(frames) - 1 and not pipe.pending
+        # capacities far too small in one slot: that frame goes through the engine's overflow loop, the others are untouched
+        pipe.engines[0].cap_factor = [0.5, 0.2, 0.1, 0.05]
+        pipe.slots[0] = None
+        for i, got in enumerate(pipe.map(frames[:3])):
+            for k in ("x_conv2", "out"):
+                assert torch.equal(got[k].features, want[i][k][0]) and torch.equal(got[k].indices, want[i][k][1]), (i, k)
+        assert pipe.engines[0].cap_factor[0] > 0.5
+
+
+@pytest.mark.gpu
 def test_capacity_overflow_regrows_eager_and_graphed(cuda):
     """Stage capacities that are too small are detected after the step (true counts live on the device),
     grown, the persistent grids wiped, and the step repeated — eager and hipGraph paths, same results."""
