@@ -93,6 +93,9 @@ struct Shared {
     float cwfc[kMaxCand][3];
     int cvalid[kMaxCand];
     int ccount[kMaxCand];
+    float cm1[kMaxCand];      // occlusion terms: range of the candidate's nearest corner
+    int cbeyond[kMaxCand];    //                  points of the frustum beyond that range
+    float cscore[kMaxCand];   // second-stage score (topk > 1: the 3D NMS walks them)
     float red_f[kThreads / 64][6];
     float q[3];
 };
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
     __syncthreads();
     const int m = (int)S.count;
     if (dbg_npts && tid == 0) dbg_npts[f] = m;
+    if (prm.count_only) return;   // (the pre-pass of MULTICAM_IOU: which frustums hold points at all)
     if (m == 0) {  // "no pts in box": the frustum is dropped (:634-637)
         if (tid == 0) out_valid[f] = 0;
         return;
@@ -230,7 +234,8 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
 
     // ---- C: frustum corners in lidar, weighted centre ---------------------------------------
     if (tid < 8) {
-        float fmax_ = fminf(qhi, prm.max_dist), fmin_ = fmaxf(qlo, 2.0f);          // :647-648
+        const float far_q = prm.search_depth > 0.f ? qlo + prm.search_depth : qhi;   // :617-622 (search_depth: a fixed depth behind the near quantile)
+        float fmax_ = fminf(far_q, prm.max_dist), fmin_ = fmaxf(qlo, 2.0f);        // :647-648
         const float lo3[3] = {x1, y1, fmin_}, hi3[3] = {x2, y2, fmax_};
         const float sx[8] = {1, 1, -1, -1, 1, 1, -1, -1}, sy[8] = {1, -1, -1, 1, 1, -1, -1, 1},
                     sz[8] = {-1, -1, -1, -1, 1, 1, 1, 1};
@@ -288,10 +293,21 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
     // ---- E: search positions along the frustum axis (:828-847) -------------------------------
     if (tid < prm.num_mags * 3) {
         const int i = tid / 3, a = tid % 3;
-        const float b0 = (S.fr[0][a] + S.fr[1][a]) / 2.0f, b1 = (S.fr[2][a] + S.fr[3][a]) / 2.0f;
-        const float b2 = (S.fr[4][a] + S.fr[5][a]) / 2.0f, b3 = (S.fr[6][a] + S.fr[7][a]) / 2.0f;
-        const float close = (b0 + b1) / 2.0f, far = (b2 + b3) / 2.0f;
-        S.bev_pts[i][a] = close + (far - close) * mags[i];
+        float close[3], vec[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const float b0 = (S.fr[0][e] + S.fr[1][e]) / 2.0f, b1 = (S.fr[2][e] + S.fr[3][e]) / 2.0f;
+            const float b2 = (S.fr[4][e] + S.fr[5][e]) / 2.0f, b3 = (S.fr[6][e] + S.fr[7][e]) / 2.0f;
+            close[e] = (b0 + b1) / 2.0f;
+            vec[e] = (b2 + b3) / 2.0f - close[e];
+        }
+        if (prm.search_depth > 0.f) {   // :841-842: the axis at unit length times the depth (a collapsed frustum gives NaN there too)
+            const float nrm = sqrtf(vec[0] * vec[0] + vec[1] * vec[1] + vec[2] * vec[2]);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) vec[e] = (vec[e] / nrm) * prm.search_depth;
+        }
+        if (prm.rand_noise) S.bev_pts[i][a] = S.wc[a] + prm.rand_noise[((size_t)f * prm.num_mags + i) * 3 + a];   // rand_center (:847)
+        else S.bev_pts[i][a] = close[a] + vec[a] * mags[i];
     }
     __syncthreads();
 
@@ -347,7 +363,48 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
         const float a1 = (bx2 - bx1) * (by2 - by1), a2 = (x2 - x1) * (y2 - y1);
         const float iw = fmaxf(fminf(bx2, x2) - fmaxf(bx1, x1), 0.f), ih = fmaxf(fminf(by2, y2) - fmaxf(by1, y1), 0.f);
         const float inter = iw * ih;
-        const float iou = inter / (a1 + a2 - inter);
+        float iou = inter / (a1 + a2 - inter);
+        if (prm.multicam) {
+            // multicam_ious (:1413-1429): the candidate against EVERY frustum of the scene with this label that holds points
+            // (this one included), each in its own camera; mean over the cameras that see it at all
+            float tot = 0.f;
+            int nz = 0;
+            for (int j = 0; j < prm.num_frustums; ++j) {
+                const float *fj = frusts + (size_t)j * 8;
+                if ((int)fj[0] != scene || (int)fj[6] != label || prm.npts_all[j] <= 0) continue;
+                const float *camj = cam_mats + ((size_t)scene * 6 + (int)fj[1]) * kCam;
+                float jx1 = INFINITY, jy1 = INFINITY, jx2 = -INFINITY, jy2 = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float u, v, d;
+                    project(S.aug_inv, S.aug_t, camj, ia, cor[k][0] + f2c[0], cor[k][1] + f2c[1], cor[k][2] + f2c[2], u, v, d);
+                    u = fminf(fmaxf(u, 0.f), (float)prm.image_w);
+                    v = fminf(fmaxf(v, 0.f), (float)prm.image_h);
+                    jx1 = fminf(jx1, u); jy1 = fminf(jy1, v); jx2 = fmaxf(jx2, u); jy2 = fmaxf(jy2, v);
+                }
+                const float ja1 = (jx2 - jx1) * (jy2 - jy1), ja2 = (fj[4] - fj[2]) * (fj[5] - fj[3]);
+                const float jw = fmaxf(fminf(jx2, fj[4]) - fmaxf(jx1, fj[2]), 0.f), jh = fmaxf(fminf(jy2, fj[5]) - fmaxf(jy1, fj[3]), 0.f);
+                const float ji = jw * jh;
+                const float v = ji / (ja1 + ja2 - ji);
+                tot = tot + v;
+                nz += v > 0.f;
+            }
+            iou = tot / ((float)nz + 1e-6f);
+        }
+        if (prm.occl_w > 0.f || prm.occl_mult) {
+            // range of the candidate's nearest corner, corners as boxes_to_corners_3d makes them from the final box (:423-426)
+            const float ca = cosf(box[6]), sa = sinf(box[6]);
+            float m1 = INFINITY;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float tx = ((k & 3) == 0 || (k & 3) == 1) ? 0.5f : -0.5f, ty = ((k & 3) == 0 || (k & 3) == 3) ? 0.5f : -0.5f, tz = k < 4 ? -0.5f : 0.5f;
+                const float lx = box[3] * tx, ly = box[4] * ty, lz = box[5] * tz;
+                const float cx = (lx * ca + ly * (-sa)) + box[0], cy = (lx * sa + ly * ca) + box[1], cz = lz + box[2];
+                m1 = fminf(m1, sqrtf(cx * cx + cy * cy + cz * cz));
+            }
+            S.cm1[c] = m1;
+        }
+        S.cbeyond[c] = 0;
 #pragma unroll
         for (int j = 0; j < 7; ++j) S.cbox[c][j] = box[j];
 #pragma unroll
@@ -375,8 +432,14 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
             y = lxyz[(size_t)i * 3 + 1];
             z = lxyz[(size_t)i * 3 + 2];
         }
+        const bool occl = prm.occl_w > 0.f || prm.occl_mult;
+        const float mag = occl ? sqrtf(x * x + y * y + z * z) : 0.f;
         for (int c = 0; c < NC; ++c) {
             if (S.cvalid[c] != 2) continue;   // wave-uniform
+            if (occl) {
+                const unsigned long long far = __ballot(have && mag > S.cm1[c]);
+                if (lane == 0 && far) atomicAdd(&S.cbeyond[c], __popcll(far));
+            }
             bool in = false;
             if (have && !(fabsf(z - S.cbox[c][2]) > S.cbox[c][5] * 0.5f)) {
                 const float sx = x - S.cbox[c][0], sy = y - S.cbox[c][1];
@@ -390,10 +453,14 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
     }
     __syncthreads();
 
-    // ---- H: second-stage score, best candidate ------------------------------------------------
+    // ---- H: second-stage score; the 3D NMS in score order and its first topk boxes (:994-1045) --------
     if (tid == 0) {
         int nmax = 0, any = 0;
-        float dmin = INFINITY, dmax = -INFINITY, emax = -INFINITY;
+        float dmin = INFINITY, dmax = -INFINITY, emax = -INFINITY, omax = -INFINITY;
+        const bool occl = prm.occl_w > 0.f || prm.occl_mult;
+        // calc_occl_scores as the reference RUNS it (:463): `mags` is (N, 1) and the in-box mask (N,), so the conjunction
+        // broadcasts to (N, N) and its sum is (points beyond the nearest corner) x (points outside the box)
+        auto occl_of = [&](int c) -> float { return (float)((long long)S.cbeyond[c] * (long long)(m - S.ccount[c])); };
         for (int c = 0; c < NC; ++c) {
             if (S.cvalid[c] >= 1) {   // dists are ranked over the distance-filtered set (:886-893)
                 dmin = fminf(dmin, S.cdist[c]);
@@ -404,10 +471,9 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
                 nmax = max(nmax, S.ccount[c]);
                 if (prm.ego_w > 0.f)   // distance of the candidate's centre to the ego vehicle (:1017-1019)
                     emax = fmaxf(emax, sqrtf(S.cbox[c][0] * S.cbox[c][0] + S.cbox[c][1] * S.cbox[c][1] + S.cbox[c][2] * S.cbox[c][2]));
+                if (occl) omax = fmaxf(omax, occl_of(c));
             }
         }
-        int best = -1;
-        float best_s = -INFINITY;
         for (int c = 0; c < NC; ++c) {
             if (S.cvalid[c] != 2) continue;
             const float soft = (float)S.ccount[c] / ((float)nmax + 1e-8f);
@@ -419,20 +485,61 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
             } else {                  // MULT, :999
                 s = soft * prm.dns_w * S.ciou[c] * prm.iou_w * dr * prm.dst_w;
             }
+            if (prm.occl_w > 0.f)     // :1007-1014
+                s = s + prm.occl_w * (1.0f - occl_of(c) / (omax + 1e-6f));
             if (prm.ego_w > 0.f) {    // :1017-1021
                 const float ego = sqrtf(S.cbox[c][0] * S.cbox[c][0] + S.cbox[c][1] * S.cbox[c][1] + S.cbox[c][2] * S.cbox[c][2]);
                 s = s + prm.ego_w * (ego / emax);
             }
-            if (s > best_s) {   // first maximum = order of a stable descending sort
-                best_s = s;
-                best = c;
+            if (prm.occl_mult)        // OCCL_MULT, :1022-1027: replaces the score
+                s = soft * S.ciou[c] * occl_of(c);
+            S.cscore[c] = s;
+        }
+        // nms_normal_gpu (:1030) in score order = pick the best unsuppressed candidate, drop those whose axis-aligned BEV
+        // footprint overlaps it beyond the threshold (iou3d_nms_kernel.cu:327-338), repeat; the first maximum is the order
+        // of a stable descending sort.  The shipped topk 1 needs the first pick only.
+        int kept = 0;
+        for (int k = 0; k < prm.topk; ++k) {
+            int best = -1;
+            float best_s = -INFINITY;
+            for (int c = 0; c < NC; ++c) {
+                if (S.cvalid[c] != 2) continue;
+                const float sc = S.cscore[c];   // (a NaN score — search_depth on a collapsed frustum — sorts first, as in torch.sort)
+                if (best < 0 || (sc != sc && best_s == best_s) || sc > best_s) {
+                    best_s = sc;
+                    best = c;
+                }
+            }
+            if (best < 0) break;
+            out_best[(size_t)f * prm.topk + k] = best;
+            out_score[(size_t)f * prm.topk + k] = best_s;
+            for (int j = 0; j < 7; ++j) out_box[((size_t)f * prm.topk + k) * 7 + j] = S.cbox[best][j];
+            ++kept;
+            S.cvalid[best] = 3;   // taken
+            if (k + 1 < prm.topk) {
+                const float *a = S.cbox[best];
+                for (int c = 0; c < NC; ++c) {
+                    if (S.cvalid[c] != 2) continue;
+                    const float *b = S.cbox[c];
+                    const float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+                    const float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+                    const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+                    const float interS = width * height;
+                    if (interS / fmaxf(a[3] * a[4] + b[3] * b[4] - interS, 1e-8f) > prm.nms_normal) S.cvalid[c] = 4;   // suppressed
+                }
             }
         }
-        out_valid[f] = any;
-        out_best[f] = best;
-        out_score[f] = any ? best_s : 0.f;
-        for (int j = 0; j < 7; ++j) out_box[(size_t)f * 7 + j] = any ? S.cbox[best][j] : 0.f;
+        for (int c = 0; c < NC; ++c)
+            if (S.cvalid[c] > 2) S.cvalid[c] = 2;   // (the dump below reports "scored")
+        out_valid[f] = kept;
+        for (int k = kept; k < prm.topk; ++k) {
+            out_best[(size_t)f * prm.topk + k] = -1;
+            out_score[(size_t)f * prm.topk + k] = 0.f;
+            for (int j = 0; j < 7; ++j) out_box[((size_t)f * prm.topk + k) * 7 + j] = 0.f;
+        }
+        (void)any;
     }
+    __syncthreads();
     if (dbg_cand)
         for (int i = tid; i < NC * 7; i += kThreads) dbg_cand[(size_t)f * NC * 7 + i] = S.cbox[i / 7][i % 7];
     if (dbg_iou)
@@ -590,7 +697,9 @@ extern "C" int fnp_boxseeker(const float *points, const int *scene_offsets, int 
     if (!params || num_scenes <= 0 || num_frustums < 0) return FNP_ERR_ARG;
     if (num_frustums == 0) return FNP_OK;
     const int NC = params->num_mags * params->num_rotations * params->num_sizes;
-    if (NC <= 0 || NC > kMaxCand || params->num_mags > 16 || params->point_stride < 3 || params->topk != 1) return FNP_ERR_ARG;
+    if (NC <= 0 || NC > kMaxCand || params->num_mags > 16 || params->point_stride < 3 || params->topk < 1 || params->topk > NC) return FNP_ERR_ARG;
+    if (params->multicam && !params->count_only && (!params->npts_all || params->num_frustums != num_frustums)) return FNP_ERR_ARG;
+    if (params->count_only && !dbg_npts) return FNP_ERR_ARG;
     if (!points || !scene_offsets || !scene_mats || !cam_mats || !frustums || !base_boxes || !base_corners || !mags ||
         !workspace || !out_valid || !out_box || !out_score || !out_best)
         return FNP_ERR_ARG;

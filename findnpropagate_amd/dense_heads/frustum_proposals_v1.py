@@ -110,16 +110,17 @@ class FrustumProposerOG(nn.Module):
         self.lq, self.uq, self.cq = lq, uq, cq
         self.iou_w, self.dst_w, self.dns_w, self.min_cam_iou = iou_w, dst_w, dns_w, min_cam_iou
         self.box_fmt = _get(model_cfg, 'BOX_FORMAT', 'xyxy')
-        # not built: MULTICAM_IOU / OCCL_MULT / occl_w (the reference's calc_occl_scores and multicam_ious paths), aln_w (a
-        # randomised torch.pca_lowrank per candidate: not reproducible), topk > 1, rand_center, search_depth — none of them
-        # is set by a shipped config (tools/cfgs/nuscenes_box_seeker_proposals.yaml:83)
-        unsupported = [n for n, v in (("MULTICAM_IOU", self.MULTICAM_IOU), ("OCCL_MULT", self.OCCL_MULT),
-                                       ("aln_w", self.aln_w), ("occl_w", self.occl_w),
-                                       ("rand_center", self.rand_center), ("search_depth", self.search_depth),
-                                       ("topk != 1", self.topk != 1), ("num_mags < 1", self.num_mags < 1),
-                                       ("BOX_FORMAT != xyxy", self.box_fmt != 'xyxy')) if v]
-        if unsupported:
-            raise NotImplementedError(f"FrustumProposerOG (fused MI355X path): options not built: {unsupported}")
+        # aln_w: the reference's own code path raises as soon as a candidate holds more than three points — IndexError at :988,
+        # a (1, N) mask on an (N, 3) tensor (fixture tests/golden/boxseeker_seed26.npz records it) — and would otherwise draw a
+        # randomised torch.pca_lowrank per candidate: there is no behaviour to mirror.  Everything else the constructor reads
+        # is built (topk through the 3D NMS, search_depth, rand_center, MULTICAM_IOU, occl_w / OCCL_MULT, xywh detections,
+        # num_mags 0): none of it is set by a shipped config (tools/cfgs/nuscenes_box_seeker_proposals.yaml:83).
+        if self.aln_w:
+            raise NotImplementedError("FrustumProposerOG: aln_w > 0 is not built — the reference itself raises IndexError "
+                                      "(frustum_proposals_v1.py:988) whenever a candidate box holds more than three points")
+        if int(self.topk) < 1:
+            raise ValueError("topk must be >= 1")
+        self.rand_noise = None   # rand_center: optional callable (F, num_mags, device) -> (F, num_mags, 3) draws (default torch.randn)
 
         anchors = torch.tensor([[4.63, 1.97, 1.74], [6.93, 2.51, 2.84], [6.37, 2.85, 3.19], [10.5, 2.94, 3.47],
                                 [12.29, 2.90, 3.87], [0.50, 2.53, 0.98], [2.11, 0.77, 1.47], [1.70, 0.60, 1.28],
@@ -136,7 +137,9 @@ class FrustumProposerOG(nn.Module):
             base_boxes[:, :, i, [3, 4, 5]] = base_boxes[:, :, i, [3, 4, 5]] * m
         self.register_buffer("base_corners", boxes_to_corners_3d(base_boxes.reshape(-1, 7)).reshape(anchors.shape[0], -1, 8, 3).contiguous(), persistent=False)
         self.register_buffer("base_boxes", base_boxes.reshape(anchors.shape[0], -1, 7).contiguous(), persistent=False)
-        self.register_buffer("mags", torch.linspace(self.mags_min, self.mags_max, self.num_mags), persistent=False)
+        # num_mags 0: one search position at the near face of the frustum (:831-834)
+        self.register_buffer("mags", torch.linspace(self.mags_min, self.mags_max, self.num_mags) if self.num_mags > 0 else torch.zeros(1),
+                             persistent=False)
 
         self.image_detector = image_detector
         if self.image_detector is None:
@@ -164,8 +167,12 @@ class FrustumProposerOG(nn.Module):
         p.lq, p.uq, p.cq = float(self.lq), float(self.uq), float(self.cq)
         p.iou_w, p.dst_w, p.dns_w = float(self.iou_w), float(self.dst_w), float(self.dns_w)
         p.min_cam_iou, p.max_dist = float(self.min_cam_iou), float(self.max_dist)
-        p.num_mags, p.num_rotations, p.num_sizes = int(self.num_mags), int(self.num_rotations), int(self.num_sizes)
-        p.topk, p.clamp_bottom = 1, int(self.clamp_bottom)
+        p.num_mags, p.num_rotations, p.num_sizes = max(int(self.num_mags), 1), int(self.num_rotations), int(self.num_sizes)
+        p.topk, p.clamp_bottom = int(self.topk), int(self.clamp_bottom)
+        p.nms_normal = float(self.nms_normal)
+        p.search_depth = float(self.search_depth) if self.search_depth is not None else 0.0
+        p.occl_w, p.occl_mult, p.multicam = float(self.occl_w), int(bool(self.OCCL_MULT)), int(bool(self.MULTICAM_IOU))
+        p.count_only, p.num_frustums, p.npts_all, p.rand_noise = 0, 0, None, None
         p.image_h, p.image_w = int(self.image_size[0]), int(self.image_size[1])
         p.point_stride, p.xyz_offset = int(point_stride), int(xyz_offset)
         p.has_img_aug, p.mult, p.ego_w = 0, int(bool(self.MULT)), float(self.ego_w)
@@ -193,7 +200,10 @@ class FrustumProposerOG(nn.Module):
                                           float(self.nms_2d), float(self.score_thr), _l.ptr(rows), rows.shape[0])
         if n < 0:
             _l.check(n, "fnp_host_enumerate_frustums")
-        return rows[:n].clone()
+        rows = rows[:n].clone()
+        if self.box_fmt != 'xyxy':   # :596-601: [x, y, w, h] detections; the 2D NMS above ran on the raw numbers, as the reference's does
+            rows[:, 4:6] += rows[:, 2:4]
+        return rows
 
     @staticmethod
     def _matrices(batch_dict):
@@ -233,13 +243,16 @@ class FrustumProposerOG(nn.Module):
                                      self.mags.to(dev).contiguous())
         return self._dev_tables[key]
 
-    def launch(self, batch_dict, debug=False):
+    def launch(self, batch_dict, debug=False, noise=None):
         """Enqueue the Box Seeker for every frustum of the batch and return WITHOUT synchronising:
         dict(frustums (F,8) f32 HOST rows [scene, cam, x1, y1, x2, y2, label, score] in the reference's enumeration
         order, d_frustums (the same on the device), out_valid (F,) i32, out_box (F,7), out_score (F,), out_best (F,) on
         the device, debug tensors), or None when the batch has no frustum.  batch_dict may carry 'points_per_scene' (host list of
         ints, the per-scene row counts the collate already knows): without it a batch of more than one scene costs one
-        host sync for the scene sizes."""
+        host sync for the scene sizes.
+        With topk > 1 the tables are in ROW form: frustum f takes rows f * topk .. f * topk + topk - 1 of frustums / d_frustums /
+        out_valid (1 for the boxes the 3D NMS kept) / out_box / out_score / out_best; out_count (F,) holds the number per frustum.
+        noise: rand_center's draws, (F, num_mags, 3) on the device (default: torch.randn there, as the reference draws them)."""
         L = _l.load()
         points = batch_dict['points']
         _l.require_device(points)
@@ -270,19 +283,38 @@ class FrustumProposerOG(nn.Module):
         scene_m, cam_m, d_fr = scene_m.to(dev, non_blocking=True), cam_m.to(dev, non_blocking=True), frusts.to(dev, non_blocking=True)
         prm = self._params(points.shape[1], 1)
         prm.has_img_aug = int(has_img_aug)
-        NC = self.num_mags * self.num_rotations * self.num_sizes
+        NM, TK = max(int(self.num_mags), 1), int(self.topk)
+        NC = NM * self.num_rotations * self.num_sizes
         ws = torch.empty((int(L.fnp_boxseeker_workspace_bytes(F, max_pts)),), dtype=torch.uint8, device=dev)
         out_valid = torch.zeros((F,), dtype=torch.int32, device=dev)
-        out_box = torch.zeros((F, 7), dtype=torch.float32, device=dev)
-        out_score = torch.zeros((F,), dtype=torch.float32, device=dev)
-        out_best = torch.full((F,), -1, dtype=torch.int32, device=dev)
+        out_box = torch.zeros((F * TK, 7), dtype=torch.float32, device=dev)
+        out_score = torch.zeros((F * TK,), dtype=torch.float32, device=dev)
+        out_best = torch.full((F * TK,), -1, dtype=torch.int32, device=dev)
+        keep = []
+        if self.rand_center:         # :847: the weighted centre plus unit Gaussian draws instead of positions along the frustum axis
+            if noise is None:
+                noise = self.rand_noise(F, NM, dev) if self.rand_noise is not None else torch.randn((F, NM, 3), dtype=torch.float32, device=dev)
+            noise = noise.to(dev).float().contiguous()
+            assert tuple(noise.shape) == (F, NM, 3)
+            prm.rand_noise = _l.ptr(noise)
+            keep.append(noise)
+        t_boxes, t_corners, t_mags = self._tables(dev)
+        if self.MULTICAM_IOU:        # pre-pass: which frustums hold points at all (only those enter the reference's lists, :683-692)
+            npts_all = torch.zeros((F,), dtype=torch.int32, device=dev)
+            prm.count_only = 1
+            rc = L.fnp_boxseeker(_l.ptr(points), _l.ptr(offsets), B, max_pts, prm, _l.ptr(scene_m), _l.ptr(cam_m),
+                                 _l.ptr(d_fr), F, _l.ptr(t_boxes), _l.ptr(t_corners), _l.ptr(t_mags), _l.ptr(ws), ws.numel(),
+                                 _l.ptr(out_valid), _l.ptr(out_box), _l.ptr(out_score), _l.ptr(out_best),
+                                 _l.ptr(npts_all), None, None, None, None, None, _l.stream())
+            _l.check(rc, "fnp_boxseeker (point counts)")
+            prm.count_only, prm.num_frustums, prm.npts_all = 0, F, _l.ptr(npts_all)
+            keep.append(npts_all)
         dbg = {}
         if debug:
             dbg = dict(npts=torch.zeros((F,), dtype=torch.int32, device=dev), frust=torch.zeros((F, 8, 3), device=dev),
                        cand=torch.zeros((F, NC, 7), device=dev), iou=torch.zeros((F, NC), device=dev),
                        count=torch.zeros((F, NC), dtype=torch.int32, device=dev),
                        valid=torch.zeros((F, NC), dtype=torch.int32, device=dev))
-        t_boxes, t_corners, t_mags = self._tables(dev)
         rc = L.fnp_boxseeker(_l.ptr(points), _l.ptr(offsets), B, max_pts, prm, _l.ptr(scene_m), _l.ptr(cam_m),
                              _l.ptr(d_fr), F, _l.ptr(t_boxes), _l.ptr(t_corners),
                              _l.ptr(t_mags), _l.ptr(ws), ws.numel(),
@@ -290,17 +322,21 @@ class FrustumProposerOG(nn.Module):
                              _l.ptr(dbg.get('npts')), _l.ptr(dbg.get('frust')), _l.ptr(dbg.get('cand')),
                              _l.ptr(dbg.get('iou')), _l.ptr(dbg.get('count')), _l.ptr(dbg.get('valid')), _l.stream())
         _l.check(rc, "fnp_boxseeker")
+        out_count = out_valid
+        if TK > 1:   # row form (device ops, no sync): one row per (frustum, rank), valid while rank < the frustum's box count
+            out_valid = (torch.arange(TK, device=dev, dtype=torch.int32)[None, :] < out_count[:, None]).to(torch.int32).reshape(-1)
+            frusts, d_fr = frusts.repeat_interleave(TK, 0), d_fr.repeat_interleave(TK, 0)
         # (the launch is asynchronous: the tensors it reads must outlive this call)
-        return dict(frustums=frusts, d_frustums=d_fr, out_valid=out_valid, out_box=out_box, out_score=out_score,
-                    out_best=out_best, dbg=dbg, _keep=(points, offsets, scene_m, cam_m, ws))
+        return dict(frustums=frusts, d_frustums=d_fr, out_valid=out_valid, out_count=out_count, out_box=out_box, out_score=out_score,
+                    out_best=out_best, dbg=dbg, _keep=(points, offsets, scene_m, cam_m, ws, keep))
 
-    def get_proposals(self, batch_dict, debug=False):
+    def get_proposals(self, batch_dict, debug=False, noise=None):
         """-> proposal_boxes (K,7) device f32, frust_labels (K,) long CPU, frust_scores (K,) f32 CPU,
         frust_batch_idx (K,) long CPU — the tuple of :1055-1067."""
         dev = batch_dict['points'].device
         empty = (torch.zeros((0, 7), device=dev), torch.zeros((0,), dtype=torch.long), torch.zeros((0,)),
                  torch.zeros((0,), dtype=torch.long))
-        r = self.launch(batch_dict, debug=debug)
+        r = self.launch(batch_dict, debug=debug, noise=noise)
         if r is None:
             return empty
         frusts, out_box = r['frustums'], r['out_box']

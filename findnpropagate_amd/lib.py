@@ -61,6 +61,9 @@ class SeekerParams(ctypes.Structure):
         ("topk", c_int), ("clamp_bottom", c_int), ("image_h", c_int), ("image_w", c_int),
         ("point_stride", c_int), ("xyz_offset", c_int),
         ("has_img_aug", c_int), ("mult", c_int), ("ego_w", c_float),
+        ("nms_normal", c_float), ("search_depth", c_float), ("occl_w", c_float),
+        ("occl_mult", c_int), ("multicam", c_int), ("count_only", c_int), ("num_frustums", c_int),
+        ("npts_all", ctypes.c_void_p), ("rand_noise", ctypes.c_void_p),
     ]
 
 

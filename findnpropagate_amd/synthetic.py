@@ -231,7 +231,14 @@ SEEKER_VARIANTS = {3: ("aug",), 4: ("aug", "flip"), 5: ("aug", "empty_cam"), 6: 
                    13: ("aug", "lone_point"), 14: ("img_aug",), 15: ("aug", "img_aug", "empty_cam")}
 # Parity seeds that run with other than the shipped PARAMS / model_cfg (the reference's optional score terms):
 # key -> (PARAMS overrides, model_cfg overrides)
-SEEKER_PARAM_VARIANTS = {16: ({"dst_w": 0.5}, {"MULT": True}), 17: ({"ego_w": 0.4}, {})}
+SEEKER_PARAM_VARIANTS = {16: ({"dst_w": 0.5}, {"MULT": True}), 17: ({"ego_w": 0.4}, {}),
+                         # the options no shipped config sets (frustum_proposals_v1.py:154-196): several boxes per frustum through
+                         # the 3D NMS, a fixed search depth, the multi-camera IoU, the occlusion terms, random search positions,
+                         # xywh detections, a single search position, and aln_w (the reference raises: see the mirror)
+                         18: ({"topk": 3, "nms_normal": 0.3}, {}), 19: ({"search_depth": 3.0}, {}), 20: ({}, {"MULTICAM_IOU": True}),
+                         21: ({"occl_w": 0.5}, {}), 22: ({}, {"OCCL_MULT": True}), 23: ({"rand_center": True}, {}),
+                         24: ({}, {"BOX_FORMAT": "xywh"}), 25: ({"num_mags": 0}, {}), 26: ({"aln_w": 0.3}, {}),
+                         27: ({"topk": 2, "search_depth": 4.0, "occl_w": 0.3, "dst_w": 0.2}, {"MULTICAM_IOU": True})}
 LONE_POINT = np.array([15.0, 0.3, 4.5], np.float32)      # elevation 16.7 deg: above the top beam (10.67 deg)
 
 

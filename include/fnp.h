@@ -476,7 +476,7 @@ typedef struct fnp_seeker_params {
     float min_cam_iou;           /* :904 */
     float max_dist;              /* :871, also caps the frustum depth (:647) */
     int num_mags, num_rotations, num_sizes;
-    int topk;                    /* must be 1 */
+    int topk;                    /* boxes per frustum: the first topk of the 3D NMS in score order (:1030-1045); >= 1 */
     int clamp_bottom;            /* :817 */
     int image_h, image_w;        /* 900, 1600 (:205) */
     int point_stride;            /* floats per point row */
@@ -484,6 +484,16 @@ typedef struct fnp_seeker_params {
     int has_img_aug;             /* cam_mats carries a non-identity img_aug_matrix (:1456-1458, :1525-1527) */
     int mult;                    /* MODEL_CFG.MULT: product instead of sum of the score terms (:997-1000) */
     float ego_w;                 /* PARAMS ego_w: + ego_w * ||centre|| / max ||centre|| (:1017-1021) */
+    /* ABI 8 — the options no shipped configuration sets (:154-196) */
+    float nms_normal;            /* threshold of that NMS on the axis-aligned BEV footprints (nms_normal_gpu, :1030) */
+    float search_depth;          /* > 0: frustum far plane = near quantile + search_depth, search axis of that length (:617-622,:841) */
+    float occl_w;                /* + occl_w * (1 - occl / max occl), occl = calc_occl_scores as it runs (:1007-1014, :408-477) */
+    int occl_mult;               /* MODEL_CFG.OCCL_MULT: score = density * IoU * occl (:1022-1027) */
+    int multicam;                /* MODEL_CFG.MULTICAM_IOU: IoU averaged over the cameras of the scene's same-label frustums (:885, :1413) */
+    int count_only;              /* pre-pass of multicam: only dbg_npts (points per frustum) is written */
+    int num_frustums;            /* rows of npts_all (= num_frustums of the call) */
+    const int *npts_all;         /* multicam: points per frustum from the count_only pre-pass (device) */
+    const float *rand_noise;     /* rand_center (:847): (num_frustums, num_mags, 3) draws added to the weighted centre, or NULL */
 } fnp_seeker_params;
 
 int64_t fnp_boxseeker_workspace_bytes(int num_frustums, int max_points_per_scene);
@@ -509,8 +519,8 @@ int fnp_host_enumerate_frustums(const float *boxes, const int64_t *labels, const
  * frustums (F,8) f32: scene, camera, x1, y1, x2, y2, label (1-based), score — already NMS'ed,
  *                        score-filtered and in the reference's enumeration order (:582-594).
  * base_boxes (10,R,7), base_corners (10,R,8,3), R = num_rotations*num_sizes (:284-298); mags (num_mags,).
- * Outputs per frustum: out_valid (1 = a candidate survived), out_box (7), out_score (second-stage
- * score), out_best (candidate index).  dbg_* are optional (NULL) per-candidate dumps:
+ * Outputs per frustum: out_valid (number of boxes, 0 .. topk), out_box (topk, 7), out_score (topk: second-stage
+ * scores), out_best (topk: candidate indices, -1 past out_valid).  dbg_* are optional (NULL) per-candidate dumps:
  * dbg_npts (F), dbg_frust (F,8,3), dbg_cand (F,NC,7), dbg_iou (F,NC), dbg_count (F,NC),
  * dbg_valid (F,NC: 0 dropped by max_dist, 1 dropped by min_cam_iou, 2 scored). */
 int fnp_boxseeker(const float *points, const int *scene_offsets, int num_scenes, int max_points_per_scene,

@@ -1,6 +1,9 @@
 """CPU restatement (numpy, float32) of the Greedy Box Seeker: FrustumProposerOG.get_proposals of
 pcdet/models/dense_heads/frustum_proposals_v1.py for the shipped configuration
-(tools/cfgs/nuscenes_box_seeker_proposals.yaml:83), without its debug/Blender branches.
+(tools/cfgs/nuscenes_box_seeker_proposals.yaml:83) and for the options no shipped configuration sets (topk > 1 through
+the 3D NMS, search_depth, rand_center, MULTICAM_IOU, occl_w / OCCL_MULT, BOX_FORMAT xywh, num_mags 0), without its
+debug/Blender branches.  aln_w is not restated: the reference's own code path raises (IndexError, :988) as soon as a
+candidate holds more than three points (fixture tests/golden/boxseeker_seed26.npz records it).
 
 TEST INFRASTRUCTURE ONLY (see oracle/fnp_oracle.c).  Pinned stage by stage against
 tests/golden/boxseeker_seed*.npz, which were produced by running the reference's own
@@ -19,7 +22,24 @@ ANCHORS = np.array([[4.63, 1.97, 1.74], [6.93, 2.51, 2.84], [6.37, 2.85, 3.19], 
 # MULT (model_cfg key, :997-1000) and ego_w (:1017-1021) are accepted in `params` too
 DEFAULT_PARAMS = dict(MULT=False, ego_w=0.0, lq=0.0, uq=0.25, cq=1.0, iou_w=1.0, nms_normal=1.0, dst_w=0.0, dns_w=1.0, min_cam_iou=0.3,
                       score_thr=0.45, nms_2d=0.4, nms_3d=0.0, clamp_bottom=1, num_sizes=1, num_mags=6, num_rotations=10,
-                      size_min=0.957, size_max=1.2, ry_min=0.0, ry_max=float(np.pi), max_dist=50.0, topk=1)
+                      size_min=0.957, size_max=1.2, ry_min=0.0, ry_max=float(np.pi), max_dist=50.0, topk=1,
+                      # options outside the shipped yaml (:154-196); model_cfg keys MULTICAM_IOU / OCCL_MULT / BOX_FORMAT included
+                      search_depth=None, rand_center=False, occl_w=0.0, OCCL_MULT=False, MULTICAM_IOU=False, BOX_FORMAT="xyxy")
+
+
+def occl_scores(boxes, xyz):
+    """calc_occl_scores (:408-477).  Meant as: per candidate the number of the frustum's points that lie beyond the
+    candidate's nearest corner (range from the sensor) without being inside it.  What the reference computes: `mags` is
+    (N, 1) (norm with keepdim, :1008) and the in-box mask (N,), so `(mags > m1) & ~mask` broadcasts to (N, N) and its sum is
+    the PRODUCT of the two counts — (points beyond the nearest corner) x (points outside the box).  Restated as it runs."""
+    mags = np.sqrt((xyz * xyz).sum(1)).astype(F)
+    corners = boxes_to_corners_3d(boxes)
+    m1 = np.sqrt((corners * corners).sum(2)).astype(F).min(1)
+    out = np.zeros((boxes.shape[0],), F)
+    for i in range(boxes.shape[0]):
+        inside = O.points_in_boxes(xyz[None], boxes[i][None, None])[0] >= 0
+        out[i] = F(int((mags > m1[i]).sum()) * int((~inside).sum()))
+    return out
 
 
 def linspace_f32(a, b, n):
@@ -145,16 +165,18 @@ def calc_iou(corners, cam_box, lidar_aug, lidar2image, img_aug=None):
     return box_iou_2d(proj, cam_box.reshape(1, 4).astype(F)).reshape(-1), proj
 
 
-def get_proposals(scene, params=None, trace=None):
+def get_proposals(scene, params=None, trace=None, noise=None):
     """scene: dict(points (N,6) [b,x,y,z,..], camera_intrinsics/camera2lidar/lidar2image (1,6,4,4),
     lidar_aug_matrix (1,4,4), dets = (boxes, labels, scores, batch_idx, cam_idx)), batch size 1.
     Returns boxes (K,7), labels (K,), scores (K,) like :1055-1067.  `trace` (list) receives one
-    dict per frustum with the intermediate values."""
+    dict per frustum with the intermediate values.  noise: rand_center's draws, one (num_mags, 3) array per frustum that
+    reaches :847, in order (the reference takes them from torch.randn)."""
     p = dict(DEFAULT_PARAMS)
     if params:
         p.update(params)
     base_boxes, base_corners = base_proposals(p)
-    mags = linspace_f32(0.0, 1.0, p["num_mags"])
+    mags = linspace_f32(0.0, 1.0, p["num_mags"]) if p["num_mags"] > 0 else np.zeros((1,), F)   # :831-834
+    noise = list(noise) if noise is not None else None
     det_boxes, det_labels, det_scores, det_b, det_c = scene["dets"]
     pts = scene["points"][scene["points"][:, 0] == 0][:, 1:4].astype(F)
     aug = scene["lidar_aug_matrix"][0].astype(F)
@@ -173,13 +195,16 @@ def get_proposals(scene, params=None, trace=None):
         for box, label, score in zip(cb, cl, cs):                            # :593
             if score < p["score_thr"]:
                 continue
+            if p["BOX_FORMAT"] != "xyxy":                                    # :599-601 (in place: the box stays xyxy from here on)
+                box = box.copy()
+                box[2:] = box[2:] + box[0:2]
             x1, y1, x2, y2 = box
             on_box = (cam_points[:, 1] < y2) & (cam_points[:, 1] >= y1) & (cam_points[:, 0] < x2) & (cam_points[:, 0] >= x1)
             bp = cam_points[on_box]
             if bp.shape[0] == 0:
                 continue
             fmin = quantile(bp[:, 2], p["lq"])                               # :616-629
-            fmax = quantile(bp[:, 2], p["uq"])
+            fmax = quantile(bp[:, 2], p["uq"]) if p["search_depth"] is None else F(fmin + F(p["search_depth"]))   # :617-622
             cz = quantile(bp[:, 2], p["cq"])
             wc_cam = np.array([[(x1 + x2) / F(2), (y1 + y2) / F(2), cz]], F)   # :630
             wc_xyz = geometry_at_image_coords(wc_cam, scene["camera2lidar"][0, c], scene["camera_intrinsics"][0, c], aug, iaug(c))
@@ -201,7 +226,13 @@ def get_proposals(scene, params=None, trace=None):
         close = (bev[0] + bev[1]) / F(2)
         far = (bev[2] + bev[3]) / F(2)
         vec = far - close
-        bev_pts = (close[None, :] + vec[None, :] * mags[:, None]).astype(F)  # :847
+        if p["search_depth"] is not None:                                    # :841-842
+            with np.errstate(invalid="ignore", divide="ignore"):             # (a collapsed frustum: 0 / 0 = NaN there too)
+                vec = (vec / np.sqrt((vec * vec).sum()).astype(F)).astype(F) * F(p["search_depth"])
+        if not p["rand_center"]:
+            bev_pts = (close[None, :] + vec[None, :] * mags[:, None]).astype(F)  # :845
+        else:
+            bev_pts = (wc_xyz.reshape(1, 3) + np.asarray(noise.pop(0), F)).astype(F)   # :847
         corners = (base_corners[label - 1][None] + bev_pts[:, None, None, :]).reshape(-1, 8, 3).astype(F)
         boxes = np.repeat(base_boxes[label - 1][None], bev_pts.shape[0], 0).copy()
         boxes[..., 0:3] = boxes[..., 0:3] + bev_pts[:, None, :]
@@ -221,7 +252,16 @@ def get_proposals(scene, params=None, trace=None):
                 trace.append(t)
             continue
         idx = np.nonzero(valid)[0]
-        ious, proj = calc_iou(corners[idx], box, aug, L, iaug(c))            # :883
+        if not p["MULTICAM_IOU"]:
+            ious, proj = calc_iou(corners[idx], box, aug, L, iaug(c))        # :883
+        else:                                                                # :885-886, multicam_ious :1413-1429
+            per = [calc_iou(corners[idx], b2, aug, scene["lidar2image"][0, c2].astype(F), iaug(c2))[0]
+                   for (_, c2, b2, _, l2, _, _) in frusts if l2 == label]
+            tot = np.zeros_like(per[0])
+            for v in per:
+                tot = (tot + v).astype(F)
+            nz = np.sum([(v > 0) for v in per], axis=0)
+            ious = (tot / (nz.astype(F) + F(1e-6))).astype(F)
         dd = np.sqrt(((wfc[idx] - wc_xyz.reshape(1, 3)) ** 2).sum(1)).astype(F)   # :886-893
         dists_ranked = (F(1) - (dd - dd.min()) / (dd.max() - dd.min() + F(1e-8))).astype(F)
         keep = ious > p["min_cam_iou"]                                       # :904
@@ -237,16 +277,26 @@ def get_proposals(scene, params=None, trace=None):
             s2 = (soft * F(p["dns_w"]) + ious * F(p["iou_w"]) + dists_ranked * F(p["dst_w"])).astype(F)   # :997
         else:
             s2 = (soft * F(p["dns_w"]) * ious * F(p["iou_w"]) * dists_ranked * F(p["dst_w"])).astype(F)   # :999
+        if p["occl_w"] > 0:                                                  # :1007-1014
+            occl = occl_scores(boxes[idx], xyz)
+            s2 = (s2 + F(p["occl_w"]) * (F(1) - occl / (occl.max() + F(1e-6)))).astype(F)
         if p["ego_w"] > 0:                                                   # :1017-1021
             ego = np.sqrt((boxes[idx, :3] ** 2).sum(1)).astype(F)
             s2 = (s2 + F(p["ego_w"]) * (ego / ego.max())).astype(F)
-        best = int(np.argmax(s2))       # sort desc + [:topk=1]; first maximum = stable order
-        t.update(idx_final=idx.copy(), counts=counts.copy(), scores=s2.copy(), best=int(idx[best]))
+        if p["OCCL_MULT"]:                                                   # :1022-1027: replaces the score
+            occl = occl_scores(boxes[idx], xyz)
+            s2 = (soft * ious * occl).astype(F)
+        # 3D NMS on the axis-aligned BEV footprints in score order, then the first topk (:1030-1045); topk 1 and threshold
+        # 1.0 (the shipped values) reduce to the first maximum of a stable descending sort
+        sel = O.nms_gpu(boxes[idx], s2, float(p["nms_normal"]), rotated=False)[: max(int(p["topk"]), 0)]
+        best = int(sel[0])
+        t.update(idx_final=idx.copy(), counts=counts.copy(), scores=s2.copy(), best=int(idx[best]), selected=idx[sel].copy())
         if trace is not None:
             trace.append(t)
-        out_boxes.append(boxes[idx[best]])
-        out_labels.append(label)
-        out_scores.append(score)
+        for b_ in sel:
+            out_boxes.append(boxes[idx[int(b_)]])
+            out_labels.append(label)
+            out_scores.append(score)
     if not out_boxes:
         return np.zeros((0, 7), F), np.zeros((0,), np.int64), np.zeros((0,), F)
     return np.stack(out_boxes).astype(F), np.array(out_labels, np.int64), np.array(out_scores, F)

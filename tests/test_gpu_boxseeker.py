@@ -112,6 +112,60 @@ def test_matches_reference_golden(cuda, seed):
         assert ((npts == 1) & dbg["has_box"].numpy()).any(), "the single-return frustum yields a box"
 
 
+@pytest.mark.parametrize("seed", [18, 19, 20, 21, 22, 23, 24, 25, 27])
+def test_option_variants_match_reference_golden(cuda, seed):
+    """The options no shipped config sets, on the kernel: topk 3 through the 3D NMS, search_depth, MULTICAM_IOU (with its
+    point-count pre-pass), occl_w, OCCL_MULT, rand_center (the reference's recorded draws), xywh detections, num_mags 0, and a
+    combination — against fixtures made by the reference's own get_proposals with those options."""
+    from test_oracle_boxseeker import boxes_equal_mod_half_turn, option_scene
+
+    d, sc, prm, noise = option_scene(seed)
+    bd, dets = _batch([sc], cuda)
+    pv = syn.SEEKER_PARAM_VARIANTS[seed]
+    head = _head(lambda _: dets, dict(PARAMS, **pv[0]), pv[1])
+    tk = int(pv[0].get("topk", 1))
+    dev_noise = None
+    with torch.no_grad():
+        if noise is not None:     # the i-th draw belongs to the i-th frustum that holds points (the reference draws at :847 only there)
+            F = head.enumerate_frustums(bd).shape[0]
+            r0 = head.launch(bd, debug=True, noise=torch.zeros((F, head.num_mags, 3), device=cuda))
+            has_pts = np.nonzero(r0["dbg"]["npts"].cpu().numpy() > 0)[0]
+            assert len(has_pts) == len(noise)
+            dev_noise = torch.zeros((F, head.num_mags, 3))
+            for f, draw in zip(has_pts, noise):
+                dev_noise[f] = torch.from_numpy(draw)
+            dev_noise = dev_noise.to(cuda)
+        r = head.launch(bd, debug=True, noise=dev_noise)
+        boxes, labels, scores, bidx = head.get_proposals(bd, noise=dev_noise)
+    assert tuple(boxes.shape) == d["out_boxes"].shape and labels.tolist() == d["out_labels"].tolist()
+    np.testing.assert_allclose(scores.numpy(), d["out_scores"], rtol=0, atol=1e-7)
+    same = boxes_equal_mod_half_turn(boxes.cpu().numpy(), d["out_boxes"])
+    assert same.mean() >= 0.9, f"{(~same).sum()} of {len(same)} boxes differ from the reference's beyond a half-turn tie"
+    # per-candidate values: the candidates the reference counted points in and their counts, frustum by frustum, and the
+    # second-stage scores of the boxes it selected (what the new score terms change) against the kernel's
+    valid, count, cand = r["dbg"]["valid"].cpu().numpy(), r["dbg"]["count"].cpu().numpy(), r["dbg"]["cand"].cpu().numpy()
+    occl = bool(pv[0].get("occl_w", 0) or pv[1].get("OCCL_MULT", False))
+    calls = 1 + int(pv[0].get("occl_w", 0) > 0) + int(bool(pv[1].get("OCCL_MULT", False)))
+    ws, sel = _ragged(d, "nms3d_scores"), _ragged(d, "nms3d_selected")
+    n_out = r["out_count"].cpu().numpy()
+    out_score = r["out_score"].cpu().numpy().reshape(-1, tk)
+    pos = k = 0
+    for f in range(valid.shape[0]):
+        ids = np.nonzero(valid[f] == 2)[0]
+        if len(ids) == 0:
+            assert n_out[f] == 0
+            continue
+        np.testing.assert_allclose(cand[f][ids], d["pib_box"][pos: pos + len(ids)], rtol=0, atol=1e-4)
+        ref_counts = d["pib_count"][pos: pos + len(ids)]
+        assert np.abs(count[f][ids] - ref_counts).max() <= 2
+        pos += calls * len(ids)
+        assert n_out[f] == min(tk, len(sel[k]))
+        ref_sel = ws[k][:, 0][sel[k][:, 0][: n_out[f]]]
+        np.testing.assert_allclose(out_score[f][: n_out[f]], ref_sel, rtol=2e-2 if occl else 0, atol=1e-4 + 2.0 / max(float(ref_counts.max()), 1.0))
+        k += 1
+    assert pos == d["pib_box"].shape[0] and k == len(ws)
+
+
 def test_matches_oracle_on_batched_scenes(cuda):
     """Four scenes (one with an augmentation matrix, one with empty cameras and a single-return frustum) in ONE launch
     == each scene through the numpy oracle; get_bboxes/forward shape."""
@@ -178,10 +232,12 @@ def test_edge_cases(cuda):
     # rerun is bit-identical
     c = _head(lambda _: dets).get_proposals(bd)
     assert torch.equal(a[0], c[0])
-    with pytest.raises(NotImplementedError):
-        _head(lambda _: dets, dict(PARAMS, topk=3))
-    with pytest.raises(NotImplementedError):
-        _head(lambda _: dets, dict(PARAMS, occl_w=0.2))
+    with pytest.raises(NotImplementedError, match="IndexError"):   # (the one option refused: the reference's own path raises)
+        _head(lambda _: dets, dict(PARAMS, aln_w=0.2))
+    # topk 3 with the shipped NMS threshold 1.0 (nothing suppressed): the three best candidates of every frustum, the first of
+    # them the topk-1 box
+    k3 = _head(lambda _: dets, dict(PARAMS, topk=3)).get_proposals(bd)
+    assert k3[0].shape[0] == 3 * a[0].shape[0] and torch.equal(k3[0][0::3], a[0]) and k3[1].tolist() == [v for v in a[1].tolist() for _ in range(3)]
 
 
 def test_head_reads_glip_files_through_its_default_detector(cuda, tmp_path):
