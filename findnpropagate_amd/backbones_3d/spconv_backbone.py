@@ -648,14 +648,16 @@ class FusedResBackbone:
             return x
 
         # stage 1 (conv_input + conv1): one SubM rulebook serves indice_keys 'subm1' and 'res1'.  16-bit engines: the rulebook
-        # kernel writes the compact form (32 bytes per row, neighbours that exist only) beside the (27, cap) table: conv_input
-        # (5 input channels: 2.3x faster on the records) reads the records, the four 16 -> 16 layers stay on the matrix
-        # kernels and the table (16-channel rows are v_dot2c work on the VALU: 30 % slower there; FNP_ELL=1 runs them and the
-        # 16 -> 32 layer on records all the same, without any table).  f32, and while rulebooks are logged: tables only.
+        # kernel writes the compact form only (32 bytes per row, the neighbours that exist; no (27, cap) table): conv_input (5
+        # input channels) sums the records on the VALU (2.3x the table kernel), the four 16 -> 16 layers and the strided
+        # 16 -> 32 layer run the matrix kernel with the records of a tile's rows expanded into LDS at the top of the tile
+        # (fnp_spconv_forward_ell_mfma: the table kernel's values bit for bit, +3 % end to end: the table was 108 of the ~170
+        # bytes such a row moves).  FNP_ELL_MFMA=0: the round's first form — table beside the records, matrix kernels on the
+        # table; FNP_ELL=1 with it: 16-channel rows on the VALU kernel.  f32, and while rulebooks are logged: tables only.
         ell = (act in (torch.bfloat16, torch.float16) and self.rulebook_log is None and S.ELL_MODE is not False
                and (int(P['in'][0].shape[2]), 16) in S.ELL_SHAPES and not isinstance(P['in'][0], S.PermutedWeight))
         ell_used = []
-        ell_all = ell and S.ELL_MODE is True
+        ell_all = ell and (S.ELL_MODE is True or (S.ELL_MODE is None and S.ELL_MFMA))
         if ell:
             rb1 = S.rulebook_subm_ell(indices, n1, grid1, int(cap1 * self.ell_pool[0]) + 64, with_table=not ell_all)
             ell_used.append((rb1._ell[2], rb1._ell[1], 0))

@@ -288,6 +288,14 @@ struct FusedRb {
     RG gi;                    // input rank grid (rows = ranks: perm unused unless the grid carries one)
     int s[3], p[3];           // stride, padding (kernel 3x3x3)
     const int *out_coords;    // (cap, 4) [b, z, y, x] of the output rows
+    // OR (ell_rec != nullptr): the rows' entries come from the COMPACT rulebook (spconv_ell.hip: 32-byte records, the entries
+    // that exist in ascending offset order, chained extension records behind the ell_cap row records).  The 16-channel
+    // layers have 2-4 of 27 neighbours: their (27, cap) table is 108 bytes per row against 32 + 32 of features, the largest
+    // stream of those launches, and its 27 entry loads per row sit in the same in-order VMEM queue as the gathers.  A wave
+    // expands the records of its tile rows into its LDS strip at the top of a tile (two 16-byte loads per row, a chain
+    // step for the 8 % of rows with more than 8 neighbours) and the sweep runs as on the table: same products, same order.
+    const unsigned *ell_rec;
+    int ell_cap;
 };
 
 // SORTED (the 128 -> 128 SubM layers of stage 4): the rows a workgroup owns are processed in an order sorted by
@@ -601,7 +609,34 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             frow0 = row0;
-            if (lane < MBT * 16) {
+            if (frb.ell_rec) {   // (uniform) entries from the compact rulebook
+                if (lane < MBT * 16) {
+                    const int r = row0 + lane;
+                    uint4 ra = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu), rb4 = ra;
+                    if (r < row_end) {
+                        const uint4 *rp = reinterpret_cast<const uint4 *>(frb.ell_rec + (size_t)r * 8);
+                        ra = rp[0];
+                        rb4 = rp[1];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 27; ++k) fstrip[k * SR + lane] = -1;
+                    while (true) {
+                        const unsigned v[8] = {ra.x, ra.y, ra.z, ra.w, rb4.x, rb4.y, rb4.z, rb4.w};
+                        unsigned link = 0xffffffffu;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const unsigned kk = v[j] >> 27;
+                            if (v[j] == 0xffffffffu) continue;
+                            if (kk < 27u) fstrip[kk * SR + lane] = (int)(v[j] & 0x7ffffffu);
+                            else link = v[j] & 0x7ffffffu;   // (slot 7 of a full record: the next record of the chain)
+                        }
+                        if (link == 0xffffffffu) break;
+                        const uint4 *rp = reinterpret_cast<const uint4 *>(frb.ell_rec + ((size_t)frb.ell_cap + link) * 8);
+                        ra = rp[0];
+                        rb4 = rp[1];
+                    }
+                }
+            } else if (lane < MBT * 16) {
                 const int r = row0 + lane;
                 if (r < row_end) {
                     const int4 c = reinterpret_cast<const int4 *>(frb.out_coords)[r];
@@ -1409,6 +1444,8 @@ extern "C" int fnp_spconv_forward_strided(const void *feat_in, int in_dtype, int
         frb.p[d] = geom->padding[d];
     }
     frb.out_coords = out_coords;
+    frb.ell_rec = nullptr;
+    frb.ell_cap = 0;
 #define FNP_FCASE(CI, CO)                                                                                                   \
     if (Cin == CI && Cout == CO) {                                                                                          \
         if (in_dtype == FNP_F16)                                                                                            \
@@ -1421,6 +1458,34 @@ extern "C" int fnp_spconv_forward_strided(const void *feat_in, int in_dtype, int
     FNP_FCASE(32, 64)
     FNP_FCASE(64, 128)
 #undef FNP_FCASE
+    return FNP_ERR_ARG;
+}
+
+// The 16-channel layers on the COMPACT rulebook, on the matrix pipe (see FusedRb): fnp_spconv_forward_ell's arguments for
+// Cin = 16; the values of fnp_spconv_forward on the (27, cap) table of the same rows, bit for bit.
+extern "C" int fnp_spconv_forward_ell_mfma(const void *feat_in, int in_dtype, int n_in_rows, const void *weight, const void *records, int cap_rows,
+                                           int pool_records, const int *n_out, void *feat_out, int out_dtype, const float *scale, const float *shift,
+                                           const void *residual, int relu, int Cin, int Cout, fnp_stream_t stream) {
+    if (!feat_in || !weight || !records || !n_out || !feat_out || cap_rows <= 0 || pool_records < 0 || n_in_rows <= 0) return FNP_ERR_ARG;
+    if ((scale == nullptr) != (shift == nullptr) || ((uintptr_t)records & 15)) return FNP_ERR_ARG;
+    if ((in_dtype != FNP_BF16 && in_dtype != FNP_F16) || out_dtype != in_dtype || Cin != 16 || (Cout != 16 && Cout != 32)) return FNP_ERR_ARG;
+    const long long xb = (long long)n_in_rows * Cin * 2;
+    if (xb >= 0x7fffffffll || (long long)cap_rows + pool_records >= (1ll << 26) || n_in_rows >= (1 << 27)) return FNP_ERR_ARG;
+    FusedRb frb{};
+    frb.ell_rec = (const unsigned *)records;
+    frb.ell_cap = cap_rows;
+    hipStream_t s = (hipStream_t)stream;
+#define FNP_ECASE(CO)                                                                                                                         \
+    if (Cout == CO) {                                                                                                                         \
+        if (in_dtype == FNP_F16)                                                                                                              \
+            return launch_mfma_k<16, CO, 27, false, _Float16, true, _Float16>(feat_in, (int)xb, weight, nullptr, cap_rows, 27, n_out, cap_rows, \
+                                                                              feat_out, scale, shift, residual, relu, 0, s, &frb);            \
+        return launch_mfma_k<16, CO, 27, false, __bf16, true>(feat_in, (int)xb, weight, nullptr, cap_rows, 27, n_out, cap_rows, feat_out,     \
+                                                              scale, shift, residual, relu, 0, s, &frb);                                      \
+    }
+    FNP_ECASE(16)
+    FNP_ECASE(32)
+#undef FNP_ECASE
     return FNP_ERR_ARG;
 }
 

@@ -132,6 +132,7 @@ SIGNATURES = {
     "fnp_ell_bytes": (c_int64, [c_int, c_int]),
     "fnp_rulebook_ell": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, P, P]),
     "fnp_spconv_forward_ell": (c_int, [P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, P, P, P, c_int, c_int, c_int, P]),
+    "fnp_spconv_forward_ell_mfma": (c_int, [P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, P, P, P, c_int, c_int, c_int, P]),
     "fnp_classsort_workspace_bytes": (c_int64, [c_int]),
     "fnp_rulebook_subm_masked": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, P, POINTER(RankGridC), POINTER(ConvGeom), P]),
     "fnp_rulebook_classsort": (c_int, [P, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P, c_int64, P]),

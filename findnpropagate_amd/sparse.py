@@ -369,8 +369,13 @@ def ell_for_strided(rb, pool_records):
     return rb
 
 
-def conv_forward_ell(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, shift=None, residual=None, relu=False):
-    """conv_forward on the compact rulebook (`rb._ell`): the sparse-neighbourhood layers.  No host sync."""
+ELL_MFMA = os.environ.get("FNP_ELL_MFMA", "1") == "1"   # 16-channel rows on records: the matrix kernel (else the VALU kernel)
+
+
+def conv_forward_ell(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, shift=None, residual=None, relu=False, mfma=None):
+    """conv_forward on the compact rulebook (`rb._ell`): the sparse-neighbourhood layers.  No host sync.
+    mfma: 16-channel rows only — True: the MFMA kernel with the records expanded per tile (fnp_spconv_forward_ell_mfma: the
+    table kernel's values bit for bit), False: the VALU kernel (another summation order); None: ELL_MFMA."""
     L = _l.load()
     rec, pool, _ = rb._ell
     K, Cout, Cin = w_packed.shape
@@ -380,10 +385,12 @@ def conv_forward_ell(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=Non
     out = torch.empty((rb.cap_out, Cout), dtype=out_dtype, device=feat_in.device)
     if residual is not None:
         assert residual.dtype == out.dtype and residual.shape[1] == Cout and residual.is_contiguous()
-    rc = L.fnp_spconv_forward_ell(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed), _l.ptr(rec), rb.cap_out, pool,
-                                  _l.ptr(n_out_dev), _l.ptr(out), _l.dtype_code(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual),
-                                  int(bool(relu)), Cin, Cout, _l.stream())
-    _l.check(rc, "fnp_spconv_forward_ell")
+    use_mfma = (ELL_MFMA if mfma is None else mfma) and Cin == 16 and feat_in.dtype in (torch.bfloat16, torch.float16) and out.dtype == feat_in.dtype
+    fn = L.fnp_spconv_forward_ell_mfma if use_mfma else L.fnp_spconv_forward_ell
+    rc = fn(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed), _l.ptr(rec), rb.cap_out, pool,
+            _l.ptr(n_out_dev), _l.ptr(out), _l.dtype_code(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual),
+            int(bool(relu)), Cin, Cout, _l.stream())
+    _l.check(rc, "fnp_spconv_forward_ell_mfma" if use_mfma else "fnp_spconv_forward_ell")
     return out
 
 

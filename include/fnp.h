@@ -344,6 +344,14 @@ int fnp_spconv_forward_ell(const void *feat_in, int in_dtype, int n_in_rows, con
                            int cap_rows, int pool_records, const int *n_out, void *feat_out, int out_dtype,
                            const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
                            fnp_stream_t stream);
+/* The same call for the 16-input-channel layers (Cin 16, Cout 16 or 32, FNP_BF16 / FNP_F16 in = out) ON THE MATRIX PIPE (ABI 8):
+ * the MFMA kernel of fnp_spconv_forward with the entries of a tile's rows expanded from the records into LDS at the top of
+ * the tile — no (27, cap) table is written or read (108 of the ~170 bytes a row of those layers moves), no entry load shares
+ * the gathers' in-order queue.  Values: fnp_spconv_forward's on the table of the same rows, bit for bit. */
+int fnp_spconv_forward_ell_mfma(const void *feat_in, int in_dtype, int n_in_rows, const void *weight, const void *records,
+                                int cap_rows, int pool_records, const int *n_out, void *feat_out, int out_dtype,
+                                const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
+                                fnp_stream_t stream);
 
 /* CLASS-SORTED sweep of the 128 -> 128 SubM layers (the four 3x3x3 convolutions of stage 4, spconv_backbone.py:219-224).
  * After three stride-2 layers a lidar surface is two cells thick: ~36 % of the stage-4 sites have neighbours only in the

@@ -147,12 +147,42 @@ def test_16_channel_layers_on_records_match_the_table_kernels(cuda, rng, cout, d
     ell = S.rulebook_subm_ell(d_idx, n_dev, grid, pool_records=n)
     res = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).to(cuda).to(dtype)
     want = S.conv_forward(x.float(), w.float(), table, n_dev, scale=sc, shift=sh, residual=res.float(), relu=True, valu=True)[:n]
-    got = S.conv_forward_ell(x, w, ell, n_dev, scale=sc, shift=sh, residual=res, relu=True)[:n]
+    got = S.conv_forward_ell(x, w, ell, n_dev, scale=sc, shift=sh, residual=res, relu=True, mfma=False)[:n]
     mfma = S.conv_forward(x, w, table, n_dev, scale=sc, shift=sh, residual=res, relu=True)[:n]
+    # the MATRIX kernel on the records (entries expanded per tile from the 32-byte records, chains included: the blob's rows
+    # hold 27 neighbours): the table kernel's values bit for bit, with and without residual / BatchNorm / ReLU
+    for residual, scale, shift, relu in ((res, sc, sh, True), (None, sc, sh, True), (None, None, None, False)):
+        a = S.conv_forward(x, w, table, n_dev, scale=scale, shift=shift, residual=residual, relu=relu)
+        b = S.conv_forward_ell(x, w, ell, n_dev, scale=scale, shift=shift, residual=residual, relu=relu, mfma=True)
+        assert torch.equal(a[:n], b[:n])
     scale = float(want.abs().max())
     assert float((got.float() - want).abs().max()) <= (1e-4 + ulp) * scale
     assert float((mfma.float() - want).abs().max()) <= (1e-4 + ulp) * scale          # (the same bar holds for the table kernel)
     assert float((got.float() != mfma.float()).float().mean()) < 0.05                # and the two agree on all but a few roundings
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n", [1, 17, 300, 40000])
+def test_strided_16_to_32_on_records_is_the_table_kernel_bit_for_bit(cuda, rng, n, dtype):
+    """the strided 16 -> 32 layer: records of the OUTPUT rows (ell_for_strided) through the matrix kernel == the (27, cap) table
+    through the matrix kernel, for sizes from one row (a partial block) to many tiles."""
+    B, shape = 2, [11, 60, 64]
+    idx = _sites(rng, B, shape, n, n >= 300)
+    n_in = idx.shape[0]
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n_in, cuda)
+    grid = S.build_grid(d_idx, n_dev, B, shape)
+    full = S.rulebook_strided(d_idx, n_dev, grid, 3, 2, 1, cap_out=n_in * 8 + 64)
+    lean = S.rulebook_strided(d_idx, n_dev, grid, 3, 2, 1, cap_out=n_in * 8 + 64, want_nbr=False)
+    n_out = int(full.out_n.item())
+    S.ell_for_strided(lean, pool_records=n_out * 3 + 8)
+    x = torch.from_numpy(rng.standard_normal((n_in, 16)).astype(np.float32)).to(cuda).to(dtype)
+    w = S.pack_weight(torch.from_numpy((rng.standard_normal((32, 3, 3, 3, 16)) * 0.2).astype(np.float32)).to(cuda), dtype)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, 32).astype(np.float32)).to(cuda)
+    sh = torch.from_numpy(rng.standard_normal(32).astype(np.float32)).to(cuda)
+    a = S.conv_forward(x, w, full, full.out_n, scale=sc, shift=sh, relu=True)
+    b = S.conv_forward_ell(x, w, lean, lean.out_n, scale=sc, shift=sh, relu=True, mfma=True)
+    assert torch.equal(a[:n_out], b[:n_out])
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
@@ -176,10 +206,19 @@ def test_backbone_on_compact_rulebooks_equals_backbone_on_tables(cuda, mode):
             outs.append({k: (r[k].features.float().clone(), r[k].indices.clone()) for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out")})
         finally:
             S.ELL_MODE = None
+    for k in outs[0]:   # the 16-channel layers run the matrix kernel on either rulebook: same values
+        assert torch.equal(outs[0][k][1], outs[1][k][1]), k
+        assert torch.equal(outs[0][k][0], outs[1][k][0]), k
+    # ... and with the VALU kernel on the records (FNP_ELL_MFMA=0): another f32 summation order in five layers, a few roundings
+    S.ELL_MODE, S.ELL_MFMA = True, False
+    try:
+        with torch.no_grad():
+            r = net.forward_points(pts, off, 3, cfg)
+        valu = {k: r[k].features.float().clone() for k in outs[0]}
+    finally:
+        S.ELL_MODE, S.ELL_MFMA = None, True
     ulp = 2.0 ** -8 if mode == "bf16" else 2.0 ** -11
     for k in outs[0]:
-        assert torch.equal(outs[0][k][1], outs[1][k][1]), k
-        a, b = outs[0][k][0], outs[1][k][0]
+        a, b = outs[0][k][0], valu[k]
         assert float((a - b).abs().max()) <= 8 * ulp * max(1.0, float(a.abs().max())), k
-        # (a different f32 summation order in five layers: single roundings flip and travel on; bf16 ~10 % of the elements, fp16 more)
         assert float((a != b).float().mean()) < 0.6, k
