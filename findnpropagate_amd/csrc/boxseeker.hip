@@ -164,6 +164,10 @@ __device__ float quantile(Shared &S, const float *__restrict__ list, int m, floa
     return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.0f - w);
 }
 
+// OPT: the instantiation that carries the options no shipped configuration sets (MULTICAM_IOU, the occlusion terms, search_depth,
+// rand_center, topk > 1).  The shipped path compiles them out: with them in one body the candidate loop holds 175 registers
+// instead of 126 and the kernel runs two waves per SIMD instead of four (57 k -> 42 k scenes/s at 64 scenes per launch).
+template <bool OPT>
 __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
     const float *__restrict__ points, const int *__restrict__ scene_off, const fnp_seeker_params prm,
     const float *__restrict__ scene_mats,   // (S, 21): aug_R 9 | aug_inv 9 | aug_t 3
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
     __syncthreads();
     const int m = (int)S.count;
     if (dbg_npts && tid == 0) dbg_npts[f] = m;
-    if (prm.count_only) return;   // (the pre-pass of MULTICAM_IOU: which frustums hold points at all)
+    if (OPT && prm.count_only) return;   // (the pre-pass of MULTICAM_IOU: which frustums hold points at all)
     if (m == 0) {  // "no pts in box": the frustum is dropped (:634-637)
         if (tid == 0) out_valid[f] = 0;
         return;
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
 
     // ---- C: frustum corners in lidar, weighted centre ---------------------------------------
     if (tid < 8) {
-        const float far_q = prm.search_depth > 0.f ? qlo + prm.search_depth : qhi;   // :617-622 (search_depth: a fixed depth behind the near quantile)
+        const float far_q = (OPT && prm.search_depth > 0.f) ? qlo + prm.search_depth : qhi;   // :617-622 (search_depth: a fixed depth behind the near quantile)
         float fmax_ = fminf(far_q, prm.max_dist), fmin_ = fmaxf(qlo, 2.0f);        // :647-648
         const float lo3[3] = {x1, y1, fmin_}, hi3[3] = {x2, y2, fmax_};
         const float sx[8] = {1, 1, -1, -1, 1, 1, -1, -1}, sy[8] = {1, -1, -1, 1, 1, -1, -1, 1},
@@ -301,12 +305,12 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
             close[e] = (b0 + b1) / 2.0f;
             vec[e] = (b2 + b3) / 2.0f - close[e];
         }
-        if (prm.search_depth > 0.f) {   // :841-842: the axis at unit length times the depth (a collapsed frustum gives NaN there too)
+        if (OPT && prm.search_depth > 0.f) {   // :841-842: the axis at unit length times the depth (a collapsed frustum gives NaN there too)
             const float nrm = sqrtf(vec[0] * vec[0] + vec[1] * vec[1] + vec[2] * vec[2]);
 #pragma unroll
             for (int e = 0; e < 3; ++e) vec[e] = (vec[e] / nrm) * prm.search_depth;
         }
-        if (prm.rand_noise) S.bev_pts[i][a] = S.wc[a] + prm.rand_noise[((size_t)f * prm.num_mags + i) * 3 + a];   // rand_center (:847)
+        if (OPT && prm.rand_noise) S.bev_pts[i][a] = S.wc[a] + prm.rand_noise[((size_t)f * prm.num_mags + i) * 3 + a];   // rand_center (:847)
         else S.bev_pts[i][a] = close[a] + vec[a] * mags[i];
     }
     __syncthreads();
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
         const float iw = fmaxf(fminf(bx2, x2) - fmaxf(bx1, x1), 0.f), ih = fmaxf(fminf(by2, y2) - fmaxf(by1, y1), 0.f);
         const float inter = iw * ih;
         float iou = inter / (a1 + a2 - inter);
-        if (prm.multicam) {
+        if (OPT && prm.multicam) {
             // multicam_ious (:1413-1429): the candidate against EVERY frustum of the scene with this label that holds points
             // (this one included), each in its own camera; mean over the cameras that see it at all
             float tot = 0.f;
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
             }
             iou = tot / ((float)nz + 1e-6f);
         }
-        if (prm.occl_w > 0.f || prm.occl_mult) {
+        if (OPT && (prm.occl_w > 0.f || prm.occl_mult)) {
             // range of the candidate's nearest corner, corners as boxes_to_corners_3d makes them from the final box (:423-426)
             const float ca = cosf(box[6]), sa = sinf(box[6]);
             float m1 = INFINITY;
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
             }
             S.cm1[c] = m1;
         }
-        S.cbeyond[c] = 0;
+        if (OPT) S.cbeyond[c] = 0;
 #pragma unroll
         for (int j = 0; j < 7; ++j) S.cbox[c][j] = box[j];
 #pragma unroll
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
             y = lxyz[(size_t)i * 3 + 1];
             z = lxyz[(size_t)i * 3 + 2];
         }
-        const bool occl = prm.occl_w > 0.f || prm.occl_mult;
+        const bool occl = OPT && (prm.occl_w > 0.f || prm.occl_mult);
         const float mag = occl ? sqrtf(x * x + y * y + z * z) : 0.f;
         for (int c = 0; c < NC; ++c) {
             if (S.cvalid[c] != 2) continue;   // wave-uniform
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
     if (tid == 0) {
         int nmax = 0, any = 0;
         float dmin = INFINITY, dmax = -INFINITY, emax = -INFINITY, omax = -INFINITY;
-        const bool occl = prm.occl_w > 0.f || prm.occl_mult;
+        const bool occl = OPT && (prm.occl_w > 0.f || prm.occl_mult);
         // calc_occl_scores as the reference RUNS it (:463): `mags` is (N, 1) and the in-box mask (N,), so the conjunction
         // broadcasts to (N, N) and its sum is (points beyond the nearest corner) x (points outside the box)
         auto occl_of = [&](int c) -> float { return (float)((long long)S.cbeyond[c] * (long long)(m - S.ccount[c])); };
@@ -485,13 +489,13 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
             } else {                  // MULT, :999
                 s = soft * prm.dns_w * S.ciou[c] * prm.iou_w * dr * prm.dst_w;
             }
-            if (prm.occl_w > 0.f)     // :1007-1014
+            if (OPT && prm.occl_w > 0.f)     // :1007-1014
                 s = s + prm.occl_w * (1.0f - occl_of(c) / (omax + 1e-6f));
             if (prm.ego_w > 0.f) {    // :1017-1021
                 const float ego = sqrtf(S.cbox[c][0] * S.cbox[c][0] + S.cbox[c][1] * S.cbox[c][1] + S.cbox[c][2] * S.cbox[c][2]);
                 s = s + prm.ego_w * (ego / emax);
             }
-            if (prm.occl_mult)        // OCCL_MULT, :1022-1027: replaces the score
+            if (OPT && prm.occl_mult)        // OCCL_MULT, :1022-1027: replaces the score
                 s = soft * S.ciou[c] * occl_of(c);
             S.cscore[c] = s;
         }
@@ -499,7 +503,8 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
         // footprint overlaps it beyond the threshold (iou3d_nms_kernel.cu:327-338), repeat; the first maximum is the order
         // of a stable descending sort.  The shipped topk 1 needs the first pick only.
         int kept = 0;
-        for (int k = 0; k < prm.topk; ++k) {
+        const int topk = OPT ? prm.topk : 1;
+        for (int k = 0; k < topk; ++k) {
             int best = -1;
             float best_s = -INFINITY;
             for (int c = 0; c < NC; ++c) {
@@ -511,12 +516,12 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
                 }
             }
             if (best < 0) break;
-            out_best[(size_t)f * prm.topk + k] = best;
-            out_score[(size_t)f * prm.topk + k] = best_s;
-            for (int j = 0; j < 7; ++j) out_box[((size_t)f * prm.topk + k) * 7 + j] = S.cbox[best][j];
+            out_best[(size_t)f * topk + k] = best;
+            out_score[(size_t)f * topk + k] = best_s;
+            for (int j = 0; j < 7; ++j) out_box[((size_t)f * topk + k) * 7 + j] = S.cbox[best][j];
             ++kept;
             S.cvalid[best] = 3;   // taken
-            if (k + 1 < prm.topk) {
+            if (k + 1 < topk) {
                 const float *a = S.cbox[best];
                 for (int c = 0; c < NC; ++c) {
                     if (S.cvalid[c] != 2) continue;
@@ -532,10 +537,10 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
         for (int c = 0; c < NC; ++c)
             if (S.cvalid[c] > 2) S.cvalid[c] = 2;   // (the dump below reports "scored")
         out_valid[f] = kept;
-        for (int k = kept; k < prm.topk; ++k) {
-            out_best[(size_t)f * prm.topk + k] = -1;
-            out_score[(size_t)f * prm.topk + k] = 0.f;
-            for (int j = 0; j < 7; ++j) out_box[((size_t)f * prm.topk + k) * 7 + j] = 0.f;
+        for (int k = kept; k < topk; ++k) {
+            out_best[(size_t)f * topk + k] = -1;
+            out_score[(size_t)f * topk + k] = 0.f;
+            for (int j = 0; j < 7; ++j) out_box[((size_t)f * topk + k) * 7 + j] = 0.f;
         }
         (void)any;
     }
@@ -707,10 +712,18 @@ extern "C" int fnp_boxseeker(const float *points, const int *scene_offsets, int 
     const int stride = max_points_per_scene > 0 ? max_points_per_scene : 1;
     float *ws_uvd = (float *)workspace;
     float *ws_xyz = ws_uvd + (size_t)num_frustums * stride * 3;
-    hipLaunchKernelGGL(boxseeker_kernel, dim3(num_frustums), dim3(kThreads), 0, (hipStream_t)stream, points,
-                       scene_offsets, *params, scene_mats, cam_mats, frustums, base_boxes, base_corners, mags, ws_uvd,
-                       ws_xyz, stride, out_valid, out_box, out_score, out_best, dbg_npts, dbg_frust, dbg_cand, dbg_iou,
-                       dbg_count, dbg_valid);
+    const bool opt = params->topk > 1 || params->search_depth > 0.f || params->occl_w > 0.f || params->occl_mult || params->multicam ||
+                     params->count_only || params->rand_noise;
+    if (opt)
+        hipLaunchKernelGGL(boxseeker_kernel<true>, dim3(num_frustums), dim3(kThreads), 0, (hipStream_t)stream, points,
+                           scene_offsets, *params, scene_mats, cam_mats, frustums, base_boxes, base_corners, mags, ws_uvd,
+                           ws_xyz, stride, out_valid, out_box, out_score, out_best, dbg_npts, dbg_frust, dbg_cand, dbg_iou,
+                           dbg_count, dbg_valid);
+    else
+        hipLaunchKernelGGL(boxseeker_kernel<false>, dim3(num_frustums), dim3(kThreads), 0, (hipStream_t)stream, points,
+                           scene_offsets, *params, scene_mats, cam_mats, frustums, base_boxes, base_corners, mags, ws_uvd,
+                           ws_xyz, stride, out_valid, out_box, out_score, out_best, dbg_npts, dbg_frust, dbg_cand, dbg_iou,
+                           dbg_count, dbg_valid);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
