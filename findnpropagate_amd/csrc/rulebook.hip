@@ -111,58 +111,7 @@ __device__ __forceinline__ unsigned long long spread16(unsigned s) {
 // wave must call it (wave-level merging: inputs in rank-grid order reach one output block from ~30 consecutive rows; the bits
 // of equal blocks are OR-ed along the wave — a lane may take in any earlier lane's bits of the same block — and the last lane
 // of each run issues the one atomic: same-address atomics serialise in L2).
-// Workgroup-level merging of the marks (round 3).  The marking kernels spend three quarters of their time in the atomics
-// themselves — read-modify-writes of words of a zeroed, sparse grid that miss L2 (1.4 M misses for 1.05 M atomics per
-// launch; a probe that finds every bit already set runs in 25 of 100 us, and fire-and-forget atomics take as long as returning
-// ones) — and issue 3.6 x more of them than their rows have distinct (wave, output block) pairs: the run merge along the
-// wave covers the first outputs of a row only, not the outputs across a block border.  A workgroup's rows of one pass are
-// 256 consecutive ranks, a compact patch: ALL their (block, bits) pairs meet in an LDS table first (compare-and-swap on the
-// block id, OR on the bits), and each distinct block costs one atomic in memory.
-constexpr int kMarkTabLog = 9, kMarkTab = 1 << kMarkTabLog;
-struct MarkTab {
-    unsigned long long key[kMarkTab];   // block id, ~0 = free
-    unsigned long long val[kMarkTab];
-};
-#ifndef FNP_MARK_TAB
-#define FNP_MARK_TAB 1
-#endif
-__device__ __forceinline__ void mark_put(MarkTab *tab, const RG &go, long long blk, unsigned long long m) {
-    if (!FNP_MARK_TAB || !tab) {
-        rg_mark_mask(go, blk, m);
-        return;
-    }
-    unsigned h = ((unsigned)blk * 0x9E3779B1u) >> (32 - kMarkTabLog);
-    for (int probe = 0; probe < 8; ++probe) {
-        const unsigned long long old = atomicCAS(&tab->key[h], ~0ull, (unsigned long long)blk);
-        if (old == ~0ull || old == (unsigned long long)blk) {
-            atomicOr(&tab->val[h], m);
-            return;
-        }
-        h = (h + 1) & (unsigned)(kMarkTab - 1);
-    }
-    rg_mark_mask(go, blk, m);   // (a crowded table: straight to memory)
-}
-// every thread of the workgroup: empty the table / write its blocks out and empty it (barriers inside)
-__device__ __forceinline__ void mark_tab_init(MarkTab *tab, int tid, int nthreads) {
-    for (int i = tid; i < kMarkTab; i += nthreads) {
-        tab->key[i] = ~0ull;
-        tab->val[i] = 0ull;
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ void mark_tab_flush(MarkTab *tab, const RG &go, int tid, int nthreads) {
-    __syncthreads();
-    for (int i = tid; i < kMarkTab; i += nthreads) {
-        const unsigned long long k = tab->key[i];
-        if (k != ~0ull) {
-            rg_mark_mask(go, (long long)k, tab->val[i]);
-            tab->key[i] = ~0ull;
-            tab->val[i] = 0ull;
-        }
-    }
-    __syncthreads();
-}
-
+// (MarkTab, mark_put, mark_tab_init / mark_tab_flush: rankgrid.cuh — shared with the voxeliser's marking kernel)
 template <int SZ, int SY, int SX>
 __device__ __forceinline__ void mark2_row(bool valid, const int4 c, const RG &go, const Geom &ge, int lane, MarkTab *tab = nullptr) {
     long long blk0 = -1;          // block of the first outputs (corner 0,0,0) and its bits

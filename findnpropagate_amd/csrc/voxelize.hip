@@ -67,6 +67,8 @@ __device__ __forceinline__ int batch_of(const int *__restrict__ off, int B, int 
 __global__ __launch_bounds__(kThreads) void vox_mark_kernel(const float *__restrict__ pts, int n, int C,
                                                             const int *__restrict__ boff, int B, fnp_voxel_cfg cfg,
                                                             RG g, long long *__restrict__ code) {
+    __shared__ MarkTab tab;   // the marks of the workgroup's 256 points meet here first (rankgrid.cuh): one atomic per distinct block
+    if (FNP_MARK_TAB) mark_tab_init(&tab, threadIdx.x, kThreads);
     const int i = blockIdx.x * kThreads + threadIdx.x;   // (whole waves stay: the shuffles below need them)
     const int lane = fnp_lane();
     long long blk = -1;
@@ -107,7 +109,8 @@ __global__ __launch_bounds__(kThreads) void vox_mark_kernel(const float *__restr
         if (lane >= d && nb == blk) m |= nm;
     }
     const long long nxt = __shfl_down(blk, 1);
-    if (blk >= 0 && (lane == 63 || nxt != blk)) rg_mark_mask(g, blk, m);
+    if (blk >= 0 && (lane == 63 || nxt != blk)) mark_put(FNP_MARK_TAB ? &tab : nullptr, g, blk, m);
+    if (FNP_MARK_TAB) mark_tab_flush(&tab, g, threadIdx.x, kThreads);
 }
 
 __global__ __launch_bounds__(kThreads) void vox_insert_kernel(int n, int maxp, int cap,
