@@ -19,10 +19,13 @@ def load(d, counter):
 def short(k):
     m = re.search(r'spconv_mfma_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E(DF16b|f)(?:Lb(\d)E(?:DF16b|DF16_)Lb(\d)E)?', k)
     if m:
-        return "spconv_mfma_kernel<%s,%s,%s,%s,%s,%s%s>" % (m.group(1), m.group(2), m.group(3), m.group(4),
-                                                            "true" if m.group(5) == "1" else "false",
-                                                            "bf16" if m.group(6) == "DF16b" else "f32",
-                                                            ",sorted" if m.group(8) == "1" else "")
+        # (,fused: the rulebook entries of a tile are made inside the kernel — from the rank grid for the strided 32 -> 64 /
+        #  64 -> 128 layers, from the compact records for the 16-channel layers; without it: the (27, cap) table)
+        return "spconv_mfma_kernel<%s,%s,%s,%s,%s,%s%s%s>" % (m.group(1), m.group(2), m.group(3), m.group(4),
+                                                              "true" if m.group(5) == "1" else "false",
+                                                              "bf16" if m.group(6) == "DF16b" else "f32",
+                                                              ",fused" if m.group(7) == "1" else "",
+                                                              ",sorted" if m.group(8) == "1" else "")
     m = re.search(r'spconv_mfma_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (__bf16|float)>', k)
     if m:
         return "spconv_mfma_kernel<%s,%s,%s,%s,%s,%s>" % (*m.groups()[:5], "bf16" if m.group(6) == "__bf16" else "f32")
