@@ -170,16 +170,111 @@ __device__ __forceinline__ f32x4_t wg_mfma(Frag8<_Float16>::type a, Frag8<_Float
 
 // T16: __bf16 or _Float16 (the reference's AMP mode): the images are moved as raw 16-bit elements, only the matrix
 // instruction differs
-template <int CIN, int COUT, typename T16>
+// PAIR LISTS (round 3).  The weight gradient of offset k only sums over the output rows that HAVE a neighbour at k — 44 %
+// (stage 2) to 54 % (stage 4) of the rows — but a sweep over all rows of the table stages a 32-row tile of dy and of (mostly
+// zero) x rows for every (tile, offset) and multiplies the zeros.  fnp_rulebook_pairs compacts every offset's column once
+// per rulebook (its two to four convolutions share it): pair_o[k][j], pair_i[k][j] = the j-th output row with a neighbour
+// at k, in ascending order, and that neighbour; count[k].  Three small launches, order-preserving (a count per 1,024-row tile,
+// a scan per offset, an emit pass), so the gradient stays bit-reproducible.
+constexpr int kPairTile = 1024;
+__global__ __launch_bounds__(kThreads) void pairs_count_kernel(const int *__restrict__ nbr, int nbr_stride, const int *__restrict__ n_out, int cap,
+                                                               int ntiles, int *__restrict__ counts) {
+    __shared__ int wsum[kThreads / 64];
+    const int n = min(*n_out, cap), k = blockIdx.y, t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < kPairTile / kThreads; ++j) {
+        const int o = t * kPairTile + j * kThreads + threadIdx.x;
+        c += (o < n && nbr[(size_t)k * nbr_stride + o] >= 0) ? 1 : 0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if (lane == 0) wsum[wave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < kThreads / 64; ++w) tot += wsum[w];
+        counts[(size_t)k * ntiles + t] = tot;
+    }
+}
+// grid (K): exclusive scan of counts[k][0 .. ntiles) in place, total -> pair_count[k]
+__global__ __launch_bounds__(kThreads) void pairs_scan_kernel(int ntiles, int *__restrict__ counts, int *__restrict__ pair_count) {
+    __shared__ int wsum[kThreads / 64];
+    __shared__ int carry_s;
+    int *row = counts + (size_t)blockIdx.x * ntiles;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int b = 0; b < ntiles; b += kThreads) {
+        const int i = b + threadIdx.x;
+        const int v = i < ntiles ? row[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int off = carry_s;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (i < ntiles) row[i] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == kThreads - 1) carry_s = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pair_count[blockIdx.x] = carry_s;
+}
+__global__ __launch_bounds__(kThreads) void pairs_emit_kernel(const int *__restrict__ nbr, int nbr_stride, const int *__restrict__ n_out, int cap,
+                                                              int ntiles, const int *__restrict__ base, int *__restrict__ pair_o,
+                                                              int *__restrict__ pair_i) {
+    __shared__ int wsum[kThreads / 64];
+    const int n = min(*n_out, cap), k = blockIdx.y, t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int pos = base[(size_t)k * ntiles + t];
+    for (int j = 0; j < kPairTile / kThreads; ++j) {   // (ascending rows: pass j covers rows t*1024 + j*256 ..)
+        const int o = t * kPairTile + j * kThreads + threadIdx.x;
+        const int id = o < n ? nbr[(size_t)k * nbr_stride + o] : -1;
+        const unsigned long long m = __ballot(id >= 0);
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = pos, tot = 0;
+        for (int w = 0; w < kThreads / 64; ++w) {
+            if (w < wave) off += wsum[w];
+            tot += wsum[w];
+        }
+        if (id >= 0) {
+            const int p = off + __popcll(m & ((1ull << lane) - 1ull));
+            pair_o[(size_t)k * nbr_stride + p] = o;
+            pair_i[(size_t)k * nbr_stride + p] = id;
+        }
+        pos += tot;
+        __syncthreads();
+    }
+}
+
+// PAIRS: the rows of offset k come from the pair lists (pair_o / pair_i / pair_count) instead of a sweep over the table column
+#ifndef FNP_WGRAD_TR_NARROW
+#define FNP_WGRAD_TR_NARROW 128
+#endif
+template <int CIN, int COUT> struct WgradTile {
+    static constexpr int NBO = COUT / 16, WB = NBO >= 4 ? 4 : NBO, WK = 4 / WB;
+    // (two buffers x WK slices x rows x (dy row + x row + padding) must leave room for several workgroups per CU)
+    static constexpr int rows = (CIN + COUT >= 256) ? 32 : (CIN + COUT >= 192 || WK > 1) ? 64 : FNP_WGRAD_TR_NARROW;
+};
+template <int CIN, int COUT, typename T16, bool PAIRS = false>
 __global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const T16 *__restrict__ x, const T16 *__restrict__ dy,
                                                               const int *__restrict__ nbr, int nbr_stride,
                                                               const int *__restrict__ n_out, int cap_out, int /*unused*/,
-                                                              float *__restrict__ partial) {
+                                                              float *__restrict__ partial, const int *__restrict__ pair_i = nullptr,
+                                                              const int *__restrict__ pair_count = nullptr) {
     constexpr int NBO = COUT / 16, NBI = CIN / 16;
     constexpr int WB = NBO >= 4 ? 4 : NBO;          // waves across output-channel blocks
     constexpr int WK = 4 / WB;                      // row slices (k-split)
     constexpr int OB = NBO / WB;                    // output-channel blocks per wave
-    constexpr int TR = 32;                          // rows per slice and tile
+    // rows per slice and tile: 32 (one MFMA step deep) where a tile is 16 MFMAs per wave (128 x 128); the narrow layers do
+    // 2-8 MFMAs per 32 rows and were bound by the tile's barrier + LDS round trip, not by rows: they take 128 / 64 rows per
+    // tile (4 / 2 MFMA steps between two barriers)
+    constexpr int TR = WgradTile<CIN, COUT>::rows;
     constexpr int GT = WB * 64;                     // threads of one k-split group
     constexpr int XCH = CIN / 8, YCH = COUT / 8;    // 16-byte chunks per row
     constexpr int SY = COUT * 2 + 16, SX = CIN * 2 + 16;   // bytes per staged row (dy / x)
@@ -189,8 +284,9 @@ __global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const T16 *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned char fnp_wg_smem[];
     __bf16 *lds = reinterpret_cast<__bf16 *>(fnp_wg_smem);     // [2 buffers][WK slices][SLICE]
 
-    const int n = min(*n_out, cap_out);
     const int k = blockIdx.y, chunk = blockIdx.x, K = gridDim.y;
+    // (PAIRS: `nbr` is pair_o, and n the number of pairs of this offset)
+    const int n = PAIRS ? min(pair_count[k], cap_out) : min(*n_out, cap_out);
     const int rows_per_chunk = ((n + (int)gridDim.x - 1) / (int)gridDim.x + 127) / 128 * 128;   // from n, not the capacity
     const int r0 = min(n, chunk * rows_per_chunk), r1 = min(n, r0 + rows_per_chunk);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -206,23 +302,38 @@ __global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const T16 *__restr
 
     constexpr int YL = (TR * YCH + GT - 1) / GT, XL = (TR * XCH + GT - 1) / GT;   // 16-byte loads per thread and tile
     uint4 ry[YL], rx[XL];
+    // The row indices run a tile ahead of the rows (round 3): a tile's time was two dependent memory round trips — index, then
+    // row — against ~0.3 us of matrix work, with the rows requested one tile ahead only (135 tiles x 1.9 us for the 128 x 128
+    // layer at 16 scenes).  fetch_idx(t) loads what fetch(t) dereferences; the loop keeps it one tile further ahead.
+    int iy[YL], ix[XL];
     // tile t of this slice covers rows r0 + (t*WK + ks)*TR .. + TR
-    auto fetch = [&](int t) {
+    auto fetch_idx = [&](int t) {
         const int base = r0 + (t * WK + ks) * TR;
 #pragma unroll
         for (int j = 0; j < YL; ++j) {
-            const int e = gtid + j * GT, rr = e / YCH, c = e % YCH, r = base + rr;
-            ry[j] = make_uint4(0u, 0u, 0u, 0u);
-            if (e < TR * YCH && r < r1) ry[j] = *reinterpret_cast<const uint4 *>(dy + (size_t)r * COUT + c * 8);
+            const int e = gtid + j * GT, rr = e / YCH, r = base + rr;
+            iy[j] = -1;
+            if (e < TR * YCH && r < r1) iy[j] = PAIRS ? nbr[(size_t)k * nbr_stride + r] : r;   // (PAIRS: the r-th output row with a neighbour at k)
         }
 #pragma unroll
         for (int j = 0; j < XL; ++j) {
-            const int e = gtid + j * GT, rr = e / XCH, c = e % XCH, r = base + rr;
+            const int e = gtid + j * GT, rr = e / XCH, r = base + rr;
+            ix[j] = -1;
+            if (e < TR * XCH && r < r1) ix[j] = PAIRS ? pair_i[(size_t)k * nbr_stride + r] : nbr[(size_t)k * nbr_stride + r];
+        }
+    };
+    auto fetch = [&]() {   // the rows behind iy / ix
+#pragma unroll
+        for (int j = 0; j < YL; ++j) {
+            const int c = (gtid + j * GT) % YCH;
+            ry[j] = make_uint4(0u, 0u, 0u, 0u);
+            if (iy[j] >= 0) ry[j] = *reinterpret_cast<const uint4 *>(dy + (size_t)iy[j] * COUT + c * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            const int c = (gtid + j * GT) % XCH;
             rx[j] = make_uint4(0u, 0u, 0u, 0u);
-            if (e < TR * XCH && r < r1) {
-                const int id = nbr[(size_t)k * nbr_stride + r];
-                if (id >= 0) rx[j] = *reinterpret_cast<const uint4 *>(x + (size_t)id * CIN + c * 8);
-            }
+            if (ix[j] >= 0) rx[j] = *reinterpret_cast<const uint4 *>(x + (size_t)ix[j] * CIN + c * 8);
         }
     };
     auto stage = [&](int buf) {
@@ -254,21 +365,29 @@ __global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const T16 *__restr
 
     const int tiles = (r1 - r0 + WK * TR - 1) / (WK * TR);   // (workgroup-uniform)
     if (tiles > 0) {
-        fetch(0);
+        fetch_idx(0);
+        fetch();
         stage(0);
+        fetch_idx(1);   // (past the last tile: every index -1)
     }
     __syncthreads();
     for (int t = 0; t < tiles; ++t) {
-        if (t + 1 < tiles) fetch(t + 1);   // global loads of the next tile fly under this tile's MFMAs
+        if (t + 1 < tiles) {
+            fetch();            // rows of tile t + 1 (its indices arrived a tile ago): in flight under this tile's MFMAs
+            fetch_idx(t + 2);   // indices of tile t + 2
+        }
         const unsigned char *img = reinterpret_cast<const unsigned char *>(lds + (size_t)((t & 1) * WK + ks) * SLICE);
-        bf16x8_t bfr[NBI];
 #pragma unroll
-        for (int b = 0; b < NBI; ++b) bfr[b] = tr_frag(img + TR * SY, SX, b * 16);
+        for (int sub = 0; sub < TR / 32; ++sub) {   // 32 rows = one MFMA step
+            bf16x8_t bfr[NBI];
 #pragma unroll
-        for (int a = 0; a < OB; ++a) {
-            const bf16x8_t afr = tr_frag(img, SY, (wb * OB + a) * 16);
+            for (int b = 0; b < NBI; ++b) bfr[b] = tr_frag(img + TR * SY + sub * 32 * SX, SX, b * 16);
 #pragma unroll
-            for (int b = 0; b < NBI; ++b) acc[a][b] = wg_mfma(afr, bfr[b], acc[a][b]);
+            for (int a = 0; a < OB; ++a) {
+                const bf16x8_t afr = tr_frag(img + sub * 32 * SY, SY, (wb * OB + a) * 16);
+#pragma unroll
+                for (int b = 0; b < NBI; ++b) acc[a][b] = wg_mfma(afr, bfr[b], acc[a][b]);
+            }
         }
         if (t + 1 < tiles) stage((t + 1) & 1);
         __syncthreads();
@@ -313,16 +432,22 @@ __global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const T16 *__restr
 template <int CIN, int COUT>
 constexpr size_t wgrad_mfma_lds() {
     constexpr int NBO = COUT / 16, WB = NBO >= 4 ? 4 : NBO, WK = 4 / WB;
-    const size_t tiles = (size_t)2 * WK * (COUT * 2 + 16 + CIN * 2 + 16) * 32, red = (size_t)COUT * CIN * 4;
+    const size_t tiles = (size_t)2 * WK * (COUT * 2 + 16 + CIN * 2 + 16) * WgradTile<CIN, COUT>::rows, red = (size_t)COUT * CIN * 4;
     return tiles > red ? tiles : red;
 }
 
 template <int CIN, int COUT, typename T16>
 void launch_wgrad_mfma(dim3 grid, hipStream_t s, const T16 *x, const T16 *dy, const int *nbr, int nbr_stride,
-                       const int *n_out, int cap_out, int rows_per_chunk, float *partial) {
-    auto kern = wgrad_mfma_kernel<CIN, COUT, T16>;
+                       const int *n_out, int cap_out, int rows_per_chunk, float *partial, const int *pair_i = nullptr,
+                       const int *pair_count = nullptr) {
     const size_t lds = wgrad_mfma_lds<CIN, COUT>();
-    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, x, dy, nbr, nbr_stride, n_out, cap_out, rows_per_chunk, partial);
+    if (pair_i) {
+        auto kern = wgrad_mfma_kernel<CIN, COUT, T16, true>;
+        hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, x, dy, nbr, nbr_stride, n_out, cap_out, rows_per_chunk, partial, pair_i, pair_count);
+    } else {
+        auto kern = wgrad_mfma_kernel<CIN, COUT, T16, false>;
+        hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, x, dy, nbr, nbr_stride, n_out, cap_out, rows_per_chunk, partial, pair_i, pair_count);
+    }
 }
 
 // row chunks per offset: the narrow layers do little matrix work per 32-row tile and are bound by the latency of a
@@ -331,7 +456,7 @@ static inline int max_chunks(int Cin, int Cout) { return (long long)Cin * Cout <
 
 template <typename TX, typename TY>
 int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, float *dw,
-              int Cin, int Cout, void *ws, int64_t ws_bytes, hipStream_t s) {
+              int Cin, int Cout, void *ws, int64_t ws_bytes, hipStream_t s, const int *pair_i = nullptr, const int *pair_count = nullptr) {
     const long long pairs = (long long)Cin * Cout, total = pairs * K;
     if (pairs > 64 * kThreads) return FNP_ERR_ARG;   // <= 128 x 128
     int chunks = fnp_divup(cap_out, 2048);
@@ -346,7 +471,7 @@ int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int
         bool done = true;
 #define FNP_WM(CI, CO)                                                                                         \
     else if (Cin == CI && Cout == CO) launch_wgrad_mfma<CI, CO, TX>(grid, s, (const TX *)x, (const TX *)dy, nbr,         \
-                                                                nbr_stride, n_out, cap_out, rows_per_chunk, partial)
+                                                                nbr_stride, n_out, cap_out, rows_per_chunk, partial, pair_i, pair_count)
         if (false) {}
         FNP_WM(16, 16);
         FNP_WM(16, 32);
@@ -357,6 +482,7 @@ int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int
         FNP_WM(128, 128);
         else done = false;
 #undef FNP_WM
+        if (!done && pair_i) return FNP_ERR_ARG;   // (pair lists: the MFMA shapes only)
         if (done) {
             FNP_LAUNCH_CHECK();
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fnp_grid_for(total, kThreads)), dim3(kThreads), 0, s,
@@ -365,6 +491,7 @@ int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int
             return FNP_OK;
         }
     }
+    if (pair_i) return FNP_ERR_ARG;
     if (pairs <= 128) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_small_kernel<TX, TY>), grid, dim3(kThreads), (size_t)128 * (Cin + Cout) * 4, s, (const TX *)x,
                            (const TY *)dy, nbr, nbr_stride, n_out, cap_out, Cin, Cout, partial);
@@ -431,5 +558,47 @@ extern "C" int fnp_spconv_wgrad(const void *feat_in, int in_dtype, const void *g
     if (in_dtype == FNP_BF16 && grad_dtype == FNP_F32)
         return run_wgrad<__bf16, float>(feat_in, grad_out, nbr, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
                                         workspace_bytes, s);
+    return FNP_ERR_ARG;
+}
+
+// Pair lists of a rulebook (see wgrad_mfma_kernel): pair_o, pair_i (K, nbr_stride) int32, pair_count (K).
+extern "C" int64_t fnp_rulebook_pairs_workspace_bytes(int K, int cap_out) {
+    if (K <= 0 || cap_out <= 0) return 0;
+    return (int64_t)K * fnp_divup(cap_out, kPairTile) * 4;
+}
+
+extern "C" int fnp_rulebook_pairs(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int *pair_o, int *pair_i,
+                                  int *pair_count, void *workspace, int64_t workspace_bytes, fnp_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!nbr || !n_out || !pair_o || !pair_i || !pair_count || !workspace || K <= 0 || K > 65535 || cap_out <= 0 || nbr_stride < cap_out)
+        return FNP_ERR_ARG;
+    if (fnp_rulebook_pairs_workspace_bytes(K, cap_out) > workspace_bytes) return FNP_ERR_WORKSPACE;
+    const int ntiles = fnp_divup(cap_out, kPairTile);
+    int *counts = (int *)workspace;
+    hipLaunchKernelGGL(pairs_count_kernel, dim3(ntiles, K), dim3(kThreads), 0, s, nbr, nbr_stride, n_out, cap_out, ntiles, counts);
+    FNP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pairs_scan_kernel, dim3(K), dim3(kThreads), 0, s, ntiles, counts, pair_count);
+    FNP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pairs_emit_kernel, dim3(ntiles, K), dim3(kThreads), 0, s, nbr, nbr_stride, n_out, cap_out, ntiles, (const int *)counts, pair_o,
+                       pair_i);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+// fnp_spconv_wgrad on the pair lists: 16-bit features and gradients of the MFMA channel pairs; FNP_ERR_ARG otherwise (take
+// fnp_spconv_wgrad).  Same sum in another grouping of the rows: equal to fnp_spconv_wgrad's up to f32 rounding, run-to-run identical.
+extern "C" int fnp_spconv_wgrad_pairs(const void *feat_in, int in_dtype, const void *grad_out, int grad_dtype, const int *pair_o,
+                                      const int *pair_i, const int *pair_count, int nbr_stride, int K, const int *n_out, int cap_out,
+                                      float *grad_weight, int Cin, int Cout, void *workspace, int64_t workspace_bytes, fnp_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!feat_in || !grad_out || !pair_o || !pair_i || !pair_count || !n_out || !grad_weight || !workspace || K <= 0 || Cin <= 0 || Cout <= 0 ||
+        cap_out <= 0 || nbr_stride < cap_out)
+        return FNP_ERR_ARG;
+    if (in_dtype == FNP_BF16 && grad_dtype == FNP_BF16)
+        return run_wgrad<__bf16, __bf16>(feat_in, grad_out, pair_o, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
+                                         workspace_bytes, s, pair_i, pair_count);
+    if (in_dtype == FNP_F16 && grad_dtype == FNP_F16)
+        return run_wgrad<_Float16, _Float16>(feat_in, grad_out, pair_o, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout,
+                                             workspace, workspace_bytes, s, pair_i, pair_count);
     return FNP_ERR_ARG;
 }

@@ -538,14 +538,49 @@ def conv_dgrad(grad_out, w_packed, nbr_t, n_in_dev, cap_in):
     return dx
 
 
-def conv_wgrad(feat_in, grad_out, rb, n_out_dev, Cin, Cout):
-    """dW (K, Cout, Cin) f32 = sum_o dy[o] (x) x[nbr[k][o]] (deterministic two-stage reduction)."""
+WGRAD_PAIR_SHAPES = {(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128)}   # (Cin, Cout) of the MFMA weight gradient
+WGRAD_PAIRS = os.environ.get("FNP_WGRAD_PAIRS", "1") == "1"
+
+
+def rulebook_pairs(rb, n_out_dev, rows=None):
+    """Pair lists of a rulebook (fnp_rulebook_pairs), kept with it (`rb._pairs` = (pair_o, pair_i, pair_count)): per kernel
+    offset the output rows that have a neighbour there, ascending, and those neighbours.  Built once per rulebook and
+    backward (the two to four convolutions of a stage share it).  No host sync.  rows: an upper bound of the row count the
+    caller knows on the host (a strided layer's table is sized for the worst case: 27 outputs per input)."""
+    L = _l.load()
+    K, stride = rb.K, rb.nbr.shape[1]
+    cap = min(rb.cap_out, int(rows)) if rows else rb.cap_out
+    dev = rb.nbr.device
+    po = torch.empty((K, stride), dtype=torch.int32, device=dev)
+    pi = torch.empty((K, stride), dtype=torch.int32, device=dev)
+    cnt = torch.empty((K,), dtype=torch.int32, device=dev)
+    ws = torch.empty((int(L.fnp_rulebook_pairs_workspace_bytes(K, cap)),), dtype=torch.uint8, device=dev)
+    rc = L.fnp_rulebook_pairs(_l.ptr(rb.nbr), stride, K, _l.ptr(n_out_dev), cap, _l.ptr(po), _l.ptr(pi), _l.ptr(cnt), _l.ptr(ws), ws.numel(),
+                              _l.stream())
+    _l.check(rc, "fnp_rulebook_pairs")
+    rb._pairs = (po, pi, cnt)
+    return rb._pairs
+
+
+def conv_wgrad(feat_in, grad_out, rb, n_out_dev, Cin, Cout, pairs=None):
+    """dW (K, Cout, Cin) f32 = sum_o dy[o] (x) x[nbr[k][o]] (deterministic two-stage reduction).
+    pairs: None = on the rulebook's pair lists where they apply (16-bit tensors, MFMA channel pairs; built on first use and
+    kept with the rulebook), False = the sweep over the table."""
     L = _l.load()
     assert feat_in.is_contiguous() and grad_out.is_contiguous()
     assert feat_in.shape[1] == Cin and grad_out.shape[1] == Cout
     dw = torch.empty((rb.K, Cout, Cin), dtype=torch.float32, device=feat_in.device)
     ws = torch.empty((int(L.fnp_spconv_wgrad_workspace_bytes(rb.K, Cin, Cout)),), dtype=torch.uint8, device=feat_in.device)
     cap = min(rb.cap_out, grad_out.shape[0])
+    use_pairs = WGRAD_PAIRS if pairs is None else pairs
+    if (use_pairs and (Cin, Cout) in WGRAD_PAIR_SHAPES and feat_in.dtype in (torch.bfloat16, torch.float16) and grad_out.dtype == feat_in.dtype
+            and not getattr(rb, "_lean", False)):
+        pr = getattr(rb, "_pairs", None) or rulebook_pairs(rb, n_out_dev, rows=cap)
+        rc = L.fnp_spconv_wgrad_pairs(_l.ptr(feat_in), _l.dtype_code(feat_in), _l.ptr(grad_out), _l.dtype_code(grad_out), _l.ptr(pr[0]), _l.ptr(pr[1]),
+                                      _l.ptr(pr[2]), rb.nbr.shape[1], rb.K, _l.ptr(n_out_dev), cap, _l.ptr(dw), Cin, Cout, _l.ptr(ws), ws.numel(),
+                                      _l.stream())
+        _l.check(rc, "fnp_spconv_wgrad_pairs")
+        return dw
     rc = L.fnp_spconv_wgrad(_l.ptr(feat_in), _l.dtype_code(feat_in), _l.ptr(grad_out), _l.dtype_code(grad_out),
                             _l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, _l.ptr(n_out_dev), cap, _l.ptr(dw), Cin, Cout,
                             _l.ptr(ws), ws.numel(), _l.stream())

@@ -74,6 +74,35 @@ def test_conv_autograd_matches_oracle(cuda, oracle, rng, dtype, tol, mode, cin, 
     assert torch.equal(conv.weight.grad, g1)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout,n", [(16, 16, 1), (32, 32, 700), (16, 32, 5000), (64, 64, 5000), (128, 128, 9000), (64, 128, 3000)])
+def test_wgrad_on_pair_lists_equals_the_table_sweep(cuda, rng, dtype, cin, cout, n):
+    """fnp_rulebook_pairs + fnp_spconv_wgrad_pairs: the pair lists name, per offset and in ascending order, exactly the output
+    rows with a neighbour there and those neighbours; the weight gradient summed over them equals the sweep over the whole
+    table up to f32 rounding of another grouping (1e-5 of the gradient's scale), and twice the same bits."""
+    from findnpropagate_amd import sparse as S
+    B, shape = 2, [7, 40, 41]
+    cells = B * shape[0] * shape[1] * shape[2]
+    lin = rng.choice(cells, size=n, replace=False)
+    b, rem = np.divmod(lin, shape[0] * shape[1] * shape[2]); z, rem = np.divmod(rem, shape[1] * shape[2]); y, x = np.divmod(rem, shape[2])
+    idx = torch.from_numpy(np.stack([b, z, y, x], 1).astype(np.int32)).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    rb = S.rulebook_subm(idx, n_dev, S.build_grid(idx, n_dev, B, shape), 3)
+    po, pi, cnt = S.rulebook_pairs(rb, n_dev)
+    nbr = rb.nbr[:, :n].cpu().numpy()
+    for k in range(27):
+        rows = np.nonzero(nbr[k] >= 0)[0]
+        assert int(cnt[k]) == len(rows)
+        assert np.array_equal(po[k, :len(rows)].cpu().numpy(), rows) and np.array_equal(pi[k, :len(rows)].cpu().numpy(), nbr[k][rows])
+    xin = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).to(cuda).to(dtype)
+    dy = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).to(cuda).to(dtype)
+    a = S.conv_wgrad(xin, dy, rb, n_dev, cin, cout, pairs=False)
+    b1 = S.conv_wgrad(xin, dy, rb, n_dev, cin, cout, pairs=True)
+    b2 = S.conv_wgrad(xin, dy, rb, n_dev, cin, cout, pairs=True)
+    assert torch.equal(b1, b2)
+    assert float((a - b1).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-6)
+
+
 def test_backbone_training_step_runs_and_matches_torch_reference_ops(cuda, rng):
     """VoxelResBackBone8x in train mode (BatchNorm with batch statistics), f32: every parameter gradient
     equals the one obtained when the convolutions are evaluated with plain torch ops (index_select + matmul
