@@ -80,6 +80,7 @@ __device__ __forceinline__ void backproject(const float *aug_R, const float *aug
 struct Shared {
     unsigned hist[256];
     unsigned sel_prefix, sel_mask, sel_k;
+    unsigned scan_w[kThreads / 64];
     unsigned count, scratch_u;
     float cam[kCam], aug_R[9], aug_inv[9], aug_t[3];
     float fr[8][3];
@@ -103,6 +104,10 @@ struct Shared {
 __device__ __forceinline__ unsigned fbits(float f) { return __float_as_uint(f); }  // depths are > 0: order preserving
 
 // k-th smallest (0-based) depth of the list: 4 x 8-bit histogram passes on the float bits.
+// LAT: the workgroup-parallel bin search (small launches: a frustum's latency is the launch's); without it thread 0 walks the
+// bins — ten times slower per pass, but free when four workgroups share a CU and the launch is bound by throughput (64 scenes
+// per launch: 56 k scenes/s against 52.6 k with the parallel search; one scene: 1,590 against 1,780 the other way round)
+template <bool LAT>
 __device__ float select_kth(Shared &S, const float *__restrict__ depth3, int m, unsigned k) {
     if (threadIdx.x == 0) {
         S.sel_prefix = 0;
@@ -118,16 +123,41 @@ __device__ float select_kth(Shared &S, const float *__restrict__ depth3, int m, 
             if ((key & mask) == prefix) atomicAdd(&S.hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned kk = S.sel_k, b = 0;
-            for (; b < 256; ++b) {
-                const unsigned h = S.hist[b];
-                if (kk < h) break;
-                kk -= h;
+        if constexpr (!LAT) {
+            if (threadIdx.x == 0) {
+                unsigned kk = S.sel_k, b = 0;
+                for (; b < 256; ++b) {
+                    const unsigned h = S.hist[b];
+                    if (kk < h) break;
+                    kk -= h;
+                }
+                S.sel_k = kk;
+                S.sel_prefix = prefix | (b << shift);
+                S.sel_mask = mask | (255u << shift);
             }
-            S.sel_k = kk;
-            S.sel_prefix = prefix | (b << shift);
-            S.sel_mask = mask | (255u << shift);
+        } else {
+            // the bin the k-th key falls into: inclusive prefix of the 256 counts across the workgroup (thread = bin), the one
+            // thread whose bin straddles k publishes it (round 3: thread 0 walking the bins one LDS read at a time was ~10 us
+            // per pass, twelve passes per frustum — a third of the kernel's latency at small batch sizes)
+            static_assert(kThreads == 256, "one thread per histogram bin");
+            const unsigned h = S.hist[threadIdx.x], kk = S.sel_k;
+            unsigned inc = h;
+            const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned t = __shfl_up(inc, d);
+                if (lane_ >= d) inc += t;
+            }
+            if (lane_ == 63) S.scan_w[wave_] = inc;
+            __syncthreads();
+            unsigned off = 0;
+            for (int w = 0; w < wave_; ++w) off += S.scan_w[w];
+            const unsigned incl = off + inc, excl = incl - h;
+            if (kk >= excl && kk < incl) {   // (exactly one thread: k < the number of keys that carry the prefix)
+                S.sel_k = kk - excl;
+                S.sel_prefix = prefix | ((unsigned)threadIdx.x << shift);
+                S.sel_mask = mask | (255u << shift);
+            }
         }
         __syncthreads();
     }
@@ -135,10 +165,11 @@ __device__ float select_kth(Shared &S, const float *__restrict__ depth3, int m, 
 }
 
 // torch.quantile(depth, q), linear interpolation via torch.lerp
+template <bool LAT>
 __device__ float quantile(Shared &S, const float *__restrict__ list, int m, float q) {
     const float rank = q * (float)(m - 1);
     const int lo = (int)floorf(rank), hi = (int)ceilf(rank);
-    const float a = select_kth(S, list, m, (unsigned)lo);
+    const float a = select_kth<LAT>(S, list, m, (unsigned)lo);
     float b = a;
     if (hi != lo) {
         // (lo+1)-th smallest: a again if a is duplicated past position lo, else the smallest key > a
@@ -167,7 +198,7 @@ __device__ float quantile(Shared &S, const float *__restrict__ list, int m, floa
 // OPT: the instantiation that carries the options no shipped configuration sets (MULTICAM_IOU, the occlusion terms, search_depth,
 // rand_center, topk > 1).  The shipped path compiles them out: with them in one body the candidate loop holds 175 registers
 // instead of 126 and the kernel runs two waves per SIMD instead of four (57 k -> 42 k scenes/s at 64 scenes per launch).
-template <bool OPT>
+template <bool OPT, bool LAT>
 __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
     const float *__restrict__ points, const int *__restrict__ scene_off, const fnp_seeker_params prm,
     const float *__restrict__ scene_mats,   // (S, 21): aug_R 9 | aug_inv 9 | aug_t 3
@@ -200,25 +231,42 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
     const int p0 = scene_off[scene], p1 = scene_off[scene + 1];
     float *list = ws_uvd + (size_t)f * ws_stride * 3;
     float *lxyz = ws_xyz + (size_t)f * ws_stride * 3;
-    for (int base = p0; base < p1; base += kThreads) {
-        const int i = base + tid;
-        bool in = false;
-        float u = 0, v = 0, d = 0;
-        if (i < p1) {
-            const float *p = points + (size_t)i * prm.point_stride + prm.xyz_offset;
-            project(S.aug_inv, S.aug_t, S.cam, ia, p[0], p[1], p[2], u, v, d);
-            const bool on_img = (v < (float)prm.image_h) && (v >= 0.f) && (u < (float)prm.image_w) && (u >= 0.f);
-            in = on_img && (v < y2) && (v >= y1) && (u < x2) && (u >= x1);
+    // (four passes of points per trip: their loads are in flight together — one load per trip made the scan of a 30 k-point
+    //  scene 118 dependent memory round trips; the order of the list is free: quantiles, extents and counts do not see it)
+    constexpr int kPB = LAT ? 4 : 1;
+    for (int base = p0; base < p1; base += kPB * kThreads) {
+        float px[kPB], py[kPB], pz[kPB];
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) {
+            const int i = base + j * kThreads + tid;
+            px[j] = py[j] = pz[j] = 0.f;
+            if (i < p1) {
+                const float *p = points + (size_t)i * prm.point_stride + prm.xyz_offset;
+                px[j] = p[0];
+                py[j] = p[1];
+                pz[j] = p[2];
+            }
         }
-        const unsigned long long mask = __ballot(in);
-        unsigned wbase = 0;
-        if (lane == 0 && mask) wbase = atomicAdd(&S.count, (unsigned)__popcll(mask));
-        wbase = __shfl(wbase, 0);
-        if (in) {
-            const unsigned pos = wbase + __popcll(mask & ((1ull << lane) - 1ull));
-            list[(size_t)pos * 3 + 0] = u;
-            list[(size_t)pos * 3 + 1] = v;
-            list[(size_t)pos * 3 + 2] = d;
+#pragma unroll
+        for (int j = 0; j < kPB; ++j) {
+            const int i = base + j * kThreads + tid;
+            bool in = false;
+            float u = 0, v = 0, d = 0;
+            if (i < p1) {
+                project(S.aug_inv, S.aug_t, S.cam, ia, px[j], py[j], pz[j], u, v, d);
+                const bool on_img = (v < (float)prm.image_h) && (v >= 0.f) && (u < (float)prm.image_w) && (u >= 0.f);
+                in = on_img && (v < y2) && (v >= y1) && (u < x2) && (u >= x1);
+            }
+            const unsigned long long mask = __ballot(in);
+            unsigned wbase = 0;
+            if (lane == 0 && mask) wbase = atomicAdd(&S.count, (unsigned)__popcll(mask));
+            wbase = __shfl(wbase, 0);
+            if (in) {
+                const unsigned pos = wbase + __popcll(mask & ((1ull << lane) - 1ull));
+                list[(size_t)pos * 3 + 0] = u;
+                list[(size_t)pos * 3 + 1] = v;
+                list[(size_t)pos * 3 + 2] = d;
+            }
         }
     }
     __syncthreads();
@@ -232,9 +280,9 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
     __threadfence_block();
 
     // ---- B: depth quantiles -----------------------------------------------------------------
-    const float qlo = quantile(S, list, m, prm.lq);
-    const float qhi = quantile(S, list, m, prm.uq);
-    const float qc = quantile(S, list, m, prm.cq);
+    const float qlo = quantile<LAT>(S, list, m, prm.lq);
+    const float qhi = quantile<LAT>(S, list, m, prm.uq);
+    const float qc = quantile<LAT>(S, list, m, prm.cq);
 
     // ---- C: frustum corners in lidar, weighted centre ---------------------------------------
     if (tid < 8) {
@@ -714,16 +762,18 @@ extern "C" int fnp_boxseeker(const float *points, const int *scene_offsets, int 
     float *ws_xyz = ws_uvd + (size_t)num_frustums * stride * 3;
     const bool opt = params->topk > 1 || params->search_depth > 0.f || params->occl_w > 0.f || params->occl_mult || params->multicam ||
                      params->count_only || params->rand_noise;
-    if (opt)
-        hipLaunchKernelGGL(boxseeker_kernel<true>, dim3(num_frustums), dim3(kThreads), 0, (hipStream_t)stream, points,
-                           scene_offsets, *params, scene_mats, cam_mats, frustums, base_boxes, base_corners, mags, ws_uvd,
-                           ws_xyz, stride, out_valid, out_box, out_score, out_best, dbg_npts, dbg_frust, dbg_cand, dbg_iou,
-                           dbg_count, dbg_valid);
-    else
-        hipLaunchKernelGGL(boxseeker_kernel<false>, dim3(num_frustums), dim3(kThreads), 0, (hipStream_t)stream, points,
-                           scene_offsets, *params, scene_mats, cam_mats, frustums, base_boxes, base_corners, mags, ws_uvd,
-                           ws_xyz, stride, out_valid, out_box, out_score, out_best, dbg_npts, dbg_frust, dbg_cand, dbg_iou,
-                           dbg_count, dbg_valid);
+    // small launches (fewer workgroups than two per CU): the instantiation built for a frustum's latency
+    const bool lat = num_frustums <= 512;
+#define FNP_BS_LAUNCH(O, L)                                                                                                     \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(boxseeker_kernel<O, L>), dim3(num_frustums), dim3(kThreads), 0, (hipStream_t)stream, points,            \
+                       scene_offsets, *params, scene_mats, cam_mats, frustums, base_boxes, base_corners, mags, ws_uvd,         \
+                       ws_xyz, stride, out_valid, out_box, out_score, out_best, dbg_npts, dbg_frust, dbg_cand, dbg_iou,        \
+                       dbg_count, dbg_valid)
+    if (opt && lat) FNP_BS_LAUNCH(true, true);
+    else if (opt) FNP_BS_LAUNCH(true, false);
+    else if (lat) FNP_BS_LAUNCH(false, true);
+    else FNP_BS_LAUNCH(false, false);
+#undef FNP_BS_LAUNCH
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
