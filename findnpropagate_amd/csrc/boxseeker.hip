@@ -273,8 +273,14 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
     const int m = (int)S.count;
     if (dbg_npts && tid == 0) dbg_npts[f] = m;
     if (OPT && prm.count_only) return;   // (the pre-pass of MULTICAM_IOU: which frustums hold points at all)
-    if (m == 0) {  // "no pts in box": the frustum is dropped (:634-637)
+    if (m == 0) {  // "no pts in box": the frustum is dropped (:634-637); every output gets its empty value (callers need not clear)
+        const int tk = OPT ? prm.topk : 1;
         if (tid == 0) out_valid[f] = 0;
+        for (int i = tid; i < tk; i += kThreads) {
+            out_best[(size_t)f * tk + i] = -1;
+            out_score[(size_t)f * tk + i] = 0.f;
+        }
+        for (int i = tid; i < tk * 7; i += kThreads) out_box[(size_t)f * tk * 7 + i] = 0.f;
         return;
     }
     __threadfence_block();
@@ -603,6 +609,110 @@ __global__ __launch_bounds__(kThreads) void boxseeker_kernel(
         for (int c = tid; c < NC; c += kThreads) dbg_valid[(size_t)f * NC + c] = S.cvalid[c];
 }
 
+// The matrices the kernel reads, made on the device from the batch's own (device) tensors: lidar_aug (S,4,4), lidar2image /
+// camera2lidar / camera_intrinsics / img_aug (S,6,4,4).  The host version of this (five device-to-host copies with their
+// synchronisations, three LAPACK calls and a dozen small tensor operations per launch) was 0.2 ms of the 0.6 ms a one-scene
+// launch costs on the host.  3x3 inverses by Gauss-Jordan elimination with partial pivoting in f32 (the reference calls
+// torch.inverse, an LU with partial pivoting too; the two agree to rounding).  One thread per (scene, camera) + one per scene.
+__device__ __forceinline__ void inv3(const float *A, int stride, float *out) {
+    float a[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a[r][c] = A[r * stride + c];
+            a[r][3 + c] = r == c ? 1.f : 0.f;
+        }
+#pragma unroll
+    for (int col = 0; col < 3; ++col) {
+        int piv = col;
+        float best = fabsf(a[col][col]);
+#pragma unroll
+        for (int r = col + 1; r < 3; ++r)
+            if (fabsf(a[r][col]) > best) {
+                best = fabsf(a[r][col]);
+                piv = r;
+            }
+#pragma unroll
+        for (int r = col + 1; r < 3; ++r)
+            if (r == piv) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const float t = a[col][c];
+                    a[col][c] = a[r][c];
+                    a[r][c] = t;
+                }
+            }
+        const float d = a[col][col];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) a[col][c] = a[col][c] / d;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (r == col) continue;
+            const float f = a[r][col];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) a[r][c] = a[r][c] - f * a[col][c];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[r * 3 + c] = a[r][3 + c];
+}
+
+__global__ __launch_bounds__(64) void seeker_prepare_kernel(const float *__restrict__ aug, const float *__restrict__ l2i,
+                                                            const float *__restrict__ c2l, const float *__restrict__ K,
+                                                            const float *__restrict__ ia, int S, float *__restrict__ scene,
+                                                            float *__restrict__ cam) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < S) {   // scene: R | inv(R) | t
+        const float *A = aug + (size_t)i * 16;
+        float *o = scene + (size_t)i * 21;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[r * 3 + c] = A[r * 4 + c];
+        inv3(A, 4, o + 9);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[18 + r] = A[r * 4 + 3];
+    }
+    if (i < S * 6) {
+        const float *L = l2i + (size_t)i * 16, *C = c2l + (size_t)i * 16, *Kc = K + (size_t)i * 16;
+        float *o = cam + (size_t)i * kCam;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[r * 3 + c] = L[r * 4 + c];
+            o[9 + r] = L[r * 4 + 3];
+            o[21 + r] = C[r * 4 + 3];
+        }
+        float kinv[9];
+        inv3(Kc, 4, kinv);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)   // camera2lidar rotation x inverse intrinsics (:1530)
+                o[12 + r * 3 + c] = (C[r * 4 + 0] * kinv[0 * 3 + c] + C[r * 4 + 1] * kinv[1 * 3 + c]) + C[r * 4 + 2] * kinv[2 * 3 + c];
+        if (ia) {
+            const float *P = ia + (size_t)i * 16;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[24 + r * 3 + c] = P[r * 4 + c];
+                o[33 + r] = P[r * 4 + 3];
+            }
+            inv3(P, 4, o + 36);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                o[24 + j] = (j % 4 == 0) ? 1.f : 0.f;
+                o[36 + j] = (j % 4 == 0) ? 1.f : 0.f;
+            }
+            o[33] = o[34] = o[35] = 0.f;
+        }
+    }
+}
+
 // Exchange records of the sharded extraction (findnpropagate_amd/extract.py): scene s of the batch gets one
 // (rows_per_scene, 9) f32 record, row 0 = [count, tag, 0 ...], rows 1.. = [box (7), detection score, label] of its
 // frustums that yielded a box, in frustum order; every other row is zeroed.  One workgroup per scene; the position of
@@ -733,6 +843,16 @@ extern "C" int fnp_host_enumerate_frustums(const float *boxes, const int64_t *la
     }
     free(idx); free(ob); free(removed);
     return n_rows;
+}
+
+extern "C" int fnp_seeker_prepare_matrices(const float *lidar_aug, const float *lidar2image, const float *camera2lidar,
+                                           const float *intrinsics, const float *img_aug, int num_scenes, float *scene_mats,
+                                           float *cam_mats, fnp_stream_t stream) {
+    if (!lidar_aug || !lidar2image || !camera2lidar || !intrinsics || !scene_mats || !cam_mats || num_scenes <= 0) return FNP_ERR_ARG;
+    hipLaunchKernelGGL(seeker_prepare_kernel, dim3(fnp_divup(num_scenes * 6, 64)), dim3(64), 0, (hipStream_t)stream, lidar_aug, lidar2image,
+                       camera2lidar, intrinsics, img_aug, num_scenes, scene_mats, cam_mats);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
 }
 
 extern "C" int64_t fnp_boxseeker_workspace_bytes(int num_frustums, int max_points_per_scene) {

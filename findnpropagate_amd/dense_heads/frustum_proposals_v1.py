@@ -11,12 +11,17 @@ the reference does >= 60 per frustum.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 
 from .. import lib as _l
+
+
+# the kernel's matrices made on the device (fnp_seeker_prepare_matrices); FNP_SEEKER_HOST_MATRICES=1: on the host with torch.inverse
+MATRICES_ON_DEVICE = os.environ.get("FNP_SEEKER_HOST_MATRICES", "0") != "1"
 
 
 def _get(cfg, key, default=None):
@@ -235,6 +240,22 @@ class FrustumProposerOG(nn.Module):
                          post.reshape(B, 6, 9), post_t, post_inv.reshape(B, 6, 9)], dim=2)
         return scene, cam.contiguous(), has_ia
 
+    @staticmethod
+    def _matrices_device(batch_dict, dev):
+        """The same matrices made on the device by fnp_seeker_prepare_matrices from the batch's device tensors (no copy to the
+        host, no synchronisation, no LAPACK call): (B,21), (B,6,45), and whether the batch carries an img_aug_matrix (applied
+        whenever present, as the reference does: an identity changes no value)."""
+        f = lambda k: batch_dict[k].detach().to(dev, torch.float32, non_blocking=True).contiguous()
+        aug, l2i, c2l, K = f('lidar_aug_matrix'), f('lidar2image'), f('camera2lidar'), f('camera_intrinsics')
+        ia = f('img_aug_matrix') if 'img_aug_matrix' in batch_dict else None
+        B = aug.shape[0]
+        assert tuple(l2i.shape) == (B, 6, 4, 4) and tuple(c2l.shape) == (B, 6, 4, 4) and tuple(K.shape) == (B, 6, 4, 4)
+        scene = torch.empty((B, 21), dtype=torch.float32, device=dev)
+        cam = torch.empty((B, 6, 45), dtype=torch.float32, device=dev)
+        _l.check(_l.load().fnp_seeker_prepare_matrices(_l.ptr(aug), _l.ptr(l2i), _l.ptr(c2l), _l.ptr(K), _l.ptr(ia), B, _l.ptr(scene), _l.ptr(cam),
+                                                       _l.stream()), "fnp_seeker_prepare_matrices")
+        return scene, cam, ia is not None
+
     def _tables(self, dev):
         """Device copies of the constant tables, kept alive across (asynchronous) launches."""
         key = str(dev)
@@ -269,27 +290,40 @@ class FrustumProposerOG(nn.Module):
             pps = [int(points.shape[0])]
         if pps is not None:
             assert len(pps) == B and sum(int(v) for v in pps) == points.shape[0]
-            offs = [0]
-            for v in pps:
-                offs.append(offs[-1] + int(v))
-            offsets = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+            # scene offsets and the frustum table cross to the device in ONE pinned transfer (offsets as int32 bits in the f32 buffer)
+            host = torch.empty((B + 1 + F * 8,), dtype=torch.float32, pin_memory=True)
+            ho = host[:B + 1].view(torch.int32)
+            acc = 0
+            ho[0] = 0
+            for b, v in enumerate(pps):
+                acc += int(v)
+                ho[b + 1] = acc
+            host[B + 1:] = frusts.reshape(-1)
+            d_host = host.to(dev, non_blocking=True)
+            offsets, d_fr = d_host[:B + 1].view(torch.int32), d_host[B + 1:].view(F, 8)
             max_pts = max(int(v) for v in pps)
         else:
             counts = torch.bincount(points[:, 0].long(), minlength=B)[:B]
             offsets = torch.zeros((B + 1,), dtype=torch.int32, device=dev)
             offsets[1:] = torch.cumsum(counts, 0).int()
             max_pts = int(counts.max().item())                                 # host sync (scene sizes)
-        scene_m, cam_m, has_img_aug = self._matrices(batch_dict)
-        scene_m, cam_m, d_fr = scene_m.to(dev, non_blocking=True), cam_m.to(dev, non_blocking=True), frusts.to(dev, non_blocking=True)
+            d_fr = frusts.to(dev, non_blocking=True)
+        if MATRICES_ON_DEVICE:
+            scene_m, cam_m, has_img_aug = self._matrices_device(batch_dict, dev)
+        else:
+            scene_m, cam_m, has_img_aug = self._matrices(batch_dict)
+            scene_m, cam_m = scene_m.to(dev, non_blocking=True), cam_m.to(dev, non_blocking=True)
         prm = self._params(points.shape[1], 1)
         prm.has_img_aug = int(has_img_aug)
         NM, TK = max(int(self.num_mags), 1), int(self.topk)
         NC = NM * self.num_rotations * self.num_sizes
         ws = torch.empty((int(L.fnp_boxseeker_workspace_bytes(F, max_pts)),), dtype=torch.uint8, device=dev)
-        out_valid = torch.zeros((F,), dtype=torch.int32, device=dev)
-        out_box = torch.zeros((F * TK, 7), dtype=torch.float32, device=dev)
-        out_score = torch.zeros((F * TK,), dtype=torch.float32, device=dev)
-        out_best = torch.full((F * TK,), -1, dtype=torch.int32, device=dev)
+        # (every output element is written by the kernel, frustums without points included: no clearing launches)
+        out_all = torch.empty((F * (1 + TK * 9),), dtype=torch.float32, device=dev)
+        out_valid = out_all[:F].view(torch.int32)
+        out_box = out_all[F:F + F * TK * 7].view(F * TK, 7)
+        out_score = out_all[F + F * TK * 7:F + F * TK * 8]
+        out_best = out_all[F + F * TK * 8:].view(torch.int32)
         keep = []
         if self.rand_center:         # :847: the weighted centre plus unit Gaussian draws instead of positions along the frustum axis
             if noise is None:

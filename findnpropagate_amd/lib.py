@@ -138,6 +138,7 @@ SIGNATURES = {
     "fnp_rulebook_classsort": (c_int, [P, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P, c_int64, P]),
     "fnp_spconv_forward_sorted": (c_int, [P, c_int, c_int, P, P, c_int, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     "fnp_boxseeker_workspace_bytes": (c_int64, [c_int, c_int]),
+    "fnp_seeker_prepare_matrices": (c_int, [P, P, P, P, P, c_int, P, P, P]),
     "fnp_host_enumerate_frustums": (c_int, [P, P, P, P, P, c_int, c_int, POINTER(c_int), c_int, c_float, c_float, P, c_int]),
     "fnp_boxseeker": (c_int, [P, P, c_int, c_int, POINTER(SeekerParams), P, P, P, c_int, P, P, P, P, c_int64,
                               P, P, P, P, P, P, P, P, P, P, P]),

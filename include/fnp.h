@@ -517,6 +517,14 @@ typedef struct fnp_seeker_params {
 
 int64_t fnp_boxseeker_workspace_bytes(int num_frustums, int max_points_per_scene);
 
+/* scene_mats (S,21) / cam_mats (S,6,45) of fnp_boxseeker made ON THE DEVICE (ABI 8) from the batch's own device tensors —
+ * lidar_aug (S,4,4), lidar2image / camera2lidar / intrinsics (S,6,4,4), img_aug (S,6,4,4) or NULL (identity) — the matrix
+ * algebra of project_to_camera / get_geometry_at_image_coords (frustum_proposals_v1.py:1431-1475, :1509-1545; the reference
+ * calls torch.inverse on 3x3 blocks: here a Gauss-Jordan elimination with partial pivoting in f32).  No host copy, no sync. */
+int fnp_seeker_prepare_matrices(const float *lidar_aug, const float *lidar2image, const float *camera2lidar,
+                                const float *intrinsics, const float *img_aug, int num_scenes, float *scene_mats,
+                                float *cam_mats, fnp_stream_t stream);
+
 /* HOST function (all pointers are host memory, no GPU work): frustum enumeration of :561-594 —
  * per scene, per camera in image_order, torchvision.batched_nms (coordinate trick, f32) on the
  * 2D detections, then the score threshold.  boxes (D,4) xyxy f32, labels/batch_idx/cam_idx (D,)
