@@ -445,6 +445,30 @@ def main():
                         row[f"pipeline_{depth}_error"] = repr(e)[:200]
             sweep[str(b)] = row
         out["batch_sweep"] = sweep
+        # The same 64-scene step with several BATCHES in flight (PointsPipeline: a hipGraph, an engine and a HIP stream per slot;
+        # results identical per batch): what a server that is handed batches back to back gets out of the card — the latency-bound
+        # index kernels of one batch run under the convolutions of another.  Reported beside `value`, which stays one batch at a time.
+        try:
+            pl = {}
+            with torch.no_grad():
+                cap = (pts.shape[0] + 65535) // 65536 * 65536
+                for depth in (2, 3):
+                    pipe = net.points_pipeline(B, cfg, depth=depth, capacity=cap)
+                    frames = [(pts, off)] * 20
+                    for r_p in pipe.map(frames[:2 * depth]):
+                        pass
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for r_p in pipe.map(frames):
+                        pass
+                    torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) / len(frames)
+                    pl[f"{depth}_batches_in_flight"] = {"scenes_per_s": B / dt, "ms_per_step": 1e3 * dt,
+                                                        "site_counts_equal_value_run": [int(c) for c in r_p["counts"]] == [int(c) for c in counts]}
+                    del pipe
+            out["pipelined"] = pl
+        except Exception as e:
+            out["pipelined"] = {"error": repr(e)[:200]}
 
     if rank == 0 and world == 1 and not args.no_secondary and not args.graph and args.dtype == "bf16":
         # SURVEY 8(d)'s secondary metrics, each from a fresh child process (best effort: never lose the headline over one)

@@ -151,6 +151,7 @@ class FrustumProposerOG(nn.Module):
             self.image_detector = self._default_detector(model_cfg, class_names)
         self.last_debug = None
         self._dev_tables = {}
+        self._order_c = None
 
     @staticmethod
     def _default_detector(model_cfg, class_names):
@@ -192,14 +193,18 @@ class FrustumProposerOG(nn.Module):
             raise RuntimeError("FrustumProposerOG needs an image_detector (PreprocessedGLIP predictions)")
         det_boxes, det_labels, det_scores, det_batch_idx, det_cam_idx = self.image_detector(batch_dict)
         L = _l.load()
-        boxes = det_boxes.detach().cpu().float().contiguous()
-        labels = det_labels.detach().cpu().long().contiguous()
-        scores = det_scores.detach().cpu().float().contiguous()
-        bidx = det_batch_idx.detach().cpu().long().contiguous()
-        cidx = det_cam_idx.detach().cpu().long().contiguous()
+
+        def host(t, dtype):   # (the detectors hand out CPU tensors of these dtypes already: nothing to convert then)
+            if t.device.type == 'cpu' and t.dtype == dtype and t.is_contiguous():
+                return t
+            return t.detach().to('cpu', dtype).contiguous()
+        boxes, scores = host(det_boxes, torch.float32), host(det_scores, torch.float32)
+        labels, bidx, cidx = host(det_labels, torch.int64), host(det_batch_idx, torch.int64), host(det_cam_idx, torch.int64)
         D = boxes.shape[0]
         rows = torch.empty((max(D, 1), 8), dtype=torch.float32)
-        order = (ctypes.c_int * len(self.image_order))(*self.image_order)
+        order = self._order_c
+        if order is None:
+            order = self._order_c = (ctypes.c_int * len(self.image_order))(*self.image_order)
         n = L.fnp_host_enumerate_frustums(_l.ptr(boxes), _l.ptr(labels), _l.ptr(scores), _l.ptr(bidx), _l.ptr(cidx), D,
                                           int(batch_dict['batch_size']), order, len(self.image_order),
                                           float(self.nms_2d), float(self.score_thr), _l.ptr(rows), rows.shape[0])
