@@ -450,9 +450,19 @@ void launch_wgrad_mfma(dim3 grid, hipStream_t s, const T16 *x, const T16 *dy, co
     }
 }
 
-// row chunks per offset: the narrow layers do little matrix work per 32-row tile and are bound by the latency of a
-// tile (barrier + loads), so they get more, shorter chunks (the partials stay small: chunks x K x Cin x Cout floats)
-static inline int max_chunks(int Cin, int Cout) { return (long long)Cin * Cout <= 4096 ? 128 : (long long)Cin * Cout <= 8192 ? 64 : 32; }
+// row chunks per offset (round 3: 128 / 64 / 32 -> 32 / 32 / 24 once the pair lists had halved the rows of an offset and the
+// tiles had grown: fewer partials to write and to add — the reduction pass reads chunks x K x Cin x Cout floats — and
+// 24 x 27 workgroups of the 128 x 128 layer are resident at once instead of a full round and a tail; -2 % of the step)
+#ifndef FNP_WG_CH1
+#define FNP_WG_CH1 32
+#endif
+#ifndef FNP_WG_CH2
+#define FNP_WG_CH2 32
+#endif
+#ifndef FNP_WG_CH3
+#define FNP_WG_CH3 24
+#endif
+static inline int max_chunks(int Cin, int Cout) { return (long long)Cin * Cout <= 4096 ? FNP_WG_CH1 : (long long)Cin * Cout <= 8192 ? FNP_WG_CH2 : FNP_WG_CH3; }
 
 template <typename TX, typename TY>
 int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, float *dw,
