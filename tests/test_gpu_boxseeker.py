@@ -166,6 +166,20 @@ def test_option_variants_match_reference_golden(cuda, seed):
     assert pos == d["pib_box"].shape[0] and k == len(ws)
 
 
+@pytest.mark.parametrize("seed", [0, 4, 14, 15])
+def test_device_matrices_equal_the_host_ones(cuda, seed):
+    """fnp_seeker_prepare_matrices (the kernel's 3x3 blocks and inverses made on the device from the batch's tensors) against the
+    host path (torch.inverse, as the reference computes them): plain scene, lidar augmentation with a flip, img_aug_matrix."""
+    from findnpropagate_amd.dense_heads import FrustumProposerOG
+    bd, _ = _batch([syn.make_seeker_scene(seed), syn.make_seeker_scene(seed + 1)], cuda)
+    hs, hc, h_ia = FrustumProposerOG._matrices(bd)
+    ds, dc, d_ia = FrustumProposerOG._matrices_device(bd, cuda)
+    assert d_ia == ("img_aug_matrix" in bd) and (d_ia or not h_ia)
+    for a, b in ((hs, ds.cpu()), (hc, dc.cpu())):
+        scale = a.abs().amax(dim=-1, keepdim=True).clamp(min=1.0)      # (rows mix pixels, metres and 1 / focal length)
+        assert float(((a - b).abs() / scale).max()) < 2e-6
+
+
 def test_matches_oracle_on_batched_scenes(cuda):
     """Four scenes (one with an augmentation matrix, one with empty cameras and a single-return frustum) in ONE launch
     == each scene through the numpy oracle; get_bboxes/forward shape."""
