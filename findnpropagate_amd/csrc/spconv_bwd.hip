@@ -462,7 +462,10 @@ void launch_wgrad_mfma(dim3 grid, hipStream_t s, const T16 *x, const T16 *dy, co
 #ifndef FNP_WG_CH3
 #define FNP_WG_CH3 24
 #endif
-static inline int max_chunks(int Cin, int Cout) { return (long long)Cin * Cout <= 4096 ? FNP_WG_CH1 : (long long)Cin * Cout <= 8192 ? FNP_WG_CH2 : FNP_WG_CH3; }
+static inline int max_chunks(int Cin, int Cout) {
+    if ((long long)Cin * Cout <= 128) return 128;   // (wgrad_small_kernel, conv_input: one accumulator per thread — it needs the workgroups)
+    return (long long)Cin * Cout <= 4096 ? FNP_WG_CH1 : (long long)Cin * Cout <= 8192 ? FNP_WG_CH2 : FNP_WG_CH3;
+}
 
 template <typename TX, typename TY>
 int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, float *dw,
