@@ -221,7 +221,10 @@ struct MfmaCfg {
 #endif
     static constexpr bool WIDE = FNP_WIDE_EPI && COUT >= 32 && !WPAIR;   // (WPAIR: no LDS left for the strips -> swap form)
     static constexpr int ESTRIDE = COUT * 2 + 16;   // bytes per staged row
-    static constexpr int epi_sites(bool win) { return win ? 8 : 16; }   // sites per strip pass (window kernels: LDS is tight)
+#ifndef FNP_EPI_SITES
+#define FNP_EPI_SITES 16
+#endif
+    static constexpr int epi_sites(bool win) { return win ? 8 : (COUT >= 128 ? FNP_EPI_SITES : 16); }   // sites per strip pass (window kernels: LDS is tight)
     static constexpr int epi_bytes(int nw, bool win, bool out16) { return (WIDE && out16 && !win) ? nw * epi_sites(win) * ESTRIDE : 0; }
     static constexpr int lds_bytes(int nw, int mb, bool win) { return LDS_BYTES + (win ? win_rows(nw, mb) * CH * 16 + WZERO : 0); }
 };
