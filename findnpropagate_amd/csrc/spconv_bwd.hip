@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kThreads) void pairs_scan_kernel(int ntiles, int *_
 }
 __global__ __launch_bounds__(kThreads) void pairs_emit_kernel(const int *__restrict__ nbr, int nbr_stride, const int *__restrict__ n_out, int cap,
                                                               int ntiles, const int *__restrict__ base, int *__restrict__ pair_o,
-                                                              int *__restrict__ pair_i) {
+                                                              int *__restrict__ pair_i, int pair_stride) {
     __shared__ int wsum[kThreads / 64];
     const int n = min(*n_out, cap), k = blockIdx.y, t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int pos = base[(size_t)k * ntiles + t];
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(kThreads) void pairs_emit_kernel(const int *__restr
         }
         if (id >= 0) {
             const int p = off + __popcll(m & ((1ull << lane) - 1ull));
-            pair_o[(size_t)k * nbr_stride + p] = o;
-            pair_i[(size_t)k * nbr_stride + p] = id;
+            pair_o[(size_t)k * pair_stride + p] = o;
+            pair_i[(size_t)k * pair_stride + p] = id;
         }
         pos += tot;
         __syncthreads();
@@ -574,16 +574,18 @@ extern "C" int fnp_spconv_wgrad(const void *feat_in, int in_dtype, const void *g
     return FNP_ERR_ARG;
 }
 
-// Pair lists of a rulebook (see wgrad_mfma_kernel): pair_o, pair_i (K, nbr_stride) int32, pair_count (K).
+// Pair lists of a rulebook (see wgrad_mfma_kernel): pair_o, pair_i (K, pair_stride) int32 with pair_stride >= cap_out — the rows
+// the caller knows to exist, not the table's stride (a strided layer's table is sized for 27 outputs per input) —, pair_count (K).
 extern "C" int64_t fnp_rulebook_pairs_workspace_bytes(int K, int cap_out) {
     if (K <= 0 || cap_out <= 0) return 0;
     return (int64_t)K * fnp_divup(cap_out, kPairTile) * 4;
 }
 
 extern "C" int fnp_rulebook_pairs(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int *pair_o, int *pair_i,
-                                  int *pair_count, void *workspace, int64_t workspace_bytes, fnp_stream_t stream) {
+                                  int pair_stride, int *pair_count, void *workspace, int64_t workspace_bytes, fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (!nbr || !n_out || !pair_o || !pair_i || !pair_count || !workspace || K <= 0 || K > 65535 || cap_out <= 0 || nbr_stride < cap_out)
+    if (!nbr || !n_out || !pair_o || !pair_i || !pair_count || !workspace || K <= 0 || K > 65535 || cap_out <= 0 || nbr_stride < cap_out ||
+        pair_stride < cap_out)
         return FNP_ERR_ARG;
     if (fnp_rulebook_pairs_workspace_bytes(K, cap_out) > workspace_bytes) return FNP_ERR_WORKSPACE;
     const int ntiles = fnp_divup(cap_out, kPairTile);
@@ -593,7 +595,7 @@ extern "C" int fnp_rulebook_pairs(const int *nbr, int nbr_stride, int K, const i
     hipLaunchKernelGGL(pairs_scan_kernel, dim3(K), dim3(kThreads), 0, s, ntiles, counts, pair_count);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(pairs_emit_kernel, dim3(ntiles, K), dim3(kThreads), 0, s, nbr, nbr_stride, n_out, cap_out, ntiles, (const int *)counts, pair_o,
-                       pair_i);
+                       pair_i, pair_stride);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
@@ -601,17 +603,17 @@ extern "C" int fnp_rulebook_pairs(const int *nbr, int nbr_stride, int K, const i
 // fnp_spconv_wgrad on the pair lists: 16-bit features and gradients of the MFMA channel pairs; FNP_ERR_ARG otherwise (take
 // fnp_spconv_wgrad).  Same sum in another grouping of the rows: equal to fnp_spconv_wgrad's up to f32 rounding, run-to-run identical.
 extern "C" int fnp_spconv_wgrad_pairs(const void *feat_in, int in_dtype, const void *grad_out, int grad_dtype, const int *pair_o,
-                                      const int *pair_i, const int *pair_count, int nbr_stride, int K, const int *n_out, int cap_out,
+                                      const int *pair_i, const int *pair_count, int pair_stride, int K, const int *n_out, int cap_out,
                                       float *grad_weight, int Cin, int Cout, void *workspace, int64_t workspace_bytes, fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!feat_in || !grad_out || !pair_o || !pair_i || !pair_count || !n_out || !grad_weight || !workspace || K <= 0 || Cin <= 0 || Cout <= 0 ||
-        cap_out <= 0 || nbr_stride < cap_out)
+        cap_out <= 0 || pair_stride < cap_out)
         return FNP_ERR_ARG;
     if (in_dtype == FNP_BF16 && grad_dtype == FNP_BF16)
-        return run_wgrad<__bf16, __bf16>(feat_in, grad_out, pair_o, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
+        return run_wgrad<__bf16, __bf16>(feat_in, grad_out, pair_o, pair_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
                                          workspace_bytes, s, pair_i, pair_count);
     if (in_dtype == FNP_F16 && grad_dtype == FNP_F16)
-        return run_wgrad<_Float16, _Float16>(feat_in, grad_out, pair_o, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout,
+        return run_wgrad<_Float16, _Float16>(feat_in, grad_out, pair_o, pair_stride, K, n_out, cap_out, grad_weight, Cin, Cout,
                                              workspace, workspace_bytes, s, pair_i, pair_count);
     return FNP_ERR_ARG;
 }

@@ -551,11 +551,11 @@ def rulebook_pairs(rb, n_out_dev, rows=None):
     K, stride = rb.K, rb.nbr.shape[1]
     cap = min(rb.cap_out, int(rows)) if rows else rb.cap_out
     dev = rb.nbr.device
-    po = torch.empty((K, stride), dtype=torch.int32, device=dev)
-    pi = torch.empty((K, stride), dtype=torch.int32, device=dev)
+    po = torch.empty((K, cap), dtype=torch.int32, device=dev)     # (cap, not the table's stride: see `rows`)
+    pi = torch.empty((K, cap), dtype=torch.int32, device=dev)
     cnt = torch.empty((K,), dtype=torch.int32, device=dev)
     ws = torch.empty((int(L.fnp_rulebook_pairs_workspace_bytes(K, cap)),), dtype=torch.uint8, device=dev)
-    rc = L.fnp_rulebook_pairs(_l.ptr(rb.nbr), stride, K, _l.ptr(n_out_dev), cap, _l.ptr(po), _l.ptr(pi), _l.ptr(cnt), _l.ptr(ws), ws.numel(),
+    rc = L.fnp_rulebook_pairs(_l.ptr(rb.nbr), stride, K, _l.ptr(n_out_dev), cap, _l.ptr(po), _l.ptr(pi), cap, _l.ptr(cnt), _l.ptr(ws), ws.numel(),
                               _l.stream())
     _l.check(rc, "fnp_rulebook_pairs")
     rb._pairs = (po, pi, cnt)
@@ -577,7 +577,7 @@ def conv_wgrad(feat_in, grad_out, rb, n_out_dev, Cin, Cout, pairs=None):
             and not getattr(rb, "_lean", False)):
         pr = getattr(rb, "_pairs", None) or rulebook_pairs(rb, n_out_dev, rows=cap)
         rc = L.fnp_spconv_wgrad_pairs(_l.ptr(feat_in), _l.dtype_code(feat_in), _l.ptr(grad_out), _l.dtype_code(grad_out), _l.ptr(pr[0]), _l.ptr(pr[1]),
-                                      _l.ptr(pr[2]), rb.nbr.shape[1], rb.K, _l.ptr(n_out_dev), cap, _l.ptr(dw), Cin, Cout, _l.ptr(ws), ws.numel(),
+                                      _l.ptr(pr[2]), pr[0].shape[1], rb.K, _l.ptr(n_out_dev), min(cap, pr[0].shape[1]), _l.ptr(dw), Cin, Cout, _l.ptr(ws), ws.numel(),
                                       _l.stream())
         _l.check(rc, "fnp_spconv_wgrad_pairs")
         return dw

@@ -414,12 +414,13 @@ int fnp_spconv_wgrad(const void *feat_in, int in_dtype, const void *grad_out, in
  * at k (44-54 % of the rows on lidar scenes); fnp_rulebook_pairs compacts every column of the table once per rulebook —
  * pair_o[k][j] = the j-th such output row (ascending), pair_i[k][j] = its neighbour, pair_count[k] — and
  * fnp_spconv_wgrad_pairs runs fnp_spconv_wgrad's sum over them (16-bit features and gradients, the MFMA channel pairs;
- * FNP_ERR_ARG otherwise: take fnp_spconv_wgrad).  pair_o / pair_i: (K, nbr_stride) int32; order-preserving, deterministic. */
+ * FNP_ERR_ARG otherwise: take fnp_spconv_wgrad).  pair_o / pair_i: (K, pair_stride) int32, pair_stride >= cap_out = the rows the
+ * caller knows to exist (not the table's stride: a strided layer's table is sized for 27 outputs per input); order-preserving. */
 int64_t fnp_rulebook_pairs_workspace_bytes(int K, int cap_out);
 int fnp_rulebook_pairs(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int *pair_o, int *pair_i,
-                       int *pair_count, void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
+                       int pair_stride, int *pair_count, void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
 int fnp_spconv_wgrad_pairs(const void *feat_in, int in_dtype, const void *grad_out, int grad_dtype, const int *pair_o,
-                           const int *pair_i, const int *pair_count, int nbr_stride, int K, const int *n_out, int cap_out,
+                           const int *pair_i, const int *pair_count, int pair_stride, int K, const int *n_out, int cap_out,
                            float *grad_weight, int Cin, int Cout, void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
