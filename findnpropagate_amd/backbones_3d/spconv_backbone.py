@@ -300,8 +300,21 @@ class _PointsGraph:
         self._body(voxel_cfg)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.vox, self.res = self._body(voxel_cfg)
+        # No cyclic garbage collection while the stream is capturing: a collection that fires inside the capture and finalises
+        # an OLDER graph or its pooled tensors (a replaced _PointsGraph, another test's engine) frees device memory in the
+        # middle of it — an error inside a destructor, i.e. std::terminate.  Seen twice in round 3 as an intermittent
+        # "Fatal Python error: Aborted" of a test run; the faulthandler trace of the second sighting ends in "Garbage-collecting"
+        # under this very `with`.  (torch.cuda.graph collects BEFORE it starts capturing; nothing stops a collection during it.)
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.vox, self.res = self._body(voxel_cfg)
+        finally:
+            if gc_was_on:
+                gc.enable()
 
     def _body(self, voxel_cfg):
         e = self.engine

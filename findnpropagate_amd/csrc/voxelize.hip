@@ -27,7 +27,9 @@ struct VoxWs {          // carve-up of the caller's workspace
     long long *code;    // (N)   (block << 6) | bit, or -1
     int *rank;          // (N)   sorted rank of the point's cell, or -1
     int *flag;          // (N)   first-point flag, then exclusive scan (first-come rank)
-    int *top;           // (cap, max_points) smallest point indices per cell, ascending
+    int *top;           // (cap, max_points) point indices per cell: the cell's points in arrival order, or — a cell with more than
+                        //                   max_points of them — its max_points smallest, ascending
+    int *cnt;           // (cap) points per cell
     int *scene;         // (3*B + 4): fc_start[B+1], out_base[B+1], misc
     int *n_sorted;      // (1)
     int *n_first;       // (1)
@@ -47,6 +49,7 @@ __host__ long long carve(VoxWs &w, char *base, long long n, int B, int cap, int 
     w.rank = (int *)take(4 * n);
     w.flag = (int *)take(4 * n);
     w.top = (int *)take(4ll * cap * maxp);
+    w.cnt = (int *)take(4ll * cap + 4);   // (+ 1: "some cell is crowded", cleared with the counters)
     w.scene = (int *)take(4ll * (3 * B + 8));
     w.n_sorted = (int *)take(4);
     w.n_first = (int *)take(4);
@@ -117,7 +120,8 @@ __global__ __launch_bounds__(kThreads) void vox_insert_kernel(int n, int maxp, i
                                                               const unsigned long long *__restrict__ bits,
                                                               const unsigned *__restrict__ base,
                                                               const long long *__restrict__ code,
-                                                              int *__restrict__ rank, int *__restrict__ top) {
+                                                              int *__restrict__ rank, int *__restrict__ top, int *__restrict__ cnt,
+                                                              int *__restrict__ crowded) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
     const long long cd = code[i];
@@ -130,7 +134,33 @@ __global__ __launch_bounds__(kThreads) void vox_insert_kernel(int n, int maxp, i
     }
     rank[i] = r;
     if (r < 0) return;
-    // bubble insert: slot j ends up holding the (j+1)-th smallest index whatever the interleaving
+    // Count and append (round 3).  The order-independent bubble insert (atomicMin down the cell's sorted list) cost 2.4 M
+    // read-modify-writes of a 77 MB array per step, almost all of them L2 misses, for cells that hold 1.6 points on average:
+    // a point now takes a slot of its cell with ONE atomic on a compact counter array (4 bytes per cell: it stays in L2) and
+    // stores its index there; which slot depends on timing, the SET of a cell's points does not, and the consumers order
+    // it.  Only a cell with more than max_points points needs the max_points SMALLEST: those cells are reset and bubble-
+    // filled by the two small kernels below.
+    const int s = atomicAdd(&cnt[r], 1);
+    if (s < maxp) top[(size_t)r * maxp + s] = i;
+    else if (s == maxp) *crowded = 1;   // (plain store of the same value by whoever sees it: the two kernels below leave at once without it)
+}
+
+// cells with more points than a voxel keeps: their list restarts empty (sentinels) ...
+__global__ __launch_bounds__(kThreads) void vox_crowded_reset_kernel(int cap, int maxp, const int *__restrict__ cnt, int *__restrict__ top,
+                                                                    const int *__restrict__ crowded) {
+    if (*crowded == 0) return;   // (uniform)
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= cap || cnt[r] <= maxp) return;
+    for (int j = 0; j < maxp; ++j) top[(size_t)r * maxp + j] = kSentinel;
+}
+// ... and every point of such a cell bubbles into it: slot j ends up holding the (j+1)-th smallest index whatever the interleaving
+__global__ __launch_bounds__(kThreads) void vox_crowded_insert_kernel(int n, int maxp, const int *__restrict__ rank, const int *__restrict__ cnt,
+                                                                     int *__restrict__ top, const int *__restrict__ crowded) {
+    if (*crowded == 0) return;   // (uniform)
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const int r = rank[i];
+    if (r < 0 || cnt[r] <= maxp) return;
     int carry = i;
     int *slots = top + (size_t)r * maxp;
     for (int j = 0; j < maxp; ++j) {
@@ -140,12 +170,20 @@ __global__ __launch_bounds__(kThreads) void vox_insert_kernel(int n, int maxp, i
     }
 }
 
+// flag[i] = point i is the FIRST point of its cell (the smallest index among the cell's kept points)
 __global__ __launch_bounds__(kThreads) void vox_flag_kernel(int n, int maxp, const int *__restrict__ rank,
-                                                            const int *__restrict__ top, int *__restrict__ flag) {
+                                                            const int *__restrict__ top, const int *__restrict__ cnt, int *__restrict__ flag) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
     const int r = rank[i];
-    flag[i] = (r >= 0 && top[(size_t)r * maxp] == i) ? 1 : 0;
+    int f = 0;
+    if (r >= 0) {
+        const int np = min(cnt[r], maxp);
+        int m = kSentinel;
+        for (int j = 0; j < np; ++j) m = min(m, top[(size_t)r * maxp + j]);
+        f = m == i ? 1 : 0;
+    }
+    flag[i] = f;
 }
 
 // one wave: per-scene first-come starts and output bases after the max_voxels cut (B <= kMaxBatch;
@@ -187,7 +225,7 @@ __global__ __launch_bounds__(64) void vox_scene_kernel(const int *__restrict__ b
 __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restrict__ pts, int C, int maxp,
                                                             const int *__restrict__ boff, int B, int max_voxels,
                                                             RankGridDims g, const long long *__restrict__ code,
-                                                            const int *__restrict__ top,
+                                                            const int *__restrict__ top, const int *__restrict__ cnt,
                                                             const int *__restrict__ fc, const int *__restrict__ scene,
                                                             const int *__restrict__ n_sorted, int cap,
                                                             int *__restrict__ perm, int *__restrict__ coords,
@@ -202,15 +240,24 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
     for (int r = ns + blockIdx.x * kThreads + threadIdx.x; r < cap; r += gridDim.x * kThreads) perm[r] = -1;
     for (int r = blockIdx.x * kThreads + threadIdx.x; r < ns; r += gridDim.x * kThreads) {
         const int *slots = top + (size_t)r * maxp;
-        const int p0 = slots[0];
+        // the cell's kept points: min(cnt, max_points) slots in arrival order (a crowded cell: already ascending); they are
+        // consumed in ASCENDING index order below — next = the smallest index above the previous one — so that sums and the
+        // (M, max_points, C) block come out as from a sorted list
+        const int np = min(cnt[r], maxp);
+        auto next_above = [&](int prev) -> int {
+            int m = kSentinel;
+            for (int j = 0; j < np; ++j) {
+                const int v = slots[j];
+                m = (v > prev && v < m) ? v : m;
+            }
+            return m;
+        };
+        const int p0 = next_above(-1);
         // the scene of the cell is in its block number: no search in the batch offsets
         const long long cd = code[p0];
         int bb, z, y, x;
         rg_decode(g, cd >> 6, (int)(cd & 63), bb, z, y, x);
         const int srank = fc[p0] - fc_start[bb];
-        // points kept = filled slots (the list holds the max_points smallest indices of the cell)
-        int np = 0;
-        for (int j = 0; j < maxp; ++j) np += slots[j] != kSentinel ? 1 : 0;
         const int id = out_base[bb] + srank;
         if (srank >= max_voxels || id >= cap) {
             // dropped by the per-scene cut: no voxel row; its cell goes behind the voxels in the coordinate
@@ -226,17 +273,18 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
         reinterpret_cast<int4 *>(coords)[id] = make_int4(bb, z, y, x);
         num_points[id] = np;
         const float norm = (float)(np < 1 ? 1 : np);
-        // per channel the sum runs in slot order, like sum(dim=1); the C loads of a point (and the next
-        // point's) are independent and in flight together: the chain is np adds long, not np * C loads
+        // per channel the sum runs in ascending point order, like sum(dim=1) over the sorted block
         if (C <= 8) {
             float s8[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) s8[c] = 0.f;
+            int pi = p0;
             for (int j = 0; j < np; ++j) {
-                const float *pr = pts + (size_t)slots[j] * C;
+                const float *pr = pts + (size_t)pi * C;
                 float v8[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) v8[c] = c < C ? pr[c] : 0.f;
+                if (j + 1 < np) pi = next_above(pi);   // (the slots are in L1: the search runs under the point's loads)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) s8[c] += v8[c];
             }
@@ -245,15 +293,22 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
                 if (c < C) mean[(size_t)id * C + c] = s8[c] / norm;
         } else {
             for (int c = 0; c < C; ++c) {
-                float s = 0.f;
-                for (int j = 0; j < np; ++j) s += pts[(size_t)slots[j] * C + c];
-                mean[(size_t)id * C + c] = s / norm;
+                float sacc = 0.f;
+                int pi = p0;
+                for (int j = 0; j < np; ++j) {
+                    sacc += pts[(size_t)pi * C + c];
+                    if (j + 1 < np) pi = next_above(pi);
+                }
+                mean[(size_t)id * C + c] = sacc / norm;
             }
         }
         if (voxels) {
             float *v = voxels + (size_t)id * maxp * C;
-            for (int j = 0; j < maxp; ++j)
-                for (int c = 0; c < C; ++c) v[j * C + c] = j < np ? pts[(size_t)slots[j] * C + c] : 0.f;
+            int pi = p0;
+            for (int j = 0; j < maxp; ++j) {
+                for (int c = 0; c < C; ++c) v[j * C + c] = j < np ? pts[(size_t)pi * C + c] : 0.f;
+                if (j + 1 < np) pi = next_above(pi);
+            }
         }
     }
 }
@@ -338,8 +393,9 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
     const int maxp = cfg->max_points, C = cfg->num_features;
     const int pgrid = fnp_divup(n, kThreads);
 
-    {   // (a fill kernel, never hipMemsetAsync on a capturable path: common.h fnp_fill_words)
-        const int frc = fnp_fill_words(w.top, (long long)n * maxp, (unsigned)kSentinel, s);
+    {   // (a fill kernel, never hipMemsetAsync on a capturable path: common.h fnp_fill_words).  The per-cell counters start at
+        // zero; the slot lists need no initial value (a cell's first min(cnt, max_points) slots are written before they are read)
+        const int frc = fnp_fill_words(w.cnt, (long long)n + 1, 0u, s);
         if (frc) return frc;
     }
     hipLaunchKernelGGL(vox_mark_kernel, dim3(pgrid), dim3(kThreads), 0, s, points, n, C, batch_offsets, B, *cfg, g, w.code);
@@ -347,9 +403,13 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
     int rc = fnp_scan::rank_grid(g, w.n_sorted, w.scan_ws, s);
     if (rc) return rc;
     hipLaunchKernelGGL(vox_insert_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, n,
-                       (const unsigned long long *)g.bits, (const unsigned *)g.base, w.code, w.rank, w.top);
+                       (const unsigned long long *)g.bits, (const unsigned *)g.base, w.code, w.rank, w.top, w.cnt, w.cnt + n);
     FNP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vox_flag_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, w.rank, w.top, w.flag);
+    hipLaunchKernelGGL(vox_crowded_reset_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, (const int *)w.cnt, w.top, (const int *)(w.cnt + n));
+    FNP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vox_crowded_insert_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, (const int *)w.rank, (const int *)w.cnt, w.top, (const int *)(w.cnt + n));
+    FNP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(vox_flag_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, w.rank, w.top, (const int *)w.cnt, w.flag);
     FNP_LAUNCH_CHECK();
     rc = fnp_scan::int32(w.flag, n, w.flag, w.n_first, w.scan_ws, s);
     if (rc) return rc;
@@ -357,7 +417,7 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
                        cfg->max_voxels, cap, w.scene, n_voxels);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(vox_emit_kernel, dim3(fnp_grid_for(n, kThreads)), dim3(kThreads), 0, s, points, C, maxp,
-                       batch_offsets, B, cfg->max_voxels, g.d, w.code, w.top, w.flag, w.scene, w.n_sorted, n,
+                       batch_offsets, B, cfg->max_voxels, g.d, w.code, w.top, (const int *)w.cnt, w.flag, w.scene, w.n_sorted, n,
                        g.perm, coords, num_points, mean_feats, voxels, n_cells, w.scene + 2 * (B + 1));
     FNP_LAUNCH_CHECK();
     return FNP_OK;
