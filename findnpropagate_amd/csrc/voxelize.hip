@@ -243,8 +243,14 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
         // the cell's kept points: min(cnt, max_points) slots in arrival order (a crowded cell: already ascending); they are
         // consumed in ASCENDING index order below — next = the smallest index above the previous one — so that sums and the
         // (M, max_points, C) block come out as from a sorted list
-        const int np = min(cnt[r], maxp);
+        const int cn = cnt[r], s0 = slots[0], s1 = maxp > 1 ? slots[1] : kSentinel;   // (independent loads: most cells hold one or two points)
+        const int np = min(cn, maxp);
         auto next_above = [&](int prev) -> int {
+            if (np <= 2) {
+                const int a = s0, b = np == 2 ? s1 : kSentinel;
+                const int lo = a < b ? a : b, hi = a < b ? b : a;
+                return lo > prev ? lo : hi;
+            }
             int m = kSentinel;
             for (int j = 0; j < np; ++j) {
                 const int v = slots[j];
