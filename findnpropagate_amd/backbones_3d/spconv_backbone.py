@@ -675,7 +675,11 @@ class FusedResBackbone:
             rb1 = S.rulebook_subm_ell(indices, n1, grid1, int(cap1 * self.ell_pool[0]) + 64, with_table=not ell_all)
             ell_used.append((rb1._ell[2], rb1._ell[1], 0))
         else:
-            rb1 = S.rulebook_subm(indices, n1, grid1, 3)
+            # (f32: the 16 -> 16 layers sweep their ranges class by class, like every f32 SubM stage below)
+            srt1 = S.f32_sorted_by_default(16, act, cap1) and self.rulebook_log is None
+            rb1 = S.rulebook_subm(indices, n1, grid1, 3, masks=srt1)
+            if srt1:
+                S.classsort_f32(rb1, n1, 16)
         x = conv(feats, P['in'], rb1, n1)
         x1 = blocks(x, rb1, n1, P['blocks1'])
         stage = [(x1, indices, n1, grid1)]
@@ -707,11 +711,14 @@ class FusedResBackbone:
             nxt = down_convs[li + 1]
             lean = tiled and self.rulebook_log is None   # (all four layers of the stage run tiled)
             mark_next = (grids[li + 2], nxt.kernel_size, nxt.stride, nxt.padding) if (lean or srt) and S.MARK_FUSED else None
-            rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3, tile_channels=ch if tiled else None, masks=srt,
+            srt32 = S.f32_sorted_by_default(ch, act, caps[li + 1]) and self.rulebook_log is None
+            rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3, tile_channels=ch if tiled else None, masks=srt or srt32,
                                  lean_table=lean, mark_next=mark_next)
             premarked = bool(getattr(rb, "_marked_next", False))
             if srt:
                 S.classsort(rb, rbs.out_n, ch)   # stage 4: the 128-channel layers sweep their rows class by class
+            if srt32:
+                S.classsort_f32(rb, rbs.out_n, ch)   # f32 engine: every stage's ranges in class order
             x = blocks(x, rb, rbs.out_n, P[blk_key], ranked=True)
             stage.append((x, rbs.out_indices, rbs.out_n, rbs.out_grid))
             x_prev, idx_prev, n_prev, g_prev = x, rbs.out_indices, rbs.out_n, rbs.out_grid

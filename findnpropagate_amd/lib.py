@@ -136,6 +136,8 @@ SIGNATURES = {
     "fnp_classsort_workspace_bytes": (c_int64, [c_int]),
     "fnp_rulebook_subm_masked": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, P, POINTER(RankGridC), POINTER(ConvGeom), P]),
     "fnp_rulebook_classsort": (c_int, [P, c_int, c_int, P, P, c_int, c_int, c_int, P, P, P, c_int64, P]),
+    "fnp_rulebook_classsort_f32": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "fnp_spconv_forward_f32_sorted": (c_int, [P, c_int, P, P, c_int, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "fnp_spconv_forward_sorted": (c_int, [P, c_int, c_int, P, P, c_int, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     "fnp_boxseeker_workspace_bytes": (c_int64, [c_int, c_int]),
     "fnp_seeker_prepare_matrices": (c_int, [P, P, P, P, P, c_int, P, P, P]),

@@ -432,6 +432,31 @@ def classsort(rb, n_out_dev, channels=128):
     return rb
 
 
+# f32 engine: the 3x3x3 SubM layers sweep every workgroup range class by class (the f32 kernel is bound by the matrix pipe and
+# skips the MFMAs of a 16-row block at offsets none of its rows has a neighbour at).  FNP_F32_SORT=0: row order (development A/B)
+F32_SORT = os.environ.get("FNP_F32_SORT", "1") != "0"
+F32_SORT_CHANNELS = {16, 32, 64, 128}
+F32_SORT_MIN_ROWS = int(os.environ.get("FNP_F32_SORT_MIN_ROWS", "32768"))
+
+
+def f32_sorted_by_default(channels, dtype, cap):
+    return F32_SORT and dtype == torch.float32 and channels in F32_SORT_CHANNELS and cap >= F32_SORT_MIN_ROWS
+
+
+def classsort_f32(rb, n_out_dev, channels):
+    """Processing order of a 3x3x3 SubM rulebook for the f32 `channels` -> `channels` layers (fnp_rulebook_classsort_f32), kept
+    with the rulebook (`rb._perm_f32[channels]`); needs the row masks of rulebook_subm(masks=True).  No host sync."""
+    L = _l.load()
+    assert rb.K == 27 and getattr(rb, "_rowmask", None) is not None
+    perm = torch.empty((rb.cap_out,), dtype=torch.int32, device=rb.nbr.device)
+    rc = L.fnp_rulebook_classsort_f32(_l.ptr(rb._rowmask), _l.ptr(n_out_dev), rb.cap_out, channels, channels, _l.ptr(perm), _l.stream())
+    _l.check(rc, "fnp_rulebook_classsort_f32")
+    if getattr(rb, "_perm_f32", None) is None:
+        rb._perm_f32 = {}
+    rb._perm_f32[channels] = perm
+    return rb
+
+
 def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, shift=None, residual=None, relu=False,
                  out=None, ranked=False, valu=False, tile=None):
     """feat_out (cap_out, Cout) = act(conv * scale + shift + residual).  No host sync.
@@ -474,6 +499,14 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
                                          rb.nbr.shape[1], _l.ptr(srt[0]), _l.ptr(srt[1]), _l.ptr(n_out_dev), cap_out, _l.ptr(out),
                                          _l.ptr(scale), _l.ptr(shift), _l.ptr(residual), int(bool(relu)), Cin, Cout, _l.stream())
         _l.check(rc, "fnp_spconv_forward_sorted")
+        return out
+    pf = (getattr(rb, "_perm_f32", None) or {}).get(Cin)
+    if (pf is not None and K == 27 and Cin == Cout and feat_in.dtype == torch.float32 and out.dtype == torch.float32 and not valu
+            and feat_in.shape[0] * Cin * 4 < 0x7fffffff):
+        rc = L.fnp_spconv_forward_f32_sorted(_l.ptr(feat_in), feat_in.shape[0], _l.ptr(w_packed), _l.ptr(rb.nbr), rb.nbr.shape[1], _l.ptr(pf),
+                                             _l.ptr(n_out_dev), cap_out, _l.ptr(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual),
+                                             int(bool(relu)), int(isinstance(w_packed, PermutedWeight)), Cin, Cout, _l.stream())
+        _l.check(rc, "fnp_spconv_forward_f32_sorted")
         return out
     if isinstance(w_packed, PermutedWeight) and feat_in.shape[0] * Cin * 4 >= 0x7fffffff:
         # the f32 MFMA kernel addresses the features with 32-bit offsets; beyond them the thread-per-element chain runs,

@@ -382,6 +382,16 @@ int fnp_spconv_forward_sorted(const void *feat_in, int dtype, int n_in_rows, con
                               const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
                               fnp_stream_t stream);
 
+/* The f32 engine's form of the class sort (the f32 3x3x3 SubM layers, 16 / 32 / 64 / 128 channels, run on v_mfma_f32_16x16x4_f32
+ * and are bound by the matrix pipe; the kernel skips the MFMAs of a (16-row block, offset) pair without any neighbour).
+ * fnp_rulebook_classsort_f32 orders the rows of every workgroup range of that kernel's grid by class (perm (cap_out) int32;
+ * rowmask as written by fnp_rulebook_subm_masked), fnp_spconv_forward_f32_sorted sweeps the ranges in that order.  Cin == Cout;
+ * wperm != 0: weight in the 4 x 4-transposed layout (FNP_HINT_W_PERMUTED).  Bit-identical to fnp_spconv_forward on f32. */
+int fnp_rulebook_classsort_f32(const unsigned *rowmask, const int *n_out, int cap_out, int Cin, int Cout, int *perm, fnp_stream_t stream);
+int fnp_spconv_forward_f32_sorted(const void *feat_in, int n_in_rows, const void *weight, const int *nbr, int nbr_stride, const int *perm,
+                                  const int *n_out, int cap_out, void *feat_out, const float *scale, const float *shift,
+                                  const void *residual, int relu, int wperm, int Cin, int Cout, fnp_stream_t stream);
+
 /* The same convolution for a STRIDED 3x3x3 layer whose rulebook has no other user (the three down-sampling
  * layers of VoxelResBackBone8x, spconv_backbone.py:207,214,221): the kernel computes the rulebook rows of its
  * tiles itself from the input rank grid and the output coordinates (fnp_rulebook_strided with nbr = NULL builds

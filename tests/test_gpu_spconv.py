@@ -267,10 +267,13 @@ def test_fused_backbone_f32_within_1e4(cuda, oracle, rng):
     _check_stage(out2["encoded_spconv_tensor"], want["out"], 1e-4, 1e-4)
 
 
-def test_fused_backbone_f32_is_the_oracle_bit_for_bit(cuda, oracle, rng):
+@pytest.mark.parametrize("sort_min_rows", [0, 1 << 30])
+def test_fused_backbone_f32_is_the_oracle_bit_for_bit(cuda, oracle, rng, sort_min_rows, monkeypatch):
     """The fp32 engine (BASELINE.json's 1e-4 mode) is not merely within 1e-4 of the CPU oracle: every convolution is the
     oracle's k-ascending fmaf chain on v_mfma_f32_16x16x4_f32, the BatchNorm fold runs in the oracle's IEEE arithmetic on
-    the host, the epilogue is one multiply, one add (+ residual add) and a compare — so all five stage outputs are EQUAL."""
+    the host, the epilogue is one multiply, one add (+ residual add) and a compare — so all five stage outputs are EQUAL.
+    Both with every SubM stage swept in class-sorted order (sort_min_rows 0: what full batches run) and in row order."""
+    monkeypatch.setattr(S, "F32_SORT_MIN_ROWS", sort_min_rows)
     net = _small_net(cuda, "fp32")
     shape = net.sparse_shape
     feats, idx = _random_sparse(rng, 2, shape, 6000, 5)
@@ -699,6 +702,45 @@ def test_class_sorted_sweep_equals_plain_sweep(cuda, rng, n, order, dtype):
     if n >= 5000 and order == "sorted":
         skipped = 1.0 - np.mean([bin(int(v)).count("1") for v in bm[:(n + 15) // 16]]) / 27.0
         assert skipped > 0.2, "a two-cell sheet leaves at least a plane of offsets empty for most blocks"
+
+
+@pytest.mark.parametrize("C", [16, 32, 64, 128])
+@pytest.mark.parametrize("n,order", [(1, "random"), (17, "random"), (400, "sorted"), (5000, "random"), (60000, "sorted")])
+def test_f32_class_sorted_sweep_equals_plain_sweep(cuda, rng, n, order, C):
+    """fnp_rulebook_classsort_f32 + fnp_spconv_forward_f32_sorted against fnp_spconv_forward on f32 (plain and 4 x 4-transposed
+    weights): perm is a permutation that keeps every row inside its workgroup range with the classes in order, and the values
+    are the same bits (so the f32 engine stays bit-identical to the CPU oracle)."""
+    B, shape = 2, [5, 60, 64] if n <= 5000 else [5, 200, 200]
+    idx = _surface_sites(rng, B, shape, n)
+    n = idx.shape[0]
+    if order == "sorted":
+        idx = idx[np.lexsort((idx[:, 1], idx[:, 3], idx[:, 2], idx[:, 0]))]
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    grid = S.build_grid(d_idx, n_dev, B, shape)
+    rb0 = S.rulebook_subm(d_idx, n_dev, grid, 3)
+    rb = S.rulebook_subm(d_idx, n_dev, grid, 3, masks=True)
+    assert torch.equal(rb0.nbr, rb.nbr)
+    w = torch.from_numpy((rng.standard_normal((C, 3, 3, 3, C)) * 0.05).astype(np.float32)).to(cuda)
+    x = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32)).to(cuda)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)).to(cuda)
+    sh = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).to(cuda)
+    res = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32)).to(cuda)
+    cases = ((None, sc, sh, True), (res, sc, sh, True), (res, None, None, False))
+    S.classsort_f32(rb, n_dev, C)
+    perm = rb._perm_f32[C][:n].cpu().numpy()
+    assert np.array_equal(np.sort(perm), np.arange(n)), "perm is a permutation of the rows"
+    masks = rb._rowmask[:n].cpu().numpy().view(np.uint32)
+    lo, hi = (masks & 0x1ff) != 0, (masks >> 18) != 0
+    cls = np.where(lo, np.where(hi, 2, 3), np.where(hi, 1, 0))[perm]
+    same = np.diff(cls) == 0
+    assert np.all(np.diff(perm)[same] > 0), "rows of a class keep their order"
+    assert np.count_nonzero(np.diff(cls) < 0) < 2048, "classes ascend inside a range"
+    for wp in (S.pack_weight(w, torch.float32), S.pack_weight(w, torch.float32, mfma_f32=True)):
+        plain = [S.conv_forward(x, wp, rb0, n_dev, scale=a, shift=b, residual=r, relu=relu, ranked=True) for r, a, b, relu in cases]
+        srt = [S.conv_forward(x, wp, rb, n_dev, scale=a, shift=b, residual=r, relu=relu, ranked=True) for r, a, b, relu in cases]
+        for a, b in zip(plain, srt):
+            assert torch.equal(a[:n], b[:n])
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
