@@ -376,7 +376,7 @@ class PointsPipeline:
             g.n_prev = n
             g.off.copy_(batch_offsets, non_blocking=True)
             g.graph.replay()
-            counts = torch.cat([s[2] for s in g.res['stages']] + [g.res['aborts']] + [u for u, _, _ in g.res['ell_used']])
+            counts = g.res['counts_dev']
             if g.counts_host is None or g.counts_host.numel() != counts.numel():
                 g.counts_host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
             g.counts_host.copy_(counts, non_blocking=True)
@@ -440,6 +440,7 @@ class FusedResBackbone:
         self.ell_pool = [0.25, 0.0625]
         self._vox_ws = None
         self._graphs = {}
+        self._ell_ctr = {}
         self._dirty = False      # a forward is in flight or died before its sparse clear: grids may hold stale bits
         # measurement hooks (bench.py): when `profile` is a list every conv launch is bracketed by
         # stream events, (tag, start, end) appended; `rulebook_log` receives (tag, Rulebook, n_dev)
@@ -455,6 +456,18 @@ class FusedResBackbone:
         t = torch.empty((1,), dtype=torch.int32, device=device)
         _l.check(_l.load().fnp_spconv_tiled_aborts_copy(_l.ptr(t), _l.stream()), "fnp_spconv_tiled_aborts_copy")
         return t
+
+    def _counts_word(self, stage, ell_used, device):
+        """enqueue ONE launch that collects what the host reads in a forward's one synchronisation — the five stage counts, the
+        library's time-out counter, the pool counters of the compact rulebooks, in that order — into a fresh int32 tensor"""
+        import ctypes
+        from .. import lib as _l
+        srcs = [s[2] for s in stage] + [None] + [u for u, _, _ in ell_used]
+        arr = (ctypes.c_void_p * len(srcs))(*[None if t is None else t.data_ptr() for t in srcs])
+        out = torch.empty((len(srcs),), dtype=torch.int32, device=device)
+        reset = sum(1 << (len(stage) + 1 + i) for i in range(len(ell_used)))   # the pool counters are the engine's: zero for the next forward
+        _l.check(_l.load().fnp_gather_counts(ctypes.cast(arr, ctypes.c_void_p), len(srcs), reset, _l.ptr(out), _l.stream()), "fnp_gather_counts")
+        return out
 
     def _check_aborts(self, value):
         """raise when the counter has grown since this engine last looked: a tiled convolution ended a workgroup early and
@@ -537,7 +550,17 @@ class FusedResBackbone:
             for gs in self._grids.values():
                 for g in gs:
                     g.zero_()
+            for c in self._ell_ctr.values():
+                c.zero_()
             self._dirty = False
+
+    def _ell_counter(self, which, device):
+        """the engine's pool counter of compact rulebook `which`: zero between forwards (the counts launch resets what it reads)"""
+        key = (str(device), which)
+        c = self._ell_ctr.get(key)
+        if c is None:
+            c = self._ell_ctr[key] = torch.zeros((1,), dtype=torch.int32, device=device)
+        return c
 
     def run_points(self, points, batch_offsets, batch_size, voxel_cfg, sync=True):
         self._ensure_clean()
@@ -573,7 +596,7 @@ class FusedResBackbone:
             g.off.copy_(batch_offsets)
             g.graph.replay()
             stage, caps, shapes = g.res['stages'], g.res['caps'], g.res['shapes']
-            counts = torch.cat([s[2] for s in stage] + [g.res['aborts']] + [u for u, _, _ in g.res['ell_used']]).cpu().tolist()   # the one host sync
+            counts = g.res['counts_dev'].cpu().tolist()   # the one host sync
             overflow = self._ell_overflow(counts, g.res['ell_used'], caps[0])
             self._check_aborts(counts.pop())
             for l in range(1, 5):
@@ -672,7 +695,7 @@ class FusedResBackbone:
         ell_used = []
         ell_all = ell and (S.ELL_MODE is True or (S.ELL_MODE is None and S.ELL_MFMA))
         if ell:
-            rb1 = S.rulebook_subm_ell(indices, n1, grid1, int(cap1 * self.ell_pool[0]) + 64, with_table=not ell_all)
+            rb1 = S.rulebook_subm_ell(indices, n1, grid1, int(cap1 * self.ell_pool[0]) + 64, with_table=not ell_all, used=self._ell_counter(0, dev))
             ell_used.append((rb1._ell[2], rb1._ell[1], 0))
         else:
             # (f32: the 16 -> 16 layers sweep their ranges class by class, like every f32 SubM stage below)
@@ -698,7 +721,7 @@ class FusedResBackbone:
             rbs = S.rulebook_strided(idx_prev, n_prev, g_prev, dconv.kernel_size, dconv.stride, dconv.padding,
                                      caps[li + 1], out_grid=grids[li + 1], want_nbr=not (fused or ell_down), premarked=premarked)
             if ell_down:
-                S.ell_for_strided(rbs, int(caps[li + 1] * self.ell_pool[1]) + 64)
+                S.ell_for_strided(rbs, int(caps[li + 1] * self.ell_pool[1]) + 64, used=self._ell_counter(1, dev))
                 ell_used.append((rbs._ell[2], rbs._ell[1], 1))
             x = conv(x_prev, P[down_key], rbs, rbs.out_n)
             # stages 2-4: rows are in rank-grid order on both sides of the SubM convolutions; where they run on the tile
@@ -731,12 +754,12 @@ class FusedResBackbone:
         # leave every persistent grid zeroed for the next call (O(rows) sparse clear, all five grids in one launch)
         S.clear_grids([(g, idx, n_cells if (l == 0 and n_cells is not None) else n) for l, (_, idx, n, g) in enumerate(stage)])
         self._dirty = False
-        aborts = self._aborts_word(dev)
+        counts_dev = self._counts_word(stage, ell_used, dev)
 
         shapes = self._stage_shapes()
         if not sync:
-            return {'stages': stage, 'shapes': shapes, 'caps': caps, 'batch_size': batch_size, 'aborts': aborts, 'ell_used': ell_used}
-        counts = torch.cat([s[2] for s in stage] + [aborts] + [u for u, _, _ in ell_used]).cpu().tolist()   # the one host sync
+            return {'stages': stage, 'shapes': shapes, 'caps': caps, 'batch_size': batch_size, 'counts_dev': counts_dev, 'ell_used': ell_used}
+        counts = counts_dev.cpu().tolist()   # the one host sync
         overflow = self._ell_overflow(counts, ell_used, cap1)
         self._check_aborts(counts.pop())
         for l in range(1, 5):

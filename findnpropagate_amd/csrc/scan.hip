@@ -115,7 +115,9 @@ int run_scan(L load, long long n, TOut *out, int *total, void *ws, hipStream_t s
 // ~98 % empty grids (the 41 x 1440 x 1440 lidar grid of a 32-scene batch has 713 k summary words: a wave
 // per word spent 85 us launching waves that retire after one load); WPW = 1 for the small dense grids of
 // the later stages, where a wave per word is the parallel form.  Three kernels, none of them a scan over
-// the per-unit counts:
+// the per-unit counts (round 3, measured and dropped: one-workgroup forms for the small grids and the 30 k point flags of a
+// one-scene forward — a launch fewer or two each, but a lone 1024-thread workgroup needs 16-65 us for what these three launches
+// do in 15: its two dependent memory round trips and three barriers run with nothing to hide them):
 //   PASS 0 : cnt[U]  = occupied cells in the blocks of unit U             (no scan: a per-lane sum)
 //   TOTALS : gtot[g] = sum of cnt over group g (64 units), ctot[c] = over chunk c (16 groups);
 //            one workgroup per chunk, coalesced

@@ -341,7 +341,7 @@ extern "C" long long fnp_ell_bytes(int cap_rows, int pool_records) {
 // SubM 3x3x3 (geom: in_shape == out_shape) or strided 3x3x3 (out_coords from fnp_rulebook_strided with nbr = NULL) rulebook in
 // the compact form.  pool_used (one int32, device) ends as the number of extension records asked for.
 extern "C" int fnp_rulebook_ell(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom, const fnp_rankgrid *in_grid,
-                                void *records, int pool_records, int *pool_used, int *nbr, fnp_stream_t stream) {
+                                void *records, int pool_records, int *pool_used, int pool_used_is_zero, int *nbr, fnp_stream_t stream) {
     if (!coords || !n_rows || cap <= 0 || !geom || !fnp_rg_valid(in_grid) || !records || pool_records < 0 || !pool_used) return FNP_ERR_ARG;
     if (((uintptr_t)records & 15) || (long long)cap + pool_records >= (1ll << 26)) return FNP_ERR_ARG;   // (32-bit byte offsets into the records)
     bool subm = true;
@@ -352,7 +352,8 @@ extern "C" int fnp_rulebook_ell(const int *coords, const int *n_rows, int cap, c
     if (in_grid->D != geom->in_shape[0] || in_grid->H != geom->in_shape[1] || in_grid->W != geom->in_shape[2]) return FNP_ERR_ARG;
     const RG g = fnp_rg_view(in_grid);
     const dim3 grid(fnp_grid_for(cap, kThreads));
-    {   // (the pool counter starts at zero: a fill kernel, not a memset — common.h)
+    if (!pool_used_is_zero) {   // (the pool counter starts at zero: a fill kernel, not a memset — common.h; a caller that keeps the
+                                // counter and has it reset when it reads it, fnp_gather_counts, saves the launch)
         const int frc = fnp_fill_words(pool_used, 1, 0u, (hipStream_t)stream);
         if (frc) return frc;
     }

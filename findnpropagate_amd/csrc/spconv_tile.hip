@@ -839,6 +839,31 @@ extern "C" int fnp_spconv_tiled_aborts_copy(int *dst, fnp_stream_t stream) {
     return FNP_OK;
 }
 
+// The per-stage counts a forward hands to the host in its one synchronisation, collected by ONE launch: dst[i] = *srcs[i], and the
+// time-out counter above where srcs[i] is NULL (a concatenation of one-word tensors plus a copy of the counter cost a one-scene
+// forward two launches and a gap).
+struct GatherJobs {
+    int *src[16];
+    int n;
+    unsigned reset_mask;
+};
+__global__ void gather_counts_kernel(GatherJobs j, int *__restrict__ dst) {
+    const int t = threadIdx.x;
+    if (t >= j.n) return;
+    dst[t] = j.src[t] ? *j.src[t] : (int)g_tile_aborts;
+    if (j.src[t] && ((j.reset_mask >> t) & 1u)) *j.src[t] = 0;   // (a counter its owner wants at zero for the next forward)
+}
+extern "C" int fnp_gather_counts(int *const *srcs, int n, unsigned reset_mask, int *dst, fnp_stream_t stream) {
+    if (!srcs || !dst || n <= 0 || n > 16) return FNP_ERR_ARG;
+    GatherJobs j;
+    for (int i = 0; i < 16; ++i) j.src[i] = i < n ? srcs[i] : nullptr;
+    j.n = n;
+    j.reset_mask = reset_mask;
+    hipLaunchKernelGGL(gather_counts_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, j, dst);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
 extern "C" int fnp_debug_tile_hold(int on) {
     const int v = on ? 1 : 0;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_hold), &v, sizeof(v)) != hipSuccess) return FNP_ERR_HIP;

@@ -69,7 +69,13 @@ __device__ __forceinline__ int batch_of(const int *__restrict__ off, int B, int 
 
 __global__ __launch_bounds__(kThreads) void vox_mark_kernel(const float *__restrict__ pts, int n, int C,
                                                             const int *__restrict__ boff, int B, fnp_voxel_cfg cfg,
-                                                            RG g, long long *__restrict__ code) {
+                                                            RG g, long long *__restrict__ code, int *__restrict__ cnt) {
+    // (the per-cell counters of vox_insert_kernel start at zero: n + 1 words, one per thread here — a launch less than a fill)
+    {
+        const int z = blockIdx.x * kThreads + threadIdx.x;
+        if (z <= n) cnt[z] = 0;
+        if (z == 0 && (long long)gridDim.x * kThreads <= n) cnt[n] = 0;   // (n a multiple of the workgroup size)
+    }
     __shared__ MarkTab tab;   // the marks of the workgroup's 256 points meet here first (rankgrid.cuh): one atomic per distinct block
     if (FNP_MARK_TAB) mark_tab_init(&tab, threadIdx.x, kThreads);
     const int i = blockIdx.x * kThreads + threadIdx.x;   // (whole waves stay: the shuffles below need them)
@@ -121,9 +127,10 @@ __global__ __launch_bounds__(kThreads) void vox_insert_kernel(int n, int maxp, i
                                                               const unsigned *__restrict__ base,
                                                               const long long *__restrict__ code,
                                                               int *__restrict__ rank, int *__restrict__ top, int *__restrict__ cnt,
-                                                              int *__restrict__ crowded) {
+                                                              int *__restrict__ crowded, int *__restrict__ late) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
+    late[i] = 0;
     const long long cd = code[i];
     int r = -1;
     if (cd >= 0) {
@@ -138,34 +145,32 @@ __global__ __launch_bounds__(kThreads) void vox_insert_kernel(int n, int maxp, i
     // read-modify-writes of a 77 MB array per step, almost all of them L2 misses, for cells that hold 1.6 points on average:
     // a point now takes a slot of its cell with ONE atomic on a compact counter array (4 bytes per cell: it stays in L2) and
     // stores its index there; which slot depends on timing, the SET of a cell's points does not, and the consumers order
-    // it.  Only a cell with more than max_points points needs the max_points SMALLEST: those cells are reset and bubble-
-    // filled by the two small kernels below.
+    // it.  Only a cell with more than max_points points needs the max_points SMALLEST: the points that came too late for a
+    // slot (late[i] = 1) are bubbled into the full list by the small kernel below.
     const int s = atomicAdd(&cnt[r], 1);
-    if (s < maxp) top[(size_t)r * maxp + s] = i;
-    else if (s == maxp) *crowded = 1;   // (plain store of the same value by whoever sees it: the two kernels below leave at once without it)
+    if (s < maxp) {
+        top[(size_t)r * maxp + s] = i;
+    } else {
+        late[i] = 1;
+        if (s == maxp) *crowded = 1;   // (plain store of the same value by whoever sees it: the kernel below leaves at once without it)
+    }
 }
 
-// cells with more points than a voxel keeps: their list restarts empty (sentinels) ...
-__global__ __launch_bounds__(kThreads) void vox_crowded_reset_kernel(int cap, int maxp, const int *__restrict__ cnt, int *__restrict__ top,
-                                                                    const int *__restrict__ crowded) {
-    if (*crowded == 0) return;   // (uniform)
-    const int r = blockIdx.x * kThreads + threadIdx.x;
-    if (r >= cap || cnt[r] <= maxp) return;
-    for (int j = 0; j < maxp; ++j) top[(size_t)r * maxp + j] = kSentinel;
-}
-// ... and every point of such a cell bubbles into it: slot j ends up holding the (j+1)-th smallest index whatever the interleaving
-__global__ __launch_bounds__(kThreads) void vox_crowded_insert_kernel(int n, int maxp, const int *__restrict__ rank, const int *__restrict__ cnt,
+// A cell with more points than a voxel keeps: its max_points slots hold the points that came first (any order); every LATE point
+// walks down the list with atomicMin, leaving the smaller of (slot, carried) behind and carrying the larger on, and drops what
+// it carries at the end.  A step preserves the multiset {slot, carried}, slots only ever decrease and a carried value never
+// decreases along its walk, so a dropped value is larger than everything the list holds at the end: the list ends as the
+// max_points smallest indices of the cell whatever the interleaving and whatever order the first-comers stand in (the consumers
+// order a list themselves).  The reset-to-sentinel kernel of the first form is gone.
+__global__ __launch_bounds__(kThreads) void vox_crowded_insert_kernel(int n, int maxp, const int *__restrict__ rank, const int *__restrict__ late,
                                                                      int *__restrict__ top, const int *__restrict__ crowded) {
     if (*crowded == 0) return;   // (uniform)
     const int i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= n) return;
-    const int r = rank[i];
-    if (r < 0 || cnt[r] <= maxp) return;
+    if (i >= n || late[i] == 0) return;
     int carry = i;
-    int *slots = top + (size_t)r * maxp;
+    int *slots = top + (size_t)rank[i] * maxp;
     for (int j = 0; j < maxp; ++j) {
         const int old = atomicMin(&slots[j], carry);
-        if (old == kSentinel) break;     // took an empty slot
         carry = old > carry ? old : carry;  // keep pushing the larger one down
     }
 }
@@ -399,21 +404,16 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
     const int maxp = cfg->max_points, C = cfg->num_features;
     const int pgrid = fnp_divup(n, kThreads);
 
-    {   // (a fill kernel, never hipMemsetAsync on a capturable path: common.h fnp_fill_words).  The per-cell counters start at
-        // zero; the slot lists need no initial value (a cell's first min(cnt, max_points) slots are written before they are read)
-        const int frc = fnp_fill_words(w.cnt, (long long)n + 1, 0u, s);
-        if (frc) return frc;
-    }
-    hipLaunchKernelGGL(vox_mark_kernel, dim3(pgrid), dim3(kThreads), 0, s, points, n, C, batch_offsets, B, *cfg, g, w.code);
+    // (the per-cell counters are zeroed by the marking kernel; the slot lists need no initial value: a cell's first
+    //  min(cnt, max_points) slots are written before they are read)
+    hipLaunchKernelGGL(vox_mark_kernel, dim3(pgrid), dim3(kThreads), 0, s, points, n, C, batch_offsets, B, *cfg, g, w.code, w.cnt);
     FNP_LAUNCH_CHECK();
     int rc = fnp_scan::rank_grid(g, w.n_sorted, w.scan_ws, s);
     if (rc) return rc;
     hipLaunchKernelGGL(vox_insert_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, n,
-                       (const unsigned long long *)g.bits, (const unsigned *)g.base, w.code, w.rank, w.top, w.cnt, w.cnt + n);
+                       (const unsigned long long *)g.bits, (const unsigned *)g.base, w.code, w.rank, w.top, w.cnt, w.cnt + n, w.flag);
     FNP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vox_crowded_reset_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, (const int *)w.cnt, w.top, (const int *)(w.cnt + n));
-    FNP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vox_crowded_insert_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, (const int *)w.rank, (const int *)w.cnt, w.top, (const int *)(w.cnt + n));
+    hipLaunchKernelGGL(vox_crowded_insert_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, (const int *)w.rank, (const int *)w.flag, w.top, (const int *)(w.cnt + n));
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(vox_flag_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, w.rank, w.top, (const int *)w.cnt, w.flag);
     FNP_LAUNCH_CHECK();

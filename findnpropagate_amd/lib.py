@@ -120,6 +120,7 @@ SIGNATURES = {
     "fnp_spconv_forward_strided": (c_int, [P, c_int, c_int, P, POINTER(RankGridC), POINTER(ConvGeom), P, P, c_int, P, c_int,
                                            P, P, c_int, c_int, c_int, P]),
     "fnp_spconv_tiled_aborts": (c_int, []),
+    "fnp_gather_counts": (c_int, [P, c_int, c_uint, P, P]),
     "fnp_spconv_tiled_aborts_copy": (c_int, [P, P]),
     "fnp_debug_tile_hold": (c_int, [c_int]),
     "fnp_tile_rulebook_bytes": (c_int64, [c_int, c_int]),
@@ -130,7 +131,7 @@ SIGNATURES = {
                                                P, P, c_int, P, P, c_int64, P]),
     "fnp_spconv_forward_tiled": (c_int, [P, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     "fnp_ell_bytes": (c_int64, [c_int, c_int]),
-    "fnp_rulebook_ell": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, P, P]),
+    "fnp_rulebook_ell": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, c_int, P, P]),
     "fnp_spconv_forward_ell": (c_int, [P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, P, P, P, c_int, c_int, c_int, P]),
     "fnp_spconv_forward_ell_mfma": (c_int, [P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, P, P, P, c_int, c_int, c_int, P]),
     "fnp_classsort_workspace_bytes": (c_int64, [c_int]),

@@ -337,35 +337,39 @@ ELL_SHAPES = {(4, 16), (5, 16), (16, 16), (16, 32)}   # (Cin, Cout) fnp_spconv_f
 ELL_MODE = {"0": False, "1": True}.get(os.environ.get("FNP_ELL", ""))   # (development / tests: forbid or force)
 
 
-def ell_rulebook(coords, n_dev, cap, geom, in_grid, pool_records, nbr=None):
+def ell_rulebook(coords, n_dev, cap, geom, in_grid, pool_records, nbr=None, used=None):
     """Compact rulebook (fnp_rulebook_ell) of the rows whose cells are `coords`: returns (records, pool_records, pool_used).
     nbr: optional (27, cap) int32 tensor that receives the table of the same rows in the same pass.
+    used: a (1,) int32 counter the caller keeps, holding ZERO (reset when it is read, fnp_gather_counts): no launch to clear one.
     No host sync: the caller reads pool_used with its other counts and discards the result when it exceeds the pool."""
     L = _l.load()
     dev = coords.device
     pool_records = max(int(pool_records), 0)
     rec = torch.empty((int(L.fnp_ell_bytes(cap, pool_records)) // 4,), dtype=torch.int32, device=dev)
-    used = torch.empty((1,), dtype=torch.int32, device=dev)
-    rc = L.fnp_rulebook_ell(_l.ptr(coords), _l.ptr(n_dev), cap, geom, in_grid.c(), _l.ptr(rec), pool_records, _l.ptr(used), _l.ptr(nbr), _l.stream())
+    kept = used is not None
+    if not kept:
+        used = torch.empty((1,), dtype=torch.int32, device=dev)
+    rc = L.fnp_rulebook_ell(_l.ptr(coords), _l.ptr(n_dev), cap, geom, in_grid.c(), _l.ptr(rec), pool_records, _l.ptr(used), int(kept), _l.ptr(nbr),
+                            _l.stream())
     _l.check(rc, "fnp_rulebook_ell")
     return rec, pool_records, used
 
 
-def rulebook_subm_ell(indices, n_dev, grid, pool_records, with_table=False):
+def rulebook_subm_ell(indices, n_dev, grid, pool_records, with_table=False, used=None):
     """SubM 3x3x3 rulebook in the compact form (`_ell` set); with_table: the (27, cap) table too, from the same pass (else
     Rulebook.nbr is None)."""
     cap = max(indices.shape[0], 1)
     geom, _ = make_geom(3, 1, 1, grid.shape, grid.shape)
     nbr = torch.empty((27, cap), dtype=torch.int32, device=indices.device) if with_table else None
     rb = Rulebook(nbr=nbr, K=27, cap_out=cap, geom=geom)
-    rb._ell = ell_rulebook(indices, n_dev, cap, geom, grid, pool_records, nbr=nbr)
+    rb._ell = ell_rulebook(indices, n_dev, cap, geom, grid, pool_records, nbr=nbr, used=used)
     return rb
 
 
-def ell_for_strided(rb, pool_records):
+def ell_for_strided(rb, pool_records, used=None):
     """Compact rulebook of a strided 3x3x3 layer built with want_nbr=False (its output coordinates + the input grid)."""
     assert rb.nbr is None and rb.in_grid is not None and rb.K == 27
-    rb._ell = ell_rulebook(rb.out_indices, rb.out_n, rb.cap_out, rb.geom, rb.in_grid, pool_records)
+    rb._ell = ell_rulebook(rb.out_indices, rb.out_n, rb.cap_out, rb.geom, rb.in_grid, pool_records, used=used)
     return rb
 
 

@@ -287,6 +287,10 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
  * test hook that makes every hand-over time out (producers stop publishing), fnp_debug_tile_hold(0) restores them. */
 int fnp_spconv_tiled_aborts(void);
 int fnp_spconv_tiled_aborts_copy(int *dst, fnp_stream_t stream);
+/* dst[i] = *srcs[i] for n <= 16 one-word device counters (srcs: HOST array of device pointers), the time-out counter above where
+ * srcs[i] is NULL: what a forward hands to the host in its one synchronisation, in one launch (capturable).  Bit i of reset_mask:
+ * *srcs[i] = 0 after it is read (a counter its owner keeps across forwards, e.g. fnp_rulebook_ell's pool_used). */
+int fnp_gather_counts(int *const *srcs, int n, unsigned reset_mask, int *dst, fnp_stream_t stream);
 int fnp_debug_tile_hold(int on);
 long long fnp_tile_rulebook_bytes(int cap_out, int channels);
 int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int channels,
@@ -330,7 +334,9 @@ int fnp_spconv_forward_tiled(const void *feat_in, int dtype, int n_in_rows, cons
  *   coords     the rows' cells: the tensor's own coordinates (SubM: geom with in_shape == out_shape, stride 1, padding 1) or
  *              the output coordinates of fnp_rulebook_strided(nbr = NULL) (strided 3x3x3: geom as given there)
  *   pool_used  one int32 (device): ends as the number of extension records the rows asked for; above pool_records the
- *              chains were cut and the caller must discard the result and come back with a larger pool
+ *              chains were cut and the caller must discard the result and come back with a larger pool.
+ *              pool_used_is_zero != 0: the word already holds zero (a counter the caller keeps and has reset when it is read,
+ *              fnp_gather_counts): the call does not spend a launch on clearing it
  *   nbr        optional (27, cap) int32 table of the same rows (fnp_rulebook_subm's / fnp_rulebook_strided's), written in the
  *              same pass: measured on MI355X the VALU convolution wins 2.3x on conv_input (5 input channels) and loses 30 %
  *              on the 16-channel layers (256 products per pair are v_dot2c work at a quarter of the FMA rate), so the
@@ -339,7 +345,7 @@ int fnp_spconv_forward_tiled(const void *feat_in, int dtype, int n_in_rows, cons
  * / FNP_F16, Cin 16, Cout 16 or 32); FNP_ERR_ARG otherwise.  weight: packed (27, Cout, Cin) in in_dtype. */
 long long fnp_ell_bytes(int cap_rows, int pool_records);
 int fnp_rulebook_ell(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom, const fnp_rankgrid *in_grid,
-                     void *records, int pool_records, int *pool_used, int *nbr, fnp_stream_t stream);
+                     void *records, int pool_records, int *pool_used, int pool_used_is_zero, int *nbr, fnp_stream_t stream);
 int fnp_spconv_forward_ell(const void *feat_in, int in_dtype, int n_in_rows, const void *weight, const void *records,
                            int cap_rows, int pool_records, const int *n_out, void *feat_out, int out_dtype,
                            const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
