@@ -168,6 +168,14 @@ def _module_forward(self, batch_dict):
     act = self._act_dtype()
     x_in = spconv.SparseConvTensor(features=voxel_features.float().contiguous(), indices=voxel_coords.int().contiguous(),
                                    spatial_shape=self.sparse_shape, batch_size=batch_size)
+    # the strided layers' rulebooks are asked for ahead of the layers before them (spconv/conv.py prefetch): the first one from
+    # the input coordinates right here, each further one by the strided layer before it
+    if x_in.features.is_cuda and torch.is_grad_enabled():
+        chain = _strided_chain(self)
+        for a, b in zip(chain, chain[1:] + [None]):
+            object.__setattr__(a, "_fnp_next", b)   # (not a registered submodule: parameter names and state_dict stay the reference's)
+        if chain and x_in.indices.shape[0] > 0:
+            chain[0].prefetch(x_in.indices, x_in.n_dev(), x_in.rank_grid(), x_in.spatial_shape, batch_size, x_in.indice_dict)
     # first conv consumes f32 point features; activations then live in `act`
     conv0 = self.conv_input[0]
     x = conv0(x_in)
@@ -178,6 +186,18 @@ def _module_forward(self, batch_dict):
     x_conv4 = _seq_forward(self.conv4, x_conv3, act)
     out = _seq_forward(self.conv_out, x_conv4, act)
     return self._pack_outputs(batch_dict, out, x_conv1, x_conv2, x_conv3, x_conv4)
+
+
+def _strided_chain(self):
+    """the strided convolutions of the backbone in forward order (the first sparse module of conv2, conv3, conv4, conv_out)"""
+    out = []
+    for name in ("conv2", "conv3", "conv4", "conv_out"):
+        m = getattr(self, name, None)
+        while isinstance(m, spconv.SparseSequential) and len(m._modules):
+            m = next(iter(m._modules.values()))
+        if isinstance(m, spconv.SparseConv3d) and not m.subm:
+            out.append(m)
+    return out
 
 
 def _seq_forward(seq, x, act):

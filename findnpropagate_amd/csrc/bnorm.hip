@@ -135,7 +135,8 @@ __global__ __launch_bounds__(kThreads) void bn_finish_kernel(const double *__res
                                                              const int *__restrict__ n_rows, int cap, int mode, float eps,
                                                              float momentum, float *__restrict__ out_a,
                                                              float *__restrict__ out_b, float *__restrict__ running_mean,
-                                                             float *__restrict__ running_var) {
+                                                             float *__restrict__ running_var, long long *__restrict__ batches_tracked) {
+    if (batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1;   // (nn.BatchNorm1d.num_batches_tracked: a torch launch less per layer)
     __shared__ double ra[kThreads], rb[kThreads];
     const int n = min(*n_rows, cap);
     // a workgroup finishes kFinC channels (grid = C / kFinC workgroups; C is a power of two >= 8)
@@ -246,14 +247,14 @@ int stats_grid(int cap, int C) {
 template <typename T>
 int run_forward(const void *x, const int *n_rows, int cap, int C, const float *gamma, const float *beta, float *rm, float *rv,
                 float momentum, float eps, const void *residual, int relu, void *y, float *save_mean, float *save_invstd,
-                void *ws, hipStream_t s) {
+                void *ws, hipStream_t s, long long *nbt) {
     const int g = stats_grid(cap, C);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_stats_kernel<T, 0>), dim3(g), dim3(kThreads), kThreads * 16 * sizeof(double), s,
                        (const T *)x, (const T *)nullptr, (const T *)nullptr, n_rows, cap, C, (const float *)nullptr,
                        (const float *)nullptr, 0, (double *)ws);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finish_kernel, dim3(C <= kFinC ? 1 : C / kFinC), dim3(kThreads), 0, s, (const double *)ws, g, C, n_rows, cap, 0, eps, momentum,
-                       save_mean, save_invstd, rm, rv);
+                       save_mean, save_invstd, rm, rv, nbt);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_apply_kernel<T>), dim3(fnp_grid_for((long long)cap * (C / 8), kThreads, 2048)), dim3(kThreads), 0,
                        s, (const T *)x, (const T *)residual, n_rows, cap, C, save_mean, save_invstd, gamma, beta, relu, (T *)y);
@@ -270,7 +271,7 @@ int run_backward(const void *dy, const void *x, const void *y, const int *n_rows
                        (const T *)x, (const T *)dy, (const T *)y, n_rows, cap, C, save_mean, save_invstd, relu, (double *)ws);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finish_kernel, dim3(C <= kFinC ? 1 : C / kFinC), dim3(kThreads), 0, s, (const double *)ws, g, C, n_rows, cap, 1, 0.f, 0.f, dbeta,
-                       dgamma, (float *)nullptr, (float *)nullptr);
+                       dgamma, (float *)nullptr, (float *)nullptr, (long long *)nullptr);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_backward_apply_kernel<T>), dim3(fnp_grid_for((long long)cap * (C / 8), kThreads, 2048)),
                        dim3(kThreads), 0, s, (const T *)dy, (const T *)x, (const T *)y, n_rows, cap, C, save_mean, save_invstd, gamma,
@@ -288,20 +289,20 @@ extern "C" int64_t fnp_bn_workspace_bytes(int C) { return C > 0 ? (int64_t)kMaxP
 extern "C" int fnp_bn_train_forward(const void *x, int dtype, const int *n_rows, int cap, int C, const float *gamma,
                                     const float *beta, float *running_mean, float *running_var, float momentum, float eps,
                                     const void *residual, int relu, void *y, float *save_mean, float *save_invstd,
-                                    void *workspace, int64_t workspace_bytes, fnp_stream_t stream) {
+                                    long long *num_batches_tracked, void *workspace, int64_t workspace_bytes, fnp_stream_t stream) {
     if (!x || !n_rows || !gamma || !beta || !y || !save_mean || !save_invstd || !workspace || !shape_ok(cap, C)) return FNP_ERR_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return FNP_ERR_ARG;
     if (workspace_bytes < fnp_bn_workspace_bytes(C)) return FNP_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == FNP_F32)
         return run_forward<float>(x, n_rows, cap, C, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, y,
-                                  save_mean, save_invstd, workspace, s);
+                                  save_mean, save_invstd, workspace, s, num_batches_tracked);
     if (dtype == FNP_BF16)
         return run_forward<__bf16>(x, n_rows, cap, C, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, y,
-                                   save_mean, save_invstd, workspace, s);
+                                   save_mean, save_invstd, workspace, s, num_batches_tracked);
     if (dtype == FNP_F16)
         return run_forward<_Float16>(x, n_rows, cap, C, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, y,
-                                     save_mean, save_invstd, workspace, s);
+                                     save_mean, save_invstd, workspace, s, num_batches_tracked);
     return FNP_ERR_ARG;
 }
 

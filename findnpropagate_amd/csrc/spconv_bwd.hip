@@ -140,12 +140,19 @@ __global__ __launch_bounds__(kThreads) void wgrad_small_kernel(const TX *__restr
     }
 }
 
+// module_cc = Cout * Cin when dw is the MODULE's layout (Cout, K, Cin) (the parameter's .grad, written here instead of by a
+// permute-copy afterwards), 0 for the packed (K, Cout, Cin)
 __global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float *__restrict__ partial, int chunks, long long total,
-                                                                float *__restrict__ dw) {
+                                                                float *__restrict__ dw, int module_cc = 0, int Cin = 1, int K = 1) {
     for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kThreads) {
         float s = 0.f;
         for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * total + e];   // fixed order
-        dw[e] = s;
+        long long o = e;
+        if (module_cc) {
+            const int k = (int)(e / module_cc), r = (int)(e % module_cc), co = r / Cin, ci = r % Cin;
+            o = ((long long)co * K + k) * Cin + ci;
+        }
+        dw[o] = s;
     }
 }
 
@@ -469,7 +476,8 @@ static inline int max_chunks(int Cin, int Cout) {
 
 template <typename TX, typename TY>
 int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, float *dw,
-              int Cin, int Cout, void *ws, int64_t ws_bytes, hipStream_t s, const int *pair_i = nullptr, const int *pair_count = nullptr) {
+              int Cin, int Cout, void *ws, int64_t ws_bytes, hipStream_t s, int layout, const int *pair_i = nullptr, const int *pair_count = nullptr) {
+    const int module_cc = layout ? Cin * Cout : 0;
     const long long pairs = (long long)Cin * Cout, total = pairs * K;
     if (pairs > 64 * kThreads) return FNP_ERR_ARG;   // <= 128 x 128
     int chunks = fnp_divup(cap_out, 2048);
@@ -499,7 +507,7 @@ int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int
         if (done) {
             FNP_LAUNCH_CHECK();
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fnp_grid_for(total, kThreads)), dim3(kThreads), 0, s,
-                               (const float *)partial, chunks, total, dw);
+                               (const float *)partial, chunks, total, dw, module_cc, Cin, K);
             FNP_LAUNCH_CHECK();
             return FNP_OK;
         }
@@ -510,7 +518,7 @@ int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int
                            (const TY *)dy, nbr, nbr_stride, n_out, cap_out, Cin, Cout, partial);
         FNP_LAUNCH_CHECK();
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fnp_grid_for(total, kThreads)), dim3(kThreads), 0, s, (const float *)partial, chunks,
-                           total, dw);
+                           total, dw, module_cc, Cin, K);
         FNP_LAUNCH_CHECK();
         return FNP_OK;
     }
@@ -523,12 +531,47 @@ int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int
 #undef FNP_WG
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fnp_grid_for(total, kThreads)), dim3(kThreads), 0, s, (const float *)partial, chunks,
-                       total, dw);
+                       total, dw, module_cc, Cin, K);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
 
 }  // namespace
+
+// The module's weight (Cout, K, Cin) f32 -> the packed slabs (K, Cout, Cin) the convolutions read, in the activation dtype, and
+// (training) the slabs the data gradient reads, in the SAME launch: mirror 1 = offsets mirrored (K - 1 - k, Cout, Cin) for the
+// SubM data gradient on the forward's table, mirror 2 = mirrored and transposed (K - 1 - k, Cin, Cout) for the tiled kernels.
+// (torch: a permute-copy and a cast per layer and step, plus a flip and a transpose-copy in the backward.)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pack_weight_kernel(const float *__restrict__ w, int Cout, int K, int Cin, T *__restrict__ packed,
+                                                               T *__restrict__ mirror, int mode) {
+    const long long total = (long long)Cout * K * Cin;
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kThreads) {
+        const int ci = (int)(e % Cin), co = (int)((e / Cin) % Cout), k = (int)(e / ((long long)Cin * Cout));   // e indexes `packed`
+        const T v = (T)w[((long long)co * K + k) * Cin + ci];
+        packed[e] = v;
+        if (mode == 1) mirror[((long long)(K - 1 - k) * Cout + co) * Cin + ci] = v;
+        else if (mode == 2) mirror[((long long)(K - 1 - k) * Cin + ci) * Cout + co] = v;
+    }
+}
+extern "C" int fnp_pack_weight(const float *weight, int Cout, int K, int Cin, int dtype, void *packed, void *mirror, int mirror_mode,
+                               fnp_stream_t stream) {
+    if (!weight || !packed || Cout <= 0 || K <= 0 || Cin <= 0 || mirror_mode < 0 || mirror_mode > 2 || (mirror_mode != 0) != (mirror != nullptr))
+        return FNP_ERR_ARG;
+    const long long total = (long long)Cout * K * Cin;
+    const dim3 grid(fnp_grid_for(total, kThreads, 1024));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FNP_F32)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_weight_kernel<float>), grid, dim3(kThreads), 0, s, weight, Cout, K, Cin, (float *)packed, (float *)mirror, mirror_mode);
+    else if (dtype == FNP_BF16)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_weight_kernel<__bf16>), grid, dim3(kThreads), 0, s, weight, Cout, K, Cin, (__bf16 *)packed, (__bf16 *)mirror, mirror_mode);
+    else if (dtype == FNP_F16)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_weight_kernel<_Float16>), grid, dim3(kThreads), 0, s, weight, Cout, K, Cin, (_Float16 *)packed, (_Float16 *)mirror, mirror_mode);
+    else
+        return FNP_ERR_ARG;
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
 
 extern "C" int fnp_rulebook_transpose(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int *nbr_t,
                                       int cap_in, fnp_stream_t stream) {
@@ -550,27 +593,27 @@ extern "C" int64_t fnp_spconv_wgrad_workspace_bytes(int K, int Cin, int Cout) {
 }
 
 extern "C" int fnp_spconv_wgrad(const void *feat_in, int in_dtype, const void *grad_out, int grad_dtype, const int *nbr,
-                                int nbr_stride, int K, const int *n_out, int cap_out, float *grad_weight, int Cin, int Cout,
+                                int nbr_stride, int K, const int *n_out, int cap_out, float *grad_weight, int grad_layout, int Cin, int Cout,
                                 void *workspace, int64_t workspace_bytes, fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!feat_in || !grad_out || !nbr || !n_out || !grad_weight || !workspace || K <= 0 || Cin <= 0 || Cout <= 0 ||
-        cap_out <= 0 || nbr_stride < cap_out)
+        cap_out <= 0 || nbr_stride < cap_out || (grad_layout != 0 && grad_layout != 1))
         return FNP_ERR_ARG;
     if (in_dtype == FNP_F32 && grad_dtype == FNP_F32)
         return run_wgrad<float, float>(feat_in, grad_out, nbr, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
-                                       workspace_bytes, s);
+                                       workspace_bytes, s, grad_layout);
     if (in_dtype == FNP_BF16 && grad_dtype == FNP_BF16)
         return run_wgrad<__bf16, __bf16>(feat_in, grad_out, nbr, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
-                                         workspace_bytes, s);
+                                         workspace_bytes, s, grad_layout);
     if (in_dtype == FNP_F16 && grad_dtype == FNP_F16)
         return run_wgrad<_Float16, _Float16>(feat_in, grad_out, nbr, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout,
-                                             workspace, workspace_bytes, s);
+                                             workspace, workspace_bytes, s, grad_layout);
     if (in_dtype == FNP_F32 && grad_dtype == FNP_BF16)
         return run_wgrad<float, __bf16>(feat_in, grad_out, nbr, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
-                                        workspace_bytes, s);
+                                        workspace_bytes, s, grad_layout);
     if (in_dtype == FNP_BF16 && grad_dtype == FNP_F32)
         return run_wgrad<__bf16, float>(feat_in, grad_out, nbr, nbr_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
-                                        workspace_bytes, s);
+                                        workspace_bytes, s, grad_layout);
     return FNP_ERR_ARG;
 }
 
@@ -604,16 +647,17 @@ extern "C" int fnp_rulebook_pairs(const int *nbr, int nbr_stride, int K, const i
 // fnp_spconv_wgrad).  Same sum in another grouping of the rows: equal to fnp_spconv_wgrad's up to f32 rounding, run-to-run identical.
 extern "C" int fnp_spconv_wgrad_pairs(const void *feat_in, int in_dtype, const void *grad_out, int grad_dtype, const int *pair_o,
                                       const int *pair_i, const int *pair_count, int pair_stride, int K, const int *n_out, int cap_out,
-                                      float *grad_weight, int Cin, int Cout, void *workspace, int64_t workspace_bytes, fnp_stream_t stream) {
+                                      float *grad_weight, int grad_layout, int Cin, int Cout, void *workspace, int64_t workspace_bytes,
+                                      fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!feat_in || !grad_out || !pair_o || !pair_i || !pair_count || !n_out || !grad_weight || !workspace || K <= 0 || Cin <= 0 || Cout <= 0 ||
-        cap_out <= 0 || pair_stride < cap_out)
+        cap_out <= 0 || pair_stride < cap_out || (grad_layout != 0 && grad_layout != 1))
         return FNP_ERR_ARG;
     if (in_dtype == FNP_BF16 && grad_dtype == FNP_BF16)
         return run_wgrad<__bf16, __bf16>(feat_in, grad_out, pair_o, pair_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
-                                         workspace_bytes, s, pair_i, pair_count);
+                                         workspace_bytes, s, grad_layout, pair_i, pair_count);
     if (in_dtype == FNP_F16 && grad_dtype == FNP_F16)
         return run_wgrad<_Float16, _Float16>(feat_in, grad_out, pair_o, pair_stride, K, n_out, cap_out, grad_weight, Cin, Cout,
-                                             workspace, workspace_bytes, s, pair_i, pair_count);
+                                             workspace, workspace_bytes, s, grad_layout, pair_i, pair_count);
     return FNP_ERR_ARG;
 }

@@ -147,12 +147,13 @@ SIGNATURES = {
                               P, P, P, P, P, P, P, P, P, P, P]),
     "fnp_rulebook_transpose": (c_int, [P, c_int, c_int, P, c_int, P, c_int, P]),
     "fnp_spconv_wgrad_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
-    "fnp_spconv_wgrad": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, c_int, P, c_int, c_int, P, c_int64, P]),
+    "fnp_spconv_wgrad": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, c_int, P, c_int, c_int, c_int, P, c_int64, P]),
+    "fnp_pack_weight": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, P]),
     "fnp_rulebook_pairs_workspace_bytes": (c_int64, [c_int, c_int]),
     "fnp_rulebook_pairs": (c_int, [P, c_int, c_int, P, c_int, P, P, c_int, P, P, c_int64, P]),
-    "fnp_spconv_wgrad_pairs": (c_int, [P, c_int, P, c_int, P, P, P, c_int, c_int, P, c_int, P, c_int, c_int, P, c_int64, P]),
+    "fnp_spconv_wgrad_pairs": (c_int, [P, c_int, P, c_int, P, P, P, c_int, c_int, P, c_int, P, c_int, c_int, c_int, P, c_int64, P]),
     "fnp_bn_workspace_bytes": (c_int64, [c_int]),
-    "fnp_bn_train_forward": (c_int, [P, c_int, P, c_int, c_int, P, P, P, P, c_float, c_float, P, c_int, P, P, P, P, c_int64, P]),
+    "fnp_bn_train_forward": (c_int, [P, c_int, P, c_int, c_int, P, P, P, P, c_float, c_float, P, c_int, P, P, P, P, P, c_int64, P]),
     "fnp_bn_train_backward": (c_int, [P, P, P, c_int, P, c_int, c_int, P, P, P, c_int, P, P, P, P, P, c_int64, P]),
     "fnp_clipcrop_plan": (c_int, [P, c_int, P, P, P, P, c_int, c_int, c_int, P, P, P]),
     "fnp_clipcrop_sample": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, P, c_int, P, P]),

@@ -297,6 +297,26 @@ def pack_weight(weight, dtype, mfma_f32=False):
     return w
 
 
+def pack_weight_train(weight, dtype, mirror=0):
+    """pack_weight for the training path in ONE launch (fnp_pack_weight): returns (packed (K, Cout, Cin), mirror slabs or None).
+    mirror 1: (K, Cout, Cin) with the offsets mirrored — what conv_dgrad of a SubM layer reads on the forward's table;
+    mirror 2: mirrored and transposed (K, Cin, Cout) — the tiled forward kernel run on the gradient.  f32 parameters only
+    (else the torch ops)."""
+    Cout, Cin = weight.shape[0], weight.shape[-1]
+    K = weight.shape[1] * weight.shape[2] * weight.shape[3]
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous() or not w.is_cuda:
+        p = pack_weight(weight, dtype)
+        m = None if mirror == 0 else p.flip(0) if mirror == 1 else p.flip(0).transpose(1, 2).contiguous()
+        return p, m
+    L = _l.load()
+    p = torch.empty((K, Cout, Cin), dtype=dtype, device=w.device)
+    m = None if mirror == 0 else torch.empty((K, Cout, Cin) if mirror == 1 else (K, Cin, Cout), dtype=dtype, device=w.device)
+    rc = L.fnp_pack_weight(_l.ptr(w), Cout, K, Cin, _l.dtype_code(p), _l.ptr(p), _l.ptr(m), mirror, _l.stream())
+    _l.check(rc, "fnp_pack_weight")
+    return p, m
+
+
 HINT_ROWS_RANKED = 1   # fnp.h FNP_HINT_ROWS_RANKED
 HINT_VALU = 2          # fnp.h FNP_HINT_VALU
 HINT_W_PERMUTED = 4    # fnp.h FNP_HINT_W_PERMUTED
@@ -599,14 +619,17 @@ def rulebook_pairs(rb, n_out_dev, rows=None):
     return rb._pairs
 
 
-def conv_wgrad(feat_in, grad_out, rb, n_out_dev, Cin, Cout, pairs=None):
+def conv_wgrad(feat_in, grad_out, rb, n_out_dev, Cin, Cout, pairs=None, module_shape=None):
     """dW (K, Cout, Cin) f32 = sum_o dy[o] (x) x[nbr[k][o]] (deterministic two-stage reduction).
     pairs: None = on the rulebook's pair lists where they apply (16-bit tensors, MFMA channel pairs; built on first use and
-    kept with the rulebook), False = the sweep over the table."""
+    kept with the rulebook), False = the sweep over the table.
+    module_shape: (Cout, kD, kH, kW, Cin) — the result in the module parameter's layout instead (same values; the final
+    reduction writes it: no permute-copy)."""
     L = _l.load()
     assert feat_in.is_contiguous() and grad_out.is_contiguous()
     assert feat_in.shape[1] == Cin and grad_out.shape[1] == Cout
-    dw = torch.empty((rb.K, Cout, Cin), dtype=torch.float32, device=feat_in.device)
+    layout = 0 if module_shape is None else 1
+    dw = torch.empty((rb.K, Cout, Cin) if module_shape is None else tuple(module_shape), dtype=torch.float32, device=feat_in.device)
     ws = torch.empty((int(L.fnp_spconv_wgrad_workspace_bytes(rb.K, Cin, Cout)),), dtype=torch.uint8, device=feat_in.device)
     cap = min(rb.cap_out, grad_out.shape[0])
     use_pairs = WGRAD_PAIRS if pairs is None else pairs
@@ -614,12 +637,12 @@ def conv_wgrad(feat_in, grad_out, rb, n_out_dev, Cin, Cout, pairs=None):
             and not getattr(rb, "_lean", False)):
         pr = getattr(rb, "_pairs", None) or rulebook_pairs(rb, n_out_dev, rows=cap)
         rc = L.fnp_spconv_wgrad_pairs(_l.ptr(feat_in), _l.dtype_code(feat_in), _l.ptr(grad_out), _l.dtype_code(grad_out), _l.ptr(pr[0]), _l.ptr(pr[1]),
-                                      _l.ptr(pr[2]), pr[0].shape[1], rb.K, _l.ptr(n_out_dev), min(cap, pr[0].shape[1]), _l.ptr(dw), Cin, Cout, _l.ptr(ws), ws.numel(),
+                                      _l.ptr(pr[2]), pr[0].shape[1], rb.K, _l.ptr(n_out_dev), min(cap, pr[0].shape[1]), _l.ptr(dw), layout, Cin, Cout, _l.ptr(ws), ws.numel(),
                                       _l.stream())
         _l.check(rc, "fnp_spconv_wgrad_pairs")
         return dw
     rc = L.fnp_spconv_wgrad(_l.ptr(feat_in), _l.dtype_code(feat_in), _l.ptr(grad_out), _l.dtype_code(grad_out),
-                            _l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, _l.ptr(n_out_dev), cap, _l.ptr(dw), Cin, Cout,
+                            _l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, _l.ptr(n_out_dev), cap, _l.ptr(dw), layout, Cin, Cout,
                             _l.ptr(ws), ws.numel(), _l.stream())
     _l.check(rc, "fnp_spconv_wgrad")
     return dw

@@ -31,12 +31,20 @@ class SparseConvFunction(torch.autograd.Function):
         # rows: the output row count when the caller knows it on the host — the output then has exactly that many rows and
         # nobody slices it afterwards (the backward of a slice zero-fills a tensor of the full capacity: 4 x 0.1 ms per
         # training step at 16 scenes)
-        w = S.pack_weight(weight, feats.dtype)
+        # the slabs the backward's data gradient reads are written by the same launch as the forward's (one kernel instead of a
+        # permute-copy and a cast here, a flip and a transpose-copy there: the training step is bound by the host's launches)
+        Cout, Cin = weight.shape[0], weight.shape[-1]
+        odd = all(int(v) & 1 for v in rb.geom.ksize)
+        subm_self = rb.out_indices is None and rb.cap_out == feats.shape[0] and odd
+        mirror = 0
+        if ctx.needs_input_grad[0] and subm_self:
+            mirror = 2 if (ranked and Cin == Cout and S.tiled_by_default(Cin, feats.dtype, rb.cap_out)) else 1
+        w, wm = S.pack_weight_train(weight, feats.dtype, mirror)
         out = S.conv_forward(feats, w, rb, n_out_dev, ranked=ranked,
                              out=None if rows is None else torch.empty((rows, weight.shape[0]), dtype=feats.dtype, device=feats.device))
         ctx.save_for_backward(feats, weight)
         ctx.rb, ctx.n_out_dev, ctx.n_in_dev, ctx.ranked = rb, n_out_dev, n_in_dev, ranked
-        ctx.w_packed = w   # (the data gradient runs on the same packed slabs: no second permute + cast per layer and step)
+        ctx.w_packed, ctx.w_mirror, ctx.mirror = w, wm, mirror
         return out
 
     @staticmethod
@@ -55,16 +63,16 @@ class SparseConvFunction(torch.autograd.Function):
                 # That identity needs a centred kernel (every size odd); an even size takes the transposed table below.
                 if ctx.ranked and Cin == Cout and S.tiled_by_default(Cin, feats.dtype, rb.cap_out):
                     # ... and on the tile rulebook where the forward ran on it: the forward kernel on (K, Cin, Cout) slabs
-                    dx = S.conv_forward(grad_out, wp.flip(0).transpose(1, 2).contiguous(), rb, n_in_dev, ranked=True)
+                    wt = ctx.w_mirror if ctx.mirror == 2 else wp.flip(0).transpose(1, 2).contiguous()
+                    dx = S.conv_forward(grad_out, wt, rb, n_in_dev, ranked=True)
                 else:
-                    dx = S.conv_dgrad(grad_out, wp.flip(0), rb.nbr, n_in_dev, feats.shape[0])
+                    dx = S.conv_dgrad(grad_out, ctx.w_mirror if ctx.mirror == 1 else wp.flip(0), rb.nbr, n_in_dev, feats.shape[0])
             else:
                 if getattr(rb, "_nbr_t", None) is None or rb._nbr_t.shape[1] != feats.shape[0]:
                     rb._nbr_t = S.rulebook_transpose(rb, n_out_dev, feats.shape[0])   # (kept with the rulebook: one per layer)
                 dx = S.conv_dgrad(grad_out, wp, rb._nbr_t, n_in_dev, feats.shape[0])
         if ctx.needs_input_grad[1]:
-            dwp = S.conv_wgrad(feats, grad_out, rb, n_out_dev, Cin, Cout)               # (K, Cout, Cin) f32
-            dw = dwp.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
+            dw = S.conv_wgrad(feats, grad_out, rb, n_out_dev, Cin, Cout, module_shape=weight.shape).to(weight.dtype)   # (f32: no copy)
         return dx, dw, None, None, None, None, None
 
 
@@ -153,17 +161,23 @@ class SparseConvolution(SparseModule):
             out = SparseConvTensor(out_feats, input.indices, input.spatial_shape, input.batch_size, input.grid,
                                    input.voxel_num, input.indice_dict, input.benchmark, n_dev, input._rank_grid)
             return out
-        # strided: the output site count is data dependent -> one host sync, like spconv itself
+        # strided: the output site count is data dependent -> one host sync, like spconv itself — unless the rulebook was
+        # asked for ahead (prefetch(): its count came back on a side stream while the layers before this one were enqueued)
         n_in = feats.shape[0]
-        kvol = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
-        out_shape = [(input.spatial_shape[d] + 2 * self.padding[d] - self.kernel_size[d]) // self.stride[d] + 1
-                     for d in range(3)]
-        cells = input.batch_size * out_shape[0] * out_shape[1] * out_shape[2]
-        cap_out = max(1, min(n_in * kvol, cells))
-        rb = S.rulebook_strided(input.indices, n_dev, input.rank_grid(), self.kernel_size, self.stride, self.padding,
-                                cap_out)
-        n_out = int(rb.out_n.item())
+        pf = input.indice_dict.pop(("prefetch", id(self)), None)
+        if pf is not None and pf[3] == input.indices.data_ptr() and pf[4] == n_in:
+            rb, cap_out = pf[0], pf[0].cap_out
+            pf[1].synchronize()
+            n_out = int(pf[2][0])
+        else:
+            rb, cap_out = self._strided_rulebook(input.indices, n_dev, input.rank_grid(), input.spatial_shape, input.batch_size, n_in)
+            n_out = int(rb.out_n.item())
         assert n_out <= cap_out
+        nxt = getattr(self, "_fnp_next", None)
+        if nxt is not None and n_out > 0 and with_grad:
+            # the NEXT strided layer's rulebook needs this layer's output coordinates only: enqueue it before this layer's own
+            # convolution, so that its count is on the host long before that layer's forward asks for it
+            nxt.prefetch(rb.out_indices[:n_out], rb.out_n, rb.out_grid, rb.out_shape, input.batch_size, input.indice_dict)
         out_feats = run(rb, rb.out_n, rows=max(n_out, 1))
         if n_out == 0:
             out_feats = out_feats[:0]
@@ -173,6 +187,48 @@ class SparseConvolution(SparseModule):
             input.indice_dict[self.indice_key] = rb
         return SparseConvTensor(out_feats, rb.out_indices[:n_out], rb.out_shape, input.batch_size, input.grid,
                                 input.voxel_num, input.indice_dict, input.benchmark, rb.out_n, rb.out_grid)
+
+
+    def _strided_rulebook(self, indices, n_dev, rank_grid, spatial_shape, batch_size, n_in):
+        kvol = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+        out_shape = [(spatial_shape[d] + 2 * self.padding[d] - self.kernel_size[d]) // self.stride[d] + 1 for d in range(3)]
+        cells = batch_size * out_shape[0] * out_shape[1] * out_shape[2]
+        cap_out = max(1, min(n_in * kvol, cells))
+        return S.rulebook_strided(indices, n_dev, rank_grid, self.kernel_size, self.stride, self.padding, cap_out), cap_out
+
+    def prefetch(self, indices, n_dev, rank_grid, spatial_shape, batch_size, indice_dict):
+        """Build this strided layer's rulebook NOW for the input whose coordinates are `indices` (it depends on nothing else) and
+        bring its output count to the host on a side stream; forward() of that input then finds it in `indice_dict` and does
+        not drain the main stream for the count.  (The training step is bound by the host: each drained sync left the GPU
+        idle for ~0.17 ms while the next layers were being enqueued.)"""
+        if self.subm or not indices.is_cuda or not PREFETCH:
+            return
+        dev = indices.device
+        rb, _ = self._strided_rulebook(indices, n_dev, rank_grid, spatial_shape, batch_size, indices.shape[0])
+        side = _side_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        side.wait_event(ready)
+        host = getattr(self, "_pf_host", None)
+        if host is None:
+            host = self._pf_host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+        done = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            host.copy_(rb.out_n, non_blocking=True)
+            done.record(side)
+        rb.out_n.record_stream(side)
+        indice_dict[("prefetch", id(self))] = (rb, done, host, indices.data_ptr(), indices.shape[0])
+
+
+PREFETCH = True   # (tests switch it off to compare with the synchronous path)
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device)
+    return _SIDE[key]
 
 
 class SubMConv3d(SparseConvolution):

@@ -13,7 +13,7 @@ from .. import lib as _l
 
 class _BNActFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, n_dev, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, n_dev, momentum, eps, relu, batches_tracked=None):
         L = _l.load()
         _l.require_device(x, n_dev)
         assert x.is_contiguous() and x.dim() == 2
@@ -27,8 +27,11 @@ class _BNActFunction(torch.autograd.Function):
             assert residual.shape == x.shape and residual.dtype == x.dtype and residual.is_contiguous()
         rc = L.fnp_bn_train_forward(_l.ptr(x), _l.dtype_code(x), _l.ptr(n_dev), max(cap, 1), C, _l.ptr(g32), _l.ptr(b32),
                                     _l.ptr(running_mean), _l.ptr(running_var), float(momentum), float(eps), _l.ptr(residual),
-                                    int(bool(relu)), _l.ptr(y), _l.ptr(mean), _l.ptr(invstd), _l.ptr(ws), ws.numel(), _l.stream())
+                                    int(bool(relu)), _l.ptr(y), _l.ptr(mean), _l.ptr(invstd), _l.ptr(batches_tracked), _l.ptr(ws), ws.numel(),
+                                    _l.stream())
         _l.check(rc, "fnp_bn_train_forward")
+        if batches_tracked is not None:
+            torch.autograd.graph.increment_version(batches_tracked)
         # the kernel wrote the running statistics through raw pointers: tell torch (FusedResBackbone.prepare() keys its
         # folded BatchNorm constants on the buffers' versions)
         torch.autograd.graph.increment_version(running_mean)
@@ -52,7 +55,7 @@ class _BNActFunction(torch.autograd.Function):
                                      _l.ptr(g32), _l.ptr(mean), _l.ptr(invstd), int(ctx.relu), _l.ptr(dx), _l.ptr(dres),
                                      _l.ptr(dgamma), _l.ptr(dbeta), _l.ptr(ws), ws.numel(), _l.stream())
         _l.check(rc, "fnp_bn_train_backward")
-        return dx, dgamma.to(ctx.param_dtype), dbeta.to(ctx.param_dtype), dres, None, None, None, None, None, None
+        return dx, dgamma.to(ctx.param_dtype), dbeta.to(ctx.param_dtype), dres, None, None, None, None, None, None, None
 
 
 ENABLED = True     # (tests switch it off to compare with the unfused torch modules)
@@ -68,7 +71,10 @@ def bn_act(x, n_dev, bn, residual=None, relu=True):
     """y = relu(bn(x) [+ residual]) over the first n_dev rows of x (cap, C) in x's dtype; bn: nn.BatchNorm1d in training
     mode (its running statistics and num_batches_tracked advance exactly like torch's forward)."""
     assert fusable(bn)
-    with torch.no_grad():
-        bn.num_batches_tracked += 1
+    nbt = bn.num_batches_tracked
+    if not (nbt.is_cuda and nbt.dtype == torch.int64):
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+        nbt = None
     return _BNActFunction.apply(x.contiguous(), bn.weight, bn.bias, None if residual is None else residual.contiguous(),
-                                bn.running_mean, bn.running_var, n_dev, bn.momentum, bn.eps, relu)
+                                bn.running_mean, bn.running_var, n_dev, bn.momentum, bn.eps, relu, nbt)

@@ -424,8 +424,15 @@ int fnp_rulebook_transpose(const int *nbr, int nbr_stride, int K, const int *n_o
 int64_t fnp_spconv_wgrad_workspace_bytes(int K, int Cin, int Cout);
 int fnp_spconv_wgrad(const void *feat_in, int in_dtype, const void *grad_out, int grad_dtype,
                      const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out,
-                     float *grad_weight, int Cin, int Cout,
+                     float *grad_weight, int grad_layout, int Cin, int Cout,
                      void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
+/* grad_layout (ABI 9): 0 = grad_weight is the packed (K, Cout, Cin), 1 = the module parameter's (Cout, K, Cin) (the final
+ * reduction writes the .grad tensor itself: no permute-copy per layer afterwards).
+ * fnp_pack_weight: the module's f32 weight (Cout, K, Cin) -> the packed (K, Cout, Cin) slabs in `dtype`, and in the same launch
+ * the slabs the data gradient of a SubM layer reads: mirror_mode 1 = (K-1-k, Cout, Cin) for fnp_spconv_dgrad on the forward's
+ * table, 2 = (K-1-k, Cin, Cout) for the tiled forward kernel run on the gradient; 0 = none (mirror NULL). */
+int fnp_pack_weight(const float *weight, int Cout, int K, int Cin, int dtype, void *packed, void *mirror, int mirror_mode,
+                    fnp_stream_t stream);
 /* PAIR LISTS of a rulebook (ABI 8), for the weight gradient: offset k only sums over the output rows that HAVE a neighbour
  * at k (44-54 % of the rows on lidar scenes); fnp_rulebook_pairs compacts every column of the table once per rulebook —
  * pair_o[k][j] = the j-th such output row (ascending), pair_i[k][j] = its neighbour, pair_count[k] — and
@@ -437,7 +444,8 @@ int fnp_rulebook_pairs(const int *nbr, int nbr_stride, int K, const int *n_out, 
                        int pair_stride, int *pair_count, void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
 int fnp_spconv_wgrad_pairs(const void *feat_in, int in_dtype, const void *grad_out, int grad_dtype, const int *pair_o,
                            const int *pair_i, const int *pair_count, int pair_stride, int K, const int *n_out, int cap_out,
-                           float *grad_weight, int Cin, int Cout, void *workspace, int64_t workspace_bytes, fnp_stream_t stream);
+                           float *grad_weight, int grad_layout, int Cin, int Cout, void *workspace, int64_t workspace_bytes,
+                           fnp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm1d in TRAINING mode on sparse rows, fused with the ReLU / residual add that follow it in post_act_block and
@@ -455,8 +463,9 @@ int fnp_spconv_wgrad_pairs(const void *feat_in, int in_dtype, const void *grad_o
 int64_t fnp_bn_workspace_bytes(int C);
 int fnp_bn_train_forward(const void *x, int dtype, const int *n_rows, int cap, int C, const float *gamma, const float *beta,
                          float *running_mean, float *running_var, float momentum, float eps, const void *residual, int relu,
-                         void *y, float *save_mean, float *save_invstd, void *workspace, int64_t workspace_bytes,
-                         fnp_stream_t stream);
+                         void *y, float *save_mean, float *save_invstd, long long *num_batches_tracked, void *workspace,
+                         int64_t workspace_bytes, fnp_stream_t stream);
+/* num_batches_tracked (ABI 9, nullable): nn.BatchNorm1d's int64 counter, advanced by one on the device with the statistics. */
 int fnp_bn_train_backward(const void *grad_out, const void *x, const void *y, int dtype, const int *n_rows, int cap, int C,
                           const float *gamma, const float *save_mean, const float *save_invstd, int relu, void *grad_x,
                           void *grad_residual, float *grad_gamma, float *grad_beta, void *workspace, int64_t workspace_bytes,

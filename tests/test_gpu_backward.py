@@ -352,3 +352,80 @@ def test_amp_training_step_as_the_reference_runs_it(cuda, rng):
             moved += 1
             assert float((d16 - d32).abs().max()) <= 3e-1 * float(d32.abs().max()) + 1e-9, k   # (the bound of the gradients above)
     assert moved > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Cout,K3,Cin", [(16, (3, 3, 3), 5), (32, (3, 3, 3), 16), (128, (3, 1, 1), 128), (64, (3, 3, 3), 64)])
+def test_pack_weight_kernel_equals_the_torch_ops(cuda, rng, dtype, Cout, K3, Cin):
+    """fnp_pack_weight: the packed slabs and both mirror forms of the training path, in one launch, against pack_weight + flip
+    (+ transpose): the same bits."""
+    from findnpropagate_amd import sparse as S
+    w = torch.from_numpy(rng.standard_normal((Cout, *K3, Cin)).astype(np.float32)).to(cuda)
+    ref = S.pack_weight(w, dtype)
+    for mirror, want in ((0, None), (1, ref.flip(0)), (2, ref.flip(0).transpose(1, 2).contiguous())):
+        p, m = S.pack_weight_train(w, dtype, mirror)
+        assert torch.equal(p, ref) and p.is_contiguous()
+        assert (m is None) if want is None else torch.equal(m, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,dtype", [(5, torch.float32), (16, torch.bfloat16), (64, torch.bfloat16), (128, torch.float16)])
+def test_wgrad_in_the_module_layout(cuda, rng, C, dtype):
+    """conv_wgrad(module_shape=...): the final reduction writes the parameter's (Cout, kD, kH, kW, Cin) layout — the packed
+    (K, Cout, Cin) result permuted, value for value."""
+    from findnpropagate_amd import sparse as S
+    Cout = 16 if C == 5 else C
+    B, shape = 2, [9, 40, 44]
+    idx = np.unique(np.stack([rng.integers(0, B, 4000), rng.integers(0, shape[0], 4000), rng.integers(0, shape[1], 4000),
+                              rng.integers(0, shape[2], 4000)], 1).astype(np.int32), axis=0)
+    n = idx.shape[0]
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    rb = S.rulebook_subm(d_idx, n_dev, S.build_grid(d_idx, n_dev, B, shape), 3)
+    x = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32)).to(cuda).to(dtype)
+    dy = torch.from_numpy(rng.standard_normal((n, Cout)).astype(np.float32)).to(cuda).to(dtype)
+    packed = S.conv_wgrad(x, dy, rb, n_dev, C, Cout)
+    module = S.conv_wgrad(x, dy, rb, n_dev, C, Cout, module_shape=(Cout, 3, 3, 3, C))
+    assert module.shape == (Cout, 3, 3, 3, C)
+    assert torch.equal(module, packed.permute(1, 0, 2).reshape(Cout, 3, 3, 3, C))
+
+
+@pytest.mark.gpu
+def test_prefetched_strided_rulebooks_change_nothing(cuda, rng):
+    """Training forward + backward with the strided layers' rulebooks asked for ahead (counts back on a side stream,
+    spconv/conv.py prefetch) against the synchronous path: same outputs, same gradients, same BatchNorm buffers, and the
+    module's parameter names are still the reference's."""
+    import copy
+    from findnpropagate_amd import synthetic as syn
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    from findnpropagate_amd.spconv import conv as C
+    grid = np.array([96, 88, 40])
+    net_a = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False, "FNP_DTYPE": "bf16"}, 5, grid), 0).to(cuda).train()
+    net_b = copy.deepcopy(net_a)
+    names = [k for k, _ in net_a.named_parameters()]
+    feats, idx = _random_sparse(rng, 2, net_a.sparse_shape, 5000, 5)
+    bd = lambda: {"voxel_features": torch.from_numpy(feats).to(cuda), "voxel_coords": torch.from_numpy(idx).to(cuda).float(), "batch_size": 2}
+    loss_of = lambda out: sum((t.features.float() ** 2).mean() for t in list(out["multi_scale_3d_features"].values()) + [out["encoded_spconv_tensor"]])
+    outs = []
+    for net, pf in ((net_a, True), (net_b, False)):
+        C.PREFETCH = pf
+        try:
+            for _ in range(2):
+                net.zero_grad()
+                out = net(bd())
+                loss_of(out).backward()
+        finally:
+            C.PREFETCH = True
+        outs.append(out)
+    assert [k for k, _ in net_a.named_parameters()] == names and not any("_fnp" in k for k in net_a.state_dict())
+    for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+        a, b = outs[0]["multi_scale_3d_features"][k], outs[1]["multi_scale_3d_features"][k]
+        assert torch.equal(a.indices, b.indices) and torch.equal(a.features, b.features), k
+    assert torch.equal(outs[0]["encoded_spconv_tensor"].features, outs[1]["encoded_spconv_tensor"].features)
+    for (k, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        assert torch.equal(pa.grad, pb.grad), k
+    for (k, ba), (_, bb) in zip(net_a.named_buffers(), net_b.named_buffers()):
+        assert torch.equal(ba, bb), k
+        if k.endswith("num_batches_tracked"):
+            assert int(ba) == 2, k

@@ -1,13 +1,13 @@
-#!/usr/bin/env python3
-"""Development: where the host time of the module-path training step goes (cProfile over 10 steps, top cumulative)."""
-import cProfile, pstats, io, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+"""Development (GPU box): where the HOST time of a training step goes (cProfile over 5 steps of tools/bench_train.py's step)."""
+import os, sys, cProfile, pstats, io
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import numpy as np, torch
 from findnpropagate_amd import sparse as S, synthetic as syn
 from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
 dev = torch.device("cuda", 0); B = 16
 grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
-net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False, "FNP_DTYPE": "bf16"}, 5, grid), 0).to(dev).train()
+net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False, "FNP_DTYPE": "bf16"}, 5, grid), 0).to(dev)
 pts, off = syn.make_batch(list(range(B)))
 cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
 vox = S.voxelize(torch.from_numpy(pts).to(dev), torch.from_numpy(off).to(dev), B, cfg)
@@ -19,13 +19,15 @@ def step():
     out = net(bd())
     loss = sum((t.features.float() ** 2).mean() for t in list(out["multi_scale_3d_features"].values()) + [out["encoded_spconv_tensor"]])
     loss.backward(); opt.step()
+net.train()
 for _ in range(3): step()
 torch.cuda.synchronize()
 import time
 t0 = time.perf_counter()
-for _ in range(10): step()
-torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t0) * 100)
+for _ in range(5): step()
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print("host enqueue ms/step %.2f, with drain %.2f" % ((t1 - t0) / 5 * 1e3, (t2 - t0) / 5 * 1e3))
 pr = cProfile.Profile(); pr.enable()
-for _ in range(10): step()
-torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
+for _ in range(5): step()
+pr.disable(); torch.cuda.synchronize()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45); print(s.getvalue()[:9000])
