@@ -447,12 +447,15 @@ def main():
         out["batch_sweep"] = sweep
         # The same 64-scene step with several BATCHES in flight (PointsPipeline: a hipGraph, an engine and a HIP stream per slot;
         # results identical per batch): what a server that is handed batches back to back gets out of the card — the latency-bound
-        # index kernels of one batch run under the convolutions of another.  Reported beside `value`, which stays one batch at a time.
+        # index kernels of one batch run under the convolutions of another.  Reported beside `value`, which stays one batch at a time,
+        # stream-launched (so that the dominant kernel can be bracketed with events inside the timed region).  With ONE batch in
+        # flight this is the hipGraph replay of the same step: the engine captures its index chain (rank grids, rulebooks, class
+        # sort: coordinates only) on a second branch that runs beside the convolutions of the stage before.
         try:
             pl = {}
             with torch.no_grad():
                 cap = (pts.shape[0] + 65535) // 65536 * 65536
-                for depth in (2, 3):
+                for depth in (1, 2, 3):   # (1: the plain hipGraph replay of the step — its index chain runs on a second branch)
                     pipe = net.points_pipeline(B, cfg, depth=depth, capacity=cap)
                     frames = [(pts, off)] * 20
                     for r_p in pipe.map(frames[:2 * depth]):
@@ -463,7 +466,7 @@ def main():
                         pass
                     torch.cuda.synchronize()
                     dt = (time.perf_counter() - t0) / len(frames)
-                    pl[f"{depth}_batches_in_flight"] = {"scenes_per_s": B / dt, "ms_per_step": 1e3 * dt,
+                    pl[f"{depth}_batch{'es' if depth > 1 else ''}_in_flight"] = {"scenes_per_s": B / dt, "ms_per_step": 1e3 * dt,
                                                         "site_counts_equal_value_run": [int(c) for c in r_p["counts"]] == [int(c) for c in counts]}
                     del pipe
             out["pipelined"] = pl

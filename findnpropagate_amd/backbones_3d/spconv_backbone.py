@@ -15,6 +15,7 @@ Mirrors pcdet/models/backbones_3d/spconv_backbone.py: same constructor signature
 """
 from functools import partial
 
+import os
 import torch
 import torch.nn as nn
 
@@ -305,6 +306,13 @@ class VoxelResBackBone8x(_BackboneBase):
         return PointsPipeline(self, batch_size, voxel_cfg, depth=depth, capacity=capacity, n_feat=n_feat)
 
 
+# the fused engine's index chain on a side stream (FusedResBackbone._run_once): None = while a hipGraph is being captured (the
+# replayed graph runs the two branches side by side: +4 to +10 % from 1 to 64 scenes), not for stream launches (measured
+# neutral at 1-32 scenes and -3 % at 64: every cross-stream event wait of a plain stream costs the convolutions their
+# L2-resident rows); FNP_TWO_STREAMS=1 / 0 forces / forbids it everywhere
+TWO_STREAMS = {"0": False, "1": True}.get(os.environ.get("FNP_TWO_STREAMS", ""))
+
+
 class _PointsGraph:
     """Static inputs + captured forward of one (batch_size, point capacity) configuration."""
     FAR = 1.0e9   # padding points: outside every range, dropped by the voxeliser
@@ -362,6 +370,11 @@ class PointsPipeline:
         self.capacity, self.n_feat = int(capacity), int(n_feat)
         self.device = device if device is not None else next(module.parameters()).device
         self.engines = [FusedResBackbone(module) for _ in range(self.depth)]
+        for e in self.engines:
+            # two frames in flight already put one frame's index kernels under another's convolutions; a second branch per
+            # graph on top of that oversubscribes the hardware queues
+            e.two_streams = self.depth == 1 or os.environ.get("FNP_PIPE_TWO", "0") == "1"
+
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.depth)]
         self.slots = [None] * self.depth      # _PointsGraph per slot, captured on first use
         self.pending = []                     # (slot, event, host counts, inputs) in submission order
@@ -461,6 +474,8 @@ class FusedResBackbone:
         self._vox_ws = None
         self._graphs = {}
         self._ell_ctr = {}
+        self._side = {}
+        self.two_streams = True   # (PointsPipeline clears it for its slots when several frames are in flight: they already overlap)
         self._dirty = False      # a forward is in flight or died before its sparse clear: grids may hold stale bits
         # measurement hooks (bench.py): when `profile` is a list every conv launch is bracketed by
         # stream events, (tag, start, end) appended; `rulebook_log` receives (tag, Rulebook, n_dev)
@@ -573,6 +588,14 @@ class FusedResBackbone:
             for c in self._ell_ctr.values():
                 c.zero_()
             self._dirty = False
+
+    def _side_stream(self, device):
+        """the engine's own stream for its index chain (_run_once)"""
+        key = str(device)
+        st = self._side.get(key)
+        if st is None:
+            st = self._side[key] = torch.cuda.Stream(device)
+        return st
 
     def _ell_counter(self, which, device):
         """the engine's pool counter of compact rulebook `which`: zero between forwards (the counts launch resets what it reads)"""
@@ -714,21 +737,52 @@ class FusedResBackbone:
                and (int(P['in'][0].shape[2]), 16) in S.ELL_SHAPES and not isinstance(P['in'][0], S.PermutedWeight))
         ell_used = []
         ell_all = ell and (S.ELL_MODE is True or (S.ELL_MODE is None and S.ELL_MFMA))
-        if ell:
-            rb1 = S.rulebook_subm_ell(indices, n1, grid1, int(cap1 * self.ell_pool[0]) + 64, with_table=not ell_all, used=self._ell_counter(0, dev))
-            ell_used.append((rb1._ell[2], rb1._ell[1], 0))
-        else:
-            # (f32: the 16 -> 16 layers sweep their ranges class by class, like every f32 SubM stage below)
-            srt1 = S.f32_sorted_by_default(16, act, cap1) and self.rulebook_log is None
-            rb1 = S.rulebook_subm(indices, n1, grid1, 3, masks=srt1)
-            if srt1:
-                S.classsort_f32(rb1, n1, 16)
-        x = conv(feats, P['in'], rb1, n1)
-        x1 = blocks(x, rb1, n1, P['blocks1'])
-        stage = [(x1, indices, n1, grid1)]
-        x_prev, idx_prev, n_prev, g_prev = x1, indices, n1, grid1
+
+        # TWO STREAMS (round 3).  Everything that builds indices — rank grids, output coordinates, rulebooks, records, the class
+        # sort — depends on coordinates only, never on features: the whole chain of the five stages is enqueued first, on the
+        # engine's side stream, one event per stage; the convolutions follow on the caller's stream and wait for their stage's
+        # event.  The index kernels (bound by atomics and latency, 1.2 ms of a 5.4 ms step at 64 scenes) then run beside the
+        # convolutions of the stage before them instead of between them.  Same kernels, same values.  Default: inside a hipGraph
+        # capture only (see TWO_STREAMS above); never while a profile or a rulebook log is being taken.
+        two = (self.profile is None and self.rulebook_log is None and feats.is_cuda and self.two_streams
+               and (TWO_STREAMS if TWO_STREAMS is not None else torch.cuda.is_current_stream_capturing()))
+        main = torch.cuda.current_stream(dev) if feats.is_cuda else None
+        side = self._side_stream(dev) if two else None
+        events = []
+
+        class _Index:   # index work goes to the side stream; leaving the block records the stage's event
+            def __enter__(ctx):
+                if two:
+                    ctx.cm = torch.cuda.stream(side)
+                    ctx.cm.__enter__()
+                return ctx
+
+            def __exit__(ctx, *exc):
+                if two:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    events.append(ev)
+                    ctx.cm.__exit__(*exc)
+                return False
+
+        if two:
+            side.wait_stream(main)   # (inputs, and the sparse clear of the previous forward, are the caller's stream's)
+
+        # ---- index chain ------------------------------------------------------------------------------------------------
+        with _Index():
+            if ell:
+                rb1 = S.rulebook_subm_ell(indices, n1, grid1, int(cap1 * self.ell_pool[0]) + 64, with_table=not ell_all, used=self._ell_counter(0, dev))
+                ell_used.append((rb1._ell[2], rb1._ell[1], 0))
+            else:
+                # (f32: the 16 -> 16 layers sweep their ranges class by class, like every f32 SubM stage below)
+                srt1 = S.f32_sorted_by_default(16, act, cap1) and self.rulebook_log is None
+                rb1 = S.rulebook_subm(indices, n1, grid1, 3, masks=srt1)
+                if srt1:
+                    S.classsort_f32(rb1, n1, 16)
         down_convs = (m.conv2[0][0], m.conv3[0][0], m.conv4[0][0], m.conv_out[0])
         premarked = False     # did the previous stage's rulebook kernel mark this strided layer's output sites already?
+        idx_prev, n_prev, g_prev = indices, n1, grid1
+        books = []
         for li, (down_key, blk_key, dconv) in enumerate((('down2', 'blocks2', m.conv2[0][0]),
                                                           ('down3', 'blocks3', m.conv3[0][0]),
                                                           ('down4', 'blocks4', m.conv4[0][0]))):
@@ -738,36 +792,54 @@ class FusedResBackbone:
             fused = (act in (torch.bfloat16, torch.float16) and self.rulebook_log is None and tuple(dconv.kernel_size) == (3, 3, 3)
                      and (int(wd.shape[2]), int(wd.shape[1])) in S.FUSED_STRIDED_SHAPES)
             ell_down = ell_all and li == 0 and tuple(dconv.kernel_size) == (3, 3, 3) and (int(wd.shape[2]), int(wd.shape[1])) in S.ELL_SHAPES
-            rbs = S.rulebook_strided(idx_prev, n_prev, g_prev, dconv.kernel_size, dconv.stride, dconv.padding,
-                                     caps[li + 1], out_grid=grids[li + 1], want_nbr=not (fused or ell_down), premarked=premarked)
-            if ell_down:
-                S.ell_for_strided(rbs, int(caps[li + 1] * self.ell_pool[1]) + 64, used=self._ell_counter(1, dev))
-                ell_used.append((rbs._ell[2], rbs._ell[1], 1))
+            with _Index():
+                rbs = S.rulebook_strided(idx_prev, n_prev, g_prev, dconv.kernel_size, dconv.stride, dconv.padding,
+                                         caps[li + 1], out_grid=grids[li + 1], want_nbr=not (fused or ell_down), premarked=premarked)
+                if ell_down:
+                    S.ell_for_strided(rbs, int(caps[li + 1] * self.ell_pool[1]) + 64, used=self._ell_counter(1, dev))
+                    ell_used.append((rbs._ell[2], rbs._ell[1], 1))
+                # stages 2-4: rows are in rank-grid order on both sides of the SubM convolutions; where they run on the tile
+                # rulebook (stage 2, 32 channels), the rulebook kernel writes it in the same pass
+                ch = int(P[blk_key][0][0][0].shape[1])
+                srt = S.sorted_by_default(ch, ch, act, caps[li + 1])
+                tiled = S.tiled_by_default(ch, act, caps[li + 1]) and S.tiled_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
+                # the SubM rulebook kernel of this stage also marks the output sites of the NEXT strided layer (the coordinates are
+                # in its registers): that layer's own marking launch goes
+                nxt = down_convs[li + 1]
+                lean = tiled and self.rulebook_log is None   # (all four layers of the stage run tiled)
+                mark_next = (grids[li + 2], nxt.kernel_size, nxt.stride, nxt.padding) if (lean or srt) and S.MARK_FUSED else None
+                srt32 = S.f32_sorted_by_default(ch, act, caps[li + 1]) and self.rulebook_log is None
+                rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3, tile_channels=ch if tiled else None, masks=srt or srt32,
+                                     lean_table=lean, mark_next=mark_next)
+                premarked = bool(getattr(rb, "_marked_next", False))
+                if srt:
+                    S.classsort(rb, rbs.out_n, ch)   # stage 4: the 128-channel layers sweep their rows class by class
+                if srt32:
+                    S.classsort_f32(rb, rbs.out_n, ch)   # f32 engine: every stage's ranges in class order
+            books.append((down_key, blk_key, rbs, rb))
+            idx_prev, n_prev, g_prev = rbs.out_indices, rbs.out_n, rbs.out_grid
+        oconv = m.conv_out[0]
+        with _Index():
+            rbo = S.rulebook_strided(idx_prev, n_prev, g_prev, oconv.kernel_size, oconv.stride, oconv.padding, caps[4],
+                                     out_grid=grids[4], premarked=premarked)
+
+        # ---- convolutions -----------------------------------------------------------------------------------------------
+        def ready(i):
+            if two:
+                main.wait_event(events[i])
+
+        ready(0)
+        x = conv(feats, P['in'], rb1, n1)
+        x1 = blocks(x, rb1, n1, P['blocks1'])
+        stage = [(x1, indices, n1, grid1)]
+        x_prev = x1
+        for li, (down_key, blk_key, rbs, rb) in enumerate(books):
+            ready(li + 1)
             x = conv(x_prev, P[down_key], rbs, rbs.out_n)
-            # stages 2-4: rows are in rank-grid order on both sides of the SubM convolutions; where they run on the tile
-            # rulebook (stage 2, 32 channels), the rulebook kernel writes it in the same pass
-            ch = int(P[blk_key][0][0][0].shape[1])
-            srt = S.sorted_by_default(ch, ch, act, caps[li + 1])
-            tiled = S.tiled_by_default(ch, act, caps[li + 1]) and S.tiled_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
-            # the SubM rulebook kernel of this stage also marks the output sites of the NEXT strided layer (the coordinates are
-            # in its registers): that layer's own marking launch goes
-            nxt = down_convs[li + 1]
-            lean = tiled and self.rulebook_log is None   # (all four layers of the stage run tiled)
-            mark_next = (grids[li + 2], nxt.kernel_size, nxt.stride, nxt.padding) if (lean or srt) and S.MARK_FUSED else None
-            srt32 = S.f32_sorted_by_default(ch, act, caps[li + 1]) and self.rulebook_log is None
-            rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3, tile_channels=ch if tiled else None, masks=srt or srt32,
-                                 lean_table=lean, mark_next=mark_next)
-            premarked = bool(getattr(rb, "_marked_next", False))
-            if srt:
-                S.classsort(rb, rbs.out_n, ch)   # stage 4: the 128-channel layers sweep their rows class by class
-            if srt32:
-                S.classsort_f32(rb, rbs.out_n, ch)   # f32 engine: every stage's ranges in class order
             x = blocks(x, rb, rbs.out_n, P[blk_key], ranked=True)
             stage.append((x, rbs.out_indices, rbs.out_n, rbs.out_grid))
-            x_prev, idx_prev, n_prev, g_prev = x, rbs.out_indices, rbs.out_n, rbs.out_grid
-        oconv = m.conv_out[0]
-        rbo = S.rulebook_strided(idx_prev, n_prev, g_prev, oconv.kernel_size, oconv.stride, oconv.padding, caps[4],
-                                 out_grid=grids[4], premarked=premarked)
+            x_prev = x
+        ready(4)
         xo = conv(x_prev, P['out'], rbo, rbo.out_n, out_dtype=final_dtype or act)
         stage.append((xo, rbo.out_indices, rbo.out_n, rbo.out_grid))
 

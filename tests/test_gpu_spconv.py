@@ -886,3 +886,29 @@ def test_fused_backbone_fp16_and_autocast(cuda, oracle, rng):
             y16 = conv(x).features
     assert y32.dtype == torch.float32 and y16.dtype == torch.float16
     np.testing.assert_allclose(y16.float().cpu().numpy(), y32.cpu().numpy(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_index_chain_on_a_second_stream_changes_nothing(cuda, mode, monkeypatch):
+    """The fused engine with its index chain (rank grids, rulebooks, records, class sort) on a side stream and the convolutions
+    waiting on one event per stage — what a captured hipGraph runs by default — forced for plain stream launches too, against
+    the one-stream engine: the same rows at every stage, bit for bit, twice in a row (the second forward starts from the grids
+    and pool counters the first one left)."""
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    from findnpropagate_amd.backbones_3d import spconv_backbone as BB
+    grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 0).to(cuda).eval()
+    net.fnp_dtype = mode
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+    pts, off = syn.make_batch([0, 1, 2])
+    pts, off = torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda)
+    outs = []
+    with torch.no_grad():
+        for two in (False, True, True):
+            monkeypatch.setattr(BB, "TWO_STREAMS", two)
+            r = net.forward_points(pts, off, 3, cfg)
+            torch.cuda.synchronize()
+            outs.append([(r[k].features.clone(), r[k].indices.clone()) for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out")])
+    for other in outs[1:]:
+        for (fa, ia), (fb, ib) in zip(outs[0], other):
+            assert torch.equal(ia, ib) and torch.equal(fa, fb)
