@@ -32,7 +32,7 @@ def short(k):
     m = re.search(r'spconv_mfma_f32_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E', k)
     if m:
         return "spconv_mfma_f32_kernel<%s,%s,%s>" % (m.group(1), m.group(2), m.group(3))
-    m = re.search(r'spconv_mfma_f32_kernel<(\d+), (\d+), (\d+), (true|false)>', k)
+    m = re.search(r'spconv_mfma_f32_kernel<(\d+), (\d+), (\d+), (true|false)(?:, (?:true|false))?>', k)
     if m:
         return "spconv_mfma_f32_kernel<%s,%s,%s>" % m.groups()[:3]
     m = re.search(r'(spconv_tile\d+_kernel)I(DF16b|DF16_)E', k) or re.search(r'(spconv_tile\d+_kernel)<(__bf16|_Float16)>', k)
@@ -49,7 +49,15 @@ if __name__ == "__main__":
            "batch": int(sys.argv[3]), "kernels": {}}
     for k, v in fetch.items():
         w = write.get(k, [0.0])
-        fk, wk = sum(v) / len(v), sum(w) / len(w)
-        out["kernels"][short(k)] = {"fetch_size_kib_raw": fk, "write_size_kib": wk, "launches": len(v),
-                                    "hbm_bytes_corrected": (2 * fk + wk) * 1024}
+        name = short(k)
+        groups = [(name, v, w)]
+        if name == "spconv_mfma_f32_kernel<128,128,3>" and len(v) % 5 == 0 and len(w) == len(v):
+            # the f32 kernel's name does not carry the kernel volume: a step launches it four times for the 3x3x3 layers of stage 4
+            # and once for conv_out (3x1x1) — dispatch order separates them
+            groups = [(name, [x for i, x in enumerate(v) if i % 5 != 4], [x for i, x in enumerate(w) if i % 5 != 4]),
+                      (name + ",k3", [x for i, x in enumerate(v) if i % 5 == 4], [x for i, x in enumerate(w) if i % 5 == 4])]
+        for nm, vv, ww in groups:
+            fk, wk = sum(vv) / len(vv), sum(ww) / len(ww)
+            out["kernels"][nm] = {"fetch_size_kib_raw": fk, "write_size_kib": wk, "launches": len(vv),
+                                  "hbm_bytes_corrected": (2 * fk + wk) * 1024}
     print(json.dumps(out, indent=1))
