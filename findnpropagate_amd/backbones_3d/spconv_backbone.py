@@ -307,9 +307,9 @@ class VoxelResBackBone8x(_BackboneBase):
 
 
 # the fused engine's index chain on a side stream (FusedResBackbone._run_once): None = while a hipGraph is being captured (the
-# replayed graph runs the two branches side by side: +4 to +10 % from 1 to 64 scenes), not for stream launches (measured
-# neutral at 1-32 scenes and -3 % at 64: every cross-stream event wait of a plain stream costs the convolutions their
-# L2-resident rows); FNP_TWO_STREAMS=1 / 0 forces / forbids it everywhere
+# replayed graph runs the two branches side by side, the ~4.5 us between its nodes overlap: +4 to +10 % from 1 to 64 scenes),
+# not for stream launches (measured neutral within a box's +-1.5 %: back-to-back launches have no such gaps to hide);
+# FNP_TWO_STREAMS=1 / 0 forces / forbids it everywhere
 TWO_STREAMS = {"0": False, "1": True}.get(os.environ.get("FNP_TWO_STREAMS", ""))
 
 
