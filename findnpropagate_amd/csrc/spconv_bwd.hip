@@ -540,7 +540,9 @@ int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int
 
 // The module's weight (Cout, K, Cin) f32 -> the packed slabs (K, Cout, Cin) the convolutions read, in the activation dtype, and
 // (training) the slabs the data gradient reads, in the SAME launch: mirror 1 = offsets mirrored (K - 1 - k, Cout, Cin) for the
-// SubM data gradient on the forward's table, mirror 2 = mirrored and transposed (K - 1 - k, Cin, Cout) for the tiled kernels.
+// SubM data gradient on the forward's table, mirror 2 = mirrored and transposed (K - 1 - k, Cin, Cout): what the forward kernel
+// reads when it runs on the gradient of a SubM layer, mirror 3 = transposed only (k, Cin, Cout): the same for a strided layer
+// on its transposed table.
 // (torch: a permute-copy and a cast per layer and step, plus a flip and a transpose-copy in the backward.)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pack_weight_kernel(const float *__restrict__ w, int Cout, int K, int Cin, T *__restrict__ packed,
@@ -552,11 +554,12 @@ __global__ __launch_bounds__(kThreads) void pack_weight_kernel(const float *__re
         packed[e] = v;
         if (mode == 1) mirror[((long long)(K - 1 - k) * Cout + co) * Cin + ci] = v;
         else if (mode == 2) mirror[((long long)(K - 1 - k) * Cin + ci) * Cout + co] = v;
+        else if (mode == 3) mirror[((long long)k * Cin + ci) * Cout + co] = v;
     }
 }
 extern "C" int fnp_pack_weight(const float *weight, int Cout, int K, int Cin, int dtype, void *packed, void *mirror, int mirror_mode,
                                fnp_stream_t stream) {
-    if (!weight || !packed || Cout <= 0 || K <= 0 || Cin <= 0 || mirror_mode < 0 || mirror_mode > 2 || (mirror_mode != 0) != (mirror != nullptr))
+    if (!weight || !packed || Cout <= 0 || K <= 0 || Cin <= 0 || mirror_mode < 0 || mirror_mode > 3 || (mirror_mode != 0) != (mirror != nullptr))
         return FNP_ERR_ARG;
     const long long total = (long long)Cout * K * Cin;
     const dim3 grid(fnp_grid_for(total, kThreads, 1024));

@@ -300,18 +300,19 @@ def pack_weight(weight, dtype, mfma_f32=False):
 def pack_weight_train(weight, dtype, mirror=0):
     """pack_weight for the training path in ONE launch (fnp_pack_weight): returns (packed (K, Cout, Cin), mirror slabs or None).
     mirror 1: (K, Cout, Cin) with the offsets mirrored — what conv_dgrad of a SubM layer reads on the forward's table;
-    mirror 2: mirrored and transposed (K, Cin, Cout) — the tiled forward kernel run on the gradient.  f32 parameters only
-    (else the torch ops)."""
+    mirror 2: mirrored and transposed (K, Cin, Cout) — the forward kernel run on the gradient of a SubM layer; mirror 3:
+    transposed only — the same for a strided layer on its transposed table.  f32 parameters only (else the torch ops)."""
     Cout, Cin = weight.shape[0], weight.shape[-1]
     K = weight.shape[1] * weight.shape[2] * weight.shape[3]
     w = weight.detach()
     if w.dtype != torch.float32 or not w.is_contiguous() or not w.is_cuda:
         p = pack_weight(weight, dtype)
-        m = None if mirror == 0 else p.flip(0) if mirror == 1 else p.flip(0).transpose(1, 2).contiguous()
+        m = (None if mirror == 0 else p.flip(0) if mirror == 1 else p.flip(0).transpose(1, 2).contiguous() if mirror == 2
+             else p.transpose(1, 2).contiguous())
         return p, m
     L = _l.load()
     p = torch.empty((K, Cout, Cin), dtype=dtype, device=w.device)
-    m = None if mirror == 0 else torch.empty((K, Cout, Cin) if mirror == 1 else (K, Cin, Cout), dtype=dtype, device=w.device)
+    m = None if mirror == 0 else torch.empty((K, Cout, Cin) if mirror == 1 else (K, Cin, Cout), dtype=dtype, device=w.device)   # (2, 3: transposed)
     rc = L.fnp_pack_weight(_l.ptr(w), Cout, K, Cin, _l.dtype_code(p), _l.ptr(p), _l.ptr(m), mirror, _l.stream())
     _l.check(rc, "fnp_pack_weight")
     return p, m
@@ -580,12 +581,17 @@ def rulebook_transpose(rb, n_out_dev, cap_in):
     return nbr_t
 
 
-def conv_dgrad(grad_out, w_packed, nbr_t, n_in_dev, cap_in):
+def conv_dgrad(grad_out, w_packed, nbr_t, n_in_dev, cap_in, pretransposed=False):
     """dx (cap_in, Cin) = sum_k W_k dy[nbr_t[k]]: the forward kernel on the transposed rulebook and slabs.
-    w_packed (K, Cout, Cin) in grad_out's dtype."""
+    w_packed (K, Cout, Cin) in grad_out's dtype; pretransposed: it is (K, Cin, Cout) already (pack_weight_train mirror 2 / 3)."""
     L = _l.load()
-    K, Cout, Cin = w_packed.shape
-    w_t = w_packed.transpose(1, 2).contiguous()            # (K, Cin, Cout): "Cout" = Cin, "Cin" = Cout
+    if pretransposed:
+        K, Cin, Cout = w_packed.shape
+        w_t = w_packed
+        assert w_t.is_contiguous()
+    else:
+        K, Cout, Cin = w_packed.shape
+        w_t = w_packed.transpose(1, 2).contiguous()            # (K, Cin, Cout): "Cout" = Cin, "Cin" = Cout
     assert grad_out.is_contiguous() and grad_out.dtype == w_t.dtype and grad_out.shape[1] == Cout
     dx = torch.empty((cap_in, Cin), dtype=grad_out.dtype, device=grad_out.device)
     rc = L.fnp_spconv_forward(_l.ptr(grad_out), _l.dtype_code(grad_out), grad_out.shape[0], _l.ptr(w_t),

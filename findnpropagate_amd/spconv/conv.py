@@ -16,6 +16,10 @@ from .core import SparseConvTensor
 from .modules import SparseModule
 
 
+def kvol_is_27(ks):
+    return tuple(int(v) for v in ks) == (3, 3, 3)
+
+
 def _triple(v):
     return [int(x) for x in v] if isinstance(v, (list, tuple)) else [int(v)] * 3
 
@@ -36,9 +40,11 @@ class SparseConvFunction(torch.autograd.Function):
         Cout, Cin = weight.shape[0], weight.shape[-1]
         odd = all(int(v) & 1 for v in rb.geom.ksize)
         subm_self = rb.out_indices is None and rb.cap_out == feats.shape[0] and odd
+        # (2: mirrored + transposed, a SubM layer's data gradient on the forward's own table; 3: transposed, a strided layer's on
+        #  its transposed table — either way the slabs the forward KERNEL reads when it runs on the gradient)
         mirror = 0
-        if ctx.needs_input_grad[0] and subm_self:
-            mirror = 2 if (ranked and Cin == Cout and S.tiled_by_default(Cin, feats.dtype, rb.cap_out)) else 1
+        if ctx.needs_input_grad[0]:
+            mirror = 2 if subm_self else 3
         w, wm = S.pack_weight_train(weight, feats.dtype, mirror)
         out = S.conv_forward(feats, w, rb, n_out_dev, ranked=ranked,
                              out=None if rows is None else torch.empty((rows, weight.shape[0]), dtype=feats.dtype, device=feats.device))
@@ -61,16 +67,19 @@ class SparseConvFunction(torch.autograd.Function):
                 # SubM: the rulebook is its own transpose up to the mirror of the offsets (input i feeds output o through
                 # offset k  <=>  o is the neighbour of i at offset K-1-k): same table, weight slabs in mirrored order.
                 # That identity needs a centred kernel (every size odd); an even size takes the transposed table below.
-                if ctx.ranked and Cin == Cout and S.tiled_by_default(Cin, feats.dtype, rb.cap_out):
-                    # ... and on the tile rulebook where the forward ran on it: the forward kernel on (K, Cin, Cout) slabs
-                    wt = ctx.w_mirror if ctx.mirror == 2 else wp.flip(0).transpose(1, 2).contiguous()
+                wt = ctx.w_mirror if ctx.mirror == 2 else wp.flip(0).transpose(1, 2).contiguous()
+                if ctx.ranked and Cin == Cout and (S.tiled_by_default(Cin, feats.dtype, rb.cap_out) or getattr(rb, "_sorted", None) is not None):
+                    # ... and on the tile rulebook (or the class-sorted sweep) where the forward ran on it
                     dx = S.conv_forward(grad_out, wt, rb, n_in_dev, ranked=True)
                 else:
-                    dx = S.conv_dgrad(grad_out, ctx.w_mirror if ctx.mirror == 1 else wp.flip(0), rb.nbr, n_in_dev, feats.shape[0])
+                    dx = S.conv_dgrad(grad_out, wt, rb.nbr, n_in_dev, feats.shape[0], pretransposed=True)
             else:
                 if getattr(rb, "_nbr_t", None) is None or rb._nbr_t.shape[1] != feats.shape[0]:
                     rb._nbr_t = S.rulebook_transpose(rb, n_out_dev, feats.shape[0])   # (kept with the rulebook: one per layer)
-                dx = S.conv_dgrad(grad_out, wp, rb._nbr_t, n_in_dev, feats.shape[0])
+                if ctx.mirror == 3:
+                    dx = S.conv_dgrad(grad_out, ctx.w_mirror, rb._nbr_t, n_in_dev, feats.shape[0], pretransposed=True)
+                else:
+                    dx = S.conv_dgrad(grad_out, wp, rb._nbr_t, n_in_dev, feats.shape[0])
         if ctx.needs_input_grad[1]:
             dw = S.conv_wgrad(feats, grad_out, rb, n_out_dev, Cin, Cout, module_shape=weight.shape).to(weight.dtype)   # (f32: no copy)
         return dx, dw, None, None, None, None, None
@@ -149,8 +158,14 @@ class SparseConvolution(SparseModule):
             rb = input.find_indice_pair(self.indice_key)
             if rb is None or rb.K != self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]:
                 ch = self.in_channels if self.in_channels == self.out_channels else 0
+                # the 128 -> 128 layers of a large enough stage sweep their rows class by class, forward and data gradient
+                # (the fused engine's kernel: same values as the plain sweep)
+                srt = bool(ranked and ch and kvol_is_27(self.kernel_size) and S.sorted_by_default(ch, ch, feats.dtype, feats.shape[0]))
                 rb = S.rulebook_subm(input.indices, n_dev, input.rank_grid(), self.kernel_size,
-                                     tile_channels=ch if ranked and ch and S.tiled_by_default(ch, feats.dtype, feats.shape[0]) else None)
+                                     tile_channels=ch if ranked and ch and S.tiled_by_default(ch, feats.dtype, feats.shape[0]) else None,
+                                     masks=srt)
+                if srt:
+                    S.classsort(rb, n_dev, ch)
                 if self.indice_key is not None:
                     input.indice_dict[self.indice_key] = rb
             out_feats = run(rb, n_dev)

@@ -430,7 +430,8 @@ int fnp_spconv_wgrad(const void *feat_in, int in_dtype, const void *grad_out, in
  * reduction writes the .grad tensor itself: no permute-copy per layer afterwards).
  * fnp_pack_weight: the module's f32 weight (Cout, K, Cin) -> the packed (K, Cout, Cin) slabs in `dtype`, and in the same launch
  * the slabs the data gradient of a SubM layer reads: mirror_mode 1 = (K-1-k, Cout, Cin) for fnp_spconv_dgrad on the forward's
- * table, 2 = (K-1-k, Cin, Cout) for the tiled forward kernel run on the gradient; 0 = none (mirror NULL). */
+ * table (which transposes them itself), 2 = (K-1-k, Cin, Cout): the forward kernel run on the gradient of a SubM layer, 3 =
+ * (k, Cin, Cout): the same for a strided layer on its transposed table (fnp_rulebook_transpose); 0 = none (mirror NULL). */
 int fnp_pack_weight(const float *weight, int Cout, int K, int Cin, int dtype, void *packed, void *mirror, int mirror_mode,
                     fnp_stream_t stream);
 /* PAIR LISTS of a rulebook (ABI 8), for the weight gradient: offset k only sums over the output rows that HAVE a neighbour

@@ -363,7 +363,7 @@ def test_pack_weight_kernel_equals_the_torch_ops(cuda, rng, dtype, Cout, K3, Cin
     from findnpropagate_amd import sparse as S
     w = torch.from_numpy(rng.standard_normal((Cout, *K3, Cin)).astype(np.float32)).to(cuda)
     ref = S.pack_weight(w, dtype)
-    for mirror, want in ((0, None), (1, ref.flip(0)), (2, ref.flip(0).transpose(1, 2).contiguous())):
+    for mirror, want in ((0, None), (1, ref.flip(0)), (2, ref.flip(0).transpose(1, 2).contiguous()), (3, ref.transpose(1, 2).contiguous())):
         p, m = S.pack_weight_train(w, dtype, mirror)
         assert torch.equal(p, ref) and p.is_contiguous()
         assert (m is None) if want is None else torch.equal(m, want)
