@@ -17,7 +17,14 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxParts = 256;   // statistics workgroups (one per CU)
+#ifndef FNP_BN_PARTS
+#define FNP_BN_PARTS 256
+#endif
+constexpr int kMaxParts = FNP_BN_PARTS;   // statistics workgroups (one per CU; 1024 measured: the passes 7 % faster, the finishing launches
+                                          // 2.4x slower — 7.2 -> 17.5 us for 42 of them per step)
+#ifndef FNP_BN_UNROLL
+#define FNP_BN_UNROLL 4
+#endif
 constexpr int kFinC = 16;        // channels per finishing workgroup
 
 __device__ __forceinline__ float ldf(const float *p, size_t i) { return p[i]; }
@@ -80,28 +87,43 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T *__restrict_
     // contiguous row range per workgroup (so that the partial order is a function of n and the grid only)
     const long long per = ((long long)n + gridDim.x - 1) / gridDim.x;
     const long long r0 = per * blockIdx.x, r1 = min((long long)n, r0 + per);
-    for (long long r = r0 + rl; r < r1; r += rows_per_iter) {
-        float xv[8];
-        load8(x + (size_t)r * C + cg * 8, xv);
-        if (MODE == 0) {
+    // U rows per trip: their loads (U, 2 U or 3 U of 16 bytes) are all requested before the first is used (one workgroup per CU:
+    // a wave that waits for one row at a time spends the pass waiting); the sums stay in row order
+    constexpr int U = FNP_BN_UNROLL;
+    for (long long r = r0 + rl; r < r1; r += (long long)U * rows_per_iter) {
+        float xv[U][8], gv[U][8], yv[U][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                sa[j] += (double)xv[j];
-                sb[j] += (double)xv[j] * (double)xv[j];
+        for (int u = 0; u < U; ++u) {
+            const long long ru = r + (long long)u * rows_per_iter;
+            if (ru < r1) {
+                load8(x + (size_t)ru * C + cg * 8, xv[u]);
+                if (MODE == 1) {
+                    load8(dy + (size_t)ru * C + cg * 8, gv[u]);
+                    if (relu) load8(y + (size_t)ru * C + cg * 8, yv[u]);
+                }
             }
-        } else {
-            float gv[8], yv[8];
-            load8(dy + (size_t)r * C + cg * 8, gv);
-            if (relu) {
-                load8(y + (size_t)r * C + cg * 8, yv);
+        }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
-            }
+        for (int u = 0; u < U; ++u) {
+            const long long ru = r + (long long)u * rows_per_iter;
+            if (ru >= r1) break;
+            if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = (xv[j] - mu[j]) * is[j];
-                sa[j] += (double)gv[j];
-                sb[j] += (double)gv[j] * (double)xh;
+                for (int j = 0; j < 8; ++j) {
+                    sa[j] += (double)xv[u][j];
+                    sb[j] += (double)xv[u][j] * (double)xv[u][j];
+                }
+            } else {
+                if (relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) gv[u][j] = yv[u][j] > 0.f ? gv[u][j] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (xv[u][j] - mu[j]) * is[j];
+                    sa[j] += (double)gv[u][j];
+                    sb[j] += (double)gv[u][j] * (double)xh;
+                }
             }
         }
     }
