@@ -89,23 +89,122 @@ __global__ __launch_bounds__(kThreads) void wgrad_partial_kernel(const TX *__res
     }
 }
 
+// PAIR LISTS, balanced (round 3, late).  With one row-chunk grid per offset, (chunks, K), every offset got the same number of
+// workgroups — but the centre offset lists EVERY row and the others 1/4 to 1/30 of them (3.6-14 neighbours of 27): its
+// workgroups ran 2-7 times longer than the rest, alone on a tenth of the CUs.  The W = chunks x K workgroups of a launch now
+// share the pairs evenly: R = rows per workgroup = ceil(total pairs / (W - K)) rounded up to 128, offset k takes ceil(n_k / R)
+// consecutive workgroups (sum <= W; the spare ones leave at once), and workgroup w writes its partial sum at partial[w].  The
+// split is a function of pair_count alone, recomputed by every workgroup and by the reduction: same order every run.
+// MEASURED (16 scenes): conv_input 137 -> 63 us, 16 x 16 32.7 -> 25.6 us — and the wide layers SLOWER (128 x 128 139 -> 172 us,
+// 64 x 64 117 -> 166, 32 x 32 124 -> 172, 32 x 64 49 -> 76): those are bound by the L2 gather rate, not by their longest
+// workgroup (the centre offset's workgroups ran alone at the end, but at the full rate of an idle L2), and ~580 equal
+// workgroups at two per CU make two rounds.  Balanced for Cin x Cout <= 256 only (kPairBalancedMax).
+constexpr int kPairBalancedMax = 256;
+struct PairSplit {
+    int k, chunk, R, n, first, count;   // offset, chunk index inside it, rows per chunk, pairs of the offset, its first workgroup and how many
+    bool live;
+};
+// (spc: the K <= 64 pair counts, clamped, in LDS — loaded by K threads at once: a lone thread walking pair_count in memory
+//  took 80 us in the reduction kernel)
+__device__ __forceinline__ void pair_counts_to_lds(const int *__restrict__ pair_count, int K, int cap_out, int *spc) {
+    if ((int)threadIdx.x < K) spc[threadIdx.x] = min(pair_count[threadIdx.x], cap_out);
+    __syncthreads();
+}
+__device__ __forceinline__ int pair_rows_per_wg(const int *spc, int K, int W) {
+    long long total = 0;
+    for (int k = 0; k < K; ++k) total += spc[k];
+    const int budget = W - K > 0 ? W - K : 1;
+    const int R = (int)(((total + budget - 1) / budget + 127) / 128 * 128);
+    return R < 128 ? 128 : R;
+}
+__device__ __forceinline__ PairSplit pair_split_of_wg(const int *spc, int K, int W, int w) {
+    PairSplit ps;
+    ps.R = pair_rows_per_wg(spc, K, W);
+    ps.live = false;
+    ps.k = 0; ps.chunk = 0; ps.n = 0; ps.first = 0; ps.count = 0;
+    int start = 0;
+    for (int k = 0; k < K; ++k) {
+        const int n = spc[k], c = (n + ps.R - 1) / ps.R;
+        if (!ps.live && w < start + c) {
+            ps.k = k; ps.chunk = w - start; ps.n = n; ps.first = start; ps.count = c; ps.live = true;
+        }
+        start += c;
+    }
+    return ps;
+}
+// dw (K, Cout, Cin) (or the module's layout) = the partial sums of each offset's workgroups, in workgroup order (K <= 64)
+__global__ __launch_bounds__(kThreads) void wgrad_reduce_pairs_kernel(const float *__restrict__ partial, const int *__restrict__ pair_count, int K,
+                                                                      int cap_out, int W, int pairs, float *__restrict__ dw, int module_cc, int Cin) {
+    __shared__ int sfirst[65], spc[64];
+    pair_counts_to_lds(pair_count, K, cap_out, spc);
+    if (threadIdx.x == 0) {   // (the split once per workgroup)
+        const int R = pair_rows_per_wg(spc, K, W);
+        int start = 0;
+        for (int j = 0; j < K; ++j) {
+            sfirst[j] = start;
+            start += (spc[j] + R - 1) / R;
+        }
+        sfirst[K] = start;
+    }
+    __syncthreads();
+    // eight lanes per element: lane j adds the partials j, j + 8, ... in order, a fixed butterfly adds the eight sums (the centre
+    // offset owns a quarter of the workgroups: one thread adding its ~230 partials in turn took 80 us)
+    const long long total = (long long)K * pairs;
+    const int sub = threadIdx.x & 7;
+    for (long long e0 = ((long long)blockIdx.x * kThreads + threadIdx.x) >> 3; e0 < ((total + 31) & ~31ll); e0 += ((long long)gridDim.x * kThreads) >> 3) {
+        const bool live = e0 < total;   // (whole waves reach the shuffles: 8 elements per wave, total rounded up to 32)
+        const long long e = live ? e0 : total - 1;
+        const int k = (int)(e / pairs), p = (int)(e % pairs);
+        const int first = sfirst[k], count = sfirst[k + 1] - first;
+        float s = 0.f;
+        for (int c = sub; c < count; c += 8) s += partial[(size_t)(first + c) * pairs + p];   // fixed order
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (live && sub == 0) {
+            long long o = e;
+            if (module_cc) {
+                const int co = p / Cin, ci = p % Cin;
+                o = ((long long)co * K + k) * Cin + ci;
+            }
+            dw[o] = s;
+        }
+    }
+}
+
 // The same sum for layers with few (Cin x Cout <= 128) pairs — conv_input, 5 -> 16 — where the kernel above leaves two thirds
 // of its threads idle and meets three barriers per 16 rows: 128-row tiles, and the 256 threads form G = 256 / pairs groups
 // that each take every G-th row of a tile; the groups' sums are added in group order at the end (fixed order).
-template <typename TX, typename TY>
+// PAIRS (round 3): the rows of offset k come from the rulebook's pair lists (nbr = pair_o, pair_i, pair_count[k] of them) instead
+// of a sweep over every row of the table: conv_input's rows have 3.6 of 27 neighbours, so seven tiles of eight staged zeros only.
+template <typename TX, typename TY, bool PAIRS>
 __global__ __launch_bounds__(kThreads) void wgrad_small_kernel(const TX *__restrict__ x, const TY *__restrict__ dy,
                                                                const int *__restrict__ nbr, int nbr_stride,
                                                                const int *__restrict__ n_out, int cap_out,
-                                                               int Cin, int Cout, float *__restrict__ partial) {
+                                                               int Cin, int Cout, float *__restrict__ partial,
+                                                               const int *__restrict__ pair_i, const int *__restrict__ pair_count) {
     constexpr int TR = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char fnp_wg_smem[];
     float *sy = reinterpret_cast<float *>(fnp_wg_smem);   // [TR][Cout]
     float *sx = sy + TR * Cout;                           // [TR][Cin]
     __shared__ int sidx[TR];
+    __shared__ int sout[TR];
     __shared__ float sred[kThreads];
-    const int n = min(*n_out, cap_out);
-    const int k = blockIdx.y, chunk = blockIdx.x, K = gridDim.y;
-    const int rows_per_chunk = ((n + (int)gridDim.x - 1) / (int)gridDim.x + 127) / 128 * 128;
+    int k = blockIdx.y, chunk = blockIdx.x;
+    const int K = gridDim.y;
+    int n, rows_per_chunk;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const bool bal = PAIRS && K <= 64;   // (uniform; the reduction's table of first workgroups holds 64 offsets)
+    __shared__ int spc[64];
+    if (bal) {   // (entries of offset k, shared evenly over the launch's workgroups)
+        pair_counts_to_lds(pair_count, K, cap_out, spc);
+        const PairSplit ps = pair_split_of_wg(spc, K, gridDim.x * gridDim.y, wg);
+        if (!ps.live) return;   // (whole workgroup, before any barrier)
+        k = ps.k; chunk = ps.chunk; n = ps.n; rows_per_chunk = ps.R;
+    } else {
+        n = PAIRS ? min(pair_count[k], cap_out) : min(*n_out, cap_out);
+        rows_per_chunk = ((n + (int)gridDim.x - 1) / (int)gridDim.x + 127) / 128 * 128;
+    }
     const int r0 = min(n, chunk * rows_per_chunk), r1 = min(n, r0 + rows_per_chunk);
     const int pairs = Cin * Cout, G = kThreads / pairs;
     const int g = threadIdx.x / pairs, p = threadIdx.x % pairs, co = p / Cin, ci = p % Cin;
@@ -114,12 +213,18 @@ __global__ __launch_bounds__(kThreads) void wgrad_small_kernel(const TX *__restr
         __syncthreads();
         if (threadIdx.x < TR) {
             const int r = t0 + threadIdx.x;
-            sidx[threadIdx.x] = r < r1 ? nbr[(size_t)k * nbr_stride + r] : -1;
+            if (PAIRS) {
+                sidx[threadIdx.x] = r < r1 ? pair_i[(size_t)k * nbr_stride + r] : -1;
+                sout[threadIdx.x] = r < r1 ? nbr[(size_t)k * nbr_stride + r] : 0;
+            } else {
+                sidx[threadIdx.x] = r < r1 ? nbr[(size_t)k * nbr_stride + r] : -1;
+                sout[threadIdx.x] = r;
+            }
         }
         __syncthreads();
         for (int e = threadIdx.x; e < TR * Cout; e += kThreads) {
             const int rr = e / Cout, c = e % Cout, r = t0 + rr;
-            sy[e] = (r < r1 && sidx[rr] >= 0) ? ld_f32(dy + (size_t)r * Cout + c) : 0.f;
+            sy[e] = (r < r1 && sidx[rr] >= 0) ? ld_f32(dy + (size_t)sout[rr] * Cout + c) : 0.f;
         }
         for (int e = threadIdx.x; e < TR * Cin; e += kThreads) {
             const int rr = e / Cin, c = e % Cin, id = sidx[rr];
@@ -136,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_small_kernel(const TX *__restr
     if (threadIdx.x < pairs) {
         float a = 0.f;
         for (int gg = 0; gg < G; ++gg) a += sred[gg * pairs + threadIdx.x];
-        partial[((size_t)chunk * K + k) * pairs + threadIdx.x] = a;
+        partial[(bal ? (size_t)wg : (size_t)chunk * K + k) * pairs + threadIdx.x] = a;
     }
 }
 
@@ -271,7 +376,7 @@ template <int CIN, int COUT> struct WgradTile {
 template <int CIN, int COUT, typename T16, bool PAIRS = false>
 __global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const T16 *__restrict__ x, const T16 *__restrict__ dy,
                                                               const int *__restrict__ nbr, int nbr_stride,
-                                                              const int *__restrict__ n_out, int cap_out, int /*unused*/,
+                                                              const int *__restrict__ n_out, int cap_out, int balanced,
                                                               float *__restrict__ partial, const int *__restrict__ pair_i = nullptr,
                                                               const int *__restrict__ pair_count = nullptr) {
     constexpr int NBO = COUT / 16, NBI = CIN / 16;
@@ -291,10 +396,22 @@ __global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const T16 *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned char fnp_wg_smem[];
     __bf16 *lds = reinterpret_cast<__bf16 *>(fnp_wg_smem);     // [2 buffers][WK slices][SLICE]
 
-    const int k = blockIdx.y, chunk = blockIdx.x, K = gridDim.y;
-    // (PAIRS: `nbr` is pair_o, and n the number of pairs of this offset)
-    const int n = PAIRS ? min(pair_count[k], cap_out) : min(*n_out, cap_out);
-    const int rows_per_chunk = ((n + (int)gridDim.x - 1) / (int)gridDim.x + 127) / 128 * 128;   // from n, not the capacity
+    int k = blockIdx.y, chunk = blockIdx.x;
+    const int K = gridDim.y;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    // (PAIRS: `nbr` is pair_o, n the number of pairs of this offset, and the launch's workgroups share ALL pairs evenly)
+    int n, rows_per_chunk;
+    const bool bal = PAIRS && balanced;   // (uniform)
+    __shared__ int spc[64];
+    if (bal) {
+        pair_counts_to_lds(pair_count, K, cap_out, spc);
+        const PairSplit ps = pair_split_of_wg(spc, K, gridDim.x * gridDim.y, wg);
+        if (!ps.live) return;   // (whole workgroup, before any barrier)
+        k = ps.k; chunk = ps.chunk; n = ps.n; rows_per_chunk = ps.R;
+    } else {
+        n = PAIRS ? min(pair_count[k], cap_out) : min(*n_out, cap_out);
+        rows_per_chunk = ((n + (int)gridDim.x - 1) / (int)gridDim.x + 127) / 128 * 128;   // from n, not the capacity
+    }
     const int r0 = min(n, chunk * rows_per_chunk), r1 = min(n, r0 + rows_per_chunk);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ks = wave / WB, wb = wave % WB;       // this wave's row slice and block column
@@ -402,7 +519,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const T16 *__restr
 
     // lane holds dW[co = blk*16 + kq*4 + r][ci = b*16 + l15]; the WK slices are added through LDS (slice 0 writes)
     float *red = reinterpret_cast<float *>(fnp_wg_smem);
-    float *out = partial + ((size_t)chunk * K + k) * (COUT * CIN);
+    float *out = partial + (bal ? (size_t)wg : (size_t)chunk * K + k) * (COUT * CIN);
     for (int pass = 1; pass < WK; ++pass) {   // (WK is 1, 2 or 4)
         __syncthreads();
         if (ks == pass) {
@@ -450,10 +567,11 @@ void launch_wgrad_mfma(dim3 grid, hipStream_t s, const T16 *x, const T16 *dy, co
     const size_t lds = wgrad_mfma_lds<CIN, COUT>();
     if (pair_i) {
         auto kern = wgrad_mfma_kernel<CIN, COUT, T16, true>;
-        hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, x, dy, nbr, nbr_stride, n_out, cap_out, rows_per_chunk, partial, pair_i, pair_count);
+        hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, x, dy, nbr, nbr_stride, n_out, cap_out, (CIN * COUT <= kPairBalancedMax && grid.y <= 64) ? 1 : 0, partial, pair_i,
+                           pair_count);
     } else {
         auto kern = wgrad_mfma_kernel<CIN, COUT, T16, false>;
-        hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, x, dy, nbr, nbr_stride, n_out, cap_out, rows_per_chunk, partial, pair_i, pair_count);
+        hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, x, dy, nbr, nbr_stride, n_out, cap_out, 0, partial, pair_i, pair_count);
     }
 }
 
@@ -506,19 +624,31 @@ int run_wgrad(const void *x, const void *dy, const int *nbr, int nbr_stride, int
         if (!done && pair_i) return FNP_ERR_ARG;   // (pair lists: the MFMA shapes only)
         if (done) {
             FNP_LAUNCH_CHECK();
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fnp_grid_for(total, kThreads)), dim3(kThreads), 0, s,
-                               (const float *)partial, chunks, total, dw, module_cc, Cin, K);
+            if (pair_i && pairs <= kPairBalancedMax && K <= 64)
+                hipLaunchKernelGGL(wgrad_reduce_pairs_kernel, dim3(fnp_grid_for(total * 8, kThreads)), dim3(kThreads), 0, s, (const float *)partial,
+                                   pair_count, K, cap_out, chunks * K, (int)pairs, dw, module_cc, Cin);
+            else
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fnp_grid_for(total, kThreads)), dim3(kThreads), 0, s,
+                                   (const float *)partial, chunks, total, dw, module_cc, Cin, K);
             FNP_LAUNCH_CHECK();
             return FNP_OK;
         }
     }
-    if (pair_i) return FNP_ERR_ARG;
+    if (pair_i && pairs > 128) return FNP_ERR_ARG;
     if (pairs <= 128) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_small_kernel<TX, TY>), grid, dim3(kThreads), (size_t)128 * (Cin + Cout) * 4, s, (const TX *)x,
-                           (const TY *)dy, nbr, nbr_stride, n_out, cap_out, Cin, Cout, partial);
+        if (pair_i)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_small_kernel<TX, TY, true>), grid, dim3(kThreads), (size_t)128 * (Cin + Cout) * 4, s, (const TX *)x,
+                               (const TY *)dy, nbr, nbr_stride, n_out, cap_out, Cin, Cout, partial, pair_i, pair_count);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_small_kernel<TX, TY, false>), grid, dim3(kThreads), (size_t)128 * (Cin + Cout) * 4, s, (const TX *)x,
+                               (const TY *)dy, nbr, nbr_stride, n_out, cap_out, Cin, Cout, partial, pair_i, pair_count);
         FNP_LAUNCH_CHECK();
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fnp_grid_for(total, kThreads)), dim3(kThreads), 0, s, (const float *)partial, chunks,
-                           total, dw, module_cc, Cin, K);
+        if (pair_i && K <= 64)
+            hipLaunchKernelGGL(wgrad_reduce_pairs_kernel, dim3(fnp_grid_for(total * 8, kThreads)), dim3(kThreads), 0, s, (const float *)partial,
+                               pair_count, K, cap_out, chunks * K, (int)pairs, dw, module_cc, Cin);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(fnp_grid_for(total, kThreads)), dim3(kThreads), 0, s, (const float *)partial, chunks,
+                               total, dw, module_cc, Cin, K);
         FNP_LAUNCH_CHECK();
         return FNP_OK;
     }
@@ -656,6 +786,9 @@ extern "C" int fnp_spconv_wgrad_pairs(const void *feat_in, int in_dtype, const v
     if (!feat_in || !grad_out || !pair_o || !pair_i || !pair_count || !n_out || !grad_weight || !workspace || K <= 0 || Cin <= 0 || Cout <= 0 ||
         cap_out <= 0 || pair_stride < cap_out || (grad_layout != 0 && grad_layout != 1))
         return FNP_ERR_ARG;
+    if (in_dtype == FNP_F32 && grad_dtype == FNP_F32 && (long long)Cin * Cout <= 128)   // (conv_input: the few-pairs kernel on the lists)
+        return run_wgrad<float, float>(feat_in, grad_out, pair_o, pair_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
+                                       workspace_bytes, s, grad_layout, pair_i, pair_count);
     if (in_dtype == FNP_BF16 && grad_dtype == FNP_BF16)
         return run_wgrad<__bf16, __bf16>(feat_in, grad_out, pair_o, pair_stride, K, n_out, cap_out, grad_weight, Cin, Cout, workspace,
                                          workspace_bytes, s, grad_layout, pair_i, pair_count);

@@ -639,8 +639,9 @@ def conv_wgrad(feat_in, grad_out, rb, n_out_dev, Cin, Cout, pairs=None, module_s
     ws = torch.empty((int(L.fnp_spconv_wgrad_workspace_bytes(rb.K, Cin, Cout)),), dtype=torch.uint8, device=feat_in.device)
     cap = min(rb.cap_out, grad_out.shape[0])
     use_pairs = WGRAD_PAIRS if pairs is None else pairs
-    if (use_pairs and (Cin, Cout) in WGRAD_PAIR_SHAPES and feat_in.dtype in (torch.bfloat16, torch.float16) and grad_out.dtype == feat_in.dtype
-            and not getattr(rb, "_lean", False)):
+    mfma_pairs = (Cin, Cout) in WGRAD_PAIR_SHAPES and feat_in.dtype in (torch.bfloat16, torch.float16) and grad_out.dtype == feat_in.dtype
+    small_pairs = Cin * Cout <= 128 and feat_in.dtype == torch.float32 and grad_out.dtype == torch.float32   # (conv_input: 3.6 of 27 neighbours per row)
+    if use_pairs and (mfma_pairs or small_pairs) and rb.nbr is not None and not getattr(rb, "_lean", False):
         pr = getattr(rb, "_pairs", None) or rulebook_pairs(rb, n_out_dev, rows=cap)
         rc = L.fnp_spconv_wgrad_pairs(_l.ptr(feat_in), _l.dtype_code(feat_in), _l.ptr(grad_out), _l.dtype_code(grad_out), _l.ptr(pr[0]), _l.ptr(pr[1]),
                                       _l.ptr(pr[2]), pr[0].shape[1], rb.K, _l.ptr(n_out_dev), min(cap, pr[0].shape[1]), _l.ptr(dw), layout, Cin, Cout, _l.ptr(ws), ws.numel(),

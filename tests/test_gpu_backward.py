@@ -429,3 +429,33 @@ def test_prefetched_strided_rulebooks_change_nothing(cuda, rng):
         assert torch.equal(ba, bb), k
         if k.endswith("num_batches_tracked"):
             assert int(ba) == 2, k
+
+
+def test_conv_input_weight_gradient_on_pair_lists(cuda, rng):
+    """The few-pairs weight-gradient kernel (conv_input: 5 -> 16, f32 features and gradients) on the rulebook's pair lists
+    against its sweep over the table: the same sum in another grouping of the rows — equal to f32 rounding, and identical
+    from run to run."""
+    from findnpropagate_amd import sparse as S
+    B, shape = 2, [9, 60, 64]
+    idx = np.unique(np.stack([rng.integers(0, B, 9000), rng.integers(0, shape[0], 9000), rng.integers(0, shape[1], 9000),
+                              rng.integers(0, shape[2], 9000)], 1).astype(np.int32), axis=0)
+    n = idx.shape[0]
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    rb = S.rulebook_subm(d_idx, n_dev, S.build_grid(d_idx, n_dev, B, shape), 3)
+    x = torch.from_numpy(rng.standard_normal((n, 5)).astype(np.float32)).to(cuda)
+    dy = torch.from_numpy(rng.standard_normal((n, 16)).astype(np.float32)).to(cuda)
+    table = S.conv_wgrad(x, dy, rb, n_dev, 5, 16, pairs=False)
+    lists = S.conv_wgrad(x, dy, rb, n_dev, 5, 16, pairs=True)
+    again = S.conv_wgrad(x, dy, rb, n_dev, 5, 16, pairs=True)
+    assert getattr(rb, "_pairs", None) is not None
+    assert torch.equal(lists, again)
+    scale = float(table.abs().max())
+    assert float((lists - table).abs().max()) <= 1e-5 * scale
+    nbr = rb.nbr[:, :n].cpu().numpy()
+    want = np.zeros((27, 16, 5), np.float64)
+    xs, dys = x.cpu().numpy().astype(np.float64), dy.cpu().numpy().astype(np.float64)
+    for k in range(27):
+        o = np.nonzero(nbr[k] >= 0)[0]
+        want[k] = dys[o].T @ xs[nbr[k][o]]
+    assert np.abs(lists.cpu().numpy() - want).max() <= 1e-5 * scale
