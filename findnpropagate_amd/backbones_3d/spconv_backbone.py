@@ -172,6 +172,12 @@ def _module_forward(self, batch_dict):
     # the strided layers' rulebooks are asked for ahead of the layers before them (spconv/conv.py prefetch): the first one from
     # the input coordinates right here, each further one by the strided layer before it
     if x_in.features.is_cuda and torch.is_grad_enabled():
+        # every layer's packed weights (and its data gradient's slabs) in one launch per dtype
+        from ..spconv import conv as _C
+        conv0 = self.conv_input[0]
+        auto = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else None
+        convs = [m for m in self.modules() if isinstance(m, spconv.SparseConvolution) and m.weight.requires_grad]
+        _C.prepack_weights([(m, auto if auto is not None else (torch.float32 if m is conv0 else act)) for m in convs])
         chain = _strided_chain(self)
         for a, b in zip(chain, chain[1:] + [None]):
             object.__setattr__(a, "_fnp_next", b)   # (not a registered submodule: parameter names and state_dict stay the reference's)

@@ -706,6 +706,53 @@ extern "C" int fnp_pack_weight(const float *weight, int Cout, int K, int Cin, in
     return FNP_OK;
 }
 
+// fnp_pack_weight for up to 32 layers in ONE launch (blockIdx.y = layer): the training forward is bound by the host's launches
+struct PackJobs {
+    const float *w[32];
+    void *packed[32], *mirror[32];
+    int cout[32], k[32], cin[32], mode[32];
+};
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pack_weight_multi_kernel(PackJobs j) {
+    const int l = blockIdx.y;
+    const float *__restrict__ w = j.w[l];
+    T *__restrict__ packed = (T *)j.packed[l];
+    T *__restrict__ mirror = (T *)j.mirror[l];
+    const int Cout = j.cout[l], K = j.k[l], Cin = j.cin[l], mode = j.mode[l];
+    const long long total = (long long)Cout * K * Cin;
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kThreads) {
+        const int ci = (int)(e % Cin), co = (int)((e / Cin) % Cout), k = (int)(e / ((long long)Cin * Cout));
+        const T v = (T)w[((long long)co * K + k) * Cin + ci];
+        packed[e] = v;
+        if (mode == 1) mirror[((long long)(K - 1 - k) * Cout + co) * Cin + ci] = v;
+        else if (mode == 2) mirror[((long long)(K - 1 - k) * Cin + ci) * Cout + co] = v;
+        else if (mode == 3) mirror[((long long)k * Cin + ci) * Cout + co] = v;
+    }
+}
+extern "C" int fnp_pack_weight_multi(int count, const float *const *weights, const int *couts, const int *ks, const int *cins, int dtype,
+                                     void *const *packed, void *const *mirrors, const int *mirror_modes, fnp_stream_t stream) {
+    if (count <= 0 || count > 32 || !weights || !couts || !ks || !cins || !packed || !mirrors || !mirror_modes) return FNP_ERR_ARG;
+    PackJobs j{};
+    long long most = 1;
+    for (int i = 0; i < count; ++i) {
+        if (!weights[i] || !packed[i] || couts[i] <= 0 || ks[i] <= 0 || cins[i] <= 0 || mirror_modes[i] < 0 || mirror_modes[i] > 3 ||
+            (mirror_modes[i] != 0) != (mirrors[i] != nullptr))
+            return FNP_ERR_ARG;
+        j.w[i] = weights[i]; j.packed[i] = packed[i]; j.mirror[i] = mirrors[i];
+        j.cout[i] = couts[i]; j.k[i] = ks[i]; j.cin[i] = cins[i]; j.mode[i] = mirror_modes[i];
+        const long long t = (long long)couts[i] * ks[i] * cins[i];
+        if (t > most) most = t;
+    }
+    const dim3 grid(fnp_grid_for(most, kThreads, 256), count);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == FNP_F32) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_weight_multi_kernel<float>), grid, dim3(kThreads), 0, s, j);
+    else if (dtype == FNP_BF16) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_weight_multi_kernel<__bf16>), grid, dim3(kThreads), 0, s, j);
+    else if (dtype == FNP_F16) hipLaunchKernelGGL(HIP_KERNEL_NAME(pack_weight_multi_kernel<_Float16>), grid, dim3(kThreads), 0, s, j);
+    else return FNP_ERR_ARG;
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
 extern "C" int fnp_rulebook_transpose(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int *nbr_t,
                                       int cap_in, fnp_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;

@@ -149,6 +149,7 @@ SIGNATURES = {
     "fnp_spconv_wgrad_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "fnp_spconv_wgrad": (c_int, [P, c_int, P, c_int, P, c_int, c_int, P, c_int, P, c_int, c_int, c_int, P, c_int64, P]),
     "fnp_pack_weight": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, P]),
+    "fnp_pack_weight_multi": (c_int, [c_int, P, P, P, P, c_int, P, P, P, P]),
     "fnp_rulebook_pairs_workspace_bytes": (c_int64, [c_int, c_int]),
     "fnp_rulebook_pairs": (c_int, [P, c_int, c_int, P, c_int, P, P, c_int, P, P, c_int64, P]),
     "fnp_spconv_wgrad_pairs": (c_int, [P, c_int, P, c_int, P, P, P, c_int, c_int, P, c_int, P, c_int, c_int, c_int, P, c_int64, P]),

@@ -318,6 +318,32 @@ def pack_weight_train(weight, dtype, mirror=0):
     return p, m
 
 
+def pack_weights_train(jobs, dtype):
+    """pack_weight_train for several layers in ONE launch (fnp_pack_weight_multi).  jobs: list of (weight, mirror mode), f32
+    contiguous CUDA parameters, at most 32; returns a list of (packed, mirror) in the same order."""
+    L = _l.load()
+    k = len(jobs)
+    assert 0 < k <= 32
+    outs, arrs = [], {n: [] for n in ("w", "p", "m", "co", "kk", "ci", "mo")}
+    for weight, mirror in jobs:
+        w = weight.detach()
+        assert w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda
+        Cout, Cin = w.shape[0], w.shape[-1]
+        K = w.shape[1] * w.shape[2] * w.shape[3]
+        p = torch.empty((K, Cout, Cin), dtype=dtype, device=w.device)
+        m = None if mirror == 0 else torch.empty((K, Cout, Cin) if mirror == 1 else (K, Cin, Cout), dtype=dtype, device=w.device)
+        outs.append((p, m))
+        for n, v in (("w", _l.ptr(w)), ("p", _l.ptr(p)), ("m", _l.ptr(m)), ("co", Cout), ("kk", K), ("ci", Cin), ("mo", mirror)):
+            arrs[n].append(v)
+    P, I = ctypes.c_void_p * k, ctypes.c_int * k
+    keep = [P(*arrs["w"]), I(*arrs["co"]), I(*arrs["kk"]), I(*arrs["ci"]), P(*arrs["p"]), P(*arrs["m"]), I(*arrs["mo"])]
+    rc = L.fnp_pack_weight_multi(k, ctypes.cast(keep[0], ctypes.c_void_p), ctypes.cast(keep[1], ctypes.c_void_p), ctypes.cast(keep[2], ctypes.c_void_p),
+                                 ctypes.cast(keep[3], ctypes.c_void_p), _l.dtype_code(outs[0][0]), ctypes.cast(keep[4], ctypes.c_void_p),
+                                 ctypes.cast(keep[5], ctypes.c_void_p), ctypes.cast(keep[6], ctypes.c_void_p), _l.stream())
+    _l.check(rc, "fnp_pack_weight_multi")
+    return outs
+
+
 HINT_ROWS_RANKED = 1   # fnp.h FNP_HINT_ROWS_RANKED
 HINT_VALU = 2          # fnp.h FNP_HINT_VALU
 HINT_W_PERMUTED = 4    # fnp.h FNP_HINT_W_PERMUTED

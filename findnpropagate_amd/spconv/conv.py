@@ -31,7 +31,7 @@ class SparseConvFunction(torch.autograd.Function):
     fp16), weight gradient accumulated in f32 and returned in the parameter's dtype."""
 
     @staticmethod
-    def forward(ctx, feats, weight, rb, n_out_dev, n_in_dev, ranked=False, rows=None):
+    def forward(ctx, feats, weight, rb, n_out_dev, n_in_dev, ranked=False, rows=None, prepacked=None):
         # rows: the output row count when the caller knows it on the host — the output then has exactly that many rows and
         # nobody slices it afterwards (the backward of a slice zero-fills a tensor of the full capacity: 4 x 0.1 ms per
         # training step at 16 scenes)
@@ -45,7 +45,11 @@ class SparseConvFunction(torch.autograd.Function):
         mirror = 0
         if ctx.needs_input_grad[0]:
             mirror = 2 if subm_self else 3
-        w, wm = S.pack_weight_train(weight, feats.dtype, mirror)
+        # prepacked: (dtype, mirror mode, packed, mirror slabs) from the backbone's one launch for all its layers
+        if prepacked is not None and prepacked[0] == feats.dtype and (mirror == 0 or prepacked[1] == mirror):
+            w, wm = prepacked[2], prepacked[3]
+        else:
+            w, wm = S.pack_weight_train(weight, feats.dtype, mirror)
         out = S.conv_forward(feats, w, rb, n_out_dev, ranked=ranked,
                              out=None if rows is None else torch.empty((rows, weight.shape[0]), dtype=feats.dtype, device=feats.device))
         ctx.save_for_backward(feats, weight)
@@ -82,7 +86,7 @@ class SparseConvFunction(torch.autograd.Function):
                     dx = S.conv_dgrad(grad_out, wp, rb._nbr_t, n_in_dev, feats.shape[0])
         if ctx.needs_input_grad[1]:
             dw = S.conv_wgrad(feats, grad_out, rb, n_out_dev, Cin, Cout, module_shape=weight.shape).to(weight.dtype)   # (f32: no copy)
-        return dx, dw, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None
 
 
 class SparseConvolution(SparseModule):
@@ -150,7 +154,10 @@ class SparseConvolution(SparseModule):
 
         def run(rb, n_out_dev, rows=None):
             if with_grad:
-                return SparseConvFunction.apply(feats, self.weight, rb, n_out_dev, n_dev, ranked, rows)
+                pre = self.__dict__.get("_fnp_prepack")   # (version, data_ptr, dtype, mode, packed, mirror): see prepack_weights
+                if pre is not None and (pre[0] != self.weight._version or pre[1] != self.weight.data_ptr()):
+                    pre = None
+                return SparseConvFunction.apply(feats, self.weight, rb, n_out_dev, n_dev, ranked, rows, None if pre is None else pre[2:])
             return S.conv_forward(feats, w, rb, n_out_dev, ranked=ranked,
                                   out=None if rows is None else torch.empty((rows, self.out_channels), dtype=feats.dtype, device=feats.device))
 
@@ -233,6 +240,25 @@ class SparseConvolution(SparseModule):
             done.record(side)
         rb.out_n.record_stream(side)
         indice_dict[("prefetch", id(self))] = (rb, done, host, indices.data_ptr(), indices.shape[0])
+
+
+def prepack_weights(convs_and_dtypes):
+    """Pack the weights of several SparseConvolution modules (and the slabs their data gradients read) in ONE launch per dtype,
+    ahead of their forwards: [(module, dtype)] -> each module remembers the result until its weight changes.  The training
+    forward is bound by the host: a pack launch per layer was 14 us of it, 21 times."""
+    groups = {}
+    for conv, dtype in convs_and_dtypes:
+        w = conv.weight
+        if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+            continue
+        odd = all(int(v) & 1 for v in conv.kernel_size)
+        groups.setdefault(dtype, []).append((conv, 2 if (conv.subm and odd) else 3))
+    for dtype, items in groups.items():
+        for i in range(0, len(items), 32):
+            part = items[i:i + 32]
+            outs = S.pack_weights_train([(c.weight, mode) for c, mode in part], dtype)
+            for (c, mode), (p, m) in zip(part, outs):
+                c.__dict__["_fnp_prepack"] = (c.weight._version, c.weight.data_ptr(), dtype, mode, p, m)
 
 
 PREFETCH = True   # (tests switch it off to compare with the synchronous path)

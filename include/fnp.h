@@ -434,6 +434,9 @@ int fnp_spconv_wgrad(const void *feat_in, int in_dtype, const void *grad_out, in
  * (k, Cin, Cout): the same for a strided layer on its transposed table (fnp_rulebook_transpose); 0 = none (mirror NULL). */
 int fnp_pack_weight(const float *weight, int Cout, int K, int Cin, int dtype, void *packed, void *mirror, int mirror_mode,
                     fnp_stream_t stream);
+/* the same for count <= 32 layers in one launch (host arrays of device pointers and shapes; one dtype for all) */
+int fnp_pack_weight_multi(int count, const float *const *weights, const int *couts, const int *ks, const int *cins, int dtype,
+                          void *const *packed, void *const *mirrors, const int *mirror_modes, fnp_stream_t stream);
 /* PAIR LISTS of a rulebook (ABI 8), for the weight gradient: offset k only sums over the output rows that HAVE a neighbour
  * at k (44-54 % of the rows on lidar scenes); fnp_rulebook_pairs compacts every column of the table once per rulebook —
  * pair_o[k][j] = the j-th such output row (ascending), pair_i[k][j] = its neighbour, pair_count[k] — and

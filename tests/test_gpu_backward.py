@@ -126,7 +126,7 @@ def test_backbone_training_step_runs_and_matches_torch_reference_ops(cuda, rng):
 
     class RefFn:   # same signature as SparseConvFunction.apply, torch ops only
         @staticmethod
-        def apply(f, weight, rb, n_out_dev, n_in_dev, ranked=False, rows=None):
+        def apply(f, weight, rb, n_out_dev, n_in_dev, ranked=False, rows=None, prepacked=None):
             n_out = int(n_out_dev.item())
             Cout, Cin = weight.shape[0], weight.shape[-1]
             wk = weight.reshape(Cout, rb.K, Cin)
