@@ -5,6 +5,9 @@ Contract (see the task statement): `python bench.py --gpus N --steps K --warmup 
 driver launches it under torch.distributed.run, one rank per GPU.  A step = one pass of the hot
 path over one batch of B synthetic 30k-point scenes already resident in HBM (workload =
 BASELINE.json configs[1]).  Scenes shard across ranks with no data-path collective (weak scaling).
+The timed step (--launch graphs, default) is replayed from two captured hipGraphs with the dominant kernel's
+four launches issued as plain launches between them, each bracketed with HIP events (`config.launch` says
+which form ran; --launch stream issues every kernel as a plain launch).
 Rank 0 prints ONE JSON line with the whole-job scenes/s plus:
   roofline     — the dominant kernel's algorithmic bytes per launch (SURVEY.md §8d formula, counts
                  taken from this run's rulebooks) / its mean launch duration measured with HIP
@@ -41,6 +44,10 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (fp32 engine, Box Seeker, extraction, training "
                                                                 "step: each a fresh child process)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket conv launches with events")
+    ap.add_argument("--launch", default="graphs", choices=["graphs", "stream"],
+                    help="how a timed step is issued: 'graphs' = replayed from two captured hipGraphs (index chain on a second branch) with "
+                         "the dominant kernel's four launches issued as plain launches between them, each bracketed with HIP events; "
+                         "'stream' = every kernel a plain stream launch (rounds 1-3's timed step)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the extra small-batch measurements (1 and 8 scenes per step)")
     return ap.parse_args()
 
@@ -202,10 +209,14 @@ def main():
     cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, syn.MAX_VOXELS_TEST)
     eng = net.engine()
 
+    probe_graphs = [False]   # the timed step replays the two-graph capture (decided below, once the dominant class is known)
+
     def step():
         with torch.no_grad():
             if args.graph and eng.rulebook_log is None and eng.profile is None:
                 return net.forward_points_graphed(pts, off, B, cfg)
+            if probe_graphs[0] and eng.rulebook_log is None:
+                return net.forward_points_graphed(pts, off, B, cfg, probe=True)
             return net.forward_points(pts, off, B, cfg)  # ends with the one host sync that sizes the outputs
 
     def barrier():
@@ -259,6 +270,16 @@ def main():
         tied = [k for k, v in per_class_ms.items() if v >= 0.85 * top]
         eng.profile_only = {min(tied, key=rate)}
         eng.profile = []
+        # The timed step: when the dominant class is the last SubM stage's (128 -> 128, 3x3x3: the engine can leave exactly those
+        # launches out of its captured graphs), the step is replayed from two hipGraphs with those four launches in between as
+        # plain launches, each between two timing events — the replayed step's throughput AND the dominant kernel's duration
+        # measured inside the same timed region.  Otherwise (or --launch stream) every kernel is a plain launch as before.
+        if args.launch == "graphs" and eng.profile_only == {(128, 128, 27)}:
+            probe_graphs[0] = True
+            for _ in range(2):   # (capture + one replay, untimed)
+                step()
+            torch.cuda.synchronize()
+            eng.profile = []
     # The timed region (EXACTLY --steps steps between two barrier + synchronize pairs, MAX over ranks) is repeated --reps
     # times back to back; `value` / `ms_per_step` are those of the MEDIAN repetition and the whole list is reported (one
     # 0.12 s region is a single draw: boxes of the pool differ by +-8 %, and so do repetitions on one box by 1-2 %).
@@ -306,7 +327,9 @@ def main():
                    "voxels_per_scene": int(counts[0] // B), "sparse_shape": [41, 1440, 1440],
                    "site_counts": [int(c) for c in counts], "weights": "seeded random init",
                    "parallelism": f"scenes sharded {world}x, no data-path collective",
-                   "launch": "hipGraph replay" if args.graph else "stream launches"},
+                   "launch": ("hipGraph replay" if args.graph else
+                              "two hipGraphs per step (index chain on a second branch) with the dominant kernel's four launches "
+                              "stream-launched between them and bracketed with HIP events" if probe_graphs[0] else "stream launches")},
     }
 
     if rank == 0 and prof:
@@ -447,10 +470,10 @@ def main():
         out["batch_sweep"] = sweep
         # The same 64-scene step with several BATCHES in flight (PointsPipeline: a hipGraph, an engine and a HIP stream per slot;
         # results identical per batch): what a server that is handed batches back to back gets out of the card — the latency-bound
-        # index kernels of one batch run under the convolutions of another.  Reported beside `value`, which stays one batch at a time,
-        # stream-launched (so that the dominant kernel can be bracketed with events inside the timed region).  With ONE batch in
-        # flight this is the hipGraph replay of the same step: the engine captures its index chain (rank grids, rulebooks, class
-        # sort: coordinates only) on a second branch that runs beside the convolutions of the stage before.
+        # index kernels of one batch run under the convolutions of another.  Reported beside `value`, which stays one batch at a time.
+        # With ONE batch in flight this is the one-graph replay of the same step (the engine captures its index chain — rank
+        # grids, rulebooks, class sort: coordinates only — on a second branch that runs beside the convolutions of the stage
+        # before); `value`'s step is the same thing cut into two graphs around the dominant kernel's launches.
         try:
             pl = {}
             with torch.no_grad():

@@ -299,12 +299,12 @@ class VoxelResBackBone8x(_BackboneBase):
         'voxel_features'."""
         return self.engine().run_points(points, batch_offsets, batch_size, voxel_cfg, sync=sync)
 
-    def forward_points_graphed(self, points, batch_offsets, batch_size, voxel_cfg, capacity=None):
+    def forward_points_graphed(self, points, batch_offsets, batch_size, voxel_cfg, capacity=None, probe=False):
         """forward_points replayed from a captured hipGraph (one graph launch instead of ~100 kernel
         launches: small batches are launch-bound).  Same results; the returned tensors are views of the
         graph's static buffers and are overwritten by the next call with the same (batch_size, capacity).
         capacity: point capacity of the graph (default: N rounded up to 64 Ki)."""
-        return self.engine().run_points_graphed(points, batch_offsets, batch_size, voxel_cfg, capacity)
+        return self.engine().run_points_graphed(points, batch_offsets, batch_size, voxel_cfg, capacity, probe=probe)
 
     def points_pipeline(self, batch_size, voxel_cfg, depth=2, capacity=65536, n_feat=5):
         """forward_points_graphed for frames that arrive one at a time, `depth` of them in flight on their own HIP streams
@@ -323,7 +323,13 @@ class _PointsGraph:
     """Static inputs + captured forward of one (batch_size, point capacity) configuration."""
     FAR = 1.0e9   # padding points: outside every range, dropped by the voxeliser
 
-    def __init__(self, engine, capacity, n_feat, batch_size, voxel_cfg, device):
+    def __init__(self, engine, capacity, n_feat, batch_size, voxel_cfg, device, probe=False):
+        # probe: the forward is captured as TWO graphs with the launches of the last SubM stage (the four 128 -> 128
+        # convolutions of VoxelResBackBone8x: the step's dominant kernel) left out between them; replay() issues those as plain
+        # launches, each bracketed with a pair of timing events when asked to.  A measurement device (bench.py: the step replayed
+        # from graphs AND its dominant kernel timed with events inside the timed region, which nodes of a graph do not allow);
+        # same kernels, same buffers, same values as the one-graph form.
+        self.probe, self.deferred, self.graph_b = bool(probe), [], None
         self.engine, self.capacity, self.batch_size = engine, capacity, batch_size
         self.pts = torch.full((capacity, n_feat), self.FAR, dtype=torch.float32, device=device)
         self.off = torch.zeros((batch_size + 1,), dtype=torch.int32, device=device)
@@ -344,11 +350,44 @@ class _PointsGraph:
         gc.collect()
         gc.disable()
         try:
-            with torch.cuda.graph(self.graph):
-                self.vox, self.res = self._body(voxel_cfg)
+            if not self.probe:
+                with torch.cuda.graph(self.graph):
+                    self.vox, self.res = self._body(voxel_cfg)
+            else:
+                self.graph_b = torch.cuda.CUDAGraph()
+                self._ctx = torch.cuda.graph(self.graph)
+                self._ctx.__enter__()
+                try:
+                    self.vox, self.res = self._body(voxel_cfg)   # (the engine calls cut() where the first graph ends)
+                finally:
+                    self._ctx.__exit__(None, None, None)
+                assert self.deferred, "the engine did not reach its cut"
         finally:
             if gc_was_on:
                 gc.enable()
+
+    def cut(self):
+        """called by the engine between the two captured halves (every forked stream rejoined): ends the first graph's capture
+        and begins the second's on the same capture stream and memory pool"""
+        self._ctx.__exit__(None, None, None)
+        self._ctx = torch.cuda.graph(self.graph_b, pool=self.graph.pool())
+        self._ctx.__enter__()
+
+    def replay(self, profile=None):
+        """one forward.  probe graphs: first half, the deferred launches (each between two timing events appended to `profile`
+        as (tag, start, end) when a list is given), second half"""
+        self.graph.replay()
+        if self.probe:
+            for tag, launch in self.deferred:
+                if profile is None:
+                    launch()
+                else:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    launch()
+                    e1.record()
+                    profile.append((tag, e0, e1))
+            self.graph_b.replay()
 
     def _body(self, voxel_cfg):
         e = self.engine
@@ -357,7 +396,8 @@ class _PointsGraph:
         grids = e._get_grids(self.batch_size, self.pts.device)
         vox = S.voxelize(self.pts, self.off, self.batch_size, voxel_cfg, grid=grids[0], workspace=e._vox_ws)
         e._vox_ws = vox['workspace']
-        res = e._run_once(vox['mean'], vox['coords'], vox['n'], self.batch_size, grids[0], sync=False, n_cells=vox['n_cells'])
+        res = e._run_once(vox['mean'], vox['coords'], vox['n'], self.batch_size, grids[0], sync=False, n_cells=vox['n_cells'],
+                          probe=self if (self.probe and self.graph_b is not None) else None)
         return vox, res
 
 
@@ -414,7 +454,7 @@ class PointsPipeline:
                 g.pts[n:g.n_prev].fill_(_PointsGraph.FAR)
             g.n_prev = n
             g.off.copy_(batch_offsets, non_blocking=True)
-            g.graph.replay()
+            g.replay()
             counts = g.res['counts_dev']
             if g.counts_host is None or g.counts_host.numel() != counts.numel():
                 g.counts_host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
@@ -626,24 +666,29 @@ class FusedResBackbone:
             res['voxel_features'] = vox['mean'][:n1]
         return res
 
-    def run_points_graphed(self, points, batch_offsets, batch_size, voxel_cfg, capacity=None):
-        assert self.profile is None and self.rulebook_log is None, "measurement hooks are not capturable"
+    def run_points_graphed(self, points, batch_offsets, batch_size, voxel_cfg, capacity=None, probe=False):
+        # probe: the two-graph form of _PointsGraph; self.profile (a list) then receives the event pairs of the launches between
+        assert (self.profile is None or probe) and self.rulebook_log is None, "measurement hooks are not capturable"
         n, C = points.shape
         capacity = int(capacity) if capacity else max(65536, (n + 65535) // 65536 * 65536)
         assert n <= capacity
         self.prepare()
-        key = (batch_size, capacity, C, str(points.device))
+        key = (batch_size, capacity, C, str(points.device), bool(probe))
         while True:
             g = self._graphs.get(key)
             if g is None or g.cap_factor != list(self.cap_factor) + list(self.ell_pool) or g.prep_key != self._prep_key:
-                g = _PointsGraph(self, capacity, C, batch_size, voxel_cfg, points.device)
+                prof, self.profile = self.profile, None   # (the capture itself is not a measurement)
+                try:
+                    g = _PointsGraph(self, capacity, C, batch_size, voxel_cfg, points.device, probe=probe)
+                finally:
+                    self.profile = prof
                 self._graphs[key] = g
             g.pts[:n].copy_(points)
             if g.n_prev > n:
                 g.pts[n:g.n_prev].fill_(_PointsGraph.FAR)
             g.n_prev = n
             g.off.copy_(batch_offsets)
-            g.graph.replay()
+            g.replay(self.profile if probe else None)
             stage, caps, shapes = g.res['stages'], g.res['caps'], g.res['shapes']
             counts = g.res['counts_dev'].cpu().tolist()   # the one host sync
             overflow = self._ell_overflow(counts, g.res['ell_used'], caps[0])
@@ -675,7 +720,7 @@ class FusedResBackbone:
             # overflow: capacities were grown and grids cleared; rebuild grid1 from the indices
             grid1 = None
 
-    def _run_once(self, feats, indices, n1, batch_size, grid1, sync, n_cells=None, final_dtype=None):
+    def _run_once(self, feats, indices, n1, batch_size, grid1, sync, n_cells=None, final_dtype=None, probe=None):
         # The persistent rank grids must be all-zero on entry and are only cleared sparsely at the end of a run: if a
         # previous run died in between (FnpError, out of memory, KeyboardInterrupt), wipe them before they are reused
         # (run_points checks before it voxelises into grid1)
@@ -830,9 +875,30 @@ class FusedResBackbone:
                                      out_grid=grids[4], premarked=premarked)
 
         # ---- convolutions -----------------------------------------------------------------------------------------------
+        joined = [False]
+
         def ready(i):
-            if two:
+            if two and not joined[0]:
                 main.wait_event(events[i])
+
+        def blocks_deferred(x, rb, n, prms):
+            # (probe: _PointsGraph) the stage's output buffers are allocated in the first graph's pool, the capture is cut, and
+            # the launches are handed over as closures: replay() issues them between the two graphs
+            plan = []
+            for p1, p2 in prms:
+                t = torch.empty((rb.cap_out, int(p1[0].shape[1])), dtype=act, device=dev)
+                y = torch.empty((rb.cap_out, int(p2[0].shape[1])), dtype=act, device=dev)
+                plan.append((x, t, y, p1, p2))
+                x = y
+            probe.cut()
+            for xin, t, y, p1, p2 in plan:
+                tag1 = (int(p1[0].shape[2]), int(p1[0].shape[1]), int(p1[0].shape[0]), False, True)
+                tag2 = (int(p2[0].shape[2]), int(p2[0].shape[1]), int(p2[0].shape[0]), True, True)
+                probe.deferred.append((tag1, lambda xin=xin, t=t, p1=p1: S.conv_forward(xin, p1[0], rb, n, out_dtype=act, scale=p1[1], shift=p1[2],
+                                                                                     relu=True, ranked=True, out=t)))
+                probe.deferred.append((tag2, lambda xin=xin, t=t, y=y, p2=p2: S.conv_forward(t, p2[0], rb, n, out_dtype=act, scale=p2[1], shift=p2[2],
+                                                                                          residual=xin, relu=True, ranked=True, out=y)))
+            return x
 
         ready(0)
         x = conv(feats, P['in'], rb1, n1)
@@ -842,7 +908,12 @@ class FusedResBackbone:
         for li, (down_key, blk_key, rbs, rb) in enumerate(books):
             ready(li + 1)
             x = conv(x_prev, P[down_key], rbs, rbs.out_n)
-            x = blocks(x, rb, rbs.out_n, P[blk_key], ranked=True)
+            if probe is not None and li == len(books) - 1:
+                ready(4)            # (a capture may end only with every forked stream rejoined)
+                joined[0] = True
+                x = blocks_deferred(x, rb, rbs.out_n, P[blk_key])
+            else:
+                x = blocks(x, rb, rbs.out_n, P[blk_key], ranked=True)
             stage.append((x, rbs.out_indices, rbs.out_n, rbs.out_grid))
             x_prev = x
         ready(4)

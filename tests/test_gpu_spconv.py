@@ -912,3 +912,34 @@ def test_index_chain_on_a_second_stream_changes_nothing(cuda, mode, monkeypatch)
     for other in outs[1:]:
         for (fa, ia), (fb, ib) in zip(outs[0], other):
             assert torch.equal(ia, ib) and torch.equal(fa, fb)
+
+
+def test_probe_graphs_equal_eager_and_time_the_dominant_launches(cuda):
+    """forward_points_graphed(probe=True): the forward captured as two graphs with the four 128 -> 128 launches of stage 4 issued
+    as plain launches between them (bench.py's timed step).  Same rows as the eager forward at every stage, twice in a row
+    and for another frame through the same graphs; with a profile list set, every step appends four (tag, start, end) event
+    pairs whose tags are the stage-4 SubM layers'."""
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 0).to(cuda).eval()
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+    eng = net.engine()
+    keys = ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out")
+    with torch.no_grad():
+        for seeds in ([0, 1, 2], [3, 4, 5], [0, 1, 2]):
+            pts, off = syn.make_batch(seeds)
+            pts, off = torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda)
+            want = net.forward_points(pts, off, 3, cfg)
+            want = [(want[k].features.clone(), want[k].indices.clone()) for k in keys]
+            eng.profile = []
+            try:
+                got = net.forward_points_graphed(pts, off, 3, cfg, capacity=131072, probe=True)
+                torch.cuda.synchronize()
+                prof = eng.profile
+            finally:
+                eng.profile = None
+            for (wf, wi), k in zip(want, keys):
+                assert torch.equal(got[k].indices, wi) and torch.equal(got[k].features, wf), k
+            assert [t[0] for t in prof] == [(128, 128, 27, False, True), (128, 128, 27, True, True)] * 2
+            assert all(e0.elapsed_time(e1) > 0.0 for _, e0, e1 in prof)
+    assert sum(1 for k in eng._graphs if k[-1] is True) == 1, "one pair of graphs served the three calls"
