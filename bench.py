@@ -188,7 +188,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("FNP_BENCH_FORCE_DIST") == "1":   # (the switch: a one-rank process group, to rehearse the N > 1 path on one GPU)
         import torch.distributed as dist_
 
         dist = dist_
@@ -276,9 +276,16 @@ def main():
         # measured inside the same timed region.  Otherwise (or --launch stream) every kernel is a plain launch as before.
         if args.launch == "graphs" and eng.profile_only == {(128, 128, 27)}:
             probe_graphs[0] = True
-            for _ in range(2):   # (capture + one replay, untimed)
+            try:
+                for _ in range(2):   # (capture + one replay, untimed)
+                    step()
+                torch.cuda.synchronize()
+            except Exception as e:   # (a capture that cannot be taken here must not cost the run its headline: plain launches then)
+                print(f"bench: two-graph step unavailable ({repr(e)[:200]}); timing plain stream launches", file=sys.stderr)
+                probe_graphs[0] = False
+                torch.cuda.synchronize()
                 step()
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
             eng.profile = []
     # The timed region (EXACTLY --steps steps between two barrier + synchronize pairs, MAX over ranks) is repeated --reps
     # times back to back; `value` / `ms_per_step` are those of the MEDIAN repetition and the whole list is reported (one
