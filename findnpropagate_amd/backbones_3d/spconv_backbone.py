@@ -329,7 +329,12 @@ class _PointsGraph:
         # launches, each bracketed with a pair of timing events when asked to.  A measurement device (bench.py: the step replayed
         # from graphs AND its dominant kernel timed with events inside the timed region, which nodes of a graph do not allow);
         # same kernels, same buffers, same values as the one-graph form.
+        # Every capture is TWO graphs, cut where the counts are final (in front of the last SubM stage): replay() copies them to
+        # pinned memory between the two and records counts_event there, so the host sizes the outputs while the second graph
+        # still runs (done_event marks its end).
         self.probe, self.deferred, self.graph_b = bool(probe), [], None
+        self.counts_dev, self.counts_pin = None, None
+        self.counts_event, self.done_event = torch.cuda.Event(), torch.cuda.Event()
         self.engine, self.capacity, self.batch_size = engine, capacity, batch_size
         self.pts = torch.full((capacity, n_feat), self.FAR, dtype=torch.float32, device=device)
         self.off = torch.zeros((batch_size + 1,), dtype=torch.int32, device=device)
@@ -350,25 +355,22 @@ class _PointsGraph:
         gc.collect()
         gc.disable()
         try:
-            if not self.probe:
-                with torch.cuda.graph(self.graph):
-                    self.vox, self.res = self._body(voxel_cfg)
-            else:
-                self.graph_b = torch.cuda.CUDAGraph()
-                self._ctx = torch.cuda.graph(self.graph)
-                self._ctx.__enter__()
-                try:
-                    self.vox, self.res = self._body(voxel_cfg)   # (the engine calls cut() where the first graph ends)
-                finally:
-                    self._ctx.__exit__(None, None, None)
-                assert self.deferred, "the engine did not reach its cut"
+            self.graph_b = torch.cuda.CUDAGraph()
+            self._ctx = torch.cuda.graph(self.graph)
+            self._ctx.__enter__()
+            try:
+                self.vox, self.res = self._body(voxel_cfg)   # (the engine calls counts_ready() where the first graph ends)
+            finally:
+                self._ctx.__exit__(None, None, None)
+            assert self.counts_dev is not None and (self.deferred or not self.probe), "the engine did not reach its cut"
         finally:
             if gc_was_on:
                 gc.enable()
 
-    def cut(self):
-        """called by the engine between the two captured halves (every forked stream rejoined): ends the first graph's capture
-        and begins the second's on the same capture stream and memory pool"""
+    def counts_ready(self, counts_dev):
+        """called by the engine where the counts are final (every forked stream rejoined): ends the first graph's capture and
+        begins the second's on the same capture stream and memory pool"""
+        self.counts_dev = counts_dev
         self._ctx.__exit__(None, None, None)
         self._ctx = torch.cuda.graph(self.graph_b, pool=self.graph.pool())
         self._ctx.__enter__()
@@ -377,6 +379,10 @@ class _PointsGraph:
         """one forward.  probe graphs: first half, the deferred launches (each between two timing events appended to `profile`
         as (tag, start, end) when a list is given), second half"""
         self.graph.replay()
+        if self.counts_pin is None:
+            self.counts_pin = torch.empty((16,), dtype=torch.int32, pin_memory=True)
+        self.counts_pin[:self.counts_dev.numel()].copy_(self.counts_dev, non_blocking=True)
+        self.counts_event.record()
         if self.probe:
             for tag, launch in self.deferred:
                 if profile is None:
@@ -387,7 +393,13 @@ class _PointsGraph:
                     launch()
                     e1.record()
                     profile.append((tag, e0, e1))
-            self.graph_b.replay()
+        self.graph_b.replay()
+        self.done_event.record()
+
+    def counts(self):
+        """the host's copy of the last replay's counts (waits for the counts only, not for the second graph)"""
+        self.counts_event.synchronize()
+        return self.counts_pin[:self.counts_dev.numel()].tolist()
 
     def _body(self, voxel_cfg):
         e = self.engine
@@ -397,7 +409,7 @@ class _PointsGraph:
         vox = S.voxelize(self.pts, self.off, self.batch_size, voxel_cfg, grid=grids[0], workspace=e._vox_ws)
         e._vox_ws = vox['workspace']
         res = e._run_once(vox['mean'], vox['coords'], vox['n'], self.batch_size, grids[0], sync=False, n_cells=vox['n_cells'],
-                          probe=self if (self.probe and self.graph_b is not None) else None)
+                          probe=self if self.graph_b is not None else None)
         return vox, res
 
 
@@ -454,23 +466,17 @@ class PointsPipeline:
                 g.pts[n:g.n_prev].fill_(_PointsGraph.FAR)
             g.n_prev = n
             g.off.copy_(batch_offsets, non_blocking=True)
-            g.replay()
-            counts = g.res['counts_dev']
-            if g.counts_host is None or g.counts_host.numel() != counts.numel():
-                g.counts_host = torch.empty(counts.shape, dtype=counts.dtype, pin_memory=True)
-            g.counts_host.copy_(counts, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(st)
+            g.replay()    # (copies the counts to pinned memory between its two graphs; done_event at the end)
         points.record_stream(st)
         batch_offsets.record_stream(st)
-        self.pending.append((d, ev, (points, batch_offsets)))
+        self.pending.append((d, None, (points, batch_offsets)))
 
     def result(self):
         """the oldest frame in flight: the dict of forward_points_graphed.  Waits for that frame only."""
-        d, ev, (points, batch_offsets) = self.pending.pop(0)
+        d, _, (points, batch_offsets) = self.pending.pop(0)
         g, e = self.slots[d], self.engines[d]
-        ev.synchronize()
-        counts = g.counts_host.tolist()
+        counts = g.counts()
+        ev = g.done_event
         overflow = e._ell_overflow(counts, g.res['ell_used'], g.res['caps'][0])
         e._check_aborts(counts.pop())
         caps = g.res['caps']
@@ -478,8 +484,9 @@ class PointsPipeline:
         torch.cuda.current_stream(self.device).wait_event(ev)   # the caller's stream reads the slot's buffers next
         if overflow:
             # a capacity was too small for this frame: the engine's own loop grows it and recaptures (synchronously; rare)
-            for pd, pev, _ in self.pending:
-                pev.synchronize()
+            ev.synchronize()
+            for pd, _, _ in self.pending:
+                self.slots[pd].done_event.synchronize()
             self.slots[d] = None
             return e.run_points_graphed(points, batch_offsets, self.batch_size, self.cfg, self.capacity)
         stage, shapes = g.res['stages'], g.res['shapes']
@@ -521,6 +528,7 @@ class FusedResBackbone:
         self._graphs = {}
         self._ell_ctr = {}
         self._side = {}
+        self._counts_pin = None
         self.two_streams = True   # (PointsPipeline clears it for its slots when several frames are in flight: they already overlap)
         self._dirty = False      # a forward is in flight or died before its sparse clear: grids may hold stale bits
         # measurement hooks (bench.py): when `profile` is a list every conv launch is bracketed by
@@ -690,7 +698,7 @@ class FusedResBackbone:
             g.off.copy_(batch_offsets)
             g.replay(self.profile if probe else None)
             stage, caps, shapes = g.res['stages'], g.res['caps'], g.res['shapes']
-            counts = g.res['counts_dev'].cpu().tolist()   # the one host sync
+            counts = g.counts()   # the one host sync: the counts' copy between the two graphs
             overflow = self._ell_overflow(counts, g.res['ell_used'], caps[0])
             self._check_aborts(counts.pop())
             for l in range(1, 5):
@@ -699,6 +707,7 @@ class FusedResBackbone:
                     overflow = True
             if not overflow:
                 break
+            torch.cuda.synchronize(points.device)                  # (the second graph of the failed forward may still be running)
             for gr in self._get_grids(batch_size, points.device):   # see _run_once: the sparse clear missed cells
                 gr.zero_()
             del self._graphs[key]                                  # recapture with the larger buffers
@@ -890,7 +899,7 @@ class FusedResBackbone:
                 y = torch.empty((rb.cap_out, int(p2[0].shape[1])), dtype=act, device=dev)
                 plan.append((x, t, y, p1, p2))
                 x = y
-            probe.cut()
+            counts_now()     # (probe: the capture is cut inside)
             for xin, t, y, p1, p2 in plan:
                 tag1 = (int(p1[0].shape[2]), int(p1[0].shape[1]), int(p1[0].shape[0]), False, True)
                 tag2 = (int(p2[0].shape[2]), int(p2[0].shape[1]), int(p2[0].shape[0]), True, True)
@@ -900,6 +909,28 @@ class FusedResBackbone:
                                                                                           residual=xin, relu=True, ranked=True, out=y)))
             return x
 
+        # THE COUNTS LEAVE EARLY (round 3, late).  Everything the host reads in a forward's one synchronisation — the five stage
+        # counts, the tiled kernels' time-out counter (their last launch is in stage 3), the pool counters of the compact
+        # rulebooks — is final once the index chain is done and the strided layer of stage 4 has been issued: the counts launch
+        # and (stream path) their copy to pinned memory go in front of the four 128 -> 128 convolutions, 30 % of the step.  The
+        # host then waits for THAT event, sizes the outputs and returns while the GPU is still convolving; the caller's next
+        # forward queues up behind it, and the ~0.1 ms the GPU used to idle between two forwards (copy back, Python, the first
+        # launches of the next forward) is gone.  The returned tensors are ordinary stream-ordered torch tensors.
+        counts_box = {}
+
+        def counts_now():
+            srcs = [(None, None, n1)] + [(None, None, b[2].out_n) for b in books] + [(None, None, rbo.out_n)]
+            cd = counts_box['dev'] = self._counts_word(srcs, ell_used, dev)
+            if probe is not None:
+                probe.counts_ready(cd)          # (_PointsGraph: the first captured graph ends here)
+            elif sync:
+                pin = self._counts_pin
+                if pin is None or pin.numel() < cd.numel():
+                    pin = self._counts_pin = torch.empty((16,), dtype=torch.int32, pin_memory=True)
+                pin[:cd.numel()].copy_(cd, non_blocking=True)
+                counts_box['ev'] = torch.cuda.Event()
+                counts_box['ev'].record()
+
         ready(0)
         x = conv(feats, P['in'], rb1, n1)
         x1 = blocks(x, rb1, n1, P['blocks1'])
@@ -908,27 +939,31 @@ class FusedResBackbone:
         for li, (down_key, blk_key, rbs, rb) in enumerate(books):
             ready(li + 1)
             x = conv(x_prev, P[down_key], rbs, rbs.out_n)
-            if probe is not None and li == len(books) - 1:
-                ready(4)            # (a capture may end only with every forked stream rejoined)
+            if li == len(books) - 1:
+                ready(4)            # (every index kernel is behind us; a capture may end only with every forked stream rejoined)
                 joined[0] = True
-                x = blocks_deferred(x, rb, rbs.out_n, P[blk_key])
+                if probe is not None and probe.probe:
+                    x = blocks_deferred(x, rb, rbs.out_n, P[blk_key])
+                else:
+                    counts_now()
+                    x = blocks(x, rb, rbs.out_n, P[blk_key], ranked=True)
             else:
                 x = blocks(x, rb, rbs.out_n, P[blk_key], ranked=True)
             stage.append((x, rbs.out_indices, rbs.out_n, rbs.out_grid))
             x_prev = x
-        ready(4)
         xo = conv(x_prev, P['out'], rbo, rbo.out_n, out_dtype=final_dtype or act)
         stage.append((xo, rbo.out_indices, rbo.out_n, rbo.out_grid))
 
         # leave every persistent grid zeroed for the next call (O(rows) sparse clear, all five grids in one launch)
         S.clear_grids([(g, idx, n_cells if (l == 0 and n_cells is not None) else n) for l, (_, idx, n, g) in enumerate(stage)])
         self._dirty = False
-        counts_dev = self._counts_word(stage, ell_used, dev)
+        counts_dev = counts_box['dev']
 
         shapes = self._stage_shapes()
         if not sync:
             return {'stages': stage, 'shapes': shapes, 'caps': caps, 'batch_size': batch_size, 'counts_dev': counts_dev, 'ell_used': ell_used}
-        counts = counts_dev.cpu().tolist()   # the one host sync
+        counts_box['ev'].synchronize()   # the one host sync: the counts' copy, not the end of the forward
+        counts = self._counts_pin[:counts_dev.numel()].tolist()
         overflow = self._ell_overflow(counts, ell_used, cap1)
         self._check_aborts(counts.pop())
         for l in range(1, 5):
