@@ -335,6 +335,7 @@ class _PointsGraph:
         self.probe, self.deferred, self.graph_b = bool(probe), [], None
         self.counts_dev, self.counts_pin = None, None
         self.counts_event, self.done_event = torch.cuda.Event(), torch.cuda.Event()
+        self._replayed = False
         self.engine, self.capacity, self.batch_size = engine, capacity, batch_size
         self.pts = torch.full((capacity, n_feat), self.FAR, dtype=torch.float32, device=device)
         self.off = torch.zeros((batch_size + 1,), dtype=torch.int32, device=device)
@@ -378,6 +379,9 @@ class _PointsGraph:
     def replay(self, profile=None):
         """one forward.  probe graphs: first half, the deferred launches (each between two timing events appended to `profile`
         as (tag, start, end) when a list is given), second half"""
+        if self._replayed:   # (the previous replay may have been issued on another stream: the buffers are shared)
+            torch.cuda.current_stream(self.pts.device).wait_event(self.done_event)
+        self._replayed = True
         self.graph.replay()
         if self.counts_pin is None:
             self.counts_pin = torch.empty((16,), dtype=torch.int32, pin_memory=True)
@@ -529,6 +533,7 @@ class FusedResBackbone:
         self._ell_ctr = {}
         self._side = {}
         self._counts_pin = None
+        self._last_done = None
         self.two_streams = True   # (PointsPipeline clears it for its slots when several frames are in flight: they already overlap)
         self._dirty = False      # a forward is in flight or died before its sparse clear: grids may hold stale bits
         # measurement hooks (bench.py): when `profile` is a list every conv launch is bracketed by
@@ -660,6 +665,8 @@ class FusedResBackbone:
         return c
 
     def run_points(self, points, batch_offsets, batch_size, voxel_cfg, sync=True):
+        if points.is_cuda and self._last_done is not None and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(points.device).wait_event(self._last_done)   # (see _run_once: forwards return early)
         self._ensure_clean()
         self._dirty = True
         grids = self._get_grids(batch_size, points.device)
@@ -736,6 +743,11 @@ class FusedResBackbone:
         if grid1 is None:
             self._ensure_clean()
         self._dirty = True
+        # (a forward returns before the GPU has finished it — the counts leave early —: a caller that comes back on ANOTHER stream
+        #  must not touch the persistent grids and workspaces before the previous forward is through)
+        capturing = feats.is_cuda and torch.cuda.is_current_stream_capturing()
+        if feats.is_cuda and not capturing and self._last_done is not None:
+            torch.cuda.current_stream(feats.device).wait_event(self._last_done)
         m, P, act = self.m, self.prepare(), self.act
         if final_dtype not in (None, act, torch.float32):
             final_dtype = None       # (the conv epilogue writes the activation dtype or f32; anything else is cast by the caller)
@@ -958,6 +970,9 @@ class FusedResBackbone:
         S.clear_grids([(g, idx, n_cells if (l == 0 and n_cells is not None) else n) for l, (_, idx, n, g) in enumerate(stage)])
         self._dirty = False
         counts_dev = counts_box['dev']
+        if feats.is_cuda and not capturing:
+            self._last_done = torch.cuda.Event()
+            self._last_done.record()
 
         shapes = self._stage_shapes()
         if not sync:

@@ -943,3 +943,49 @@ def test_probe_graphs_equal_eager_and_time_the_dominant_launches(cuda):
             assert [t[0] for t in prof] == [(128, 128, 27, False, True), (128, 128, 27, True, True)] * 2
             assert all(e0.elapsed_time(e1) > 0.0 for _, e0, e1 in prof)
     assert sum(1 for k in eng._graphs if k[-1] is True) == 1, "one pair of graphs served the three calls"
+
+
+def test_forwards_that_return_early_are_safe_across_streams(cuda):
+    """A forward returns once its counts are on the host, with the GPU still convolving.  Calling the engine again from
+    ANOTHER stream right away (eager and replayed) must wait for the forward before it: alternating streams and frames, every
+    result equals the one computed with a device synchronisation after each call."""
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 0).to(cuda).eval()
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+    frames = []
+    for seeds in ([0, 1], [2, 3], [4, 5]):
+        pts, off = syn.make_batch(seeds)
+        frames.append((torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda)))
+    keys = ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out")
+    with torch.no_grad():
+        want = []
+        for pts, off in frames:
+            r = net.forward_points(pts, off, 2, cfg)
+            torch.cuda.synchronize()
+            want.append([(r[k].features.clone(), r[k].indices.clone()) for k in keys])
+        streams = [torch.cuda.Stream(cuda), torch.cuda.Stream(cuda)]
+        torch.cuda.synchronize()
+        # eager: six forwards issued back to back on alternating streams, nothing synchronised in between (each call's outputs
+        # are its own tensors)
+        got = []
+        for i in range(6):
+            pts, off = frames[i % 3]
+            with torch.cuda.stream(streams[i % 2]):
+                r = net.forward_points(pts, off, 2, cfg)
+                got.append([(r[k].features, r[k].indices) for k in keys])
+        torch.cuda.synchronize()
+        for i, g in enumerate(got):
+            for (gf, gi), (wf, wi) in zip(g, want[i % 3]):
+                assert torch.equal(gi, wi) and torch.equal(gf, wf), i
+        # replayed: the outputs are views of the graphs' buffers (valid until the next call), so each call's copies are taken on
+        # its stream and the next stream waits for them; the replay itself still has to wait for the previous replay's end
+        for i in range(6):
+            pts, off = frames[i % 3]
+            streams[i % 2].wait_stream(streams[(i + 1) % 2])
+            with torch.cuda.stream(streams[i % 2]):
+                r = net.forward_points_graphed(pts, off, 2, cfg, capacity=131072)
+                g = [(r[k].features.clone(), r[k].indices.clone()) for k in keys]
+            streams[i % 2].synchronize()
+            for (gf, gi), (wf, wi) in zip(g, want[i % 3]):
+                assert torch.equal(gi, wi) and torch.equal(gf, wf), i
