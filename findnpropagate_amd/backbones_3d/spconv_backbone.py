@@ -449,7 +449,6 @@ class PointsPipeline:
         if g is None or g.cap_factor != list(e.cap_factor) + list(e.ell_pool) or g.prep_key != e._prep_key:
             torch.cuda.synchronize(self.device)   # (capture: nothing else of this pipeline may be in flight)
             g = _PointsGraph(e, self.capacity, self.n_feat, self.batch_size, self.cfg, self.device)
-            g.counts_host = None
             self.slots[d] = g
         return g
 
