@@ -368,10 +368,14 @@ __global__ __launch_bounds__(kThreads) void pairs_emit_kernel(const int *__restr
 #ifndef FNP_WGRAD_TR_NARROW
 #define FNP_WGRAD_TR_NARROW 128
 #endif
+#ifndef FNP_WGRAD_TR_WIDE
+#define FNP_WGRAD_TR_WIDE 64   // (128 x 128; 32 -> 64 rows per tile at the end of round 3: twice the MFMAs between two barriers, still two
+                                //  workgroups per CU: 142 -> 122 us per launch at 16 scenes — the kernel is bound by its per-tile round trip)
+#endif
 template <int CIN, int COUT> struct WgradTile {
     static constexpr int NBO = COUT / 16, WB = NBO >= 4 ? 4 : NBO, WK = 4 / WB;
     // (two buffers x WK slices x rows x (dy row + x row + padding) must leave room for several workgroups per CU)
-    static constexpr int rows = (CIN + COUT >= 256) ? 32 : (CIN + COUT >= 192 || WK > 1) ? 64 : FNP_WGRAD_TR_NARROW;
+    static constexpr int rows = (CIN + COUT >= 256) ? FNP_WGRAD_TR_WIDE : (CIN + COUT >= 192 || WK > 1) ? 64 : FNP_WGRAD_TR_NARROW;
 };
 template <int CIN, int COUT, typename T16, bool PAIRS = false>
 __global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const T16 *__restrict__ x, const T16 *__restrict__ dy,
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(kThreads) void wgrad_mfma_kernel(const T16 *__restr
     constexpr int WB = NBO >= 4 ? 4 : NBO;          // waves across output-channel blocks
     constexpr int WK = 4 / WB;                      // row slices (k-split)
     constexpr int OB = NBO / WB;                    // output-channel blocks per wave
-    // rows per slice and tile: 32 (one MFMA step deep) where a tile is 16 MFMAs per wave (128 x 128); the narrow layers do
+    // rows per slice and tile: 64 where a 32-row step is 16 MFMAs per wave (128 x 128; 32 until the end of round 3); the narrow layers do
     // 2-8 MFMAs per 32 rows and were bound by the tile's barrier + LDS round trip, not by rows: they take 128 / 64 rows per
     // tile (4 / 2 MFMA steps between two barriers)
     constexpr int TR = WgradTile<CIN, COUT>::rows;
