@@ -11,3 +11,4 @@ from .core import SparseConvTensor  # noqa: E402,F401
 from .modules import SparseModule, SparseSequential  # noqa: E402,F401
 from .conv import SparseConv3d, SparseConvolution, SubMConv3d  # noqa: E402,F401
 from . import conv, modules, utils  # noqa: E402,F401
+from . import pytorch  # noqa: E402,F401  (INTEGRATION.md §2 aliases `spconv.pytorch` from this attribute)

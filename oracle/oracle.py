@@ -294,6 +294,50 @@ def round_bf16(a):
 
 
 # ---------------------------------------------------------------- VoxelResBackBone8x
+# The layer graph as data (spconv_backbone.py:193-234); backbone_forward executes this table and
+# tests/test_backbone_tree.py holds it to the module tree the reference's own constructor builds
+# (tests/golden/backbone_tree.json).  ("subm" | "down", prefix, cout, kernel, stride, padding, indice_key)
+# is a convolution + BatchNorm + ReLU (post_act_block, :8-27 / conv_input, conv_out); ("block", prefix,
+# planes, indice_key) a SparseBasicBlock (:30-67): conv1-bn1-relu-conv2-bn2-(+identity)-relu.
+RES_BACKBONE8X = (
+    ("subm", "conv_input", 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), "subm1", None),          # :193-197
+    ("block", "conv1.0", 16, "res1", None),                                             # :200-203
+    ("block", "conv1.1", 16, "res1", "x_conv1"),
+    ("down", "conv2.0", 32, (3, 3, 3), (2, 2, 2), (1, 1, 1), "spconv2", None),           # :205-210
+    ("block", "conv2.1", 32, "res2", None),
+    ("block", "conv2.2", 32, "res2", "x_conv2"),
+    ("down", "conv3.0", 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), "spconv3", None),           # :212-217
+    ("block", "conv3.1", 64, "res3", None),
+    ("block", "conv3.2", 64, "res3", "x_conv3"),
+    ("down", "conv4.0", 128, (3, 3, 3), (2, 2, 2), (0, 1, 1), "spconv4", None),          # :219-224
+    ("block", "conv4.1", 128, "res4", None),
+    ("block", "conv4.2", 128, "res4", "x_conv4"),
+    ("down", "conv_out", 128, (3, 1, 1), (2, 1, 1), "last_pad", "spconv_down2", "out"),  # :228-234
+)
+
+
+def backbone_layers(input_channels=5, last_pad=0):
+    """RES_BACKBONE8X flattened to its 21 convolutions in execution order: dicts with the conv's
+    state_dict prefix, its BatchNorm's prefix, subm, in/out channels, kernel, stride, padding,
+    indice_key, whether a residual is added before the ReLU, and the output name it closes."""
+    out, cin = [], int(input_channels)
+    for e in RES_BACKBONE8X:
+        if e[0] == "block":
+            _, prefix, planes, key, name = e
+            for j, (c, b) in enumerate((("conv1", "bn1"), ("conv2", "bn2"))):
+                out.append(dict(conv=f"{prefix}.{c}", bn=f"{prefix}.{b}", subm=True, cin=cin, cout=planes,
+                                kernel=[3, 3, 3], stride=[1, 1, 1], padding=[1, 1, 1], indice_key=key,
+                                residual=(j == 1), output=name if j == 1 else None))
+                cin = planes
+        else:
+            kind, prefix, cout, k, s, p, key, name = e
+            p = _triple(last_pad) if isinstance(p, str) else list(p)
+            out.append(dict(conv=f"{prefix}.0", bn=f"{prefix}.1", subm=(kind == "subm"), cin=cin, cout=cout,
+                            kernel=list(k), stride=list(s), padding=p, indice_key=key, residual=False, output=name))
+            cin = cout
+    return out
+
+
 def backbone_forward(params, voxel_features, voxel_coords, batch_size, sparse_shape, bf16=False, last_pad=0):
     """VoxelResBackBone8x.forward (spconv_backbone.py:243-295) in eval mode.
 
@@ -317,33 +361,21 @@ def backbone_forward(params, voxel_features, voxel_coords, batch_size, sparse_sh
         y.rulebooks = x.rulebooks
         return y
 
-    def basic_block(x, prefix, key):  # SparseBasicBlock.forward, spconv_backbone.py:51-67
-        o = subm_conv(x, W(f"{prefix}.conv1.weight"), key)
-        o = post(o, o.features, f"{prefix}.bn1")
-        o2 = subm_conv(o, W(f"{prefix}.conv2.weight"), key)
-        return post(o2, o2.features, f"{prefix}.bn2", residual=x.features)
-
-    def down(x, prefix, stride, padding):  # post_act_block conv_type='spconv', :8-27
-        o = sparse_conv(x, W(f"{prefix}.0.weight"), stride, padding)
-        return post(o, o.features, f"{prefix}.1")
-
     x = SparseTensor(voxel_features, voxel_coords, sparse_shape, batch_size)
-    o = subm_conv(x, W("conv_input.0.weight"), "subm1")                    # :193-197
-    x = post(o, o.features, "conv_input.1")
-    x = basic_block(x, "conv1.0", "res1")                                   # :200-203
-    x_conv1 = basic_block(x, "conv1.1", "res1")
-    x = down(x_conv1, "conv2.0", 2, 1)                                      # :205-210
-    x = basic_block(x, "conv2.1", "res2")
-    x_conv2 = basic_block(x, "conv2.2", "res2")
-    x = down(x_conv2, "conv3.0", 2, 1)                                      # :212-217
-    x = basic_block(x, "conv3.1", "res3")
-    x_conv3 = basic_block(x, "conv3.2", "res3")
-    x = down(x_conv3, "conv4.0", 2, (0, 1, 1))                              # :219-224
-    x = basic_block(x, "conv4.1", "res4")
-    x_conv4 = basic_block(x, "conv4.2", "res4")
-    o = sparse_conv(x_conv4, W("conv_out.0.weight"), (2, 1, 1), last_pad)   # :228-234, kernel (3,1,1)
-    out = post(o, o.features, "conv_out.1")
-    return {"x_conv1": x_conv1, "x_conv2": x_conv2, "x_conv3": x_conv3, "x_conv4": x_conv4, "out": out}
+    outs, identity = {}, None
+    for L in backbone_layers(np.asarray(voxel_features).shape[1], last_pad):
+        w = W(L["conv"] + ".weight")
+        assert list(w.shape) == [L["cout"], *L["kernel"], L["cin"]], (L["conv"], w.shape)
+        if L["subm"]:
+            if L["conv"].endswith(".conv1"):          # SparseBasicBlock.forward (:51-67): identity = x
+                identity = x.features
+            o = subm_conv(x, w, L["indice_key"])
+        else:
+            o = sparse_conv(x, w, L["stride"], L["padding"])
+        x = post(o, o.features, L["bn"], residual=identity if L["residual"] else None)
+        if L["output"]:
+            outs[L["output"]] = x
+    return outs
 
 
 # ---- recall bookkeeping and class NMS (host logic around the IoU / NMS operators) ----------------

@@ -1,0 +1,179 @@
+"""The backbone's layer graph held to what the REFERENCE's own constructors and forward() produce.
+
+tests/golden/backbone_tree.json and backbone_forward.npz were made by
+tests/golden/make_backbone_tree_golden.py: the reference's pcdet/models/backbones_3d/spconv_backbone.py
+(:8-67 post_act_block / SparseBasicBlock, :70-181 VoxelBackBone8x, :184-295 VoxelResBackBone8x), imported
+from /root/reference with `spconv` aliased exactly as INTEGRATION.md §2 prescribes, constructed for
+transfusion_lidar.yaml's arguments, and run once (forward, eval mode) on a small scene with the
+convolution primitive backed by the CPU oracle.  Three things are held to it here: the product's
+module classes, the oracle's layer table (oracle.RES_BACKBONE8X / backbone_layers, which
+backbone_forward executes), and — in the -m gpu set — the product's engines' outputs.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+TREE = json.load(open(os.path.join(HERE, "golden", "backbone_tree.json")))
+OUTPUTS = ("out", "x_conv1", "x_conv2", "x_conv3", "x_conv4")
+
+
+def _fixture():
+    return np.load(os.path.join(HERE, "golden", "backbone_forward.npz"))
+
+
+def _describe(m):
+    from findnpropagate_amd import spconv
+    d = {"class": type(m).__name__}
+    if isinstance(m, spconv.conv.SparseConvolution):
+        d.update(in_channels=m.in_channels, out_channels=m.out_channels, kernel_size=list(m.kernel_size),
+                 stride=list(m.stride), padding=list(m.padding), subm=bool(m.subm), indice_key=m.indice_key,
+                 bias=m.bias is not None)
+    elif isinstance(m, nn.BatchNorm1d):
+        d.update(num_features=m.num_features, eps=m.eps, momentum=m.momentum, affine=m.affine,
+                 track_running_stats=m.track_running_stats)
+    return d
+
+
+@pytest.mark.parametrize("cls_name", ["VoxelResBackBone8x", "VoxelBackBone8x"])
+def test_product_module_tree_is_the_reference_constructors(cls_name):
+    from findnpropagate_amd import backbones_3d
+    want = TREE[cls_name]
+    ctor = want["ctor"]
+    net = getattr(backbones_3d, cls_name)(ctor["model_cfg"], ctor["input_channels"], np.array(ctor["grid_size"]))
+    got = [{"name": n, **_describe(m)} for n, m in net.named_modules() if n]
+    assert [g["name"] for g in got] == [w["name"] for w in want["modules"]]
+    for g, w in zip(got, want["modules"]):
+        assert g == w, (g, w)
+    sd = {k: [list(t.shape), str(t.dtype).replace("torch.", "")] for k, t in net.state_dict().items()}
+    assert list(sd) == list(want["state_dict"]) or sorted(sd) == sorted(want["state_dict"])
+    assert sd == want["state_dict"]
+    assert [int(v) for v in net.sparse_shape] == want["sparse_shape"]
+    assert net.num_point_features == want["num_point_features"]
+    assert dict(net.backbone_channels) == want["backbone_channels"]
+
+
+def test_oracle_layer_table_is_the_reference_forward_order():
+    """oracle.backbone_layers() — the table oracle.backbone_forward executes — against the order in which the
+    reference's forward() reached its convolutions and BatchNorms, and the arguments its constructor gave them."""
+    want = TREE["VoxelResBackBone8x"]
+    mods = {m["name"]: m for m in want["modules"]}
+    calls = want["call_order"]
+    convs = [n for n in calls if mods[n]["class"] in ("SubMConv3d", "SparseConv3d")]
+    layers = O.backbone_layers(want["ctor"]["input_channels"], 0)
+    assert [L["conv"] for L in layers] == convs and len(convs) == 21
+    for L in layers:
+        m = mods[L["conv"]]
+        assert (m["in_channels"], m["out_channels"]) == (L["cin"], L["cout"]), L
+        assert m["kernel_size"] == L["kernel"] and m["subm"] == L["subm"] and m["indice_key"] == L["indice_key"], L
+        assert m["bias"] is False
+        if not L["subm"]:                       # (a SubM layer's stride / padding arguments are not used by spconv)
+            assert m["stride"] == L["stride"] and m["padding"] == L["padding"], L
+        i = calls.index(L["conv"])
+        assert calls[i + 1] == L["bn"], (calls[i:i + 3], L)            # conv -> its BatchNorm, nothing between
+        bn = mods[L["bn"]]
+        assert bn["class"] == "BatchNorm1d" and bn["num_features"] == L["cout"] and bn["eps"] == 1e-3 and bn["momentum"] == 0.01
+        # ReLU follows directly except behind bn2 of a block, where the residual add comes first (then the block's relu)
+        assert mods[calls[i + 2]]["class"] == "ReLU"
+    # a SparseBasicBlock shares one ReLU module: relu is called twice per block, once after bn1 and once after the add
+    assert sum(1 for n in calls if mods[n]["class"] == "ReLU") == 21
+    assert want["forward_keys"] == ["encoded_spconv_tensor", "encoded_spconv_tensor_stride", "multi_scale_3d_features",
+                                    "multi_scale_3d_strides"]
+    assert want["encoded_spconv_tensor_stride"] == 8
+    assert want["multi_scale_3d_strides"] == {"x_conv1": 1, "x_conv2": 2, "x_conv3": 4, "x_conv4": 8}
+
+
+def _weights(fx, dtype="fp32"):
+    from findnpropagate_amd import synthetic as syn
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    net = VoxelResBackBone8x({"USE_BIAS": False, "FNP_DTYPE": dtype}, 5, fx["grid_size"])
+    syn.init_backbone_weights(net, int(fx["weight_seed"])).eval()
+    chk = np.array([float(np.abs(v.detach().numpy()).astype(np.float64).sum()) for v in net.state_dict().values()])
+    assert np.allclose(chk, fx["state_checksum"], rtol=1e-12), "weight recipe drifted from the fixture's"
+    return net
+
+
+def test_oracle_backbone_forward_reproduces_the_reference_forward():
+    fx = _fixture()
+    net = _weights(fx)
+    sd = {k: t.detach().numpy() for k, t in net.state_dict().items()}
+    got = O.backbone_forward(sd, fx["voxel_features"], fx["voxel_coords"], 1, net.sparse_shape)
+    for k in OUTPUTS:
+        assert np.array_equal(got[k].indices, fx[k + "_indices"]), k
+        assert got[k].spatial_shape == fx[k + "_spatial_shape"].tolist()
+        w = fx[k + "_features"]
+        # torch's BatchNorm1d (eval) against the oracle's folded scale / shift: rounding only
+        assert np.abs(got[k].features - w).max() <= 1e-5 * max(1.0, np.abs(w).max()), k
+
+
+def test_integration_shim_runs_as_documented():
+    """INTEGRATION.md §2's first code block, executed verbatim in a fresh interpreter, followed by what
+    pcdet/utils/spconv_utils.py:3-10 does with the aliased module."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2."):]
+    block = sec[sec.index("```python") + len("```python"):]
+    block = block[:block.index("```")]
+    assert 'sys.modules["spconv"]' in block and 'sys.modules["spconv.pytorch"]' in block
+    tail = (
+        "\nimport spconv\n"
+        "assert float(spconv.__version__[2:]) >= 2.2\n"
+        "spconv.constants.SPCONV_USE_DIRECT_TABLE = False\n"
+        "import spconv.pytorch as spconv\n"
+        "import torch.nn as nn\n"
+        "assert issubclass(spconv.SubMConv3d, spconv.conv.SparseConvolution) and issubclass(spconv.SparseConv3d, spconv.conv.SparseConvolution)\n"
+        "assert issubclass(spconv.SparseSequential, nn.Module) and issubclass(spconv.SparseModule, nn.Module)\n"
+        "m = spconv.SparseSequential(spconv.SubMConv3d(5, 16, 3, padding=1, bias=False, indice_key='subm1'), nn.BatchNorm1d(16), nn.ReLU())\n"
+        "assert list(m.state_dict()) [0] == '0.weight' and tuple(m[0].weight.shape) == (16, 3, 3, 3, 5)\n"
+        "import pcdet.ops.iou3d_nms.iou3d_nms_cuda as a, pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda as b\n"
+        "assert hasattr(a, 'boxes_overlap_bev_gpu') and hasattr(a, 'nms_gpu') and hasattr(b, 'points_in_boxes_gpu')\n"
+        "print('shim ok')\n")
+    # `import pcdet.ops...` resolves through sys.modules only if the parents exist: the reference's own package does that;
+    # here two empty parents stand for it
+    head = ("import sys, types\n"
+            "for n in ('pcdet', 'pcdet.ops', 'pcdet.ops.iou3d_nms', 'pcdet.ops.roiaware_pool3d'):\n"
+            "    m = types.ModuleType(n); m.__path__ = []; sys.modules[n] = m\n")
+    r = subprocess.run([sys.executable, "-c", head + block + tail], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "shim ok" in r.stdout, r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["fused_fp32", "module_fp32", "fused_bf16"])
+def test_product_engines_reproduce_the_reference_forward(path):
+    """The product on the fixture's inputs against what the reference's forward() produced (over the oracle's
+    convolution primitive): site sets equal, f32 features within 1e-4 of the feature scale (the reference runs torch's
+    BatchNorm1d, the engines a folded scale / shift), bf16 within its storage precision."""
+    fx = _fixture()
+    dev = torch.device("cuda", 0)
+    net = _weights(fx, "bf16" if path.endswith("bf16") else "fp32").to(dev)
+    feats = torch.from_numpy(fx["voxel_features"]).to(dev)
+    coords = torch.from_numpy(fx["voxel_coords"]).to(dev)
+    bd = {"voxel_features": feats, "voxel_coords": coords, "batch_size": 1}
+    with torch.no_grad():
+        if path.startswith("module"):
+            from findnpropagate_amd.backbones_3d.spconv_backbone import _module_forward
+            bd = _module_forward(net, bd)        # the layer-by-layer path INTEGRATION §2's plain shim gives the reference
+        else:
+            bd = net(bd)
+    got = {"out": bd["encoded_spconv_tensor"], **bd["multi_scale_3d_features"]}
+    assert bd["encoded_spconv_tensor_stride"] == 8
+    tol = 1e-4 if path.endswith("fp32") else 3e-2
+    for k in OUTPUTS:
+        gi, wi = got[k].indices.cpu().numpy(), fx[k + "_indices"]
+        s = got[k].spatial_shape
+        assert list(s) == fx[k + "_spatial_shape"].tolist()
+        key = lambda i: ((i[:, 1].astype(np.int64) * s[1]) + i[:, 2]) * s[2] + i[:, 3]
+        go, wo = np.argsort(key(gi)), np.argsort(key(wi))
+        assert np.array_equal(gi[go], wi[wo]), (path, k)
+        g, w = got[k].features.float().cpu().numpy()[go], fx[k + "_features"][wo]
+        err = np.abs(g - w).max()
+        assert err <= tol * max(1.0, np.abs(w).max()), (path, k, err)
