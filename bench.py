@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step region; `value` is the median one, the list is reported")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (fp32 engine, Box Seeker, extraction, training "
                                                                 "step: each a fresh child process)")
+    ap.add_argument("--secondary-budget", type=float, default=420.0, help="wall-clock seconds all secondary child processes may take together; "
+                                                                          "those that do not fit are skipped and say so")
     ap.add_argument("--no-events", action="store_true", help="do not bracket conv launches with events")
     ap.add_argument("--launch", default="graphs", choices=["graphs", "stream"],
                     help="how a timed step is issued: 'graphs' = replayed from two captured hipGraphs (index chain on a second branch) with "
@@ -164,6 +166,64 @@ def min_traffic_bytes(tag, n_out, b, tile_record_per_row=58):
     return n_out * (cin * b + cout * b * (2 if res else 1) + tile_record_per_row) + K * cin * cout * b
 
 
+STRIDED_CLASSES = {(16, 32, 27), (32, 64, 27), (64, 128, 27), (128, 128, 3)}   # the four SparseConv3d layers (spconv_backbone.py:205-234)
+
+
+def rulebook_bytes_per_row(key, dtype):
+    """bytes of rulebook a launch of this layer class reads per output row, in the format the engine gives it (DESIGN.md
+    section 3): compact 32-byte records (stage 1 and 16 -> 32), 58-byte tile-rulebook rows (32 -> 32, 64 -> 64), the int32
+    table (K x 4) for the class-sorted 128 -> 128 sweep and conv_out, nothing for the strided layers that resolve their
+    neighbours inside the kernel; the f32 engine runs on tables throughout"""
+    cin, cout, K = key
+    if dtype != "bf16":
+        return 4 * K
+    if key in ((5, 16, 27), (16, 16, 27), (16, 32, 27)):
+        return 32
+    if key in ((32, 32, 27), (64, 64, 27)):
+        return 58
+    if key in ((32, 64, 27), (64, 128, 27)):
+        return 0
+    return 4 * K
+
+
+def step_roofline(layers, n_points, n_voxels, b, dtype, ms_per_step, mfma_peak):
+    """The whole step against the two PHYSICAL roofs.  layers: [(tag, P, n_out)] in execution order.
+    min_traffic = what one step has to move through HBM if every tensor crossed it exactly once per use:
+      voxeliser  N x 20 B points in, M x (16 B coords + 20 B means) out;
+      per conv   n_in x Cin x b in + n_out x Cout x b out (+ n_out x Cout x b residual) + K x Cin x Cout x b weights
+                 + its rulebook rows (rulebook_bytes_per_row) read once per launch and written once per rulebook;
+      conv_input reads the f32 means (20 B per row), conv_out writes f32 (the boundary dtype).
+    dense_equivalent_flops = sum over convs of 2 x n_out x K x Cin x Cout (what an output-stationary sweep multiplies,
+    absent-neighbour zeros included); algorithmic_flops = sum of 2 x P x Cin x Cout (pairs that exist)."""
+    byts = n_points * 20 + n_voxels * 36
+    dense = alg = 0.0
+    n_prev, seen_rb = n_voxels, set()
+    for i, (tag, P, n) in enumerate(layers):
+        cin, cout, K, res = tag[:4]
+        key = (cin, cout, K)
+        n_in = n_prev if key in STRIDED_CLASSES else n
+        b_in = 4 if i == 0 else b
+        b_out = 4 if i == len(layers) - 1 else b
+        rb = rulebook_bytes_per_row(key, dtype)
+        byts += n_in * cin * b_in + n * cout * b_out + (n * cout * b if res else 0) + K * cin * cout * b_in + n * rb
+        rb_id = (key in STRIDED_CLASSES, n, rb)
+        if rb_id not in seen_rb:            # (a rulebook is written once and shared by the layers of its indice_key)
+            seen_rb.add(rb_id)
+            byts += n * rb
+        dense += 2.0 * n * K * cin * cout
+        alg += 2.0 * P * cin * cout
+        n_prev = n
+    t = ms_per_step * 1e-3
+    return {"min_traffic_bytes": float(byts), "hbm_GBps_min_traffic": byts / t / 1e9, "frac_hbm_min_traffic": byts / t / 1e9 / 8000.0,
+            "dense_equivalent_flops": dense, "mfma_TFLOPs_dense_equivalent": dense / t / 1e12,
+            "frac_mfma_dense_equivalent": dense / t / 1e12 / mfma_peak,
+            "algorithmic_flops": alg, "mfma_TFLOPs_algorithmic": alg / t / 1e12, "ms_per_step": ms_per_step,
+            "floor_ms": {"hbm": byts / 8e12 * 1e3, "mfma": dense / (mfma_peak * 1e12) * 1e3},
+            "note": "physical roofs of the WHOLE step: minimum HBM traffic (every tensor once per use, rulebooks in the engine's formats) / "
+                    "ms_per_step / 8 TB/s, and dense-equivalent matrix flops / ms_per_step / the dense MFMA peak of the dtype; `frac` above "
+                    "stays SURVEY 8(d)'s gather-equivalent figure for the dominant kernel"}
+
+
 def child_json(cmd, timeout):
     """last JSON line a child process prints (secondary measurements run in fresh processes: their own allocator history,
     hipGraph capture without this process's event-timed launches before it)"""
@@ -233,12 +293,14 @@ def main():
     rb_log, eng.rulebook_log = eng.rulebook_log, None
     counts = res["counts"]
     stats = {}
+    layers_in_order = []
     for tag, rb, n_dev in rb_log:
         n = int(n_dev.item())
         key = id(rb.nbr)
         if key not in stats:
             stats[key] = int((rb.nbr[:, :n] >= 0).sum().item())
         stats.setdefault(("tags", tag), []).append((stats[key], n))
+        layers_in_order.append((tag, stats[key], n))
     torch.cuda.synchronize()
 
     # Which layer class dominates, and the per-class times quoted beside the roofline, come from a few
@@ -422,6 +484,8 @@ def main():
             # f32 runs on v_mfma_f32_16x16x4_f32 at the f32 vector rate (157.3 TFLOP/s dense): that pipe, not memory, bounds it
             out["roofline"] = {"bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s", "frac": tflops / 157.3,
                                "hbm_gbs_algorithmic": achieved, **common}
+        out["roofline"]["step"] = step_roofline(layers_in_order, int(pts.shape[0]), int(counts[0]), b, args.dtype,
+                                                1e3 * elapsed / args.steps, mfma_peak)
 
     if rank == 0 and world == 1 and not args.no_sweep and not args.graph:
         # Extra fields (the headline stays `value` at --batch): the same path at 1 and 8 scenes per step — batch size 1 is
@@ -510,6 +574,10 @@ def main():
         # SURVEY 8(d)'s secondary metrics, each from a fresh child process (best effort: never lose the headline over one)
         py, T = sys.executable, os.path.join(ROOT, "tools")
         sec = {}
+        # the headline is safe before any child starts: one line on stderr (stdout keeps its ONE line, printed at the end)
+        print("bench: headline before the secondary measurements: " + json.dumps({k: out[k] for k in ("metric", "value", "unit", "ms_per_step")}),
+              file=sys.stderr, flush=True)
+        t_budget = time.perf_counter() + args.secondary_budget     # one wall-clock budget for all of them
         jobs = {
             "fp32_engine": ([py, os.path.abspath(__file__), "--batch", str(B), "--dtype", "fp32", "--no-sweep", "--no-secondary", "--cpu-scenes", "0",
                              "--steps", "5", "--warmup", "2", "--reps", "3"], 240),
@@ -519,8 +587,12 @@ def main():
             "first_bev_block": ([py, os.path.join(T, "bench_bev.py"), "--batch", "16"], 240),
         }
         for name, (cmd, to) in jobs.items():
+            left = t_budget - time.perf_counter()
+            if left < 20:
+                sec[name] = {"skipped": f"the shared budget of {args.secondary_budget:.0f} s for secondary measurements was spent"}
+                continue
             try:
-                j = child_json(cmd, to)
+                j = child_json(cmd, min(to, left))
                 if name == "fp32_engine":
                     j = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "scenes_per_step": B,
                          "repetitions": j.get("repetitions"), "note": "FNP_DTYPE fp32: v_mfma_f32_16x16x4_f32, bit-identical to the CPU oracle (the 1e-4 mode)",

@@ -192,6 +192,8 @@ def _module_forward(self, batch_dict):
     x_conv3 = _seq_forward(self.conv3, x_conv2, act)
     x_conv4 = _seq_forward(self.conv4, x_conv3, act)
     out = _seq_forward(self.conv_out, x_conv4, act)
+    if x_in.features.is_cuda and torch.is_grad_enabled():
+        _C.end_of_backbone_forward(convs + [c for c in chain if c not in convs], x_in.indice_dict)   # (the autograd nodes hold their own slabs; nothing stale stays on the modules)
     return self._pack_outputs(batch_dict, out, x_conv1, x_conv2, x_conv3, x_conv4)
 
 
@@ -379,8 +381,12 @@ class _PointsGraph:
     def replay(self, profile=None):
         """one forward.  probe graphs: first half, the deferred launches (each between two timing events appended to `profile`
         as (tag, start, end) when a list is given), second half"""
+        cur = torch.cuda.current_stream(self.pts.device)
         if self._replayed:   # (the previous replay may have been issued on another stream: the buffers are shared)
-            torch.cuda.current_stream(self.pts.device).wait_event(self.done_event)
+            cur.wait_event(self.done_event)
+        # ... and so may an EAGER forward of the same engine (it shares the persistent grids and workspaces and returns early)
+        if self.engine._last_done is not None and self.engine._last_done is not self.done_event:
+            cur.wait_event(self.engine._last_done)
         self._replayed = True
         self.graph.replay()
         if self.counts_pin is None:
@@ -399,6 +405,7 @@ class _PointsGraph:
                     profile.append((tag, e0, e1))
         self.graph_b.replay()
         self.done_event.record()
+        self.engine._last_done = self.done_event     # an eager forward issued next, on any stream, waits for this replay
 
     def counts(self):
         """the host's copy of the last replay's counts (waits for the counts only, not for the second graph)"""
@@ -490,6 +497,13 @@ class PointsPipeline:
             ev.synchronize()
             for pd, _, _ in self.pending:
                 self.slots[pd].done_event.synchronize()
+            for l in range(1, 5):
+                if counts[l] > caps[l]:
+                    e.cap_factor[l - 1] = max(e.cap_factor[l - 1] * 2.0, counts[l] * 1.25 / caps[0])
+            torch.cuda.synchronize(self.device)
+            for gr in e._get_grids(self.batch_size, self.device):   # rows beyond a capacity were never emitted: the sparse clear missed their cells
+                gr.zero_()
+            e._dirty = False
             self.slots[d] = None
             return e.run_points_graphed(points, batch_offsets, self.batch_size, self.cfg, self.capacity)
         stage, shapes = g.res['stages'], g.res['shapes']
@@ -990,6 +1004,9 @@ class FusedResBackbone:
             for g in grids:
                 g.zero_()
             self._dirty = False
+            if feats.is_cuda and not capturing:
+                self._last_done = torch.cuda.Event()     # (a caller on another stream must come behind the wipe too)
+                self._last_done.record()
             return None
         tensors = []
         for l, (x, idx, n, g) in enumerate(stage):

@@ -231,9 +231,7 @@ class SparseConvolution(SparseModule):
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
         side.wait_event(ready)
-        host = getattr(self, "_pf_host", None)
-        if host is None:
-            host = self._pf_host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+        host = _pinned_word()     # (a word of this prefetch's own: module replicas and forwards in flight never share one)
         done = torch.cuda.Event()
         with torch.cuda.stream(side):
             host.copy_(rb.out_n, non_blocking=True)
@@ -263,6 +261,30 @@ def prepack_weights(convs_and_dtypes):
 
 PREFETCH = True   # (tests switch it off to compare with the synchronous path)
 _SIDE = {}
+_PIN_RING, _PIN_NEXT = None, [0]
+
+
+def _pinned_word():
+    """one int32 of pinned host memory out of a ring of 256 (a forward has at most four prefetches in flight; a word comes
+    round again after 256 of them)"""
+    global _PIN_RING
+    if _PIN_RING is None:
+        _PIN_RING = torch.empty((256,), dtype=torch.int32, pin_memory=True)
+    i = _PIN_NEXT[0]
+    _PIN_NEXT[0] = (i + 1) % 256
+    return _PIN_RING[i:i + 1]
+
+
+def end_of_backbone_forward(convs, indice_dict=None):
+    """What prepack_weights / prefetch left on the modules is state of ONE backbone forward: the packed and mirrored slabs
+    (a later call of a layer outside the backbone, after an in-place edit through .data that does not bump the parameter's
+    version, must repack), the link to the next strided layer, and rulebooks prefetched for a layer that never ran."""
+    for c in convs:
+        c.__dict__.pop("_fnp_prepack", None)
+        c.__dict__.pop("_fnp_next", None)
+    if indice_dict is not None:
+        for k in [k for k in indice_dict if isinstance(k, tuple) and k and k[0] == "prefetch"]:
+            del indice_dict[k]
 
 
 def _side_stream(device):
