@@ -886,8 +886,12 @@ class FusedResBackbone:
                 # stages 2-4: rows are in rank-grid order on both sides of the SubM convolutions; where they run on the tile
                 # rulebook (stage 2, 32 channels), the rulebook kernel writes it in the same pass
                 ch = int(P[blk_key][0][0][0].shape[1])
-                srt = S.sorted_by_default(ch, ch, act, caps[li + 1])
-                tiled = S.tiled_by_default(ch, act, caps[li + 1]) and S.tiled_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
+                # wide tiles (round 4; 64 and 128 channels from a capacity on that gives every CU several tiles): they replace the
+                # 128-row tiles of stage 3 and the class-sorted gather sweep of stage 4
+                wide = (S.wide_by_default(ch, act, caps[li + 1]) and S.wide_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
+                        and self.rulebook_log is None)
+                srt = S.sorted_by_default(ch, ch, act, caps[li + 1]) and not wide
+                tiled = wide or (S.tiled_by_default(ch, act, caps[li + 1]) and S.tiled_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1]))
                 # the SubM rulebook kernel of this stage also marks the output sites of the NEXT strided layer (the coordinates are
                 # in its registers): that layer's own marking launch goes
                 nxt = down_convs[li + 1]
@@ -895,7 +899,7 @@ class FusedResBackbone:
                 mark_next = (grids[li + 2], nxt.kernel_size, nxt.stride, nxt.padding) if (lean or srt) and S.MARK_FUSED else None
                 srt32 = S.f32_sorted_by_default(ch, act, caps[li + 1]) and self.rulebook_log is None
                 rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3, tile_channels=ch if tiled else None, masks=srt or srt32,
-                                     lean_table=lean, mark_next=mark_next)
+                                     lean_table=lean, mark_next=mark_next, wide=wide)
                 premarked = bool(getattr(rb, "_marked_next", False))
                 if srt:
                     S.classsort(rb, rbs.out_n, ch)   # stage 4: the 128-channel layers sweep their rows class by class

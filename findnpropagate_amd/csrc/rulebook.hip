@@ -256,23 +256,24 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_kernel(const int *__res
 // LEAN: the int32 table is written only for the rows of tiles that hold an ESCAPE entry — the only rows the tiled
 // convolutions ever look up in it (rank-ordered inputs: ~1e-5 of the tiles; the 108 bytes per row of the full table were
 // two thirds of this kernel's stores).  For a caller whose every consumer of the table is fnp_spconv_forward_tiled.
-template <typename G, bool LEAN = false>
-__global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows, int cap,
+// NT: threads per workgroup = rows per pass (a multiple of the tile: the wide 512-row tiles take 512)
+template <typename G, bool LEAN = false, int NT = kThreads>
+__global__ __launch_bounds__(NT) void subm_nbr_row_tile_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows, int cap,
                                                                      RG g, int *__restrict__ nbr, unsigned char *__restrict__ tile_rb,
                                                                      MarkJob mk = MarkJob{}) {
-    constexpr int K = tilerb::kK, TPP = kThreads / G::TILE;   // tiles per pass
-    static_assert(kThreads % G::TILE == 0 && TPP * G::OVF <= kThreads, "at most one table slot per thread");
-    __shared__ __attribute__((aligned(16))) int strips[kThreads / 64][K * 64];
+    constexpr int K = tilerb::kK, TPP = NT / G::TILE;   // tiles per pass
+    static_assert(NT % G::TILE == 0 && TPP * G::OVF <= NT, "at most one table slot per thread");
+    __shared__ __attribute__((aligned(16))) int strips[NT / 64][K * 64];
     __shared__ int table[TPP][G::OVF];
-    __shared__ int esc[kThreads / 32];
+    __shared__ int esc[NT / 32];
     __shared__ unsigned short lut[G::WIN + 2];
     int *strip_wave = strips[threadIdx.x >> 6];
     const int n = min(*n_rows, cap), tid = threadIdx.x, lane = fnp_lane();
-    tilerb::fill_lut<G>(lut, tid, kThreads);
-    for (int base = blockIdx.x * kThreads; base < n; base += gridDim.x * kThreads) {   // (whole workgroups stay in the loop)
+    tilerb::fill_lut<G>(lut, tid, NT);
+    for (int base = blockIdx.x * NT; base < n; base += gridDim.x * NT) {   // (whole workgroups stay in the loop)
         const int o = base + tid;
         if (tid < TPP * G::OVF) (&table[0][0])[tid] = -1;
-        if (tid < kThreads / 32) esc[tid] = 0;
+        if (tid < NT / 32) esc[tid] = 0;
         int4 cm = make_int4(0, 0, 0, 0);
         if (o < n) cm = reinterpret_cast<const int4 *>(coords)[o];
         if (mk.on) mark_job_row(mk, o < n, cm, lane);
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_tile_kernel(const int *
         __syncthreads();   // every far row has its slot, every entry is in the strips
         // the entries leave 16 bytes (8 rows of one offset) per lane
         constexpr int CPK = G::TILE / 8, CPT = K * CPK;   // chunks per offset, per tile
-        for (int c = tid; c < TPP * CPT; c += kThreads) {
+        for (int c = tid; c < TPP * CPT; c += NT) {
             const int tlc = c / CPT, cc = c % CPT, k = cc / CPK, r8 = tlc * G::TILE + (cc % CPK) * 8;   // r8: first row, inside the pass
             const int tc = base / G::TILE + tlc;
 #ifdef FNP_RBT_ABLATE
@@ -467,6 +468,40 @@ extern "C" int fnp_rulebook_subm_tiled(const int *coords, const int *n_rows, int
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G64>), dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0,
                            (hipStream_t)stream, coords, n_rows, cap, fnp_rg_view(grid), nbr, (unsigned char *)tile_rb);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+// The same two entry points for the WIDE tile rulebooks (tilerb.cuh G64W / G128W: fnp_spconv_forward_wtiled); lean != 0: the
+// int32 table receives the rows of escape tiles only.
+extern "C" int fnp_rulebook_subm_wtiled(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom, const fnp_rankgrid *grid,
+                                        int *nbr, int channels, void *tile_rb, int lean, const fnp_rankgrid *mark_grid,
+                                        const fnp_conv_geom *mark_geom, fnp_stream_t stream) {
+    if (!coords || !n_rows || cap <= 0 || !nbr || !tile_rb || !geom_ok(geom) || !fnp_rg_valid(grid)) return FNP_ERR_ARG;
+    if (!shape_is(grid, geom->in_shape) || ((uintptr_t)tile_rb & 15) || (channels != 64 && channels != 128)) return FNP_ERR_ARG;
+    for (int d = 0; d < 3; ++d)
+        if (geom->ksize[d] != 3) return FNP_ERR_ARG;
+    MarkJob mk;
+    if (!make_mark_job(grid, mark_grid, mark_geom, mk)) return FNP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char *t = (unsigned char *)tile_rb;
+    if (channels == 64) {
+        constexpr int NT = tilerb::G64W::TILE;   // (a workgroup pass = one tile)
+        if (lean)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G64W, true, NT>), dim3(fnp_grid_for(cap, NT)), dim3(NT), 0, s, coords, n_rows,
+                               cap, fnp_rg_view(grid), nbr, t, mk);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G64W, false, NT>), dim3(fnp_grid_for(cap, NT)), dim3(NT), 0, s, coords, n_rows,
+                               cap, fnp_rg_view(grid), nbr, t, mk);
+    } else {
+        constexpr int NT = tilerb::G128W::TILE;
+        if (lean)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G128W, true, NT>), dim3(fnp_grid_for(cap, NT)), dim3(NT), 0, s, coords, n_rows,
+                               cap, fnp_rg_view(grid), nbr, t, mk);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G128W, false, NT>), dim3(fnp_grid_for(cap, NT)), dim3(NT), 0, s, coords, n_rows,
+                               cap, fnp_rg_view(grid), nbr, t, mk);
+    }
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }

@@ -63,12 +63,12 @@ __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restric
                                                             unsigned char *__restrict__ out) {
     constexpr int RL = G::TILE / 4, NG = 256 / RL, NJ = (kK + NG - 1) / NG;   // lanes per offset, offsets per pass, passes
     __shared__ int table[G::OVF];
-    __shared__ int esc[8];
+    __shared__ int esc[16];
     const int n = min(*n_out, cap);
     const int t = blockIdx.x, tile_base = t * G::TILE, tid = threadIdx.x;
     if (tile_base >= n) return;
     if (tid < G::OVF) table[tid] = -1;
-    if (tid < 8) esc[tid] = 0;
+    if (tid < 16) esc[tid] = 0;
     __syncthreads();
     const int wlo = max(0, tile_base - G::HALO), kq = tid / RL, r0 = (tid % RL) * 4, row0 = tile_base + r0;
     int4 id[NJ];
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restric
     }
     __syncthreads();
     if (tid < G::OVF) reinterpret_cast<int *>(rec + G::REC_FAR)[tid] = table[tid];
-    if (tid < 16) rec[G::REC_ESC + tid] = tid < 8 ? (unsigned char)esc[tid] : 0;
+    if (tid < 16) rec[G::REC_ESC + tid] = (unsigned char)esc[tid];
 }
 
 // Development-only timing probes (results are wrong; the shipped library has 0): 1 = escape entries are taken as absent,
@@ -867,6 +867,27 @@ extern "C" int fnp_gather_counts(int *const *srcs, int n, unsigned reset_mask, i
 extern "C" int fnp_debug_tile_hold(int on) {
     const int v = on ? 1 : 0;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_hold), &v, sizeof(v)) != hipSuccess) return FNP_ERR_HIP;
+    return FNP_OK;
+}
+
+extern "C" long long fnp_wtile_rulebook_bytes(int cap_out, int channels) {
+    if (cap_out <= 0) return 0;
+    if (channels == 64) return (long long)fnp_divup(cap_out, tilerb::G64W::TILE) * tilerb::G64W::REC;
+    if (channels == 128) return (long long)fnp_divup(cap_out, tilerb::G128W::TILE) * tilerb::G128W::REC;
+    return 0;
+}
+
+extern "C" int fnp_wtile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int channels, void *tile_rb,
+                                        fnp_stream_t stream) {
+    if (!nbr || !n_out || !tile_rb || K != kK || cap_out <= 0 || nbr_stride < cap_out || (channels != 64 && channels != 128)) return FNP_ERR_ARG;
+    if ((uintptr_t)tile_rb & 15) return FNP_ERR_ARG;
+    if (channels == 64)
+        hipLaunchKernelGGL(tile_rulebook_kernel<tilerb::G64W>, dim3(fnp_divup(cap_out, tilerb::G64W::TILE)), dim3(256), 0, (hipStream_t)stream, nbr, nbr_stride,
+                           n_out, cap_out, (unsigned char *)tile_rb);
+    else
+        hipLaunchKernelGGL(tile_rulebook_kernel<tilerb::G128W>, dim3(fnp_divup(cap_out, tilerb::G128W::TILE)), dim3(256), 0, (hipStream_t)stream, nbr, nbr_stride,
+                           n_out, cap_out, (unsigned char *)tile_rb);
+    FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
 

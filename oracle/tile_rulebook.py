@@ -11,7 +11,14 @@ ESCAPE = 0xFFFF
 GEOMETRY = {  # channels -> (TILE, HALO, OVF, ROW_BYTES)
     32: (256, 32, 256, 64),
     64: (128, 64, 128, 128),
+    # WIDE tiles (tilerb.cuh G64W / G128W; fnp_wtile_rulebook_build): entries in 16-byte units, window split by row mod 4
+    "w64": (512, 64, 256, 128),
+    "w128": (256, 32, 160, 256),
 }
+
+
+def is_wide(channels):
+    return isinstance(channels, str)
 
 
 def record_bytes(channels):
@@ -20,16 +27,23 @@ def record_bytes(channels):
 
 
 def swizzle(channels, rs):
-    """Swizzle bits (entry bits 4..) of the image row at slot rs."""
+    """Swizzle bits of the image row at slot rs: byte-address bits 4.. (XOR swizzle), or for the wide geometries the rotation in
+    16-byte units (entry low bits)."""
     if channels == 32:
         return ((-(rs >> 2)) & 3) << 4
-    return ((rs >> 1) & 7) << 4
+    if channels == 64:
+        return ((rs >> 1) & 7) << 4
+    if channels == "w64":
+        return rs & 6
+    return (2 * rs) & 15
 
 
 def decode(tile_rb, n, channels):
     """tile_rb: uint8 array; returns (nbr (27, n) int64 with -2 where the entry is an escape, escape flags (tiles, TILE//32))."""
     tile, halo, ovf, rowb = GEOMETRY[channels]
     win, zero, rec = tile + 2 * halo, tile + 2 * halo + ovf, record_bytes(channels)
+    unit = rowb // 16 if is_wide(channels) else rowb       # what one image row spans in the entry's unit
+    split = {"w64": 8, "w128": 4}.get(channels, 2)
     ntiles = (n + tile - 1) // tile
     recs = np.asarray(tile_rb[: ntiles * rec], dtype=np.uint8).reshape(ntiles, rec)
     codes = recs[:, : K * tile * 2].copy().view(np.uint16).reshape(ntiles, K, tile).astype(np.int64)
@@ -39,11 +53,11 @@ def decode(tile_rb, n, channels):
     for t in range(ntiles):
         c = codes[t]
         is_esc = c == ESCAPE
-        rs = c // rowb
-        assert np.all(is_esc | ((c % rowb) == swizzle(channels, rs))), "entry swizzle bits"
+        rs = c // unit
+        assert np.all(is_esc | ((c % unit) == swizzle(channels, rs))), "entry swizzle bits"
         wlo = max(0, t * tile - halo)
-        half = win // 2
-        d = np.where(rs < half, 2 * rs, 2 * (rs - half) + 1)                     # window slot -> window position
+        part = win // split
+        d = (rs % part) * split + rs // part                                      # window slot -> window position
         ids = np.where(rs < win, wlo + d, -1)
         in_ovf = (rs >= win) & (rs < zero) & ~is_esc
         ids = np.where(in_ovf, far[t][np.clip(rs - win, 0, ovf - 1)], ids)
