@@ -585,6 +585,8 @@ def main():
             "extraction": ([py, os.path.join(T, "bench_extract.py"), "--scenes", "256", "--force-collective"], 240),
             "train_step": ([py, os.path.join(T, "bench_train.py"), "--batch", "16"], 240),
             "first_bev_block": ([py, os.path.join(T, "bench_bev.py"), "--batch", "16"], 240),
+            # the density transfusion_lidar.yaml feeds the backbone (nuscenes_dataset.yaml:5 MAX_SWEEPS 10): emulated 10-sweep scenes
+            "ten_sweep": ([py, os.path.join(T, "bench_sweeps.py"), "--batch", "8"], 240),
         }
         for name, (cmd, to) in jobs.items():
             left = t_budget - time.perf_counter()

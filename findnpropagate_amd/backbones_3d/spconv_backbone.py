@@ -342,7 +342,7 @@ class _PointsGraph:
         self.pts = torch.full((capacity, n_feat), self.FAR, dtype=torch.float32, device=device)
         self.off = torch.zeros((batch_size + 1,), dtype=torch.int32, device=device)
         self.n_prev = 0
-        self.cap_factor = list(engine.cap_factor) + list(engine.ell_pool)
+        self.cap_factor = engine._graph_key()
         self.prep_key = engine._prep_key
         # warm-up on a side stream (allocations of persistent grids/workspaces, lazy kernel attributes), then capture
         self._body(voxel_cfg)
@@ -453,7 +453,7 @@ class PointsPipeline:
         e = self.engines[d]
         e.prepare()
         g = self.slots[d]
-        if g is None or g.cap_factor != list(e.cap_factor) + list(e.ell_pool) or g.prep_key != e._prep_key:
+        if g is None or g.cap_factor != e._graph_key() or g.prep_key != e._prep_key:
             torch.cuda.synchronize(self.device)   # (capture: nothing else of this pipeline may be in flight)
             g = _PointsGraph(e, self.capacity, self.n_feat, self.batch_size, self.cfg, self.device)
             self.slots[d] = g
@@ -547,6 +547,13 @@ class FusedResBackbone:
         self._side = {}
         self._counts_pin = None
         self._last_done = None
+        # TILE GATE (round 4).  The tile-rulebook kernels of stages 2-3 are ahead of the gather kernels only while (nearly) every
+        # neighbour of a tile sits in its LDS image: the rulebook kernel counts the 32-row groups that hold an escape entry, the
+        # count comes back with the forward's one synchronisation, and a stage whose share exceeds TILE_ESC_MAX runs on the gather
+        # kernels for the next TILE_REPROBE eager forwards (then the tiles are tried, and measured, again).  Single-sweep lidar:
+        # ~1e-5; the 10-sweep density of transfusion_lidar.yaml: 2 % / 11 % of the groups, tiled kernels 4-8 % slower (measured).
+        self.tile_off = {}            # stage index li (0: stage 2, 1: stage 3) -> eager forwards left on the gather kernels
+        self.tile_escape_share = {}   # last measured share per stage (diagnostics; bench.py reports it)
         self.two_streams = True   # (PointsPipeline clears it for its slots when several frames are in flight: they already overlap)
         self._dirty = False      # a forward is in flight or died before its sparse clear: grids may hold stale bits
         # measurement hooks (bench.py): when `profile` is a list every conv launch is bracketed by
@@ -586,12 +593,30 @@ class FusedResBackbone:
             raise _l.FnpError(f"spconv_tile32_kernel: {int(value) - seen} hand-over wait(s) timed out during this forward; "
                               "its features are incomplete")
 
+    TILE_ESC_MAX = float(os.environ.get("FNP_TILE_ESC_MAX", "0.004"))
+    TILE_REPROBE = int(os.environ.get("FNP_TILE_REPROBE", "64"))
+
+    def _heur_key(self):
+        """what a captured graph bakes in besides capacities: which tiled stages run on the gather kernels"""
+        return [li for li in sorted(self.tile_off) if self.tile_off[li] > 0]
+
+    def _graph_key(self):
+        return list(self.cap_factor) + list(self.ell_pool) + ["off"] + self._heur_key()
+
     def _ell_overflow(self, counts, ell_used, cap1):
-        """pops the pool counters of the compact rulebooks off `counts`; True when a pool was too small (its factor is grown:
-        the caller reruns, as for a row capacity)"""
+        """pops the engine's extra counters off `counts`: the pool counters of the compact rulebooks — True when a pool was too
+        small (its factor is grown: the caller reruns, as for a row capacity) — and the escape-group counters of the tiled stages
+        (the tile gate above: never a rerun, the result is correct either way)"""
         over = False
         for used_t, pool, which in reversed(ell_used):
             used = counts.pop()
+            if isinstance(which, tuple):          # ("esc", li): 32-row groups of stage li + 2 with an escape entry
+                li = which[1]
+                share = used / max(1.0, counts[li + 1] / 32.0)
+                self.tile_escape_share[li] = share
+                if share > self.TILE_ESC_MAX:
+                    self.tile_off[li] = self.TILE_REPROBE
+                continue
             if used > pool:
                 self.ell_pool[which] = max(self.ell_pool[which] * 2.0, used * 1.25 / max(cap1 * (self.cap_factor[0] if which else 1.0), 1))
                 over = True
@@ -704,7 +729,7 @@ class FusedResBackbone:
         key = (batch_size, capacity, C, str(points.device), bool(probe))
         while True:
             g = self._graphs.get(key)
-            if g is None or g.cap_factor != list(self.cap_factor) + list(self.ell_pool) or g.prep_key != self._prep_key:
+            if g is None or g.cap_factor != self._graph_key() or g.prep_key != self._prep_key:
                 prof, self.profile = self.profile, None   # (the capture itself is not a measurement)
                 try:
                     g = _PointsGraph(self, capacity, C, batch_size, voxel_cfg, points.device, probe=probe)
@@ -761,6 +786,9 @@ class FusedResBackbone:
         capturing = feats.is_cuda and torch.cuda.is_current_stream_capturing()
         if feats.is_cuda and not capturing and self._last_done is not None:
             torch.cuda.current_stream(feats.device).wait_event(self._last_done)
+        if not capturing:
+            for li in list(self.tile_off):      # (eager forwards count the gather-kernel period down; a captured graph keeps its choice)
+                self.tile_off[li] = max(0, self.tile_off[li] - 1)
         m, P, act = self.m, self.prepare(), self.act
         if final_dtype not in (None, act, torch.float32):
             final_dtype = None       # (the conv epilogue writes the activation dtype or f32; anything else is cast by the caller)
@@ -891,15 +919,21 @@ class FusedResBackbone:
                 wide = (S.wide_by_default(ch, act, caps[li + 1]) and S.wide_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
                         and self.rulebook_log is None)
                 srt = S.sorted_by_default(ch, ch, act, caps[li + 1]) and not wide
-                tiled = wide or (S.tiled_by_default(ch, act, caps[li + 1]) and S.tiled_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1]))
+                tiled = wide or (S.tiled_by_default(ch, act, caps[li + 1]) and S.tiled_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
+                                 and self.tile_off.get(li, 0) <= 0)
                 # the SubM rulebook kernel of this stage also marks the output sites of the NEXT strided layer (the coordinates are
                 # in its registers): that layer's own marking launch goes
                 nxt = down_convs[li + 1]
                 lean = tiled and self.rulebook_log is None   # (all four layers of the stage run tiled)
                 mark_next = (grids[li + 2], nxt.kernel_size, nxt.stride, nxt.padding) if (lean or srt) and S.MARK_FUSED else None
                 srt32 = S.f32_sorted_by_default(ch, act, caps[li + 1]) and self.rulebook_log is None
+                esc_ctr = self._ell_counter(("esc", li), dev) if (lean and not wide and S.TILE_MODE is None) else None
                 rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3, tile_channels=ch if tiled else None, masks=srt or srt32,
-                                     lean_table=lean, mark_next=mark_next, wide=wide)
+                                     lean_table=lean, mark_next=mark_next, wide=wide, esc_counter=esc_ctr)
+                if esc_ctr is not None:
+                    ell_used.append((esc_ctr, None, ("esc", li)))
+                if self.tile_off.get(li, 0) > 0:
+                    rb._no_tile = True
                 premarked = bool(getattr(rb, "_marked_next", False))
                 if srt:
                     S.classsort(rb, rbs.out_n, ch)   # stage 4: the 128-channel layers sweep their rows class by class

@@ -126,7 +126,7 @@ SIGNATURES = {
     "fnp_tile_rulebook_bytes": (c_int64, [c_int, c_int]),
     "fnp_tile_rulebook_build": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P]),
     "fnp_rulebook_subm_tiled": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, P]),
-    "fnp_rulebook_subm_tiled_lean": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, POINTER(RankGridC), POINTER(ConvGeom), P]),
+    "fnp_rulebook_subm_tiled_lean": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, POINTER(RankGridC), POINTER(ConvGeom), P, P]),
     "fnp_rulebook_strided_premarked": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), POINTER(RankGridC),
                                                P, P, c_int, P, P, c_int64, P]),
     "fnp_spconv_forward_tiled": (c_int, [P, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),

@@ -192,13 +192,14 @@ def clear_grids(jobs):
 
 
 # --------------------------------------------------------------------------------- rulebooks
-def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None, masks=False, lean_table=False, mark_next=None, wide=False):
+def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None, masks=False, lean_table=False, mark_next=None, wide=False, esc_counter=None):
     """tile_channels (32 or 64, 3x3x3 only): also write the tile rulebook the `tile_channels`-channel layers of this rulebook
     run on (conv_forward's tiled path finds it with the rulebook), in the same pass.
     masks (3x3x3 only): also write the per-row neighbour masks (`rb._rowmask`) the class sort of the 128-channel layers starts from.
     lean_table (with tile_channels): the int32 table gets only the rows the tiled convolutions can ask it for (tiles with escape
     entries) — for a caller that runs nothing but conv_forward's tiled path on this rulebook (`rb._lean` is set: conv_forward
     refuses any other kernel on it).
+    esc_counter (with lean_table): a (1,) int32 device counter that receives += the number of 32-row groups with an escape entry.
     wide (with tile_channels 64 or 128): the WIDE tile rulebook (fnp_rulebook_subm_wtiled; conv_forward's wide-tile path).
     mark_next (with lean_table or masks): (out_grid, ksize, stride, padding) of the strided convolution that consumes these rows —
     the kernel marks its output sites in out_grid (all zero) on the way; rulebook_strided(..., premarked=True) then skips its
@@ -230,7 +231,7 @@ def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None, masks=False, 
         t = torch.empty((L.fnp_tile_rulebook_bytes(cap, tile_channels),), dtype=torch.uint8, device=indices.device)
         if lean_table:
             rc = L.fnp_rulebook_subm_tiled_lean(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), tile_channels, _l.ptr(t), mg, mgeom,
-                                                _l.stream())
+                                                _l.ptr(esc_counter), _l.stream())
         else:
             rc = L.fnp_rulebook_subm_tiled(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), tile_channels, _l.ptr(t), _l.stream())
         _l.check(rc, "fnp_rulebook_subm_tiled")
@@ -410,7 +411,7 @@ def tiled_fits(n_in_rows, channels, nbr_stride, cap_out):
 
 # ... and the ones that take it by themselves (measured at 64 scenes, per layer: 32 channels 0.305 -> 0.18 ms; 64 channels
 # 0.43 -> 0.385 ms, +1 % end to end)
-TILED_AUTO = (32, 64)
+TILED_AUTO = tuple(int(v) for v in os.environ.get("FNP_TILED_AUTO", "32,64").split(",") if v)   # (development A/B: e.g. FNP_TILED_AUTO=32)
 
 
 # --------------------------------------------------------------------------------- compact rulebook (sparse-neighbourhood layers)
@@ -553,6 +554,8 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
     _l.require_device(feat_in, w_packed, rb.nbr, n_out_dev)
     if tile is None:
         tile = TILE_MODE
+    if tile is None and getattr(rb, "_no_tile", False):   # (the fused engine's tile gate: this rulebook's stage runs on the gather kernels)
+        tile = False
     K, Cout, Cin = w_packed.shape
     assert K == rb.K and feat_in.shape[1] == Cin and feat_in.dtype == w_packed.dtype
     assert feat_in.is_contiguous() and w_packed.is_contiguous()

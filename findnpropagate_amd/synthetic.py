@@ -91,6 +91,30 @@ def make_scene(seed, n_beams=32, n_azimuth=1084, n_boxes=20, return_boxes=False)
     return pts
 
 
+def make_sweeps_scene(seed, sweeps=10):
+    """A 10-sweep-sized input (tools/cfgs/dataset_configs/nuscenes_dataset.yaml:5 MAX_SWEEPS 10 under
+    nuscenes_models/transfusion_lidar.yaml: ~250-300 k points and up to the 120 k / 160 k voxel caps per sample): `sweeps`
+    synthetic sweeps of the same seeded static world from ego positions ~0.5 m apart, the time channel = sweep age, points of
+    all sweeps concatenated oldest last (as the reference's get_lidar_with_sweeps appends them) and cut to the x / y range."""
+    parts = []
+    for j in range(sweeps):
+        p = make_scene(seed).copy()
+        p[:, 0] += 0.5 * j + 0.013 * j * j
+        p[:, 1] += 0.07 * j
+        p[:, 4] = 0.05 * j
+        parts.append(p)
+    p = np.concatenate(parts, 0)
+    r = POINT_CLOUD_RANGE
+    return np.ascontiguousarray(p[(p[:, 0] >= r[0]) & (p[:, 0] <= r[3]) & (p[:, 1] >= r[1]) & (p[:, 1] <= r[4])])
+
+
+def make_sweeps_batch(seeds, sweeps=10):
+    scenes = [make_sweeps_scene(s, sweeps) for s in seeds]
+    off = np.zeros(len(scenes) + 1, np.int32)
+    off[1:] = np.cumsum([s.shape[0] for s in scenes])
+    return np.concatenate(scenes, 0), off
+
+
 def make_batch(seeds):
     """Concatenate scenes: points (N,5) f32, batch_offsets (B+1,) int32."""
     scenes = [make_scene(s) for s in seeds]

@@ -309,7 +309,13 @@ int fnp_rulebook_subm_tiled(const int *coords, const int *n_rows, int cap, const
  * bytes per row this kernel stores.  nbr must still be a (27, cap) buffer; rows outside such tiles stay unwritten. */
 int fnp_rulebook_subm_tiled_lean(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom,
                                  const fnp_rankgrid *grid, int *nbr, int channels, void *tile_rb,
-                                 const fnp_rankgrid *mark_grid, const fnp_conv_geom *mark_geom, fnp_stream_t stream);
+                                 const fnp_rankgrid *mark_grid, const fnp_conv_geom *mark_geom, int *escape_groups,
+                                 fnp_stream_t stream);
+/* escape_groups (ABI 10, nullable): a device counter that receives += the number of 32-row groups whose entries hold an escape:
+ * the statistic the tiled convolutions' advantage rests on (a group with an escape fetches through the int32 table).  Measured
+ * on the synthetic scenes: ~1e-5 of the groups at single-sweep density (tiled kernels 1.15-2.1x the gather kernels), 2 % / 11 %
+ * (32 / 64 channels) at the 10-sweep density of transfusion_lidar.yaml (tiled kernels 4-8 % SLOWER): the fused engine reads
+ * the counter with its per-forward counts and runs a stage on the gather kernels while it exceeds 0.4 %. */
 /* mark_grid / mark_geom (both NULL: none; also on fnp_rulebook_subm_masked): the rows whose rulebook is built are the input
  * sites of the NEXT strided convolution (mark_geom, in_shape = their grid); while the kernel has their coordinates in its
  * registers it also marks that convolution's output sites in mark_grid (all zero on entry), so that

@@ -1,0 +1,140 @@
+"""The workload transfusion_lidar.yaml actually feeds the backbone: 10 aggregated sweeps (tools/cfgs/dataset_configs/
+nuscenes_dataset.yaml:5 MAX_SWEEPS 10; nuscenes_models/transfusion_lidar.yaml:54-59 caps of 120 k / 160 k voxels) — ~300 k
+points and ~150 k voxels per scene, nine times the single-sweep scenes of the other full-grid tests — on the full
+41 x 1440 x 1440 grid: voxel rows bit-exact against the oracle's sequential voxeliser (with the `max_voxels` rule firing in
+the middle of a scene), site sets of every stage, the f32 engine equal to the oracle bit for bit, bf16 features against the
+bf16-emulating oracle.  The engine's heuristics (class-sorted sweep of stage 4, tile windows of stages 2-3) were sized on
+single-sweep geometry: the statistics they rest on are printed by bench.py's secondary.ten_sweep; here only results count."""
+import numpy as np
+import pytest
+import torch
+
+from findnpropagate_amd import lib as _l
+from findnpropagate_amd import sparse as S
+from findnpropagate_amd import synthetic as syn
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+GRID = [41, 1440, 1440]
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda", 0)
+
+
+def _key(i, s):
+    return ((i[:, 0].astype(np.int64) * s[0] + i[:, 1]) * s[1] + i[:, 2]) * s[2] + i[:, 3]
+
+
+def _net(cuda, dtype):
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    return syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False, "FNP_DTYPE": dtype}, 5, grid), seed=0).to(cuda).eval()
+
+
+def _oracle_voxels(seeds, max_voxels):
+    coords, feats, kept = [], [], []
+    for b, s in enumerate(seeds):
+        v, c, n = O.voxelize(syn.make_sweeps_scene(s), syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, syn.MAX_POINTS_PER_VOXEL, max_voxels)
+        coords.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
+        feats.append(O.mean_vfe(v, n))
+        kept.append(n)
+    return np.concatenate(coords), np.concatenate(feats), np.concatenate(kept)
+
+
+def _check_sites(res, coords, batch):
+    shape, idx = GRID, coords
+    for name, (k, s, p) in (("x_conv2", (3, 2, 1)), ("x_conv3", (3, 2, 1)), ("x_conv4", (3, 2, (0, 1, 1))), ("out", ((3, 1, 1), (2, 1, 1), 0))):
+        idx, shape, _, _, _ = O.rulebook_strided(idx, shape, k, s, p)
+        got = res[name]
+        assert got.spatial_shape == shape and got.indices.shape[0] == idx.shape[0], name
+        assert np.array_equal(np.sort(_key(got.indices.cpu().numpy(), shape)), np.sort(_key(idx, shape))), name
+
+
+def _sorted_feats(t):
+    i = t.indices.cpu().numpy() if hasattr(t.indices, "cpu") else t.indices
+    f = t.features.float().cpu().numpy() if hasattr(t.features, "cpu") else t.features
+    o = np.argsort(_key(i, t.spatial_shape))
+    return f[o]
+
+
+def test_ten_sweep_scene_with_the_voxel_cap_firing_f32_is_the_oracle(cuda):
+    """One 10-sweep scene with max_voxels = 60,000 (the scene has ~150 k occupied cells: the `continue` of the sequential
+    voxeliser fires from point ~60 k on, later points still join voxels that exist): coordinates, first-come order, point
+    counts and mean features bit-exact; the f32 engine's five outputs array_equal to the oracle's."""
+    seeds, cap = (31,), 60000
+    pts, off = syn.make_sweeps_batch(seeds)
+    assert pts.shape[0] > 250000
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, cap)
+    net = _net(cuda, "fp32")
+    aborts0 = _l.load().fnp_spconv_tiled_aborts()
+    with torch.no_grad():
+        res = net.forward_points(torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda), 1, cfg)
+    coords, feats, kept = _oracle_voxels(seeds, cap)
+    assert coords.shape[0] == cap, "the cap must fire for this test to mean anything"
+    assert np.array_equal(res["voxel_coords"].cpu().numpy(), coords)
+    assert np.array_equal(res["voxel_num_points"].cpu().numpy(), kept)
+    assert np.array_equal(res["voxel_features"].cpu().numpy(), feats)
+    _check_sites(res, coords, 1)
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    want = O.backbone_forward(sd, feats, coords, 1, GRID)
+    for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out"):
+        assert np.array_equal(_sorted_feats(res[name]), _sorted_feats(want[name])), name
+    assert _l.load().fnp_spconv_tiled_aborts() == aborts0
+
+
+def test_two_ten_sweep_scenes_bf16_engine(cuda):
+    """Two 10-sweep scenes (the eval cap of 160,000 voxels does not fire on them: ~150 k each) through the default bf16 engine —
+    every heuristic of the fused path at 10-sweep density (300 k rows in stage 1, 450 k in stage 2): voxel rows bit-exact, site
+    sets equal, features against the bf16-emulating oracle with the bounds of the single-sweep full-grid test, and the rerun
+    bit-identical (grids left clean)."""
+    seeds = (32, 33)
+    pts, off = syn.make_sweeps_batch(seeds)
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, syn.MAX_VOXELS_TEST)
+    net = _net(cuda, "bf16")
+    d_pts, d_off = torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda)
+    with torch.no_grad():
+        res = net.forward_points(d_pts, d_off, 2, cfg)
+        res2 = net.forward_points(d_pts, d_off, 2, cfg)
+    coords, feats, kept = _oracle_voxels(seeds, syn.MAX_VOXELS_TEST)
+    assert coords.shape[0] > 250000
+    assert np.array_equal(res["voxel_coords"].cpu().numpy(), coords)
+    assert np.array_equal(res["voxel_features"].cpu().numpy(), feats)
+    _check_sites(res, coords, 2)
+    assert torch.equal(res["out"].features, res2["out"].features)
+    sd = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    want = O.backbone_forward(sd, feats, coords, 2, GRID, bf16=True)
+    for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out"):
+        g, w = _sorted_feats(res[name]), _sorted_feats(want[name])
+        bad = np.abs(g - w) > 3e-2 + 3e-2 * np.abs(w)
+        assert bad.mean() <= 0.01, (name, bad.mean())
+        ulp = 2.0 ** -8 * max(1.0, np.abs(w).max())      # one bf16 ulp at the tensor's scale
+        assert np.abs(g - w).max() <= 4 * ulp, (name, np.abs(g - w).max(), ulp)
+
+
+def test_tile_gate_switches_on_the_measured_escape_share(cuda):
+    """The tile-rulebook kernels of stages 2-3 are taken by a measured statistic, not by a stage number: the rulebook kernel
+    counts the 32-row groups with an escape entry, the engine reads the count with its per-forward counts and runs a stage on the
+    gather kernels while the share exceeds TILE_ESC_MAX.  Single-sweep scenes stay on tiles (share ~1e-5); a 10-sweep scene
+    switches at least stage 3 off for the next forwards; results are the same bits either way."""
+    if S.TILE_MODE is not None:
+        pytest.skip("FNP_TILE forces the kernel")
+    net = _net(cuda, "bf16")
+    eng = net.engine()
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, syn.MAX_VOXELS_TEST)
+    p1, o1 = syn.make_batch((5, 6))
+    with torch.no_grad():
+        net.forward_points(torch.from_numpy(p1).to(cuda), torch.from_numpy(o1).to(cuda), 2, cfg)
+    assert eng._heur_key() == [] and all(v < eng.TILE_ESC_MAX for v in eng.tile_escape_share.values()) and len(eng.tile_escape_share) == 2
+    p10, o10 = syn.make_sweeps_batch((34,))
+    d_p, d_o = torch.from_numpy(p10).to(cuda), torch.from_numpy(o10).to(cuda)
+    with torch.no_grad():
+        a = net.forward_points(d_p, d_o, 1, cfg)        # tiles (and the measurement)
+        assert 1 in eng._heur_key(), eng.tile_escape_share
+        b = net.forward_points(d_p, d_o, 1, cfg)        # stage 3 (at least) on the gather kernels
+    for name in ("x_conv2", "x_conv3", "x_conv4", "out"):
+        assert torch.equal(a[name].features, b[name].features), name
+    assert eng.tile_off[1] == eng.TILE_REPROBE - 1

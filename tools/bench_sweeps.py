@@ -17,28 +17,43 @@ grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_
 net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 0).to(dev).eval()
 
 
-def scene(seed):
-    parts = []
-    for j in range(args.sweeps):
-        p = syn.make_scene(seed).copy()           # same world (seeded), ego moved along x: points shift
-        p[:, 0] += 0.5 * j + 0.013 * j * j
-        p[:, 1] += 0.07 * j
-        p[:, 4] = 0.05 * j
-        parts.append(p)
-    p = np.concatenate(parts, 0)
-    r = syn.POINT_CLOUD_RANGE
-    return np.ascontiguousarray(p[(p[:, 0] >= r[0]) & (p[:, 0] <= r[3]) & (p[:, 1] >= r[1]) & (p[:, 1] <= r[4])])
-
-
-scenes = [scene(s) for s in range(B)]
-off = np.zeros(B + 1, np.int32); off[1:] = np.cumsum([s.shape[0] for s in scenes])
-pts = torch.from_numpy(np.concatenate(scenes, 0)).to(dev); offd = torch.from_numpy(off).to(dev)
+pts_np, off = syn.make_sweeps_batch(list(range(B)), args.sweeps)
+pts = torch.from_numpy(pts_np).to(dev); offd = torch.from_numpy(off).to(dev)
 cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, syn.MAX_VOXELS_TEST)
 with torch.no_grad():
     for _ in range(3): r = net.forward_points(pts, offd, B, cfg)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(args.reps): r = net.forward_points(pts, offd, B, cfg)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.reps
+# what the engine's heuristics rest on, measured on THIS density (they were sized on single-sweep scenes): the share of the
+# (tile, offset) pairs the class-sorted 128 -> 128 sweep skips, the share of 32-row groups of the tiled stages that hold an
+# escape entry, neighbours per row of each SubM stage
+eng = net.engine()
+stats = {}
+with torch.no_grad():
+    eng.rulebook_log = []
+    net.forward_points(pts, offd, B, cfg)
+    log, eng.rulebook_log = eng.rulebook_log, None
+seen = set()
+for tag, rb, n_dev in log:
+    cin, cout, K, has_res, ranked = tag
+    if K != 27 or cin != cout or cin in seen:
+        continue
+    seen.add(cin)
+    n = int(n_dev.item())
+    row = {"rows": n, "neighbours_per_row": round(float((rb.nbr[:, :n] >= 0).sum().item()) / max(n, 1), 2)}
+    if cin in (32, 64):
+        t = S.tile_rulebook(rb, n_dev, cin)
+        REC, TR = (14864, 256) if cin == 32 else (7440, 128)
+        nt = (n + TR - 1) // TR
+        row["groups_with_escape"] = round(t.view(-1, REC)[:nt, REC - 16:REC - 16 + TR // 32].float().mean().item(), 6)
+    if cin == 128 and S.sorted_by_default(128, 128, torch.bfloat16, rb.cap_out):
+        S.classsort(rb, n_dev, 128)
+        bm = rb._sorted[1][: (n + 15) // 16].cpu().numpy().view(np.uint32)
+        nt24 = len(bm) // 24
+        tm = np.bitwise_or.reduce(bm[: nt24 * 24].reshape(nt24, 24), axis=1) if nt24 else bm
+        row["tile_offsets_skipped(384-row tiles in sorted order, approx)"] = round(1.0 - float(np.mean([bin(int(v)).count("1") for v in tm])) / 27, 3)
+    stats[f"{cin}x{cout}"] = row
 print(json.dumps({"scenes_per_step": B, "sweeps": args.sweeps, "points_per_scene": int(pts.shape[0] // B),
                   "voxels_per_scene": r["counts"][0] // B, "site_counts": r["counts"], "ms_per_step": round(dt * 1e3, 3),
-                  "scenes_per_s": round(B / dt, 1)}))
+                  "scenes_per_s": round(B / dt, 1), "tiled_aborts": int(S._l.load().fnp_spconv_tiled_aborts()), "layer_stats": stats}))
