@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step region; `value` is the median one, the list is reported")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (fp32 engine, Box Seeker, extraction, training "
                                                                 "step: each a fresh child process)")
-    ap.add_argument("--secondary-budget", type=float, default=420.0, help="wall-clock seconds all secondary child processes may take together; "
+    ap.add_argument("--secondary-budget", type=float, default=540.0, help="wall-clock seconds all secondary child processes may take together; "
                                                                           "those that do not fit are skipped and say so")
     ap.add_argument("--no-events", action="store_true", help="do not bracket conv launches with events")
     ap.add_argument("--launch", default="graphs", choices=["graphs", "stream"],
@@ -587,6 +587,8 @@ def main():
             "first_bev_block": ([py, os.path.join(T, "bench_bev.py"), "--batch", "16"], 240),
             # the density transfusion_lidar.yaml feeds the backbone (nuscenes_dataset.yaml:5 MAX_SWEEPS 10): emulated 10-sweep scenes
             "ten_sweep": ([py, os.path.join(T, "bench_sweeps.py"), "--batch", "8"], 240),
+            # the f32 result on the BF16 matrix pipe (FNP_DTYPE: bf16x3), with its measured deviation from the f32 engine
+            "fp32_grade_engine": ([py, os.path.join(T, "bench_x3.py"), "--batch", str(B)], 240),
         }
         for name, (cmd, to) in jobs.items():
             left = t_budget - time.perf_counter()

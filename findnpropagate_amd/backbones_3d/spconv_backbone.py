@@ -91,14 +91,15 @@ class _BackboneBase(nn.Module):
         # with fp32 accumulation on v_mfma_f32_16x16x32 — or 'fp32' (v_mfma_f32_16x16x4_f32: the reference's default
         # precision, bit-comparable with the CPU oracle, BASELINE.json's 1e-4 mode)
         self.fnp_dtype = str(_cfg_get(model_cfg, 'FNP_DTYPE', 'bf16')).lower()
-        assert self.fnp_dtype in ('bf16', 'fp16', 'fp32'), self.fnp_dtype
+        assert self.fnp_dtype in ('bf16', 'fp16', 'fp32', 'bf16x3'), self.fnp_dtype
         # dtype of what crosses the reference boundary (encoded_spconv_tensor, multi_scale_3d_features): the reference
         # contract is float32 (its BaseBEVBackbone / heads are f32 modules), so that is the default whatever the
         # engine computes in; 'native' hands out the engine's own storage dtype (bf16 / fp16) without a cast
         self.fnp_out_dtype = str(_cfg_get(model_cfg, 'FNP_OUT_DTYPE', 'fp32')).lower()
 
     def _act_dtype(self):
-        return {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}[self.fnp_dtype]
+        # (bf16x3: f32 tensors between the layers and at the boundary; the engine keeps their (hi, lo) bf16 split beside them)
+        return {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16, 'bf16x3': torch.float32}[self.fnp_dtype]
 
     def _boundary_dtype(self):
         return {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16,
@@ -533,6 +534,12 @@ class FusedResBackbone:
     def __init__(self, module: VoxelResBackBone8x):
         self.m = module
         self.act = module._act_dtype()
+        # bf16x3 (round 4): the f32 result to ~1e-5 relative on the BF16 matrix pipe.  Activations travel as f32 rows plus their
+        # split x = hi + lo into two bf16 tensors (fnp_split_bf16), weights (BatchNorm scale folded in) as W = W_hi + W_lo, and a
+        # convolution is three launches of the bf16 kernels with f32 outputs chained through `residual`:
+        #   t = lo * W_hi (+ identity);  t = hi * W_lo + t;  y = relu(hi * W_hi + shift + t)
+        # (the lo * W_lo term, 2^-16 of a product, is dropped).  conv_input reads the f32 voxel means on the f32 kernel.
+        self.x3 = getattr(module, 'fnp_dtype', '') == 'bf16x3'
         self._prep = None
         self._prep_key = None
         self._grids = {}
@@ -647,17 +654,42 @@ class FusedResBackbone:
         if self._prep_key == key:
             return self._prep
         P = {}
+        fold = self._fold_x3 if self.x3 else (lambda c, b: self._fold(c, b, self.act))
         P['in'] = self._fold(m.conv_input[0], m.conv_input[1], torch.float32)  # f32 features in
         for name, seq, first in (('1', m.conv1, 0), ('2', m.conv2, 1), ('3', m.conv3, 1), ('4', m.conv4, 1)):
             if first:
-                P['down' + name] = self._fold(seq[0][0], seq[0][1], self.act)
+                P['down' + name] = fold(seq[0][0], seq[0][1])
             blocks = []
             for blk in list(seq._modules.values())[first:]:
-                blocks.append((self._fold(blk.conv1, blk.bn1, self.act), self._fold(blk.conv2, blk.bn2, self.act)))
+                blocks.append((fold(blk.conv1, blk.bn1), fold(blk.conv2, blk.bn2)))
             P['blocks' + name] = blocks
-        P['out'] = self._fold(m.conv_out[0], m.conv_out[1], self.act)
+        P['out'] = fold(m.conv_out[0], m.conv_out[1])
         self._prep, self._prep_key = P, key
         return P
+
+    def _fold_x3(self, conv, bn):
+        """bf16x3: (W_hi, W_lo, shift) with BatchNorm(eval)'s scale folded into the weights before the split (the chained
+        launches add their f32 partial results unscaled); W_hi + W_lo == scale * W to 2^-17; packed (K, Cout, Cin) bf16."""
+        w32, scale, shift = self._fold(conv, bn, torch.float32)
+        w32 = w32.as_subclass(torch.Tensor) if isinstance(w32, S.PermutedWeight) else w32
+        wf = S.pack_weight(conv.weight, torch.float32).float() * scale.view(1, -1, 1)      # plain (K, Cout, Cin) layout
+        hi = wf.to(torch.bfloat16)
+        lo = (wf - hi.float()).to(torch.bfloat16)
+        return (hi.contiguous(), lo.contiguous(), torch.ones_like(scale)), None, shift
+
+    def _split(self, y, n):
+        hi, lo = S.split_bf16(y, n)
+        return (hi, lo, y)
+
+    def _conv_x3(self, x, prm, rb, n, residual, out):
+        """one convolution of the bf16x3 engine (see __init__): x = (hi, lo, f32 rows); returns the same triple of the output"""
+        (whi, wlo, ones), _, shift = prm
+        res = None if residual is None else residual[2]
+        t = S.conv_forward(x[1], whi, rb, n, out_dtype=torch.float32, residual=res, tile=False, wide=False)
+        t = S.conv_forward(x[0], wlo, rb, n, out_dtype=torch.float32, residual=t, out=t, tile=False, wide=False)
+        y = S.conv_forward(x[0], whi, rb, n, out_dtype=torch.float32, scale=ones, shift=shift, residual=t, relu=True, out=t if out is None else out,
+                           tile=False, wide=False)
+        return self._split(y, n)
 
     # ---- persistent rank grids (zero between calls; cleared sparsely after use) -----------
     def _stage_shapes(self):
@@ -800,6 +832,8 @@ class FusedResBackbone:
         caps = [cap1] + [max(256, int(cap1 * f)) for f in self.cap_factor]
 
         def conv(x, prm, rb, n, residual=None, out_dtype=act, ranked=False):
+            if self.x3 and isinstance(prm[0], tuple):
+                return self._conv_x3(x, prm, rb, n, residual, None)
             w, sc, sh = prm
             tag = (int(w.shape[2]), int(w.shape[1]), int(w.shape[0]), residual is not None, ranked)  # Cin, Cout, K, res
             if self.rulebook_log is not None:
@@ -888,7 +922,7 @@ class FusedResBackbone:
                 ell_used.append((rb1._ell[2], rb1._ell[1], 0))
             else:
                 # (f32: the 16 -> 16 layers sweep their ranges class by class, like every f32 SubM stage below)
-                srt1 = S.f32_sorted_by_default(16, act, cap1) and self.rulebook_log is None
+                srt1 = S.f32_sorted_by_default(16, act, cap1) and self.rulebook_log is None and not self.x3
                 rb1 = S.rulebook_subm(indices, n1, grid1, 3, masks=srt1)
                 if srt1:
                     S.classsort_f32(rb1, n1, 16)
@@ -913,7 +947,8 @@ class FusedResBackbone:
                     ell_used.append((rbs._ell[2], rbs._ell[1], 1))
                 # stages 2-4: rows are in rank-grid order on both sides of the SubM convolutions; where they run on the tile
                 # rulebook (stage 2, 32 channels), the rulebook kernel writes it in the same pass
-                ch = int(P[blk_key][0][0][0].shape[1])
+                w0 = P[blk_key][0][0][0]
+                ch = int((w0[0] if isinstance(w0, tuple) else w0).shape[1])
                 # wide tiles (round 4; 64 and 128 channels from a capacity on that gives every CU several tiles): they replace the
                 # 128-row tiles of stage 3 and the class-sorted gather sweep of stage 4
                 wide = (S.wide_by_default(ch, act, caps[li + 1]) and S.wide_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
@@ -926,7 +961,7 @@ class FusedResBackbone:
                 nxt = down_convs[li + 1]
                 lean = tiled and self.rulebook_log is None   # (all four layers of the stage run tiled)
                 mark_next = (grids[li + 2], nxt.kernel_size, nxt.stride, nxt.padding) if (lean or srt) and S.MARK_FUSED else None
-                srt32 = S.f32_sorted_by_default(ch, act, caps[li + 1]) and self.rulebook_log is None
+                srt32 = S.f32_sorted_by_default(ch, act, caps[li + 1]) and self.rulebook_log is None and not self.x3
                 esc_ctr = self._ell_counter(("esc", li), dev) if (lean and not wide and S.TILE_MODE is None) else None
                 rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3, tile_channels=ch if tiled else None, masks=srt or srt32,
                                      lean_table=lean, mark_next=mark_next, wide=wide, esc_counter=esc_ctr)
@@ -996,8 +1031,11 @@ class FusedResBackbone:
 
         ready(0)
         x = conv(feats, P['in'], rb1, n1)
+        if self.x3:
+            x = self._split(x, n1)      # (conv_input ran on the f32 kernel: exact; from here on (hi, lo, f32) triples)
+        f32_of = (lambda t: t[2]) if self.x3 else (lambda t: t)
         x1 = blocks(x, rb1, n1, P['blocks1'])
-        stage = [(x1, indices, n1, grid1)]
+        stage = [(f32_of(x1), indices, n1, grid1)]
         x_prev = x1
         for li, (down_key, blk_key, rbs, rb) in enumerate(books):
             ready(li + 1)
@@ -1012,10 +1050,10 @@ class FusedResBackbone:
                     x = blocks(x, rb, rbs.out_n, P[blk_key], ranked=True)
             else:
                 x = blocks(x, rb, rbs.out_n, P[blk_key], ranked=True)
-            stage.append((x, rbs.out_indices, rbs.out_n, rbs.out_grid))
+            stage.append((f32_of(x), rbs.out_indices, rbs.out_n, rbs.out_grid))
             x_prev = x
         xo = conv(x_prev, P['out'], rbo, rbo.out_n, out_dtype=final_dtype or act)
-        stage.append((xo, rbo.out_indices, rbo.out_n, rbo.out_grid))
+        stage.append((f32_of(xo), rbo.out_indices, rbo.out_n, rbo.out_grid))
 
         # leave every persistent grid zeroed for the next call (O(rows) sparse clear, all five grids in one launch)
         S.clear_grids([(g, idx, n_cells if (l == 0 and n_cells is not None) else n) for l, (_, idx, n, g) in enumerate(stage)])

@@ -622,6 +622,16 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
     return out
 
 
+def split_bf16(x, n_dev):
+    """f32 rows (cap, C) -> (hi, lo) bf16 with hi + lo == x to 2^-17 of |x| (fnp_split_bf16); rows >= n are left undefined."""
+    L = _l.load()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _l.check(L.fnp_split_bf16(_l.ptr(x), _l.ptr(n_dev), x.shape[0], x.shape[1], _l.ptr(hi), _l.ptr(lo), _l.stream()), "fnp_split_bf16")
+    return hi, lo
+
+
 def conv_forward_strided(feat_in, w_packed, rb, scale=None, shift=None, relu=False, out=None):
     """A strided 3x3x3 convolution whose rulebook rows are computed inside the kernel (rb from
     rulebook_strided(..., want_nbr=False)).  bf16 or fp16, (Cin, Cout) in {(16,32), (32,64), (64,128)}.  Same result as

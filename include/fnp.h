@@ -355,6 +355,12 @@ int fnp_spconv_forward_wtiled(const void *feat_in, int dtype, int n_in_rows, con
                               const float *scale, const float *shift, const void *residual, int relu,
                               int Cin, int Cout, fnp_stream_t stream);
 
+/* f32 rows -> two bf16 tensors hi = bf16(x), lo = bf16(x - hi) (ABI 10): hi + lo equals x to 2^-17 of |x|.  The activation
+ * format of the fused backbone's "bf16x3" precision (FNP_DTYPE: bf16x3): every convolution is three fnp_spconv_forward launches
+ * with f32 outputs chained through `residual` — lo x W_hi, hi x W_lo, hi x W_hi — on the bf16 matrix pipe, the f32 result to
+ * ~1e-5 relative.  Rows >= *n_rows are not touched; C a multiple of 4. */
+int fnp_split_bf16(const float *x, const int *n_rows, int cap_rows, int C, void *hi, void *lo, fnp_stream_t stream);
+
 /* COMPACT RULEBOOK for the sparse-neighbourhood layers (conv_input 5 -> 16, the four 16 -> 16 SubM layers, the strided
  * 16 -> 32 layer: spconv_backbone.py:193-210).  A stage-1 voxel has 3.6 of its 27 neighbours, an output site of the first
  * strided layer 2.1 of 27 inputs: the (27, cap) int32 table spends 108 bytes per row on that and the matrix kernel a gather

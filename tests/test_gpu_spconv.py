@@ -676,6 +676,44 @@ def test_wide_tile_kernel_equals_gather_kernel(cuda, rng, n, order, dtype, C):
         S.conv_forward(x, wp, rb2, n_dev, ranked=True, tile=False, wide=False)
 
 
+def test_bf16x3_engine_is_f32_grade_on_the_bf16_matrix_pipe(cuda, oracle):
+    """FNP_DTYPE: bf16x3 — activations as f32 rows + their split x = hi + lo into two bf16 tensors (fnp_split_bf16), weights (with
+    the BatchNorm scale folded in) as W_hi + W_lo, every convolution three launches of the bf16 MFMA kernels with f32 outputs
+    chained through `residual` (lo x W_hi, hi x W_lo, hi x W_hi) — against the f32 CPU oracle: same site sets, and every one of
+    the five outputs within 3e-5 of its feature scale (measured 0.7-1.1e-5; the bf16 engine: 4e-3; the f32 engine: 0).  The
+    split itself: hi + lo == x to 2^-17 |x|, rows past n untouched."""
+    x = torch.randn((1000, 64), device=cuda) * torch.logspace(-3, 3, 64, device=cuda)
+    n_dev = S.device_scalar(900, cuda)
+    hi, lo = S.split_bf16(x, n_dev)
+    assert torch.equal(hi[:900], x[:900].bfloat16())
+    assert ((hi[:900].float() + lo[:900].float() - x[:900]).abs() <= x[:900].abs() * 2.0 ** -16).all()
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    rng_hi = [-14.4, -14.4, -5.0, 14.4, 14.4, 3.0]
+    grid = np.round((np.array(rng_hi[3:]) - np.array(rng_hi[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    pts = syn.make_scene(3)
+    pts = pts[(np.abs(pts[:, 0]) < 14.4) & (np.abs(pts[:, 1]) < 14.4)]
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, rng_hi, 5, 10, 160000)
+    off = torch.tensor([0, pts.shape[0]], dtype=torch.int32, device=cuda)
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False, "FNP_DTYPE": "bf16x3"}, 5, grid), 0).to(cuda).eval()
+    with torch.no_grad():
+        res = net.forward_points(torch.from_numpy(pts).to(cuda), off, 1, cfg)
+        res2 = net.forward_points(torch.from_numpy(pts).to(cuda), off, 1, cfg)
+    v, c, n = oracle.voxelize(pts, syn.VOXEL_SIZE, rng_hi, 10, 160000)
+    coords = np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)
+    assert np.array_equal(res["voxel_coords"].cpu().numpy(), coords)
+    sd = {k: t.detach().cpu().numpy() for k, t in net.state_dict().items()}
+    want = oracle.backbone_forward(sd, oracle.mean_vfe(v, n), coords, 1, net.sparse_shape)
+    for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out"):
+        got, w = res[name], want[name]
+        assert got.features.dtype == torch.float32
+        gi, wi = got.indices.cpu().numpy(), w.indices
+        go, wo = np.argsort(_key(gi, got.spatial_shape)), np.argsort(_key(wi, w.spatial_shape))
+        assert np.array_equal(gi[go], wi[wo]), name
+        g, f = got.features.cpu().numpy()[go], w.features[wo]
+        assert np.abs(g - f).max() <= 3e-5 * max(1.0, np.abs(f).max()), (name, np.abs(g - f).max(), np.abs(f).max())
+        assert torch.equal(got.features, res2[name].features), name     # (deterministic; grids left clean)
+
+
 def _surface_sites(rng, B, shape, n):
     """sites on a two-cell-thick wavy sheet: like a lidar surface after stride-2 layers, most sites have neighbours in only
     one of the two adjacent z planes (what the class sort separates)."""

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Secondary measurement: the 1e-4-grade engine on the bf16 matrix pipe (FNP_DTYPE: bf16x3 — features and weights split into two
+bf16 terms, three bf16 MFMA products per term pair, f32 accumulate and f32 activations between layers) — scenes/s at B scenes
+per step, and its largest absolute deviation from the f32 engine (which is the CPU oracle bit for bit) at the five outputs."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from findnpropagate_amd import sparse as S, synthetic as syn
+from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=64); ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--warmup", type=int, default=2); ap.add_argument("--check-scenes", type=int, default=4)
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+mk = lambda dt: syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False, "FNP_DTYPE": dt}, 5, grid), 0).to(dev).eval()
+cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, syn.MAX_VOXELS_TEST)
+net = mk("bf16x3")
+# accuracy against the f32 engine on a few scenes
+ref = mk("fp32")
+p, o = syn.make_batch(list(range(args.check_scenes)))
+p, o = torch.from_numpy(p).to(dev), torch.from_numpy(o).to(dev)
+err = {}
+with torch.no_grad():
+    a = net.forward_points(p, o, args.check_scenes, cfg)
+    b = ref.forward_points(p, o, args.check_scenes, cfg)
+for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out"):
+    assert torch.equal(a[name].indices, b[name].indices)
+    d = (a[name].features.float() - b[name].features.float()).abs()
+    err[name] = {"max_abs_err": float(d.max()), "feature_scale": float(b[name].features.abs().max()),
+                 "rows_over_1e-4": float((d.max(dim=1).values > 1e-4).float().mean())}
+del ref
+B = args.batch
+p, o = syn.make_batch(list(range(B)))
+p, o = torch.from_numpy(p).to(dev), torch.from_numpy(o).to(dev)
+with torch.no_grad():
+    for _ in range(args.warmup):
+        net.forward_points(p, o, B, cfg)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = net.forward_points(p, o, B, cfg)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+print(json.dumps({"engine": "bf16x3: features and weights as hi + lo bf16, three v_mfma_f32_16x16x32_bf16 products per pair, f32 accumulate, f32 activations",
+                  "scenes_per_step": B, "value": B / dt, "unit": "scenes/s", "ms_per_step": 1e3 * dt, "site_counts": [int(c) for c in r["counts"]],
+                  "max_abs_err_vs_f32_engine": max(e["max_abs_err"] for e in err.values()), "per_output": err,
+                  "note": "the f32 engine (secondary.fp32_engine) is the CPU oracle bit for bit; 1e-4 absolute is BASELINE.json's tolerance"}))
