@@ -36,6 +36,8 @@ def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stri
     elif conv_type == 'spconv':
         conv = spconv.SparseConv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
                                    bias=False, indice_key=indice_key)
+    elif conv_type == 'inverseconv':
+        conv = spconv.SparseInverseConv3d(in_channels, out_channels, kernel_size, indice_key=indice_key, bias=False)
     else:
         raise NotImplementedError
     return spconv.SparseSequential(conv, norm_fn(out_channels), nn.ReLU())

@@ -9,6 +9,6 @@ __version__ = "2.3.6"
 from . import constants  # noqa: E402,F401
 from .core import SparseConvTensor  # noqa: E402,F401
 from .modules import SparseModule, SparseSequential  # noqa: E402,F401
-from .conv import SparseConv3d, SparseConvolution, SubMConv3d  # noqa: E402,F401
+from .conv import SparseConv3d, SparseConvolution, SparseInverseConv3d, SubMConv3d  # noqa: E402,F401
 from . import conv, modules, utils  # noqa: E402,F401
 from . import pytorch  # noqa: E402,F401  (INTEGRATION.md §2 aliases `spconv.pytorch` from this attribute)

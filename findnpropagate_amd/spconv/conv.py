@@ -206,6 +206,8 @@ class SparseConvolution(SparseModule):
         if self.bias is not None:
             out_feats = out_feats + self.bias.to(out_feats.dtype)
         if self.indice_key is not None:
+            # (with the input side: SparseInverseConv3d of the same indice_key maps back onto exactly these sites)
+            rb._in_side = (input.indices, list(input.spatial_shape), n_dev, input._rank_grid)
             input.indice_dict[self.indice_key] = rb
         return SparseConvTensor(out_feats, rb.out_indices[:n_out], rb.out_shape, input.batch_size, input.grid,
                                 input.voxel_num, input.indice_dict, input.benchmark, rb.out_n, rb.out_grid)
@@ -306,3 +308,43 @@ class SparseConv3d(SparseConvolution):
                  indice_key=None, algo=None, fp32_accum=None, name=None):
         super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, False,
                          indice_key=indice_key, algo=algo, fp32_accum=fp32_accum, name=name)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    """spconv.SparseInverseConv3d (post_act_block conv_type 'inverseconv', spconv_backbone.py:16-17; used by
+    pcdet/models/backbones_3d/spconv_unet.py's up-sampling path only): the inverse of the SparseConv3d that shares its
+    indice_key.  It runs on THAT layer's indice pairs with the two sides swapped — out[i] = sum over the pairs (k, i, o) of
+    in[o] W_k — so its output sites are exactly the input sites of the paired layer (same order, same spatial shape), and it
+    has its own weight (out_channels, kD, kH, kW, in_channels).  Inference only (the UNet's training path is outside SURVEY
+    section 8): the transposed rulebook is the one the paired layer's data gradient uses (fnp_rulebook_transpose), the
+    convolution the ordinary forward kernel on it."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key=None, bias=True, algo=None, fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, 1, 0, 1, 1, bias, False, indice_key=indice_key, algo=algo,
+                         fp32_accum=fp32_accum, name=name)
+        self.inverse = True
+
+    def forward(self, input: SparseConvTensor):
+        assert isinstance(input, SparseConvTensor)
+        rb = input.find_indice_pair(self.indice_key)
+        if rb is None or getattr(rb, "_in_side", None) is None or rb.nbr is None:
+            raise ValueError(f"SparseInverseConv3d(indice_key={self.indice_key!r}): no SparseConv3d with this indice_key has run on the way here")
+        if torch.is_grad_enabled() and (self.weight.requires_grad or input.features.requires_grad):
+            raise NotImplementedError("SparseInverseConv3d: inference only (training the UNet decoder is outside the hot path)")
+        kvol = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+        assert rb.K == kvol, "kernel size differs from the paired convolution's"
+        in_idx, in_shape, n_in_dev, in_grid = rb._in_side
+        feats = input.features.detach()
+        if feats.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            feats = feats.to(torch.bfloat16)
+        feats = feats.contiguous()
+        cap_in = max(in_idx.shape[0], 1)
+        nbr_t = getattr(rb, "_nbr_t", None)
+        if nbr_t is None or nbr_t.shape[1] != cap_in:
+            nbr_t = rb._nbr_t = S.rulebook_transpose(rb, rb.out_n, cap_in)
+        rbt = S.Rulebook(nbr=nbr_t, K=rb.K, cap_out=cap_in, geom=rb.geom)
+        out_feats = S.conv_forward(feats, self.packed_weight(feats.dtype), rbt, n_in_dev, tile=False, wide=False)[: in_idx.shape[0]]
+        if self.bias is not None:
+            out_feats = out_feats + self.bias.to(out_feats.dtype)
+        return SparseConvTensor(out_feats, in_idx, in_shape, input.batch_size, input.grid, input.voxel_num, input.indice_dict,
+                                input.benchmark, n_in_dev, in_grid)

@@ -265,6 +265,25 @@ def sparse_conv(x, weight, stride, padding):
     return SparseTensor(conv_apply(x.features, weight, pin, pout, pn, out_idx.shape[0]), out_idx, out_shape, x.batch_size)
 
 
+def inverse_conv(x, weight, paired):
+    """spconv.SparseInverseConv3d forward (post_act_block 'inverseconv', spconv_backbone.py:16-17; spconv_unet.py): the indice
+    pairs of the SparseConv3d with the same indice_key, the two sides swapped — out[i] += in[o] W_k for every pair (k, i, o) of
+    `paired` = (in_indices, in_shape, pin, pout, pn) of that layer; weight (Cout, kD, kH, kW, Cin).  Output sites = the paired
+    layer's input sites.  numpy, f64 accumulation (small cases)."""
+    in_idx, in_shape, pin, pout, pn = paired
+    weight = _f32(weight)
+    Cout, Cin = weight.shape[0], weight.shape[-1]
+    K = int(np.prod(weight.shape[1:4]))
+    w = weight.reshape(Cout, K, Cin).astype(np.float64)
+    out = np.zeros((in_idx.shape[0], Cout), np.float64)
+    f = _f32(x.features).astype(np.float64)
+    for k in range(K):
+        m = int(pn[k])
+        if m:
+            np.add.at(out, pin[k, :m], f[pout[k, :m]] @ w[:, k, :].T)
+    return SparseTensor(out.astype(np.float32), in_idx, in_shape, x.batch_size)
+
+
 def bn_fold(bn, eps=1e-3):
     """bn = dict(weight, bias, running_mean, running_var) -> (scale, shift) f32."""
     C = bn["weight"].shape[0]

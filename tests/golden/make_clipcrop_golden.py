@@ -64,7 +64,7 @@ def main():
     sys.modules["torchvision.utils"].save_image = lambda *a, **k: None
     sys.modules["torchvision.transforms"].ToPILImage = object
     mod = importlib.import_module("pcdet.models.dense_heads.clip_box_classification")
-    for seed in (0, 1):
+    for seed in ([int(a) for a in sys.argv[1:]] or [0, 1, 2]):
         head = object.__new__(mod.CLIPBoxClassification)
         torch.nn.Module.__init__(head)
         head.image_order = [2, 0, 1, 5, 3, 4]
@@ -80,6 +80,18 @@ def main():
         rng = np.random.default_rng(500 + seed)
         boxes = boxes.astype(np.float32)
         boxes[:, :2] += rng.normal(scale=0.3, size=(boxes.shape[0], 2)).astype(np.float32)
+        if seed == 2:
+            # boxes the projection has to clip: around the ego itself (corners behind every camera and in front of it), a tall one
+            # right at a camera (its rectangle runs off two image borders), one wholly behind the front camera, one whose corners
+            # straddle a camera plane at a grazing angle (clip_box_classification.py:217-377: on-image test, clipped bounding box,
+            # square crop >= 64 px)
+            extra = np.array([[0.6, 0.1, -0.9, 4.6, 2.0, 1.7, 0.3],
+                              [2.2, 1.6, 0.2, 1.2, 1.0, 3.2, 0.0],
+                              [-6.0, 0.4, -0.8, 4.2, 1.9, 1.6, 3.0],
+                              [1.0, -2.4, -1.0, 3.8, 1.8, 1.5, 1.35],
+                              [0.2, 2.0, -1.2, 0.7, 0.7, 1.8, 0.8]], np.float32)
+            boxes = np.concatenate([boxes[:6], extra]).astype(np.float32)
+            cls = np.concatenate([cls[:6], np.array([0, 8, 0, 1, 8])])
         cams = syn.make_cameras(1)
         lidar_aug = np.eye(4, dtype=np.float32)
         if seed == 1:                                  # a non-trivial lidar augmentation (rotation + shift)

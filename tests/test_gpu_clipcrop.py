@@ -34,7 +34,7 @@ class FakeClip:   # the stand-in encoder of the golden generator
         return (pooled @ self.P).half()
 
 
-@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("seed", [0, 1, 2])   # (2: boxes around the ego and at a camera — corners behind cameras, rectangles clipped at two borders)
 def test_clip_crop_scoring_matches_reference_golden(cuda, seed):
     from findnpropagate_amd.dense_heads import CLIPBoxClassification
     g = np.load(os.path.join(GOLD, f"clipcrop_seed{seed}.npz"))

@@ -714,6 +714,40 @@ def test_bf16x3_engine_is_f32_grade_on_the_bf16_matrix_pipe(cuda, oracle):
         assert torch.equal(got.features, res2[name].features), name     # (deterministic; grids left clean)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("ksp", [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0)), ((2, 2, 2), (2, 2, 2), (0, 0, 0))])
+def test_sparse_inverse_conv_undoes_the_paired_layer_sites(cuda, rng, oracle, ksp, dtype, tol):
+    """spconv.SparseInverseConv3d (spconv_backbone.py:16-17 'inverseconv'; the UNet's up-sampling path): it runs on the indice
+    pairs of the SparseConv3d that shares its indice_key with the two sides swapped, so its output sites are that layer's INPUT
+    sites in their order; values against the oracle's pair-by-pair sum."""
+    from findnpropagate_amd import spconv
+    k, st, pd = ksp
+    B, shape, n, C1, C2 = 2, [9, 20, 22], 1500, 16, 32
+    feats, idx = _random_sparse(rng, B, shape, n, C1)
+    down = spconv.SparseConv3d(C1, C2, k, stride=st, padding=pd, bias=False, indice_key="sp").to(cuda)
+    up = spconv.SparseInverseConv3d(C2, C1, k, indice_key="sp", bias=False).to(cuda)
+    x = spconv.SparseConvTensor(torch.from_numpy(feats).to(cuda).to(dtype), torch.from_numpy(idx).to(cuda), shape, B)
+    with torch.no_grad():
+        y = down(x)
+        z = up(y)
+    assert z.spatial_shape == shape and torch.equal(z.indices, x.indices) and z.features.shape == (n, C1)
+    out_idx, out_shape, pin, pout, pn = oracle.rulebook_strided(idx, shape, k, st, pd)
+    yo = oracle.SparseTensor(oracle.conv_apply(x.features.float().cpu().numpy(), down.weight.detach().cpu().numpy(), pin, pout, pn, out_idx.shape[0]),
+                             out_idx, out_shape, B)
+    # the product's strided output rows come in rank-grid order: compare through the cell keys
+    go, wo = np.argsort(_key(y.indices.cpu().numpy(), out_shape)), np.argsort(_key(out_idx, out_shape))
+    yf = y.features.float().cpu().numpy()
+    assert np.allclose(yf[go], yo.features[wo], rtol=tol, atol=tol * max(1.0, np.abs(yo.features).max()))
+    # inverse: feed the oracle the product's own y (row order mapped), so that only the inverse layer is under test
+    y_in_oracle_order = np.empty_like(yo.features)
+    y_in_oracle_order[wo] = yf[go]
+    zo = oracle.inverse_conv(oracle.SparseTensor(y_in_oracle_order, out_idx, out_shape, B), up.weight.detach().cpu().numpy(), (idx, shape, pin, pout, pn))
+    zf = z.features.float().cpu().numpy()
+    assert np.allclose(zf, zo.features, rtol=tol, atol=tol * max(1.0, np.abs(zo.features).max()))
+    with pytest.raises(ValueError, match="indice_key"):
+        spconv.SparseInverseConv3d(C2, C1, k, indice_key="other", bias=False).to(cuda)(y)
+
+
 def _surface_sites(rng, B, shape, n):
     """sites on a two-cell-thick wavy sheet: like a lidar surface after stride-2 layers, most sites have neighbours in only
     one of the two adjacent z planes (what the class sort separates)."""
