@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): bench JSON, rocprofv3 kernel stats, the two PMC traffic passes and the SQ counter
 # pass of the same command, all under gpurun_out/<tag>/.  usage: tools/profile_round.sh <tag> [batch]
-TAG=${1:-round}; B=${2:-64}; shift; shift; EXTRA="$@"   # extra bench.py args, e.g. --dtype fp32
+TAG=${1:-round}; B=${2:-128}; shift; shift; EXTRA="$@"   # extra bench.py args, e.g. --dtype fp32
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/$TAG
 mkdir -p $O/stats $O/fetch $O/write $O/sq
 cd /tmp && export TMPDIR=/tmp
