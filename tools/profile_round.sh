@@ -7,6 +7,10 @@ mkdir -p $O/stats $O/fetch $O/write $O/sq
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --batch $B $EXTRA > $O/bench_b$B.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --batch $B --cpu-scenes 0 --no-sweep --no-secondary $EXTRA > $O/bench_under_rocprof.json 2>/dev/null
+# the same step with every kernel a plain stream launch (no second branch: kernels do not overlap, so per-kernel averages are
+# comparable with the bench line's per_class, which comes from bracketed stream launches)
+mkdir -p $O/stats_stream
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_stream -- python3 $R/bench.py --batch $B --cpu-scenes 0 --no-sweep --no-secondary --launch stream $EXTRA > $O/bench_stream_under_rocprof.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --batch $B --cpu-scenes 0 --no-sweep --no-secondary $EXTRA --steps 3 --warmup 2 --reps 1 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --batch $B --cpu-scenes 0 --no-sweep --no-secondary $EXTRA --steps 3 --warmup 2 --reps 1 > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/sq -- python3 $R/bench.py --batch $B --cpu-scenes 0 --no-sweep --no-secondary $EXTRA --steps 3 --warmup 2 --reps 1 > /dev/null 2>&1
