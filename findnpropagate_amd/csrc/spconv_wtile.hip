@@ -38,8 +38,28 @@ template <typename T> struct W16 {
     typedef T v8 __attribute__((ext_vector_type(8)));
     typedef T v4 __attribute__((ext_vector_type(4)));
 };
-__device__ __forceinline__ f32x4 wmfma(W16<__bf16>::v8 a, W16<__bf16>::v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f32x4 wmfma(W16<_Float16>::v8 a, W16<_Float16>::v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// MFMA with the accumulator PINNED: C and D are the same AGPR quad (inline asm, "+a").  Through the builtin hipcc puts the 128
+// accumulator registers of this kernel in AGPRs all the same but moves them about (v_accvgpr_read / mov / write, ~40 per step
+// around MFMAs whose C and D differ): the sweep then runs at half the matrix rate even with its LDS reads removed (measured).
+#ifndef FNP_WTILE_ASM_MFMA
+#define FNP_WTILE_ASM_MFMA 1
+#endif
+__device__ __forceinline__ f32x4 wmfma(W16<__bf16>::v8 a, W16<__bf16>::v8 b, f32x4 c) {
+#if FNP_WTILE_ASM_MFMA
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x4 wmfma(W16<_Float16>::v8 a, W16<_Float16>::v8 b, f32x4 c) {
+#if FNP_WTILE_ASM_MFMA
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
 
 using tilerb::kEscape;
 using tilerb::kK;
@@ -75,8 +95,8 @@ template <int C> struct WCfg {
 #endif
 
 // Development-only phase clocks (FNP_WTILE_STAMP builds): every wave sums the s_memtime ticks of each phase of a tile;
-// fnp_debug_wtile_stamps() returns and clears the sums.  [0] sweep, [1] residual + epilogue, [2] wait for the other waves,
-// [3] image -> LDS + barrier + the next image's requests
+// fnp_debug_wtile_stamps() returns and clears the sums.  [0] sweep (+ the next image's requests), [1] wait for the other waves,
+// [2] image -> LDS, [3] epilogue + barrier
 #ifdef FNP_WTILE_STAMP
 __device__ unsigned long long g_wtile_stamps[8];
 #define FNP_WS_NOW(v) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -342,25 +362,31 @@ __global__ __launch_bounds__(256, 1) void spconv_wtile_kernel(const TAct *__rest
     // ---------------------------------------------------------------------------------------- epilogue of one tile
     // the arithmetic of spconv_mfma_kernel (scale / shift, residual, ReLU, one rounding), 16 bytes per lane: the 8-byte pieces of
     // two channel blocks are exchanged between the lane rows q, q ^ 1 of a site (v_permlane16_swap)
+    uint4 rv[MB][NB / 2];   // residual rows: all requested right behind the sweep (one latency, not one per block)
+    auto req_residual = [&](const int tile_base) {
+        const int row_end = min(n, tile_base + G::TILE);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int kp = 0; kp < NB / 2; ++kp) {
+                const int r = tile_base + rloc + mb;
+                rv[mb][kp] = make_uint4(0u, 0u, 0u, 0u);
+                if (residual && r < row_end)
+                    rv[mb][kp] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(residual) + (size_t)r * (C * 2) + kp * 64 + poff);
+            }
+    };
     auto epilogue = [&](const int tile_base) {
         const int row_end = min(n, tile_base + G::TILE);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int r = tile_base + rloc + mb;
             const bool live = r < row_end;
-            uint4 rv[NB / 2];
-#pragma unroll
-            for (int kp = 0; kp < NB / 2; ++kp) {
-                rv[kp] = make_uint4(0u, 0u, 0u, 0u);
-                if (residual && live)
-                    rv[kp] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(residual) + (size_t)r * (C * 2) + kp * 64 + poff);
-            }
 #pragma unroll
             for (int kp = 0; kp < NB / 2; ++kp) {
                 uint2 ra = make_uint2(0u, 0u), rbb = make_uint2(0u, 0u);
                 if (residual) {
-                    auto t0 = __builtin_amdgcn_permlane16_swap(rv[kp].x, rv[kp].z, false, false);
-                    auto t1 = __builtin_amdgcn_permlane16_swap(rv[kp].y, rv[kp].w, false, false);
+                    auto t0 = __builtin_amdgcn_permlane16_swap(rv[mb][kp].x, rv[mb][kp].z, false, false);
+                    auto t1 = __builtin_amdgcn_permlane16_swap(rv[mb][kp].y, rv[mb][kp].w, false, false);
                     ra = make_uint2(t0[0], t1[0]);    // block 2 kp,     channels q*4 .. q*4+3
                     rbb = make_uint2(t0[1], t1[1]);   // block 2 kp + 1
                 }
@@ -429,19 +455,24 @@ __global__ __launch_bounds__(256, 1) void spconv_wtile_kernel(const TAct *__rest
         else sweep(std::false_type{}, tile_base);
 #endif
         FNP_WS(0);
-        epilogue(tile_base);
-        FNP_WS(1);
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the inline-asm MFMAs' results are read below: no hazard padding by the compiler)
+        req_residual(tile_base);
         publish_far_ids();                 // (of tile t + 2, requested by stage(t + 1))
         lds_barrier();                     // every wave has left the image and the ring
-        FNP_WS(2);
+        FNP_WS(1);
+        // image -> LDS BEFORE the epilogue issues its stores: the wait for the image's loads (issued before the sweep loop) cannot be
+        // counted across that loop, so it is vmcnt(0) — behind the stores it waited until all of them had reached memory (measured:
+        // 16 k cycles per tile); here it waits for the residual rows just requested, which the epilogue needs next anyway
         if (t + 1 < t_end) {               // (uniform)
             put_image();
             slab_put(0, wreg[0]);
             slab_put(1, wreg[1]);
 #pragma unroll
             for (int k = 0; k < 3; ++k) ecur[k] = enext[k];
-            lds_barrier();
         }
+        FNP_WS(2);
+        epilogue(tile_base);               // (its stores drain during the next sweep)
+        lds_barrier();                     // the image and the first two slabs are in LDS
         FNP_WS(3);
     }
 #ifdef FNP_WTILE_STAMP

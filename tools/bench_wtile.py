@@ -70,7 +70,7 @@ for tag, rb, n_dev in log:
         raw.fnp_debug_wtile_stamps(buf)
         S.conv_forward(x, w, rb, n_dev, scale=sc, shift=sh, residual=resid, relu=True, ranked=True, wide=True)
         torch.cuda.synchronize(); raw.fnp_debug_wtile_stamps(buf)
-        print(json.dumps({"wtile_cycles_per_tile_and_wave[sweep,epilogue,wait,put+barrier]": [round(buf[i] / (nt_ * 4)) for i in range(4)]}))
+        print(json.dumps({"wtile_cycles_per_tile_and_wave[sweep,wait,put,epilogue+barrier]": [round(buf[i] / (nt_ * 4)) for i in range(4)]}))
     dense = 2.0 * n * K * cin * cout
     row = {"layer": f"{cin}x{cout}", "rows": n, "tiles": nt_, "equal": bool(torch.equal(outs["current"][:n], outs["wide"][:n])),
            "groups_with_escape": round(esc.float().mean().item(), 5), "far_rows_per_tile": round(far.mean().item(), 1), "far_rows_max": int(far.max().item())}
