@@ -88,6 +88,9 @@ template <int C> struct WCfg {
 #ifndef FNP_WTILE_SCHED
 #define FNP_WTILE_SCHED 1
 #endif
+#ifndef FNP_WTILE_SLOTS
+#define FNP_WTILE_SLOTS 1
+#endif
 // Development-only timing probes (results are wrong; the shipped library has 0): 1 = no MFMA, 2 = no fragment reads,
 // 4 = no weight-slab streaming, 8 = no barrier per step, 16 = no sweep at all
 #ifndef FNP_WTILE_ABLATE
@@ -325,10 +328,87 @@ __global__ __launch_bounds__(256, 1) void spconv_wtile_kernel(const TAct *__rest
         if (!(FNP_WTILE_ABLATE & 4)) slab_req(2, wst);
         load_frags(0, 0, 0, 0, 0);
         // one step; PAR = s & 1 and the offset's parity are compile-time, the offset itself is not (13 + 1 trips of two offsets)
+        // SLOTS (the plain sweep; FNP_WTILE_SLOTS).  One wave per SIMD has nobody to issue into its gaps, and with the MFMAs as
+        // inline asm (pinned accumulators) the compiler's scheduler neither recognises them as matrix instructions nor spreads the
+        // other work between them: left alone it issues a half-step's ~60 LDS / VALU instructions first and its 32 MFMAs behind
+        // (measured: MFMAs at half their rate; a bare loop of the same asm MFMAs runs at 16.9 cycles each, tools/repro/mfma_rate.hip).
+        // So a half-step is written out as 32 slots — one MFMA, then at most a few instructions of side work, fenced by
+        // sched_barrier(0) so that the order stands: the 12 fragment reads of the next half-step in the first slots (they land
+        // long before the half ends), address arithmetic, the entry conversion and the slab hand-over behind them.
+        auto mfma_at = [&](auto set_tag, auto i_tag) {
+            constexpr int set = decltype(set_tag)::value, i = decltype(i_tag)::value, mb = i / NB, nb = i % NB;
+            const frag8 xv = *reinterpret_cast<const frag8 *>(&fb[set][mb]);
+            if (FNP_WTILE_ABLATE & 1) asm volatile("" ::"v"(fa[set][nb]), "v"(xv));
+            else acc[nb][mb] = wmfma(fa[set][nb], xv, acc[nb][mb]);
+        };
+        // side work of a half-step as numbered pieces: [0, NB) A reads, [NB, NB + MB) B reads (address + read), then `extra` pieces
+        auto read_piece = [&](auto j_tag, int ring_slot, int eset, int kh, int ks, auto set_tag) {
+            constexpr int j = decltype(j_tag)::value, set = decltype(set_tag)::value;
+            if (FNP_WTILE_ABLATE & 2) return;
+            if constexpr (j < NB) {
+                const uint4 tw = (wl + ring_slot * SLOTC)[aoff[ks] + j * 16 * 8];
+                fa[set][j] = *reinterpret_cast<const frag8 *>(&tw);
+            } else {
+                constexpr int mb = j - NB;
+                const unsigned cc = (unsigned)(kh * 8 + ks * 4) << 4;
+                const unsigned a = (e4[eset][mb] & ~MASK4) | ((e4[eset][mb] + q4 + cc) & MASK4);
+                fb[set][mb] = *reinterpret_cast<const u32x4 *>(img + a);
+            }
+        };
+        auto cvt_piece = [&](auto mb_tag, const ewords e, int set) {   // one block of entries_cvt (plain sweep: no escapes)
+            constexpr int mb = decltype(mb_tag)::value;
+            const unsigned em = (mb & 1) ? e[mb >> 1] >> 16 : e[mb >> 1] & 0xffffu;
+            e4[set][mb] = em << 4;
+        };
+        auto half_slots = [&](auto set_tag, auto second_tag, auto kpar_tag, auto kh_tag, const int k) {
+            constexpr int set = decltype(set_tag)::value;            // register set the MFMAs read; the reads fill set ^ 1
+            constexpr bool second = decltype(second_tag)::value;
+            constexpr int KP = decltype(kpar_tag)::value, KHv = decltype(kh_tag)::value;
+            constexpr int PAR = (KH == 1) ? KP : KHv;
+            constexpr bool last_kh = KHv == KH - 1;
+            const int s = k * KH + KHv;
+            // where the reads of this half go: first half -> (s, ks = 1) of the same ring slot; second -> (s + 1, ks = 0) of the other
+            constexpr int r_slot = second ? (PAR ^ 1) : PAR;
+            constexpr int r_eset = second ? (last_kh ? (KP ^ 1) : KP) : KP;
+            constexpr int r_kh = second ? (last_kh ? 0 : KHv + 1) : KHv;
+            constexpr int r_ks = second ? 0 : 1;
+            constexpr int NR = NB + MB;                              // 12 fragment reads
+            auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+            fence();
+#define FNP_SLOT(I)                                                                                                        \
+            mfma_at(std::integral_constant<int, set>{}, std::integral_constant<int, (I)>{});                               \
+            fence();                                                                                                       \
+            if constexpr ((I) < NR) {                                                                                      \
+                read_piece(std::integral_constant<int, (I)>{}, r_slot, r_eset, r_kh, r_ks, std::integral_constant<int, set ^ 1>{}); \
+                fence();                                                                                                   \
+            } else if constexpr (second && last_kh && (I) >= NR && (I) < NR + MB) {                                        \
+                cvt_piece(std::integral_constant<int, (I) - NR>{}, eraw[KP], KP);   /* offset k + 2 into the set offset k leaves */ \
+                fence();                                                                                                   \
+            } else if constexpr (second && (I) == NR + MB) {                                                               \
+                if (!(FNP_WTILE_ABLATE & 4)) { slab_put(PAR, wst); slab_req(s + 3, wst); }                                 \
+                fence();                                                                                                   \
+            } else if constexpr (!second && last_kh && (I) == NR) {                                                        \
+                eraw[KP ^ 1] = entries_load(ebase, k + 3);                                                                 \
+                fence();                                                                                                   \
+            }
+            FNP_SLOT(0) FNP_SLOT(1) FNP_SLOT(2) FNP_SLOT(3) FNP_SLOT(4) FNP_SLOT(5) FNP_SLOT(6) FNP_SLOT(7)
+            FNP_SLOT(8) FNP_SLOT(9) FNP_SLOT(10) FNP_SLOT(11) FNP_SLOT(12) FNP_SLOT(13) FNP_SLOT(14) FNP_SLOT(15)
+            FNP_SLOT(16) FNP_SLOT(17) FNP_SLOT(18) FNP_SLOT(19) FNP_SLOT(20) FNP_SLOT(21) FNP_SLOT(22) FNP_SLOT(23)
+            FNP_SLOT(24) FNP_SLOT(25) FNP_SLOT(26) FNP_SLOT(27) FNP_SLOT(28) FNP_SLOT(29) FNP_SLOT(30) FNP_SLOT(31)
+#undef FNP_SLOT
+        };
         auto step = [&](auto kpar_tag, auto kh_tag, const int k) {
             constexpr int KP = decltype(kpar_tag)::value, KHv = decltype(kh_tag)::value;
             constexpr int PAR = (KH == 1) ? KP : KHv;        // s & 1
             const int s = k * KH + KHv;
+            if constexpr (!ESC && FNP_WTILE_SLOTS) {
+                // NOTE the second half's entry conversion writes the set offset k's B reads used: those reads (of (s, ks = 1)) are
+                // all issued in the first half, in front of the barrier
+                half_slots(std::integral_constant<int, 0>{}, std::false_type{}, kpar_tag, kh_tag, k);
+                if (!(FNP_WTILE_ABLATE & 8)) lds_barrier();
+                half_slots(std::integral_constant<int, 1>{}, std::true_type{}, kpar_tag, kh_tag, k);
+                return;
+            }
             // first half: MFMAs of (s, 0); fragments of (s, 1) from the same slot; the entries of offset k + 3 requested
             load_frags(PAR, KP, KHv, 1, 1);
             if (KHv == KH - 1) eraw[KP ^ 1] = entries_load(ebase, k + 3);   // (eraw[KP ^ 1] held offset k + 1: taken out a step ago)
