@@ -114,6 +114,9 @@ __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restric
 #ifndef FNP_TILE64_SCHED
 #define FNP_TILE64_SCHED 1
 #endif
+#ifndef FNP_TILE64_SPREAD
+#define FNP_TILE64_SPREAD 1
+#endif
 #ifndef FNP_TILE_PSLEEP
 #define FNP_TILE_PSLEEP 8
 #endif
@@ -553,23 +556,34 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
     int *const id_lds = reinterpret_cast<int *>(img + XB + EB + 16);   // [OVF] far-row ids of the tile being requested
     float *const ss_lds = reinterpret_cast<float *>(img + XB + EB + 16 + G::OVF * 4);   // [2][C] BatchNorm scale, shift (read per tile from LDS, not L2)
     if (tid < 2 * C) ss_lds[tid] = scale ? (tid < C ? scale[tid] : shift[tid - C]) : (tid < C ? 1.f : 0.f);
-    auto req_tile = [&](int t) {   // (far_id holds tile t's ids; they pass through LDS to the lanes that fetch the rows)
+    // The next tile's image is requested in PIECES (FNP_TILE64_SPREAD, round 4): vector-memory loads return in order, so behind one
+    // burst of all 14 image loads the weight slab requested at the sweep's first offset — waited for at its second — came back
+    // only after the whole image (~42 KB per workgroup) had arrived; one piece per offset, issued behind that offset's slab
+    // request, keeps every such wait one load deep.
+    constexpr int NPIECE = NWL + NEL + NOL;
+    auto req_piece = [&](int t, int j) {
         const unsigned ro = rec_off(t);
-        const unsigned wbase = t < t_end ? (unsigned)max(0, t * G::TILE - G::HALO) * G::ROWB + (unsigned)tid * 16u : 0x80000000u;
-#pragma unroll
-        for (int j = 0; j < NWL; ++j) pwin[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, wbase + j * (NT * 16), 0, 0);
-#pragma unroll
-        for (int j = 0; j < NEL; ++j)
-            pent[j] = __builtin_amdgcn_raw_buffer_load_b128(trsrc, (tid + j * NT < EB / 16) ? ro + (unsigned)(tid + j * NT) * 16u : 0x80000000u, 0, 0);
-        pesc = __builtin_amdgcn_raw_buffer_load_b8(trsrc, tid < NW ? ro + (unsigned)(G::REC_ESC + tid) : 0x80000000u, 0, 0);
+        if (j < NWL) {
+            const unsigned wbase = t < t_end ? (unsigned)max(0, t * G::TILE - G::HALO) * G::ROWB + (unsigned)tid * 16u : 0x80000000u;
+            pwin[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, wbase + j * (NT * 16), 0, 0);
+        } else if (j < NWL + NEL) {
+            const int e = j - NWL;
+            pent[e] = __builtin_amdgcn_raw_buffer_load_b128(trsrc, (tid + e * NT < EB / 16) ? ro + (unsigned)(tid + e * NT) * 16u : 0x80000000u, 0, 0);
+            if (e == 0) pesc = __builtin_amdgcn_raw_buffer_load_b8(trsrc, tid < NW ? ro + (unsigned)(G::REC_ESC + tid) : 0x80000000u, 0, 0);
+        } else if (j < NPIECE) {
+            const unsigned p = (unsigned)tid + (j - NWL - NEL) * NT;
+            const int key = id_lds[p / CH];
+            povf[j - NWL - NEL] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, key >= 0 ? (unsigned)key * G::ROWB + (p % CH) * 16u : 0x80000000u, 0, 0);
+        }
+    };
+    auto req_ids = [&](int t) {    // (far_id holds tile t's ids; they pass through LDS to the lanes that fetch the rows)
         if (tid < G::OVF) id_lds[tid] = t < t_end ? far_id : -1;   // (a load that was not issued left 0, which is a row)
         __syncthreads();
+    };
+    auto req_tile = [&](int t) {
+        req_ids(t);
 #pragma unroll
-        for (int j = 0; j < NOL; ++j) {
-            const unsigned p = (unsigned)tid + j * NT;
-            const int key = id_lds[p / CH];
-            povf[j] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, key >= 0 ? (unsigned)key * G::ROWB + (p % CH) * 16u : 0x80000000u, 0, 0);
-        }
+        for (int j = 0; j < NPIECE; ++j) req_piece(t, j);
     };
     auto put_tile = [&]() {
 #pragma unroll
@@ -611,7 +625,8 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
             for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[h * SLABC + st_pos + j * NT]) = wreg[h][j];
         __syncthreads();
         FNP_STAMP(2);   // (image + slabs 0, 1 -> LDS, barrier)
-        req_tile(t + 1);        // (one more barrier inside: the ids' pass through LDS)
+        if (FNP_TILE64_SPREAD) req_ids(t + 1);   // (the image's loads follow piece by piece inside the sweep)
+        else req_tile(t + 1);   // (one more barrier inside: the ids' pass through LDS)
         req_far_ids(t + 2);
         FNP_STAMP(3);   // (next tile requested)
         f32x4 acc[NB][MB];
@@ -686,6 +701,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
                     for (int j = 0; j < NSL; ++j)
                         wslab[(k + 1) & 1][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)(k + 3) * (C * C * 2), 0);
                 }
+                if (FNP_TILE64_SPREAD && k >= 1 && k <= NPIECE) req_piece(t + 1, k - 1);
                 if (k == kK - 6) req_residual();
                 const unsigned e_new = entry(k + 3);
                 if (k + 1 < kK) {
