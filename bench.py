@@ -397,6 +397,10 @@ def main():
                    "voxels_per_scene": int(counts[0] // B), "sparse_shape": [41, 1440, 1440],
                    "site_counts": [int(c) for c in counts], "weights": "seeded random init",
                    "parallelism": f"scenes sharded {world}x, no data-path collective",
+                   # the statistic the tile-rulebook kernels are gated on (share of 32-row groups with an escape entry, stages 2 / 3;
+                   # above 0.004 a stage runs on the gather kernels) and which stages that switched off in this run
+                   "tile_gate": {"escape_share": {f"stage{li + 2}": round(v, 6) for li, v in sorted(eng.tile_escape_share.items())},
+                                 "stages_on_gather_kernels": [li + 2 for li in eng._heur_key()]},
                    "launch": ("hipGraph replay" if args.graph else
                               "two hipGraphs per step (index chain on a second branch) with the dominant kernel's four launches "
                               "stream-launched between them and bracketed with HIP events" if probe_graphs[0] else "stream launches")},
