@@ -712,6 +712,10 @@ def test_bf16x3_engine_is_f32_grade_on_the_bf16_matrix_pipe(cuda, oracle):
         g, f = got.features.cpu().numpy()[go], w.features[wo]
         assert np.abs(g - f).max() <= 3e-5 * max(1.0, np.abs(f).max()), (name, np.abs(g - f).max(), np.abs(f).max())
         assert torch.equal(got.features, res2[name].features), name     # (deterministic; grids left clean)
+    with torch.no_grad():    # ... and replayed from the captured hipGraphs
+        res3 = net.forward_points_graphed(torch.from_numpy(pts).to(cuda), off, 1, cfg)
+    for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out"):
+        assert torch.equal(res[name].features, res3[name].features) and torch.equal(res[name].indices, res3[name].indices), name
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 3e-2)])
