@@ -317,6 +317,8 @@ class VoxelResBackBone8x(_BackboneBase):
         return PointsPipeline(self, batch_size, voxel_cfg, depth=depth, capacity=capacity, n_feat=n_feat)
 
 
+X3_FAST = os.environ.get("FNP_X3_FAST", "1") != "0"   # bf16x3: cross terms on the bf16-out fast kernels (0: three f32-out gather launches per layer)
+
 # the fused engine's index chain on a side stream (FusedResBackbone._run_once): None = while a hipGraph is being captured (the
 # replayed graph runs the two branches side by side, the ~4.5 us between its nodes overlap: +4 to +10 % from 1 to 64 scenes),
 # not for stream launches (measured neutral within a box's +-1.5 %: back-to-back launches have no such gaps to hide);
@@ -683,10 +685,20 @@ class FusedResBackbone:
         hi, lo = S.split_bf16(y, n)
         return (hi, lo, y)
 
-    def _conv_x3(self, x, prm, rb, n, residual, out):
+    def _conv_x3(self, x, prm, rb, n, residual, out, ranked=False):
         """one convolution of the bf16x3 engine (see __init__): x = (hi, lo, f32 rows); returns the same triple of the output"""
         (whi, wlo, ones), _, shift = prm
         res = None if residual is None else residual[2]
+        C = int(whi.shape[1])
+        if X3_FAST and ranked and (C in getattr(rb, "_tile_rb", {}) or (C == 128 and getattr(rb, "_sorted", None) is not None)):
+            # the two cross terms are 2^-8 of the result: bf16 precision is enough for them, so they run on the FAST bf16-out kernels
+            # of the bf16 engine (tile rulebook / class-sorted sweep) chained through a bf16 residual; only the main product keeps an
+            # f32 output (no ReLU: the sum and the ReLU are folded into the split)
+            t = S.conv_forward(x[1], whi, rb, n, ranked=True)
+            t = S.conv_forward(x[0], wlo, rb, n, residual=t, ranked=True, out=t)
+            y = S.conv_forward(x[0], whi, rb, n, out_dtype=torch.float32, scale=ones, shift=shift, residual=res, relu=False, tile=False, wide=False)
+            hi, lo = S.split_bf16_add(y, t, n, relu=True)
+            return (hi, lo, y)
         t = S.conv_forward(x[1], whi, rb, n, out_dtype=torch.float32, residual=res, tile=False, wide=False)
         t = S.conv_forward(x[0], wlo, rb, n, out_dtype=torch.float32, residual=t, out=t, tile=False, wide=False)
         y = S.conv_forward(x[0], whi, rb, n, out_dtype=torch.float32, scale=ones, shift=shift, residual=t, relu=True, out=t if out is None else out,
@@ -835,7 +847,7 @@ class FusedResBackbone:
 
         def conv(x, prm, rb, n, residual=None, out_dtype=act, ranked=False):
             if self.x3 and isinstance(prm[0], tuple):
-                return self._conv_x3(x, prm, rb, n, residual, None)
+                return self._conv_x3(x, prm, rb, n, residual, None, ranked)
             w, sc, sh = prm
             tag = (int(w.shape[2]), int(w.shape[1]), int(w.shape[0]), residual is not None, ranked)  # Cin, Cout, K, res
             if self.rulebook_log is not None:
@@ -955,13 +967,14 @@ class FusedResBackbone:
                 # 128-row tiles of stage 3 and the class-sorted gather sweep of stage 4
                 wide = (S.wide_by_default(ch, act, caps[li + 1]) and S.wide_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
                         and self.rulebook_log is None)
-                srt = S.sorted_by_default(ch, ch, act, caps[li + 1]) and not wide
-                tiled = wide or (S.tiled_by_default(ch, act, caps[li + 1]) and S.tiled_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
+                act_k = torch.bfloat16 if (self.x3 and X3_FAST) else act     # (bf16x3: its cross terms run on the bf16 engine's kernels)
+                srt = S.sorted_by_default(ch, ch, act_k, caps[li + 1]) and not wide
+                tiled = wide or (S.tiled_by_default(ch, act_k, caps[li + 1]) and S.tiled_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
                                  and self.tile_off.get(li, 0) <= 0)
                 # the SubM rulebook kernel of this stage also marks the output sites of the NEXT strided layer (the coordinates are
                 # in its registers): that layer's own marking launch goes
                 nxt = down_convs[li + 1]
-                lean = tiled and self.rulebook_log is None   # (all four layers of the stage run tiled)
+                lean = tiled and self.rulebook_log is None and not self.x3   # (all four layers of the stage run tiled; bf16x3 also needs the table)
                 mark_next = (grids[li + 2], nxt.kernel_size, nxt.stride, nxt.padding) if (lean or srt) and S.MARK_FUSED else None
                 srt32 = S.f32_sorted_by_default(ch, act, caps[li + 1]) and self.rulebook_log is None and not self.x3
                 esc_ctr = self._ell_counter(("esc", li), dev) if (lean and not wide and S.TILE_MODE is None) else None

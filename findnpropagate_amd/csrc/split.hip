@@ -8,12 +8,25 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-// one thread = 4 consecutive elements (16 bytes in, 8 + 8 bytes out); rows past *n_rows are not touched
-__global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict__ x, const int *__restrict__ n_rows, int cap_rows, int C,
+// one thread = 4 consecutive elements (16 bytes in, 8 + 8 bytes out); rows past *n_rows are not touched.
+// ADD: x + float(t) (a bf16 tensor: the two cross terms of a bf16x3 convolution, which need bf16 precision only), then ReLU if
+// asked, written back to y (f32) before the split.
+template <bool ADD>
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict__ x, const __bf16 *__restrict__ t, int relu,
+                                                         const int *__restrict__ n_rows, int cap_rows, int C, float *__restrict__ y,
                                                          __bf16 *__restrict__ hi, __bf16 *__restrict__ lo) {
     const long long total4 = (long long)min(*n_rows, cap_rows) * C / 4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
-        const f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+        f32x4 v = reinterpret_cast<const f32x4 *>(x)[i];
+        if constexpr (ADD) {
+            const bf16x4 tv = reinterpret_cast<const bf16x4 *>(t)[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = v[j] + (float)tv[j];
+                if (relu) v[j] = v[j] < 0.f ? 0.f : v[j];
+            }
+            reinterpret_cast<f32x4 *>(y)[i] = v;
+        }
         bf16x4 h, l;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -31,8 +44,19 @@ extern "C" int fnp_split_bf16(const float *x, const int *n_rows, int cap_rows, i
     if (!x || !n_rows || !hi || !lo || cap_rows <= 0 || C <= 0 || (C & 3)) return FNP_ERR_ARG;
     if (((uintptr_t)x & 15) || ((uintptr_t)hi & 7) || ((uintptr_t)lo & 7)) return FNP_ERR_ARG;
     const long long total4 = (long long)cap_rows * C / 4;
-    hipLaunchKernelGGL(split_bf16_kernel, dim3(fnp_grid_for(total4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, x, n_rows, cap_rows, C,
-                       (__bf16 *)hi, (__bf16 *)lo);
+    hipLaunchKernelGGL(split_bf16_kernel<false>, dim3(fnp_grid_for(total4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, x, (const __bf16 *)nullptr, 0,
+                       n_rows, cap_rows, C, (float *)nullptr, (__bf16 *)hi, (__bf16 *)lo);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+extern "C" int fnp_split_bf16_add(const float *x, const void *t, int relu, const int *n_rows, int cap_rows, int C, float *y, void *hi, void *lo,
+                                  fnp_stream_t stream) {
+    if (!x || !t || !y || !n_rows || !hi || !lo || cap_rows <= 0 || C <= 0 || (C & 3)) return FNP_ERR_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)t & 7) || ((uintptr_t)hi & 7) || ((uintptr_t)lo & 7)) return FNP_ERR_ARG;
+    const long long total4 = (long long)cap_rows * C / 4;
+    hipLaunchKernelGGL(split_bf16_kernel<true>, dim3(fnp_grid_for(total4, 256, 4096)), dim3(256), 0, (hipStream_t)stream, x, (const __bf16 *)t, relu,
+                       n_rows, cap_rows, C, y, (__bf16 *)hi, (__bf16 *)lo);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }

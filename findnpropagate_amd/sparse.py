@@ -632,6 +632,17 @@ def split_bf16(x, n_dev):
     return hi, lo
 
 
+def split_bf16_add(x, t, n_dev, relu=True):
+    """y = relu(x + float(t)) written over x (f32), and its (hi, lo) bf16 split (fnp_split_bf16_add)."""
+    L = _l.load()
+    assert x.dtype == torch.float32 and t.dtype == torch.bfloat16 and x.shape == t.shape and x.is_contiguous() and t.is_contiguous()
+    hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _l.check(L.fnp_split_bf16_add(_l.ptr(x), _l.ptr(t), int(bool(relu)), _l.ptr(n_dev), x.shape[0], x.shape[1], _l.ptr(x), _l.ptr(hi), _l.ptr(lo),
+                                  _l.stream()), "fnp_split_bf16_add")
+    return hi, lo
+
+
 def conv_forward_strided(feat_in, w_packed, rb, scale=None, shift=None, relu=False, out=None):
     """A strided 3x3x3 convolution whose rulebook rows are computed inside the kernel (rb from
     rulebook_strided(..., want_nbr=False)).  bf16 or fp16, (Cin, Cout) in {(16,32), (32,64), (64,128)}.  Same result as

@@ -360,6 +360,11 @@ int fnp_spconv_forward_wtiled(const void *feat_in, int dtype, int n_in_rows, con
  * with f32 outputs chained through `residual` — lo x W_hi, hi x W_lo, hi x W_hi — on the bf16 matrix pipe, the f32 result to
  * ~1e-5 relative.  Rows >= *n_rows are not touched; C a multiple of 4. */
 int fnp_split_bf16(const float *x, const int *n_rows, int cap_rows, int C, void *hi, void *lo, fnp_stream_t stream);
+/* The same behind y = x + float(t) (t: a bf16 tensor of the same shape; then ReLU if relu != 0), y written as f32 (y == x allowed):
+ * where the two cross terms of a bf16x3 convolution were summed in bf16 by the fast bf16-out kernels (they are 2^-8 of the result
+ * and need bf16 precision only) and only the main product ran with an f32 output. */
+int fnp_split_bf16_add(const float *x, const void *t, int relu, const int *n_rows, int cap_rows, int C, float *y, void *hi,
+                       void *lo, fnp_stream_t stream);
 
 /* COMPACT RULEBOOK for the sparse-neighbourhood layers (conv_input 5 -> 16, the four 16 -> 16 SubM layers, the strided
  * 16 -> 32 layer: spconv_backbone.py:193-210).  A stage-1 voxel has 3.6 of its 27 neighbours, an output site of the first

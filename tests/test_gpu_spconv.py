@@ -680,7 +680,7 @@ def test_bf16x3_engine_is_f32_grade_on_the_bf16_matrix_pipe(cuda, oracle):
     """FNP_DTYPE: bf16x3 — activations as f32 rows + their split x = hi + lo into two bf16 tensors (fnp_split_bf16), weights (with
     the BatchNorm scale folded in) as W_hi + W_lo, every convolution three launches of the bf16 MFMA kernels with f32 outputs
     chained through `residual` (lo x W_hi, hi x W_lo, hi x W_hi) — against the f32 CPU oracle: same site sets, and every one of
-    the five outputs within 3e-5 of its feature scale (measured 0.7-1.1e-5; the bf16 engine: 4e-3; the f32 engine: 0).  The
+    the five outputs within 3e-5 of its feature scale (measured 0.7-1.5e-5; the bf16 engine: 4e-3; the f32 engine: 0).  The
     split itself: hi + lo == x to 2^-17 |x|, rows past n untouched."""
     x = torch.randn((1000, 64), device=cuda) * torch.logspace(-3, 3, 64, device=cuda)
     n_dev = S.device_scalar(900, cuda)
