@@ -38,7 +38,9 @@ template <typename T> struct W16 {
     typedef T v8 __attribute__((ext_vector_type(8)));
     typedef T v4 __attribute__((ext_vector_type(4)));
 };
-// MFMA with the accumulator PINNED: C and D are the same AGPR quad (inline asm, "+a").  Through the builtin hipcc puts the 128
+// MFMA with the accumulator PINNED: C and D are the same AGPR quad (inline asm, "+a"; the s_nop in front covers what the compiler
+// would pad by itself around a builtin: a register it wrote or reloaded just before — an accumulator's zero, a spilled operand —
+// read by the MFMA too early came out as NaN in the fourth register of some accumulators).  Through the builtin hipcc puts the 128
 // accumulator registers of this kernel in AGPRs all the same but moves them about (v_accvgpr_read / mov / write, ~40 per step
 // around MFMAs whose C and D differ): the sweep then runs at half the matrix rate even with its LDS reads removed (measured).
 #ifndef FNP_WTILE_ASM_MFMA
@@ -46,7 +48,7 @@ template <typename T> struct W16 {
 #endif
 __device__ __forceinline__ f32x4 wmfma(W16<__bf16>::v8 a, W16<__bf16>::v8 b, f32x4 c) {
 #if FNP_WTILE_ASM_MFMA
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     return c;
 #else
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -54,7 +56,7 @@ __device__ __forceinline__ f32x4 wmfma(W16<__bf16>::v8 a, W16<__bf16>::v8 b, f32
 }
 __device__ __forceinline__ f32x4 wmfma(W16<_Float16>::v8 a, W16<_Float16>::v8 b, f32x4 c) {
 #if FNP_WTILE_ASM_MFMA
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    asm volatile("s_nop 3\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     return c;
 #else
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -81,7 +83,7 @@ template <int C> struct WCfg {
     static constexpr int XB = (G::WIN + G::OVF + 1) * G::ROWB;   // the image
     static constexpr int NWL = G::WIN * CH / NT, NOL = G::OVF * CH / NT;
     static constexpr int LDS = 2 * SLOTC * 16 + XB + 64 + G::OVF * 4 + 2 * C * 4;
-    static_assert(G::TILE == NW * WR && NB * MB == 32 && G::WIN * CH % NT == 0 && G::OVF * CH % NT == 0 && SLOTC % NT == 0 && G::OVF <= NT, "shape");
+    static_assert(NB + MB + 1 + MB * 2 * KH <= 30 && G::TILE == NW * WR && NB * MB == 32 && G::WIN * CH % NT == 0 && G::OVF * CH % NT == 0 && SLOTC % NT == 0 && G::OVF <= NT, "shape");
     static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
@@ -90,6 +92,9 @@ template <int C> struct WCfg {
 #endif
 #ifndef FNP_WTILE_SLOTS
 #define FNP_WTILE_SLOTS 1
+#endif
+#ifndef FNP_WTILE_SPREAD
+#define FNP_WTILE_SPREAD 1
 #endif
 // Development-only timing probes (results are wrong; the shipped library has 0): 1 = no MFMA, 2 = no fragment reads,
 // 4 = no weight-slab streaming, 8 = no barrier per step, 16 = no sweep at all
@@ -209,6 +214,31 @@ __global__ __launch_bounds__(256, 1) void spconv_wtile_kernel(const TAct *__rest
         else pesc = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(trsrc, tid < Cfg::NW ? ro + (unsigned)(G::REC_ESC + tid * 2) : 0x80000000u, 0, 0);
         req_far_ids(t + 1);
     };
+    // the same loads ONE AT A TIME (piece J of NPIECES), for the plain sweep, which issues one per half-step: vector memory returns in
+    // order, so behind a burst of all of them the sweep's own loads (weight slabs, entries) wait for the whole image
+    constexpr int NPIECES = NWL + NOL + 3 + 1 + 2 * NSL + 1;
+    auto stage_piece = [&](auto j_tag, int t) {
+        constexpr int J = decltype(j_tag)::value;
+        const unsigned ro = rec_off(t);
+        if constexpr (J < NWL) {
+            const unsigned wbase = t < t_end ? (unsigned)max(0, t * G::TILE - G::HALO) * G::ROWB + (unsigned)tid * 16u : 0x80000000u;
+            pwin[J] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, wbase + J * (NT * 16), 0, 0);
+        } else if constexpr (J < NWL + NOL) {
+            const unsigned p = (unsigned)tid + (J - NWL) * NT;
+            const int key = t < t_end ? id_lds[p / CH] : -1;
+            povf[J - NWL] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, key >= 0 ? (unsigned)key * G::ROWB + (p % CH) * 16u : 0x80000000u, 0, 0);
+        } else if constexpr (J < NWL + NOL + 3) {
+            enext[J - NWL - NOL] = entries_load(ro + (unsigned)rloc * 2u, J - NWL - NOL);
+        } else if constexpr (J == NWL + NOL + 3) {
+            if constexpr (WR / 32 == 4) pesc = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(trsrc, tid < Cfg::NW ? ro + (unsigned)(G::REC_ESC + tid * 4) : 0x80000000u, 0, 0);
+            else pesc = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(trsrc, tid < Cfg::NW ? ro + (unsigned)(G::REC_ESC + tid * 2) : 0x80000000u, 0, 0);
+        } else if constexpr (J < NWL + NOL + 4 + 2 * NSL) {
+            constexpr int w = J - (NWL + NOL + 4), h = w / NSL, j = w % NSL;     // slab h (steps 0 and 1 of the next sweep), chunk j
+            wreg[h][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wsrc[j], (unsigned)(h / KH) * (unsigned)(C * C * 2) + (unsigned)(h % KH) * 128u, 0);
+        } else if constexpr (J == NPIECES - 1) {
+            req_far_ids(t + 1);
+        }
+    };
     auto publish_far_ids = [&]() {   // far_id -> LDS; visible behind the next barrier
         if (tid < G::OVF) id_lds[tid] = far_id;
     };
@@ -234,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void spconv_wtile_kernel(const TAct *__rest
     ewords ecur[3];   // the CURRENT tile's entries of offsets 0, 1, 2 (copied out of enext before the next tile is staged)
 
     // ---------------------------------------------------------------------------------------- the sweep of one tile
-    auto sweep = [&](auto esc_tag, const int tile_base) {
+    auto sweep = [&](auto esc_tag, const int tile_base, const int t_next) {
         constexpr bool ESC = decltype(esc_tag)::value;
         // entries of offset k: MB 16-bit image addresses (this lane's rows of the blocks 0..MB-1), kept as one word per block, the
         // address pre-shifted to bytes (a fragment address is an and, an add3 and an and-or); ESC: the byte offset of the row in
@@ -264,6 +294,7 @@ __global__ __launch_bounds__(256, 1) void spconv_wtile_kernel(const TAct *__rest
         };
         frag8 fa[2][NB];
         u32x4 fb[2][MB];
+        unsigned baddr[2][MB][2 * KH];   // (plain sweep) LDS byte address of the B fragment of (offset set, block, half-step)
         // fragments of half-step (step s = KH k + kh, ks) into register set `set`; A from ring slot s & 1
         auto load_frags = [&](int ring_slot, int eset, int kh, int ks, int set) {
             if (FNP_WTILE_ABLATE & 2) return;
@@ -322,6 +353,9 @@ __global__ __launch_bounds__(256, 1) void spconv_wtile_kernel(const TAct *__rest
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // (inline-asm MFMAs: the compiler pads no hazards around them — the accumulators' v_accvgpr_write zeros must have landed
+        //  before the first MFMA reads them as C; without this the last-written registers came out as NaN on some tiles)
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
         entries_cvt(ecur[0], 0, 0);
         entries_cvt(ecur[1], 1, 1);
         eraw[0] = ecur[2];
@@ -350,17 +384,24 @@ __global__ __launch_bounds__(256, 1) void spconv_wtile_kernel(const TAct *__rest
                 fa[set][j] = *reinterpret_cast<const frag8 *>(&tw);
             } else {
                 constexpr int mb = j - NB;
-                const unsigned cc = (unsigned)(kh * 8 + ks * 4) << 4;
-                const unsigned a = (e4[eset][mb] & ~MASK4) | ((e4[eset][mb] + q4 + cc) & MASK4);
-                fb[set][mb] = *reinterpret_cast<const u32x4 *>(img + a);
+                fb[set][mb] = *reinterpret_cast<const u32x4 *>(img + baddr[eset][mb][kh * 2 + ks]);   // (address made offsets ago: one instruction)
             }
+        };
+        // the B-fragment addresses of an offset (MB blocks x 2 KH half-steps), one per piece, made a step before their first use in
+        // slots that have nothing else to do: a read slot is then ONE instruction (a dependent and / add / and-or chain in front of
+        // each read cost the single wave ~20 cycles per read)
+        auto addr_piece = [&](auto m_tag, int eset) {
+            constexpr int M = decltype(m_tag)::value, mb = M / (2 * KH), idx = M % (2 * KH);
+            const unsigned cc = (unsigned)((idx / 2) * 8 + (idx % 2) * 4) << 4;
+            baddr[eset][mb][idx] = (e4[eset][mb] & ~MASK4) | ((e4[eset][mb] + q4 + cc) & MASK4);
         };
         auto cvt_piece = [&](auto mb_tag, const ewords e, int set) {   // one block of entries_cvt (plain sweep: no escapes)
             constexpr int mb = decltype(mb_tag)::value;
             const unsigned em = (mb & 1) ? e[mb >> 1] >> 16 : e[mb >> 1] & 0xffffu;
             e4[set][mb] = em << 4;
         };
-        auto half_slots = [&](auto set_tag, auto second_tag, auto kpar_tag, auto kh_tag, const int k) {
+        auto half_slots = [&](auto set_tag, auto second_tag, auto kpar_tag, auto kh_tag, auto hs_tag, const int k) {
+            constexpr int HS = decltype(hs_tag)::value;              // index of this half-step in the sweep, or -1 (no image piece)
             constexpr int set = decltype(set_tag)::value;            // register set the MFMAs read; the reads fill set ^ 1
             constexpr bool second = decltype(second_tag)::value;
             constexpr int KP = decltype(kpar_tag)::value, KHv = decltype(kh_tag)::value;
@@ -390,6 +431,12 @@ __global__ __launch_bounds__(256, 1) void spconv_wtile_kernel(const TAct *__rest
             } else if constexpr (!second && last_kh && (I) == NR) {                                                        \
                 eraw[KP ^ 1] = entries_load(ebase, k + 3);                                                                 \
                 fence();                                                                                                   \
+            } else if constexpr (!second && KHv == 0 && (I) > NR && (I) <= NR + MB * 2 * KH) {                             \
+                addr_piece(std::integral_constant<int, (I) - NR - 1>{}, KP ^ 1);   /* offset k + 1's addresses, from its entries */ \
+                fence();                                                                                                   \
+            } else if constexpr (FNP_WTILE_SPREAD && (I) == 30 && HS >= 0 && HS < NPIECES) {                                                   \
+                stage_piece(std::integral_constant<int, (HS >= 0 && HS < NPIECES) ? HS : 0>{}, t_next);                     \
+                fence();                                                                                                   \
             }
             FNP_SLOT(0) FNP_SLOT(1) FNP_SLOT(2) FNP_SLOT(3) FNP_SLOT(4) FNP_SLOT(5) FNP_SLOT(6) FNP_SLOT(7)
             FNP_SLOT(8) FNP_SLOT(9) FNP_SLOT(10) FNP_SLOT(11) FNP_SLOT(12) FNP_SLOT(13) FNP_SLOT(14) FNP_SLOT(15)
@@ -397,16 +444,16 @@ __global__ __launch_bounds__(256, 1) void spconv_wtile_kernel(const TAct *__rest
             FNP_SLOT(24) FNP_SLOT(25) FNP_SLOT(26) FNP_SLOT(27) FNP_SLOT(28) FNP_SLOT(29) FNP_SLOT(30) FNP_SLOT(31)
 #undef FNP_SLOT
         };
-        auto step = [&](auto kpar_tag, auto kh_tag, const int k) {
-            constexpr int KP = decltype(kpar_tag)::value, KHv = decltype(kh_tag)::value;
+        auto step = [&](auto kpar_tag, auto kh_tag, const int k, auto hs_tag) {
+            constexpr int KP = decltype(kpar_tag)::value, KHv = decltype(kh_tag)::value, HS0 = decltype(hs_tag)::value;
             constexpr int PAR = (KH == 1) ? KP : KHv;        // s & 1
             const int s = k * KH + KHv;
             if constexpr (!ESC && FNP_WTILE_SLOTS) {
                 // NOTE the second half's entry conversion writes the set offset k's B reads used: those reads (of (s, ks = 1)) are
                 // all issued in the first half, in front of the barrier
-                half_slots(std::integral_constant<int, 0>{}, std::false_type{}, kpar_tag, kh_tag, k);
+                half_slots(std::integral_constant<int, 0>{}, std::false_type{}, kpar_tag, kh_tag, std::integral_constant<int, HS0>{}, k);
                 if (!(FNP_WTILE_ABLATE & 8)) lds_barrier();
-                half_slots(std::integral_constant<int, 1>{}, std::true_type{}, kpar_tag, kh_tag, k);
+                half_slots(std::integral_constant<int, 1>{}, std::true_type{}, kpar_tag, kh_tag, std::integral_constant<int, (HS0 < 0 ? -1 : HS0 + 1)>{}, k);
                 return;
             }
             // first half: MFMAs of (s, 0); fragments of (s, 1) from the same slot; the entries of offset k + 3 requested
@@ -427,15 +474,50 @@ __global__ __launch_bounds__(256, 1) void spconv_wtile_kernel(const TAct *__rest
             interleave(std::integral_constant<int, NSL>{});
         };
         if (!(FNP_WTILE_ABLATE & 16)) {
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using NOHS = std::integral_constant<int, -1>;
+            if constexpr (!ESC && FNP_WTILE_SLOTS) {
+                // plain sweep: the addresses of offset 0 now (offset 1's are made in step 0), and the first KU offsets written out with
+                // one piece of the next image per half-step; KU even, 2 KH KU >= NPIECES
+                constexpr int KU = ((NPIECES + 2 * KH - 1) / (2 * KH) + 1) & ~1;
+                static_assert(KU <= kK - 1 && (KU & 1) == 0, "image pieces fit the sweep");
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int idx = 0; idx < 2 * KH; ++idx)
+                        baddr[0][mb][idx] = (e4[0][mb] & ~MASK4) | ((e4[0][mb] + q4 + ((unsigned)((idx / 2) * 8 + (idx % 2) * 4) << 4)) & MASK4);
+                // (the fragments of (0, 0) were read by load_frags above, through e4: same addresses)
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // (see the accumulators' zeros above)
+#define FNP_UOFF(K)                                                                                                          \
+                if constexpr ((K) < KU) {                                                                                    \
+                    step(std::integral_constant<int, (K) & 1>{}, I0{}, (K), std::integral_constant<int, 2 * KH * (K)>{});    \
+                    if constexpr (KH == 2) step(std::integral_constant<int, (K) & 1>{}, I1{}, (K), std::integral_constant<int, 2 * KH * (K) + 2>{}); \
+                }
+                FNP_UOFF(0) FNP_UOFF(1) FNP_UOFF(2) FNP_UOFF(3) FNP_UOFF(4) FNP_UOFF(5) FNP_UOFF(6) FNP_UOFF(7) FNP_UOFF(8) FNP_UOFF(9)
+                FNP_UOFF(10) FNP_UOFF(11) FNP_UOFF(12) FNP_UOFF(13) FNP_UOFF(14) FNP_UOFF(15) FNP_UOFF(16) FNP_UOFF(17) FNP_UOFF(18) FNP_UOFF(19)
+                FNP_UOFF(20) FNP_UOFF(21) FNP_UOFF(22) FNP_UOFF(23) FNP_UOFF(24) FNP_UOFF(25)
+#undef FNP_UOFF
 #pragma unroll 1
-            for (int k = 0; k + 1 < kK; k += 2) {
-                step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, k);
-                if constexpr (KH == 2) step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, k);
-                step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, k + 1);
-                if constexpr (KH == 2) step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, k + 1);
+                for (int k = KU; k + 1 < kK; k += 2) {
+                    step(I0{}, I0{}, k, NOHS{});
+                    if constexpr (KH == 2) step(I0{}, I1{}, k, NOHS{});
+                    step(I1{}, I0{}, k + 1, NOHS{});
+                    if constexpr (KH == 2) step(I1{}, I1{}, k + 1, NOHS{});
+                }
+                step(I0{}, I0{}, kK - 1, NOHS{});
+                if constexpr (KH == 2) step(I0{}, I1{}, kK - 1, NOHS{});
+            } else {
+#pragma unroll 1
+                for (int k = 0; k + 1 < kK; k += 2) {
+                    step(I0{}, I0{}, k, NOHS{});
+                    if constexpr (KH == 2) step(I0{}, I1{}, k, NOHS{});
+                    step(I1{}, I0{}, k + 1, NOHS{});
+                    if constexpr (KH == 2) step(I1{}, I1{}, k + 1, NOHS{});
+                }
+                step(I0{}, I0{}, kK - 1, NOHS{});
+                if constexpr (KH == 2) step(I0{}, I1{}, kK - 1, NOHS{});
             }
-            step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, kK - 1);
-            if constexpr (KH == 2) step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, kK - 1);
         }
     };
 
@@ -524,15 +606,24 @@ __global__ __launch_bounds__(256, 1) void spconv_wtile_kernel(const TAct *__rest
     lds_barrier();
     for (int t = t_begin; t < t_end; ++t) {
         const int tile_base = t * G::TILE;
-        // the NEXT tile's image travels memory -> registers during this sweep (its far ids were published behind the last barrier)
-        stage(t + 1);
-        slab_req(0, wreg[0]);   // (the next sweep's first two slabs)
-        slab_req(1, wreg[1]);
+        // the NEXT tile's image travels memory -> registers during this sweep (its far ids were published behind the last barrier): the
+        // plain sweep requests it piece by piece, one load per half-step; a sweep with escapes (rare) in one burst in front
 #ifdef FNP_WTILE_NOESC   // (development: register budget of the plain sweep alone)
-        sweep(std::false_type{}, tile_base);
+        sweep(std::false_type{}, tile_base, t + 1);
 #else
-        if (esc_flags[wave]) sweep(std::true_type{}, tile_base);
-        else sweep(std::false_type{}, tile_base);
+        if (esc_flags[wave] || !FNP_WTILE_SLOTS) {
+            stage(t + 1);
+            slab_req(0, wreg[0]);   // (the next sweep's first two slabs)
+            slab_req(1, wreg[1]);
+            sweep(std::true_type{}, tile_base, t + 1);
+        } else {
+            if (!FNP_WTILE_SPREAD) {
+                stage(t + 1);
+                slab_req(0, wreg[0]);
+                slab_req(1, wreg[1]);
+            }
+            sweep(std::false_type{}, tile_base, t + 1);
+        }
 #endif
         FNP_WS(0);
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (the inline-asm MFMAs' results are read below: no hazard padding by the compiler)
