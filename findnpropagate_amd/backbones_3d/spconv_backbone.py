@@ -317,6 +317,7 @@ class VoxelResBackBone8x(_BackboneBase):
         return PointsPipeline(self, batch_size, voxel_cfg, depth=depth, capacity=capacity, n_feat=n_feat)
 
 
+X3_FUSED = os.environ.get("FNP_X3_FUSED", "1") != "0"   # bf16x3: the main product's epilogue adds the cross terms and writes the split
 X3_FAST = os.environ.get("FNP_X3_FAST", "1") != "0"   # bf16x3: cross terms on the bf16-out fast kernels (0: three f32-out gather launches per layer)
 
 # the fused engine's index chain on a side stream (FusedResBackbone._run_once): None = while a hipGraph is being captured (the
@@ -685,15 +686,25 @@ class FusedResBackbone:
         hi, lo = S.split_bf16(y, n)
         return (hi, lo, y)
 
-    def _conv_x3(self, x, prm, rb, n, residual, out, ranked=False):
-        """one convolution of the bf16x3 engine (see __init__): x = (hi, lo, f32 rows); returns the same triple of the output"""
+    def _conv_x3(self, x, prm, rb, n, residual, out, ranked=False, want_f32=True):
+        """one convolution of the bf16x3 engine (see __init__): x = (hi, lo, f32 rows); returns the same triple of the output
+        (want_f32=False: the f32 rows are None — the first convolution of a residual block, of which only the split is read)"""
         (whi, wlo, ones), _, shift = prm
         res = None if residual is None else residual[2]
         C = int(whi.shape[1])
-        if X3_FAST and ranked and (C in getattr(rb, "_tile_rb", {}) or (C == 128 and getattr(rb, "_sorted", None) is not None)):
-            # the two cross terms are 2^-8 of the result: bf16 precision is enough for them, so they run on the FAST bf16-out kernels
-            # of the bf16 engine (tile rulebook / class-sorted sweep) chained through a bf16 residual; only the main product keeps an
-            # f32 output (no ReLU: the sum and the ReLU are folded into the split)
+        fast = X3_FAST and ranked and (C in getattr(rb, "_tile_rb", {}) or (C == 128 and getattr(rb, "_sorted", None) is not None))
+        if X3_FAST and X3_FUSED and (fast or (int(whi.shape[2]), C) in S.SPLIT_SHAPES):
+            # the two cross terms are 2^-8 of the result: bf16 precision is enough for them, so they run with bf16 outputs (on the
+            # bf16 engine's tile-rulebook / class-sorted kernels where the stage has them) chained through a bf16 residual; only the
+            # main product keeps f32, and ITS epilogue adds them, applies the ReLU and writes the f32 rows with their (hi, lo) split
+            # (conv_forward_split; FNP_X3_FUSED=0: f32-out gather kernel + a split pass)
+            kw = dict(ranked=True) if fast else dict(tile=False, wide=False)
+            t = S.conv_forward(x[1], whi, rb, n, **kw)
+            t = S.conv_forward(x[0], wlo, rb, n, residual=t, out=t, **kw)
+            y, hi, lo = S.conv_forward_split(x[0], whi, rb, n, scale=ones, shift=shift, residual=res, addend=t, relu=True, ranked=ranked,
+                                             tile=None if fast else False, want_f32=want_f32)
+            return (hi, lo, y)
+        if fast:
             t = S.conv_forward(x[1], whi, rb, n, ranked=True)
             t = S.conv_forward(x[0], wlo, rb, n, residual=t, ranked=True, out=t)
             y = S.conv_forward(x[0], whi, rb, n, out_dtype=torch.float32, scale=ones, shift=shift, residual=res, relu=False, tile=False, wide=False)
@@ -845,9 +856,9 @@ class FusedResBackbone:
             grid1 = S.build_grid(indices, n1, batch_size, m.sparse_shape, keep_order=True, grid=grids[0])
         caps = [cap1] + [max(256, int(cap1 * f)) for f in self.cap_factor]
 
-        def conv(x, prm, rb, n, residual=None, out_dtype=act, ranked=False):
+        def conv(x, prm, rb, n, residual=None, out_dtype=act, ranked=False, want_f32=True):
             if self.x3 and isinstance(prm[0], tuple):
-                return self._conv_x3(x, prm, rb, n, residual, None, ranked)
+                return self._conv_x3(x, prm, rb, n, residual, None, ranked, want_f32)
             w, sc, sh = prm
             tag = (int(w.shape[2]), int(w.shape[1]), int(w.shape[0]), residual is not None, ranked)  # Cin, Cout, K, res
             if self.rulebook_log is not None:
@@ -883,7 +894,7 @@ class FusedResBackbone:
 
         def blocks(x, rb, n, prms, ranked=False):
             for p1, p2 in prms:
-                t = conv(x, p1, rb, n, ranked=ranked)
+                t = conv(x, p1, rb, n, ranked=ranked, want_f32=False)     # (bf16x3: only the split of t is read)
                 x = conv(t, p2, rb, n, residual=x, ranked=ranked)
             return x
 
@@ -974,7 +985,7 @@ class FusedResBackbone:
                 # the SubM rulebook kernel of this stage also marks the output sites of the NEXT strided layer (the coordinates are
                 # in its registers): that layer's own marking launch goes
                 nxt = down_convs[li + 1]
-                lean = tiled and self.rulebook_log is None and not self.x3   # (all four layers of the stage run tiled; bf16x3 also needs the table)
+                lean = tiled and self.rulebook_log is None and (not self.x3 or (X3_FAST and X3_FUSED))   # (all four layers of the stage run tiled)
                 mark_next = (grids[li + 2], nxt.kernel_size, nxt.stride, nxt.padding) if (lean or srt) and S.MARK_FUSED else None
                 srt32 = S.f32_sorted_by_default(ch, act, caps[li + 1]) and self.rulebook_log is None and not self.x3
                 esc_ctr = self._ell_counter(("esc", li), dev) if (lean and not wide and S.TILE_MODE is None) else None

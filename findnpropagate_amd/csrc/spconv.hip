@@ -313,6 +313,15 @@ struct SortedRb {
     const unsigned *blockmask;
 };
 
+// f32 outputs only (the bf16x3 engine's main product, fnp_spconv_forward_split): a 16-bit addend (its two cross terms, which need
+// 16-bit precision only) joins the sum before the ReLU, and the f32 result also leaves as a (hi, lo) pair of 16-bit rows with
+// hi + lo == y to 2^-17 |y| — the next layer's operands, written where they are made instead of by a pass of their own.
+struct SplitOut {
+    const void *addend;
+    void *hi, *lo;
+    int relu;   // (applied after the addend; the kernel's own `relu` is 0 then)
+};
+
 // rows [row_begin, row_end) of workgroup range `range` of `G` when n rows are cut at 16-row blocks: the split of
 // spconv_mfma_kernel, shared with the class-sort pass (which must sort exactly the rows a workgroup will own)
 __device__ __forceinline__ void fnp_range_rows(int n, int range, int G, int &row_begin, int &row_end) {
@@ -370,10 +379,10 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
                                                              const int *__restrict__ n_out, int cap,
                                                              TOut *__restrict__ y, const float *__restrict__ scale,
                                                              const float *__restrict__ shift,
-                                                             const TOut *__restrict__ residual, int relu, int hints, FusedRb frb, SortedRb srb) {
+                                                             const TOut *__restrict__ residual, int relu, int hints, FusedRb frb, SortedRb srb, SplitOut so) {
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
     constexpr int NWX = NwOf<CIN, COUT, NWO>::value;
-    static_assert(!SORTED || (KVOL == 27 && !WIN && !FUSED && !Cfg::PAIR && !Cfg::ALLK && sizeof(TOut) == 2), "sorted sweep: wide double-buffered 3x3x3 layers");
+    static_assert(!SORTED || (KVOL == 27 && !WIN && !FUSED && !Cfg::PAIR && !Cfg::ALLK), "sorted sweep: wide double-buffered 3x3x3 layers");
     using bf16x8 = typename Vec16<TAct>::v8;   // (named after the default activation type)
     using bf16x4 = typename Vec16<TAct>::v4;
     static_assert(sizeof(TOut) == 4 || std::is_same<TOut, TAct>::value, "16-bit outputs have the activation type");
@@ -894,7 +903,7 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
         // epilogue: lane holds out[site = row0 + mb*16 + l15][c0 .. c0+3], c0 = nb*16 + q*4
         // (window kernel: measured slower with either strip placement — 194 -> 200 / 214 us — and keeps the narrow form)
         constexpr bool WIDE = Cfg::WIDE && sizeof(TOut) == 2 && !WIN;
-        static_assert(!SORTED || WIDE, "sorted sweep: the wide epilogue addresses rows through perm");
+        static_assert(!SORTED || WIDE || sizeof(TOut) == 4, "sorted sweep: the wide and the f32 epilogue address rows through perm");
         if constexpr (WIDE) {
             constexpr int EH = Cfg::epi_sites(WIN);   // sites per strip pass
             constexpr int LPR = COUT / 8;        // 16-byte chunks (lanes) per row
@@ -1047,8 +1056,10 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
             }
 #pragma unroll
             for (int mb = 0; mb < MBT; ++mb) {
-                const int r = row0 + mb * 16 + l15;
-                if (r >= row_end) continue;
+                const int rpos = row0 + mb * 16 + l15;
+                if (rpos >= row_end) continue;
+                int r = rpos;
+                if constexpr (SORTED) r = srb.perm[rpos];   // (class-sorted sweep: the row behind this position)
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = scale ? acc[nb][mb][j] * sc[j] + sh[j] : acc[nb][mb][j];
@@ -1067,7 +1078,26 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
                     bf16x4 o = {(TAct)v[0], (TAct)v[1], (TAct)v[2], (TAct)v[3]};
                     *reinterpret_cast<bf16x4 *>(yp) = o;
                 } else {
-                    *reinterpret_cast<float4 *>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (so.hi) {   // (SplitOut: the launcher passed relu = 0; so.relu follows the addend)
+                        if (so.addend) {
+                            const bf16x4 tv = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const TAct *>(so.addend) + (size_t)r * COUT + c0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = v[j] + (float)tv[j];
+                        }
+                        if (so.relu) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.f ? 0.f : v[j];
+                        }
+                        bf16x4 h, l;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            h[j] = (TAct)v[j];
+                            l[j] = (TAct)(v[j] - (float)h[j]);
+                        }
+                        *reinterpret_cast<bf16x4 *>(reinterpret_cast<TAct *>(so.hi) + (size_t)r * COUT + c0) = h;
+                        *reinterpret_cast<bf16x4 *>(reinterpret_cast<TAct *>(so.lo) + (size_t)r * COUT + c0) = l;
+                    }
+                    if (y) *reinterpret_cast<float4 *>(yp) = make_float4(v[0], v[1], v[2], v[3]);   // (null with SplitOut: only the split is wanted)
                 }
             }
         }
@@ -1116,7 +1146,7 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
 template <int CIN, int COUT, int KVOL, bool WIN, typename TOut, bool FUSED = false, typename TAct = __bf16, bool SORTED = false, int NWO = 0>
 int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
                   void *y, const float *scale, const float *shift, const void *residual, int relu, int hints, hipStream_t s,
-                  const FusedRb *frb_in = nullptr, const SortedRb *srb_in = nullptr, int *grid_only = nullptr) {
+                  const FusedRb *frb_in = nullptr, const SortedRb *srb_in = nullptr, int *grid_only = nullptr, const SplitOut *so_in = nullptr) {
     // 16-site blocks per wave: 4 (64 sites); 3 for 128 output channels (accumulators = COUT/16 * MB * 4
     // registers; 4 spills heavily, 3 spills ~16 registers outside the offset loop and measured 13 %
     // faster than 2 on MI355X: fewer weight-slab sweeps per site); 2 for the 16 -> 16 layers
@@ -1177,7 +1207,8 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
         return FNP_OK;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWX * 64), lds, s, (const TAct *)x, x_bytes, (const TAct *)w,
-                       nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu, hints, frb, srb);
+                       nbr, nbr_stride, K, n_out, cap, (TOut *)y, scale, shift, (const TOut *)residual, relu, hints, frb, srb,
+                       so_in ? *so_in : SplitOut{nullptr, nullptr, nullptr, 0});
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
@@ -1202,12 +1233,12 @@ template <int CIN, int COUT> struct HasWindow { static constexpr bool value = (F
 template <int CIN, int COUT, typename TOut, typename TAct>
 int launch_mfma(const void *x, int x_bytes, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out,
                 int cap, void *y, const float *scale, const float *shift, const void *residual, int relu, int hints,
-                hipStream_t s) {
+                hipStream_t s, const SplitOut *so = nullptr) {
     if (K == 27) {
         if constexpr (HasWindow<CIN, COUT>::value) {
             if (hints & FNP_HINT_ROWS_RANKED)
                 return launch_mfma_k<CIN, COUT, 27, true, TOut, false, TAct>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale,
-                                                                shift, residual, relu, hints, s);
+                                                                shift, residual, relu, hints, s, nullptr, nullptr, nullptr, so);
         }
         if constexpr (CIN == 128 && COUT == 128 && sizeof(TOut) == 2) {
             // fewer rows than the persistent grid has 384-row tiles: the four-wave form (see NwOf)
@@ -1216,10 +1247,10 @@ int launch_mfma(const void *x, int x_bytes, const void *w, const int *nbr, int n
                                                                                         residual, relu, hints, s);
         }
         return launch_mfma_k<CIN, COUT, 27, false, TOut, false, TAct>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift,
-                                                         residual, relu, hints, s);
+                                                         residual, relu, hints, s, nullptr, nullptr, nullptr, so);
     }
     return launch_mfma_k<CIN, COUT, 0, false, TOut, false, TAct>(x, x_bytes, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual,
-                                                    relu, hints, s);
+                                                    relu, hints, s, nullptr, nullptr, nullptr, so);
 }
 
 template <typename TIn, typename TOut>
@@ -1323,13 +1354,13 @@ __global__ __launch_bounds__(kSortThreads) void classsort_place_kernel(const uns
 template <typename TAct, typename TOut>
 int dispatch_16(const void *x, long long n_in, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
                   void *y, const float *scale, const float *shift, const void *residual, int relu, int hints, int Cin,
-                  int Cout, hipStream_t s) {
+                  int Cout, hipStream_t s, const SplitOut *so = nullptr) {
     const long long xb = n_in * Cin * 2;
     const bool fits = xb > 0 && xb < 0x7fffffffll;   // 32-bit buffer offsets of the MFMA path
 #define FNP_CASE(CI, CO)                                                                                       \
     if (fits && Cin == CI && Cout == CO)                                                                       \
         return launch_mfma<CI, CO, TOut, TAct>(x, (int)xb, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual,\
-                                         relu, hints, s);
+                                         relu, hints, s, so);
     FNP_CASE(16, 16)
     FNP_CASE(16, 32)
     FNP_CASE(32, 32)
@@ -1342,6 +1373,7 @@ int dispatch_16(const void *x, long long n_in, const void *w, const int *nbr, in
     FNP_CASE(64, 32)
     FNP_CASE(128, 64)
 #undef FNP_CASE
+    if (so) return FNP_ERR_ARG;   // (the split outputs are the matrix kernel's)
     return launch_valu<TAct, TOut>(x, w, nbr, nbr_stride, K, n_out, cap, y, scale, shift, residual, relu, Cin, Cout, s);
 }
 
@@ -1419,6 +1451,25 @@ extern "C" int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_ro
                                                 residual, relu, hints, Cin, Cout, s);
         return FNP_ERR_ARG;
     }
+    return FNP_ERR_ARG;
+}
+
+extern "C" int fnp_spconv_forward_split(const void *feat_in, int in_dtype, int n_in_rows, const void *weight, const int *nbr, int nbr_stride,
+                                        int K, const int *n_out, int cap_out, float *feat_out, const float *scale, const float *shift,
+                                        const float *residual, const void *addend, int relu, int hints, int Cin, int Cout, void *out_hi,
+                                        void *out_lo, fnp_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!feat_in || !weight || !nbr || !n_out || !out_hi || !out_lo || K <= 0 || Cin <= 0 || Cout <= 0 || cap_out <= 0 ||
+        nbr_stride < cap_out || n_in_rows <= 0 || (scale == nullptr) != (shift == nullptr))   // (feat_out may be null: only the split is written)
+        return FNP_ERR_ARG;
+    if ((((uintptr_t)out_hi | (uintptr_t)out_lo | (uintptr_t)addend) & 7) || ((uintptr_t)feat_out & 15)) return FNP_ERR_ARG;
+    const SplitOut so{addend, out_hi, out_lo, relu};
+    if (in_dtype == FNP_BF16)
+        return dispatch_16<__bf16, float>(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift, residual, 0, hints,
+                                          Cin, Cout, s, &so);
+    if (in_dtype == FNP_F16)
+        return dispatch_16<_Float16, float>(feat_in, n_in_rows, weight, nbr, nbr_stride, K, n_out, cap_out, feat_out, scale, shift, residual, 0, hints,
+                                            Cin, Cout, s, &so);
     return FNP_ERR_ARG;
 }
 
@@ -1546,5 +1597,35 @@ extern "C" int fnp_spconv_forward_sorted(const void *feat_in, int dtype, int n_i
     if (dtype == FNP_F16)
         return launch_mfma_k<128, 128, 27, false, _Float16, false, _Float16, true>(feat_in, (int)xb, weight, nbr, nbr_stride, 27, n_out, cap_out, feat_out,
                                                                                     scale, shift, residual, relu, 0, (hipStream_t)stream, nullptr, &srb);
+    return FNP_ERR_ARG;
+}
+
+extern "C" int fnp_spconv_forward_sorted_split(const void *feat_in, int dtype, int n_in_rows, const void *weight, const int *nbr, int nbr_stride,
+                                               const int *perm, const unsigned *blockmask, const int *n_out, int cap_out, float *feat_out,
+                                               const float *scale, const float *shift, const float *residual, const void *addend, int relu,
+                                               int Cin, int Cout, void *out_hi, void *out_lo, fnp_stream_t stream) {
+    if (!feat_in || !weight || !nbr || !perm || !blockmask || !n_out || !out_hi || !out_lo || cap_out <= 0 || nbr_stride < cap_out || n_in_rows <= 0)
+        return FNP_ERR_ARG;
+    if ((scale == nullptr) != (shift == nullptr) || Cin != 128 || Cout != 128) return FNP_ERR_ARG;
+    if ((((uintptr_t)out_hi | (uintptr_t)out_lo | (uintptr_t)addend) & 7) || ((uintptr_t)feat_out & 15)) return FNP_ERR_ARG;
+    const long long xb = (long long)n_in_rows * Cin * 2;
+    if (xb >= 0x7fffffffll) return FNP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    // perm / blockmask were made for the workgroup ranges of the 16-bit-output sweep (fnp_rulebook_classsort): this launch must cut
+    // the rows the same way
+    int g16 = 0, g32 = 0;
+    launch_mfma_k<128, 128, 27, false, __bf16, false, __bf16, true>(nullptr, 0, nullptr, nullptr, cap_out, 27, n_out, cap_out, nullptr, nullptr, nullptr, nullptr,
+                                                                    0, 0, s, nullptr, nullptr, &g16);
+    launch_mfma_k<128, 128, 27, false, float, false, __bf16, true>(nullptr, 0, nullptr, nullptr, cap_out, 27, n_out, cap_out, nullptr, nullptr, nullptr, nullptr,
+                                                                   0, 0, s, nullptr, nullptr, &g32);
+    if (g16 != g32) return FNP_ERR_ARG;
+    const SortedRb srb{perm, blockmask};
+    const SplitOut so{addend, out_hi, out_lo, relu};
+    if (dtype == FNP_BF16)
+        return launch_mfma_k<128, 128, 27, false, float, false, __bf16, true>(feat_in, (int)xb, weight, nbr, nbr_stride, 27, n_out, cap_out, feat_out, scale, shift,
+                                                                              residual, 0, 0, s, nullptr, &srb, nullptr, &so);
+    if (dtype == FNP_F16)
+        return launch_mfma_k<128, 128, 27, false, float, false, _Float16, true>(feat_in, (int)xb, weight, nbr, nbr_stride, 27, n_out, cap_out, feat_out, scale,
+                                                                                shift, residual, 0, 0, s, nullptr, &srb, nullptr, &so);
     return FNP_ERR_ARG;
 }

@@ -169,13 +169,49 @@ __device__ int g_tile_hold;          // test hook (fnp_debug_tile_hold): produce
 // is row 32 w + 2 l15 + mb, so the two entries of a lane sit in one 32-bit word of the natural [offset][row] table.
 // Neighbours of such a column set are rows of ONE parity, so the window image keeps even and odd rows in separate halves:
 // what a fragment read touches is then 16 consecutive 64-byte rows, as in a dense tile.
+// X3 (fnp_spconv_forward_tiled_split, the bf16x3 engine's main product): the epilogue keeps f32 — f32 residual in, a 16-bit addend
+// (the two cross terms) joined before the ReLU, f32 rows out AND their (hi, lo) 16-bit split, the next layer's operands.  The
+// kernel's own y / residual are unused then.
+struct X3Args {
+    const float *residual;
+    const void *addend;
+    float *y;
+    void *hi, *lo;
+};
 template <typename TAct>
+__device__ __forceinline__ void x3_store(const X3Args &a, size_t elem, float (&v)[4], int relu) {
+    typedef TAct act4 __attribute__((ext_vector_type(4)));
+    if (a.residual) {
+        const float4 r4 = *reinterpret_cast<const float4 *>(a.residual + elem);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    }
+    if (a.addend) {
+        const act4 t4 = *reinterpret_cast<const act4 *>(reinterpret_cast<const TAct *>(a.addend) + elem);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += (float)t4[j];
+    }
+    if (relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.f ? 0.f : v[j];
+    }
+    act4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (TAct)v[j];
+        l[j] = (TAct)(v[j] - (float)h[j]);
+    }
+    if (a.y) *reinterpret_cast<float4 *>(a.y + elem) = make_float4(v[0], v[1], v[2], v[3]);   // (null: only the split is wanted)
+    *reinterpret_cast<act4 *>(reinterpret_cast<TAct *>(a.hi) + elem) = h;
+    *reinterpret_cast<act4 *>(reinterpret_cast<TAct *>(a.lo) + elem) = l;
+}
+
+template <typename TAct, bool X3 = false>
 __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__restrict__ x, int x_bytes, const TAct *__restrict__ w,
                                                                  const unsigned char *__restrict__ tile_rb, int rb_bytes,
                                                                  const int *__restrict__ nbr, int nbr_stride,
                                                                  const int *__restrict__ n_out, int cap, TAct *__restrict__ y,
                                                                  const float *__restrict__ scale, const float *__restrict__ shift,
-                                                                 const TAct *__restrict__ residual, int relu) {
+                                                                 const TAct *__restrict__ residual, int relu, X3Args x3) {
     using frag8 = typename V16<TAct>::v8;
     using act4 = typename V16<TAct>::v4;
     constexpr int MB = 2, NCW = 8, NPW = 8, NT = 1024, PT = NPW * 64, NB = kC / 16;
@@ -442,6 +478,18 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
         for (int mb = 0; mb < MB; ++mb) {
             const int r = tile_base + rloc + mb;
             const bool live = r < row_end;
+            if constexpr (X3) {
+                if (live) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = scale ? acc[h][mb][j] * sc[h][j] + sh[h][j] : acc[h][mb][j];
+                        x3_store<TAct>(x3, (size_t)r * kC + h * 16 + q * 4, v, relu);
+                    }
+                }
+                continue;
+            }
             uint2 ra = make_uint2(0u, 0u), rbb = make_uint2(0u, 0u);
             if (residual) {
                 auto t0 = __builtin_amdgcn_permlane16_swap(rv[mb].x, rv[mb].z, false, false);
@@ -492,13 +540,13 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
 // loads, the row-address arithmetic and the gather instructions, which (not the matrix work) bound it.  128-row tiles,
 // one 256-thread workgroup (4 waves x 32 rows), two workgroups per CU (one fills its image while the other sweeps); the
 // image of the next tile travels memory -> registers during the sweep and registers -> LDS between two sweeps.
-template <typename TAct>
+template <typename TAct, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__restrict__ x, int x_bytes, const TAct *__restrict__ w,
                                                                 const unsigned char *__restrict__ tile_rb, int rb_bytes,
                                                                 const int *__restrict__ nbr, int nbr_stride,
                                                                 const int *__restrict__ n_out, int cap, TAct *__restrict__ y,
                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
-                                                                const TAct *__restrict__ residual, int relu) {
+                                                                const TAct *__restrict__ residual, int relu, X3Args x3) {
     using G = G64;
     using frag8 = typename V16<TAct>::v8;
     using act4 = typename V16<TAct>::v4;
@@ -747,6 +795,24 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
         for (int mb = 0; mb < MB; ++mb) {
             const int r = tile_base + rloc + mb;
             const bool live = r < row_end;
+            if constexpr (X3) {
+                if (live) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int c0 = nb * 16 + q * 4;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = acc[nb][mb][j];
+                        if (scale) {
+                            const float4 s4 = *reinterpret_cast<const float4 *>(ss_lds + c0);
+                            const float4 h4 = *reinterpret_cast<const float4 *>(ss_lds + C + c0);
+                            v[0] = v[0] * s4.x + h4.x; v[1] = v[1] * s4.y + h4.y; v[2] = v[2] * s4.z + h4.z; v[3] = v[3] * s4.w + h4.w;
+                        }
+                        x3_store<TAct>(x3, (size_t)r * C + c0, v, relu);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int kp = 0; kp < NB / 2; ++kp) {
                 uint2 ra = make_uint2(0u, 0u), rbb = make_uint2(0u, 0u);
@@ -795,10 +861,11 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
 constexpr int kLds64 = 2 * 64 * 8 * 16 + (G64::WIN + G64::OVF + 1) * G64::ROWB + kK * G64::TILE * 2 + 16 + G64::OVF * 4 + 2 * 64 * 4;
 static_assert(2 * kLds64 <= 160 * 1024, "two workgroups per CU");
 
-template <typename TAct>
+template <typename TAct, bool X3 = false>
 int launch_tile64(const void *x, long long x_bytes, const void *w, const void *tile_rb, long long rb_bytes, const int *nbr, int nbr_stride,
-                  const int *n_out, int cap, void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s) {
-    auto kern = spconv_tile64_kernel<TAct>;
+                  const int *n_out, int cap, void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s,
+                  X3Args x3 = X3Args{nullptr, nullptr, nullptr, nullptr, nullptr}) {
+    auto kern = spconv_tile64_kernel<TAct, X3>;
     static bool raised = false;   // (idempotent; a race only repeats the call)
     if (!raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds64) != hipSuccess) return FNP_ERR_HIP;
@@ -807,15 +874,16 @@ int launch_tile64(const void *x, long long x_bytes, const void *w, const void *t
     const int tiles = fnp_divup(cap, G64::TILE);
     const int grid = tiles < 512 ? tiles : 512;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLds64, s, (const TAct *)x, (int)x_bytes, (const TAct *)w, (const unsigned char *)tile_rb, (int)rb_bytes,
-                       nbr, nbr_stride, n_out, cap, (TAct *)y, scale, shift, (const TAct *)residual, relu);
+                       nbr, nbr_stride, n_out, cap, (TAct *)y, scale, shift, (const TAct *)residual, relu, x3);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
 
-template <typename TAct>
+template <typename TAct, bool X3 = false>
 int launch_tile32(const void *x, long long x_bytes, const void *w, const void *tile_rb, long long rb_bytes, const int *nbr, int nbr_stride,
-                  const int *n_out, int cap, void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s) {
-    auto kern = spconv_tile32_kernel<TAct>;
+                  const int *n_out, int cap, void *y, const float *scale, const float *shift, const void *residual, int relu, hipStream_t s,
+                  X3Args x3 = X3Args{nullptr, nullptr, nullptr, nullptr, nullptr}) {
+    auto kern = spconv_tile32_kernel<TAct, X3>;
     static bool raised = false;   // (idempotent; a race only repeats the call)
     if (!raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return FNP_ERR_HIP;
@@ -824,7 +892,7 @@ int launch_tile32(const void *x, long long x_bytes, const void *w, const void *t
     const int tiles = fnp_divup(cap, kTile);
     const int grid = tiles < 256 ? tiles : 256;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), kLds, s, (const TAct *)x, (int)x_bytes, (const TAct *)w, (const unsigned char *)tile_rb, (int)rb_bytes,
-                       nbr, nbr_stride, n_out, cap, (TAct *)y, scale, shift, (const TAct *)residual, relu);
+                       nbr, nbr_stride, n_out, cap, (TAct *)y, scale, shift, (const TAct *)residual, relu, x3);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
@@ -944,6 +1012,30 @@ extern "C" int fnp_spconv_forward_tiled(const void *feat_in, int dtype, int n_in
     } else {
         if (dtype == FNP_BF16) return launch_tile64<__bf16>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, feat_out, scale, shift, residual, relu, s);
         if (dtype == FNP_F16) return launch_tile64<_Float16>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, feat_out, scale, shift, residual, relu, s);
+    }
+    return FNP_ERR_ARG;
+}
+
+extern "C" int fnp_spconv_forward_tiled_split(const void *feat_in, int dtype, int n_in_rows, const void *weight, const void *tile_rb, const int *nbr,
+                                              int nbr_stride, const int *n_out, int cap_out, float *feat_out, const float *scale, const float *shift,
+                                              const float *residual, const void *addend, int relu, int Cin, int Cout, void *out_hi, void *out_lo,
+                                              fnp_stream_t stream) {
+    if (!feat_in || !weight || !tile_rb || !nbr || !n_out || !out_hi || !out_lo || cap_out <= 0 || nbr_stride < cap_out || n_in_rows <= 0)
+        return FNP_ERR_ARG;   // (feat_out may be null: only the split is written)
+    if ((scale == nullptr) != (shift == nullptr) || Cin != Cout || (Cin != 32 && Cin != 64)) return FNP_ERR_ARG;
+    const long long xb = (long long)n_in_rows * Cin * 2, rbb = fnp_tile_rulebook_bytes(cap_out, Cin);
+    if (xb >= 0x7fffffffll || (long long)kK * nbr_stride * 4 >= 0x7fffffffll || rbb >= 0x7fffffffll) return FNP_ERR_ARG;
+    if (((uintptr_t)tile_rb & 15) || ((uintptr_t)feat_in & 15) || ((uintptr_t)feat_out & 15) || ((uintptr_t)weight & 15) || ((uintptr_t)residual & 15) ||
+        (((uintptr_t)addend | (uintptr_t)out_hi | (uintptr_t)out_lo) & 7))
+        return FNP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const X3Args x3{residual, addend, feat_out, out_hi, out_lo};
+    if (Cin == 32) {
+        if (dtype == FNP_BF16) return launch_tile32<__bf16, true>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, nullptr, scale, shift, nullptr, relu, s, x3);
+        if (dtype == FNP_F16) return launch_tile32<_Float16, true>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, nullptr, scale, shift, nullptr, relu, s, x3);
+    } else {
+        if (dtype == FNP_BF16) return launch_tile64<__bf16, true>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, nullptr, scale, shift, nullptr, relu, s, x3);
+        if (dtype == FNP_F16) return launch_tile64<_Float16, true>(feat_in, xb, weight, tile_rb, rbb, nbr, nbr_stride, n_out, cap_out, nullptr, scale, shift, nullptr, relu, s, x3);
     }
     return FNP_ERR_ARG;
 }

@@ -136,6 +136,9 @@ SIGNATURES = {
     "fnp_spconv_forward_wtiled": (c_int, [P, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     "fnp_split_bf16": (c_int, [P, P, c_int, c_int, P, P, P]),
     "fnp_split_bf16_add": (c_int, [P, P, c_int, P, c_int, c_int, P, P, P, P]),
+    "fnp_spconv_forward_split": (c_int, [P, c_int, c_int, P, P, c_int, c_int, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "fnp_spconv_forward_sorted_split": (c_int, [P, c_int, c_int, P, P, c_int, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, P, P, P]),
+    "fnp_spconv_forward_tiled_split": (c_int, [P, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, P, c_int, c_int, c_int, P, P, P]),
     "fnp_ell_bytes": (c_int64, [c_int, c_int]),
     "fnp_rulebook_ell": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, c_int, P, P]),
     "fnp_spconv_forward_ell": (c_int, [P, c_int, c_int, P, P, c_int, c_int, P, P, c_int, P, P, P, c_int, c_int, c_int, P]),

@@ -622,6 +622,61 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
     return out
 
 
+# (Cin, Cout) the matrix kernel behind fnp_spconv_forward_split covers
+SPLIT_SHAPES = {(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (32, 16), (64, 32), (128, 64)}
+
+
+def conv_forward_split(feat_in, w_packed, rb, n_out_dev, scale=None, shift=None, residual=None, addend=None, relu=True, ranked=False, tile=None,
+                       want_f32=True):
+    """The bf16x3 engine's main product (fnp_spconv_forward_split / _tiled_split): 16-bit features and weights,
+    y = act(conv * scale + shift + residual (f32) + float(addend) (16-bit)), returned as (y f32, hi, lo) with hi = 16bit(y),
+    lo = 16bit(y - hi) — conv_forward(out_dtype=float32, relu=False) followed by split_bf16_add, bit for bit, in one launch.
+    ranked / tile: as conv_forward (the 32 -> 32 and 64 -> 64 layers of ranked tensors run on the tile rulebook).
+    want_f32=False: y is not written (returned as None) — a layer of which only the split is read.  No host sync."""
+    L = _l.load()
+    _l.require_device(feat_in, w_packed, rb.nbr, n_out_dev)
+    K, Cout, Cin = w_packed.shape
+    assert K == rb.K and feat_in.shape[1] == Cin and feat_in.dtype == w_packed.dtype and feat_in.dtype in (torch.bfloat16, torch.float16)
+    assert feat_in.is_contiguous() and w_packed.is_contiguous() and not isinstance(w_packed, PermutedWeight)
+    cap_out, dev = rb.cap_out, feat_in.device
+    y = torch.empty((cap_out, Cout), dtype=torch.float32, device=dev) if want_f32 else None
+    hi = torch.empty((cap_out, Cout), dtype=feat_in.dtype, device=dev)
+    lo = torch.empty((cap_out, Cout), dtype=feat_in.dtype, device=dev)
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.shape == hi.shape and residual.is_contiguous()
+    if addend is not None:
+        assert addend.dtype == feat_in.dtype and addend.shape == hi.shape and addend.is_contiguous()
+    if scale is not None:
+        assert scale.dtype == torch.float32 and shift.dtype == torch.float32
+    if tile is None:
+        tile = TILE_MODE
+    if tile is None and getattr(rb, "_no_tile", False):
+        tile = False
+    if (K == 27 and Cin == Cout and Cin in TILED_CHANNELS and (tile or (tile is None and ranked and tiled_by_default(Cin, feat_in.dtype, cap_out)))
+            and tiled_fits(feat_in.shape[0], Cin, rb.nbr.shape[1], cap_out)):
+        rc = L.fnp_spconv_forward_tiled_split(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
+                                              _l.ptr(tile_rulebook(rb, n_out_dev, Cin)), _l.ptr(rb.nbr), rb.nbr.shape[1], _l.ptr(n_out_dev), cap_out,
+                                              _l.ptr(y), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual), _l.ptr(addend), int(bool(relu)), Cin, Cout,
+                                              _l.ptr(hi), _l.ptr(lo), _l.stream())
+        _l.check(rc, "fnp_spconv_forward_tiled_split")
+        return y, hi, lo
+    if getattr(rb, "_lean", False):
+        raise _l.FnpError("this rulebook's int32 table holds the rows of escape tiles only (rulebook_subm(lean_table=True)): "
+                          "only the tiled convolution of its channel count may run on it")
+    srt = getattr(rb, "_sorted", None)
+    if srt is not None and ranked and K == 27 and (Cin, Cout) in SORTED_SHAPES and feat_in.shape[0] * Cin * 2 < 0x7fffffff:
+        rc = L.fnp_spconv_forward_sorted_split(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed), _l.ptr(rb.nbr), rb.nbr.shape[1],
+                                               _l.ptr(srt[0]), _l.ptr(srt[1]), _l.ptr(n_out_dev), cap_out, _l.ptr(y), _l.ptr(scale), _l.ptr(shift),
+                                               _l.ptr(residual), _l.ptr(addend), int(bool(relu)), Cin, Cout, _l.ptr(hi), _l.ptr(lo), _l.stream())
+        _l.check(rc, "fnp_spconv_forward_sorted_split")
+        return y, hi, lo
+    rc = L.fnp_spconv_forward_split(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed), _l.ptr(rb.nbr), rb.nbr.shape[1], K,
+                                    _l.ptr(n_out_dev), cap_out, _l.ptr(y), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual), _l.ptr(addend),
+                                    int(bool(relu)), HINT_ROWS_RANKED if ranked else 0, Cin, Cout, _l.ptr(hi), _l.ptr(lo), _l.stream())
+    _l.check(rc, "fnp_spconv_forward_split")
+    return y, hi, lo
+
+
 def split_bf16(x, n_dev):
     """f32 rows (cap, C) -> (hi, lo) bf16 with hi + lo == x to 2^-17 of |x| (fnp_split_bf16); rows >= n are left undefined."""
     L = _l.load()

@@ -366,6 +366,28 @@ int fnp_split_bf16(const float *x, const int *n_rows, int cap_rows, int C, void 
 int fnp_split_bf16_add(const float *x, const void *t, int relu, const int *n_rows, int cap_rows, int C, float *y, void *hi,
                        void *lo, fnp_stream_t stream);
 
+/* The bf16x3 engine's MAIN product with the sum and the split in its epilogue (ABI 11): fnp_spconv_forward with 16-bit features and
+ * weights and an f32 output,
+ *     y = act( conv * scale + shift + residual (f32, nullable) + float(addend) (16-bit rows of the features' dtype, nullable) ),
+ * written as f32 rows (feat_out) AND as their split out_hi = 16bit(y), out_lo = 16bit(y - out_hi) — what fnp_spconv_forward (f32 out,
+ * no ReLU) followed by fnp_split_bf16_add computes, bit for bit, without the pass over the rows in between (it was 12 % of a
+ * bf16x3 forward).  feat_out may be NULL: only the split is written (a layer whose f32 rows nobody reads).  Shapes of the matrix
+ * kernel only (FNP_ERR_ARG otherwise).  fnp_spconv_forward_tiled_split: the same on the
+ * tile rulebook (fnp_spconv_forward_tiled's arguments and conditions; Cin == Cout == 32 or 64); fnp_spconv_forward_sorted_split:
+ * the same as the class-sorted sweep of the 128 -> 128 layers (fnp_spconv_forward_sorted's arguments and conditions). */
+int fnp_spconv_forward_split(const void *feat_in, int in_dtype, int n_in_rows, const void *weight, const int *nbr, int nbr_stride,
+                             int K, const int *n_out, int cap_out, float *feat_out, const float *scale, const float *shift,
+                             const float *residual, const void *addend, int relu, int hints, int Cin, int Cout, void *out_hi,
+                             void *out_lo, fnp_stream_t stream);
+int fnp_spconv_forward_sorted_split(const void *feat_in, int dtype, int n_in_rows, const void *weight, const int *nbr, int nbr_stride,
+                                    const int *perm, const unsigned *blockmask, const int *n_out, int cap_out, float *feat_out,
+                                    const float *scale, const float *shift, const float *residual, const void *addend, int relu,
+                                    int Cin, int Cout, void *out_hi, void *out_lo, fnp_stream_t stream);
+int fnp_spconv_forward_tiled_split(const void *feat_in, int dtype, int n_in_rows, const void *weight, const void *tile_rb,
+                                   const int *nbr, int nbr_stride, const int *n_out, int cap_out, float *feat_out,
+                                   const float *scale, const float *shift, const float *residual, const void *addend, int relu,
+                                   int Cin, int Cout, void *out_hi, void *out_lo, fnp_stream_t stream);
+
 /* COMPACT RULEBOOK for the sparse-neighbourhood layers (conv_input 5 -> 16, the four 16 -> 16 SubM layers, the strided
  * 16 -> 32 layer: spconv_backbone.py:193-210).  A stage-1 voxel has 3.6 of its 27 neighbours, an output site of the first
  * strided layer 2.1 of 27 inputs: the (27, cap) int32 table spends 108 bytes per row on that and the matrix kernel a gather

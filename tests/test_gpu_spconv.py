@@ -718,6 +718,58 @@ def test_bf16x3_engine_is_f32_grade_on_the_bf16_matrix_pipe(cuda, oracle):
         assert torch.equal(res[name].features, res3[name].features) and torch.equal(res[name].indices, res3[name].indices), name
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout,n", [(16, 16, 3000), (16, 32, 3000), (32, 32, 1), (32, 32, 5000), (64, 64, 513), (64, 64, 5000), (64, 128, 3000),
+                                        (128, 128, 3000), (128, 128, 40000), (32, 32, 40000), (64, 64, 40000)])
+def test_split_epilogue_equals_convolution_then_split_pass(cuda, rng, cin, cout, n, dtype):
+    """fnp_spconv_forward_split / fnp_spconv_forward_tiled_split (the bf16x3 engine's main product: f32 residual and a 16-bit addend
+    joined before the ReLU, f32 rows AND their (hi, lo) split written by the convolution's epilogue) against the two launches they
+    replace — fnp_spconv_forward with an f32 output and no ReLU, then fnp_split_bf16_add: bit-identical y, hi and lo, on the
+    gather kernel and (32 -> 32, 64 -> 64, sorted rows) on the tile rulebook, with and without residual / addend; rows past n stay
+    untouched."""
+    B, shape = 2, [9, 40, 41] if n <= 5000 else [21, 80, 80]
+    feats, idx = _random_sparse(rng, B, shape, n, cin)
+    idx = idx[np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))]
+    d_idx = torch.from_numpy(idx).to(cuda)
+    n_dev = S.device_scalar(n, cuda)
+    rb = S.rulebook_subm(d_idx, n_dev, S.build_grid(d_idx, n_dev, B, shape), 3)
+    wp = S.pack_weight(torch.from_numpy((rng.standard_normal((cout, 3, 3, 3, cin)) * 0.1).astype(np.float32)).to(cuda), dtype)
+    x = torch.from_numpy(feats).to(cuda).to(dtype)
+    ones = torch.ones(cout, device=cuda)
+    sh = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(cuda)
+    res = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).to(cuda)
+    add = torch.from_numpy((rng.standard_normal((n, cout)) * 0.01).astype(np.float32)).to(cuda).to(dtype)
+    tiled = cin == cout and cin in (32, 64)
+    for residual, addend, relu in ((res, add, True), (None, add, True), (res, None, True), (None, None, False)):
+        y0 = S.conv_forward(x, wp, rb, n_dev, out_dtype=torch.float32, scale=ones, shift=sh, residual=residual, relu=False, tile=False, wide=False)
+        if addend is not None:
+            if dtype == torch.bfloat16:
+                hi0, lo0 = S.split_bf16_add(y0, addend, n_dev, relu=relu)
+            else:   # (the split pass is bf16 only: restated here)
+                y0[:n] = y0[:n] + addend.float()
+                if relu:
+                    y0[:n].clamp_(min=0)
+                hi0 = y0.to(dtype); lo0 = (y0 - hi0.float()).to(dtype)
+        else:
+            if relu:
+                y0[:n].clamp_(min=0)
+            hi0 = y0.to(dtype); lo0 = (y0 - hi0.float()).to(dtype)
+        for tile in ((False, True, "sorted") if tiled else (False, "sorted") if (cin, cout) == (128, 128) else (False,)):
+            if tile == "sorted":
+                if (cin, cout) != (128, 128):
+                    continue
+                rbs = S.rulebook_subm(d_idx, n_dev, S.build_grid(d_idx, n_dev, B, shape), 3, masks=True)
+                S.classsort(rbs, n_dev, 128)     # fnp_spconv_forward_sorted_split: the class-sorted sweep with the same epilogue
+                y, hi, lo = S.conv_forward_split(x, wp, rbs, n_dev, scale=ones, shift=sh, residual=residual, addend=addend, relu=relu, ranked=True)
+            else:
+                y, hi, lo = S.conv_forward_split(x, wp, rb, n_dev, scale=ones, shift=sh, residual=residual, addend=addend, relu=relu, ranked=True, tile=tile)
+            tag = (residual is not None, addend is not None, tile)
+            assert torch.equal(y[:n], y0[:n]), tag
+            assert torch.equal(hi[:n], hi0[:n]) and torch.equal(lo[:n], lo0[:n]), tag
+            if dtype == torch.bfloat16:
+                assert ((hi[:n].float() + lo[:n].float() - y[:n]).abs() <= y[:n].abs() * 2.0 ** -16).all()
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 3e-2)])
 @pytest.mark.parametrize("ksp", [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0)), ((2, 2, 2), (2, 2, 2), (0, 0, 0))])
 def test_sparse_inverse_conv_undoes_the_paired_layer_sites(cuda, rng, oracle, ksp, dtype, tol):
