@@ -247,11 +247,21 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = None
+
+
 def stream():
     """hipStream_t of torch's current stream, as an integer handle for the ABI."""
-    import torch
+    global _raw_stream
+    if _raw_stream is None:
+        import torch
 
-    return torch.cuda.current_stream().cuda_stream
+        raw, dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if raw is not None and dev is not None:   # (0.2 us instead of 2.8 for torch.cuda.current_stream().cuda_stream: one call per launch)
+            _raw_stream = lambda: raw(dev())
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream
+    return _raw_stream()
 
 
 def dtype_code(t):

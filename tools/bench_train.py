@@ -21,9 +21,13 @@ n = int(vox["n"].item())
 bd = lambda: {"voxel_features": vox["mean"][:n], "voxel_coords": vox["coords"][:n].float(), "batch_size": B}
 opt = torch.optim.SGD(net.parameters(), lr=1e-4)
 
-def fwd():
+def fwd(all_outputs=True):
+    # the stand-in loss: mean of squares.  all_outputs: over the four multi-scale tensors and the encoded tensor (`train_step_ms`, every
+    # round's definition); False: over `encoded_spconv_tensor` alone — the only backbone output transfusion_lidar.yaml's graph consumes
+    # (HeightCompression, height_compression.py:20-21; `multi_scale_3d_features` feed PV-RCNN / Voxel R-CNN heads only)
     out = net(bd())
-    return sum((t.features.float() ** 2).mean() for t in list(out["multi_scale_3d_features"].values()) + [out["encoded_spconv_tensor"]])
+    ts = (list(out["multi_scale_3d_features"].values()) if all_outputs else []) + [out["encoded_spconv_tensor"]]
+    return sum((t.features.float() ** 2).mean() for t in ts)
 
 def timed(fn, reps):
     for _ in range(2): fn()
@@ -33,16 +37,28 @@ def timed(fn, reps):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
-def step():
+def step(all_outputs=True):
     opt.zero_grad(set_to_none=True)
-    loss = fwd(); loss.backward(); opt.step()
+    loss = fwd(all_outputs); loss.backward(); opt.step()
 
 net.train()
 ms_step = timed(step, args.reps)
+ms_step_enc = timed(lambda: step(False), args.reps)
+# what the stand-in loss itself costs (forward + backward of the five mean-of-squares on detached copies of the outputs)
+with torch.no_grad():
+    o = net(bd())
+leaves = [t.features.detach().clone().requires_grad_(True) for t in list(o["multi_scale_3d_features"].values()) + [o["encoded_spconv_tensor"]]]
+def loss_only():
+    for l in leaves: l.grad = None
+    sum((l.float() ** 2).mean() for l in leaves).backward()
+ms_loss = timed(loss_only, args.reps)
+del o, leaves
 with torch.no_grad():
     ms_fwd_train = timed(fwd, args.reps)          # module path, BN batch statistics, no graph
 net.eval()
 with torch.no_grad():
     ms_fwd_eval = timed(lambda: net(bd()), args.reps)   # fused inference path
-print(json.dumps({"batch": B, "voxels": n, "dtype": args.dtype, "train_step_ms": round(ms_step, 2), "module_forward_ms": round(ms_fwd_train, 2),
+print(json.dumps({"batch": B, "voxels": n, "dtype": args.dtype, "train_step_ms": round(ms_step, 2),
+                  "train_step_ms_loss_on_encoded_tensor_only": round(ms_step_enc, 2), "stand_in_loss_alone_ms": round(ms_loss, 2),
+                  "module_forward_ms": round(ms_fwd_train, 2),
                   "fused_eval_forward_ms": round(ms_fwd_eval, 2), "scenes_per_s_train": round(B / ms_step * 1e3, 1)}))
