@@ -409,7 +409,13 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
 #ifndef FNP_WD4
 #define FNP_WD4 1
 #endif
-    constexpr bool WD4 = FNP_WD4 && !ALLK && ((NW == 8 && NCH == KS && NCH == 4) || (NWO == 4 && NCH == 2 * KS && KS == 4));
+#ifndef FNP_WD4_64128
+#define FNP_WD4_64128 1
+#endif
+    // (64 -> 128, four waves: 4 chunks per thread and slab, two per MFMA step — the same two-offsets-ahead register pipeline; its
+    //  step-by-step staging left a one-scene launch waiting for the L2 once per offset: 33 us, 18.6 with no staging at all)
+    constexpr bool WD4 = FNP_WD4 && !ALLK && (((NW == 8 || (FNP_WD4_64128 && NW == 4 && CIN == 128 && COUT == 64)) && NCH == KS && NCH == 4) || (NWO == 4 && NCH == 2 * KS && KS == 4) ||
+                                              (FNP_WD4_64128 && NW == 4 && NCH == 2 * KS && KS == 2 && CIN == 64 && COUT == 128));
     constexpr int WDN = WD4 ? NCH / KS : 1;   // chunks per thread and MFMA step (2 in the four-wave small-input form)
     constexpr bool WPAIR = Cfg::WPAIR && WD4;
     static_assert(CIN % 16 == 0 && COUT % 16 == 0, "channel counts must be multiples of 16");
@@ -752,8 +758,12 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
         uint4 we0 = wd0, we1 = wd0, we2 = wd0, we3 = wd0;                          // (WDN == 2: the second chunk of a step)
         if (WD4 && !(FNP_ABLATE & 2)) {
             const uint4 *w1 = wslab(WPAIR ? 2 : 1);
-            wd0 = w1[tid]; wd1 = w1[tid + WDN * NT]; wd2 = w1[tid + 2 * WDN * NT]; wd3 = w1[tid + 3 * WDN * NT];
-            if constexpr (WDN == 2) { we0 = w1[tid + NT]; we1 = w1[tid + 3 * NT]; we2 = w1[tid + 5 * NT]; we3 = w1[tid + 7 * NT]; }
+            wd0 = w1[tid]; wd1 = w1[tid + WDN * NT];
+            if constexpr (KS > 2) { wd2 = w1[tid + 2 * WDN * NT]; wd3 = w1[tid + 3 * WDN * NT]; }
+            if constexpr (WDN == 2) {
+                we0 = w1[tid + NT]; we1 = w1[tid + 3 * NT];
+                if constexpr (KS > 2) { we2 = w1[tid + 5 * NT]; we3 = w1[tid + 7 * NT]; }
+            }
         }
         FNP_MS(2);
         for (int k0 = 0; k0 < Kt; k0 += PFK) {
@@ -1157,11 +1167,14 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
 #ifndef FNP_MB3232
 #define FNP_MB3232 2
 #endif
+#ifndef FNP_MB_SMALL
+#define FNP_MB_SMALL 2   // (blocks per wave of the four-wave small-input form)
+#endif
 #ifndef FNP_MB6464
 #define FNP_MB6464 2
 #endif
     constexpr int NWX = NwOf<CIN, COUT, NWO>::value;
-    constexpr int MB = NWO ? 2 : COUT >= 128 ? FNP_MB128 : (CIN == 16 && COUT <= 32) ? 2 : (CIN == 32 && COUT == 32) ? FNP_MB3232 : (CIN == 64 && COUT == 64) ? FNP_MB6464 : 4;
+    constexpr int MB = NWO ? FNP_MB_SMALL : COUT >= 128 ? FNP_MB128 : (CIN == 16 && COUT <= 32) ? 2 : (CIN == 32 && COUT == 32) ? FNP_MB3232 : (CIN == 64 && COUT == 64) ? FNP_MB6464 : 4;
     using Cfg = MfmaCfg<CIN, COUT, KVOL>;
     auto kern = spconv_mfma_kernel<CIN, COUT, MB, KVOL, WIN, TOut, FUSED, TAct, SORTED, NWO>;
     constexpr int lds = Cfg::lds_bytes(NWX, MB, WIN) + Cfg::epi_bytes(NWX, WIN, sizeof(TOut) == 2) +
