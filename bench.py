@@ -510,12 +510,15 @@ def main():
                     try:
                         for _ in range(5):
                             fwd(p_b, o_b, b, cfg)
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        for _ in range(50):
-                            r_b = fwd(p_b, o_b, b, cfg)
-                        torch.cuda.synchronize()
-                        dt = (time.perf_counter() - t0) / 50
+                        dts = []
+                        for _ in range(3):   # (three regions of 20 steps, the median: one hiccup inside a single region was the number before)
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                            for _ in range(20):
+                                r_b = fwd(p_b, o_b, b, cfg)
+                            torch.cuda.synchronize()
+                            dts.append((time.perf_counter() - t0) / 20)
+                        dt = sorted(dts)[1]
                         row[f"ms_per_step_{mode}"], row[f"scenes_per_s_{mode}"] = 1e3 * dt, b / dt
                         row[f"site_counts_{mode}"] = [int(c) for c in r_b["counts"]]
                     except Exception as e:   # the extra field is best effort: never lose the headline over it
