@@ -138,3 +138,32 @@ def test_tile_gate_switches_on_the_measured_escape_share(cuda):
     for name in ("x_conv2", "x_conv3", "x_conv4", "out"):
         assert torch.equal(a[name].features, b[name].features), name
     assert eng.tile_off[1] == eng.TILE_REPROBE - 1
+
+
+def test_ten_sweep_scene_bf16x3_engine_with_and_without_tiles(cuda):
+    """FNP_DTYPE: bf16x3 at 10-sweep density: the first forward runs stages 2-3 on the tile rulebook with a lean int32 table
+    (2 % / 11 % of the 32-row groups fetch through it: the escape path of all three launches of a layer, the split epilogue
+    included), the second — the tile gate has switched — on the gather kernels with the full table.  Both against the f32
+    engine (= the oracle bit for bit): same sites, every output within 3e-5 of its feature scale; and the two agree to the same
+    bound (the cross terms are rounded to bf16 by either path)."""
+    if S.TILE_MODE is not None:
+        pytest.skip("FNP_TILE forces the kernel")
+    pts, off = syn.make_sweeps_batch((35,))
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, syn.MAX_VOXELS_TEST)
+    d_p, d_o = torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda)
+    x3, ref = _net(cuda, "bf16x3"), _net(cuda, "fp32")
+    aborts0 = _l.load().fnp_spconv_tiled_aborts()
+    with torch.no_grad():
+        a = x3.forward_points(d_p, d_o, 1, cfg)
+        assert 1 in x3.engine()._heur_key(), x3.engine().tile_escape_share
+        b = x3.forward_points(d_p, d_o, 1, cfg)
+        want = ref.forward_points(d_p, d_o, 1, cfg)
+    for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out"):
+        assert torch.equal(a[name].indices, want[name].indices) and torch.equal(b[name].indices, want[name].indices), name
+        w = want[name].features
+        scale = max(1.0, float(w.abs().max()))
+        for got in (a, b):
+            assert got[name].features.dtype == torch.float32
+            err = float((got[name].features - w).abs().max())
+            assert err <= 3e-5 * scale, (name, err, scale)
+    assert _l.load().fnp_spconv_tiled_aborts() == aborts0
