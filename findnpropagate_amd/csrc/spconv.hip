@@ -237,6 +237,9 @@ struct MfmaCfg {
 #ifndef FNP_ABLATE
 #define FNP_ABLATE 0
 #endif
+#ifndef FNP_NT_STORE
+#define FNP_NT_STORE 0   // (development: output rows stored with the non-temporal hint — measured within the noise of a box, round 4)
+#endif
 // L2 line-touch prefetch of the rows above a tile (bit 0) — see run_tile
 #ifndef FNP_PF
 #define FNP_PF 0
@@ -995,7 +998,13 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
                         int ro = r;
                         if constexpr (SORTED) ro = orow[mb][h][i];
                         const u32x4 t = *reinterpret_cast<const u32x4 *>(eb + (i * SPI + wsite) * ES + wchunk * 16);
-                        if (r < row_end && !(FNP_ABLATE & 128)) *reinterpret_cast<u32x4 *>(y + (size_t)ro * COUT + wchunk * 8) = t;
+                        if (r < row_end && !(FNP_ABLATE & 128)) {
+#if FNP_NT_STORE
+                            __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(y + (size_t)ro * COUT + wchunk * 8));
+#else
+                            *reinterpret_cast<u32x4 *>(y + (size_t)ro * COUT + wchunk * 8) = t;
+#endif
+                        }
                     }
                 }
             }

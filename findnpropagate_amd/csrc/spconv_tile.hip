@@ -25,6 +25,9 @@
 #include "tilerb.cuh"
 #include <type_traits>
 
+#ifndef FNP_NT_STORE
+#define FNP_NT_STORE 0   // (development: output rows stored with the non-temporal hint)
+#endif
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -849,8 +852,14 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
                 }
                 auto t0 = __builtin_amdgcn_permlane16_swap(o[0].x, o[1].x, false, false);
                 auto t1 = __builtin_amdgcn_permlane16_swap(o[0].y, o[1].y, false, false);
-                if (live)
+                if (live) {
+#if FNP_NT_STORE
+                    typedef unsigned int nt4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store((nt4){t0[0], t1[0], t0[1], t1[1]}, reinterpret_cast<nt4 *>(reinterpret_cast<unsigned char *>(y) + (size_t)r * (C * 2) + kp * 64 + poff));
+#else
                     *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(y) + (size_t)r * (C * 2) + kp * 64 + poff) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+#endif
+                }
             }
         }
         FNP_STAMP(5);   // (epilogue)
