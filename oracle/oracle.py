@@ -335,12 +335,29 @@ RES_BACKBONE8X = (
 )
 
 
-def backbone_layers(input_channels=5, last_pad=0):
-    """RES_BACKBONE8X flattened to its 21 convolutions in execution order: dicts with the conv's
+# VoxelBackBone8x (spconv_backbone.py:70-181; the plain variant: post_act_block rows only, 64 channels in stage 4)
+PLAIN_BACKBONE8X = (
+    ("subm", "conv_input", 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), "subm1", None),          # :90-94
+    ("subm", "conv1.0", 16, (3, 3, 3), (1, 1, 1), (1, 1, 1), "subm1", "x_conv1"),         # :97-99
+    ("down", "conv2.0", 32, (3, 3, 3), (2, 2, 2), (1, 1, 1), "spconv2", None),           # :101-106
+    ("subm", "conv2.1", 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), "subm2", None),
+    ("subm", "conv2.2", 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), "subm2", "x_conv2"),
+    ("down", "conv3.0", 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), "spconv3", None),           # :108-113
+    ("subm", "conv3.1", 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), "subm3", None),
+    ("subm", "conv3.2", 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), "subm3", "x_conv3"),
+    ("down", "conv4.0", 64, (3, 3, 3), (2, 2, 2), (0, 1, 1), "spconv4", None),           # :115-120
+    ("subm", "conv4.1", 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), "subm4", None),
+    ("subm", "conv4.2", 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), "subm4", "x_conv4"),
+    ("down", "conv_out", 128, (3, 1, 1), (2, 1, 1), "last_pad", "spconv_down2", "out"),  # :126-132
+)
+
+
+def backbone_layers(input_channels=5, last_pad=0, table=None):
+    """RES_BACKBONE8X (or `table`) flattened to its convolutions in execution order: dicts with the conv's
     state_dict prefix, its BatchNorm's prefix, subm, in/out channels, kernel, stride, padding,
     indice_key, whether a residual is added before the ReLU, and the output name it closes."""
     out, cin = [], int(input_channels)
-    for e in RES_BACKBONE8X:
+    for e in (RES_BACKBONE8X if table is None else table):
         if e[0] == "block":
             _, prefix, planes, key, name = e
             for j, (c, b) in enumerate((("conv1", "bn1"), ("conv2", "bn2"))):
@@ -357,8 +374,9 @@ def backbone_layers(input_channels=5, last_pad=0):
     return out
 
 
-def backbone_forward(params, voxel_features, voxel_coords, batch_size, sparse_shape, bf16=False, last_pad=0):
-    """VoxelResBackBone8x.forward (spconv_backbone.py:243-295) in eval mode.
+def backbone_forward(params, voxel_features, voxel_coords, batch_size, sparse_shape, bf16=False, last_pad=0, table=None):
+    """VoxelResBackBone8x.forward (spconv_backbone.py:243-295) in eval mode (table=PLAIN_BACKBONE8X: VoxelBackBone8x.forward,
+    :134-181).
 
     params: dict name -> ndarray with the reference state_dict keys
     ('conv_input.0.weight', 'conv_input.1.weight', ..., 'conv1.0.conv1.weight', ...), conv
@@ -382,7 +400,7 @@ def backbone_forward(params, voxel_features, voxel_coords, batch_size, sparse_sh
 
     x = SparseTensor(voxel_features, voxel_coords, sparse_shape, batch_size)
     outs, identity = {}, None
-    for L in backbone_layers(np.asarray(voxel_features).shape[1], last_pad):
+    for L in backbone_layers(np.asarray(voxel_features).shape[1], last_pad, table):
         w = W(L["conv"] + ".weight")
         assert list(w.shape) == [L["cout"], *L["kernel"], L["cin"]], (L["conv"], w.shape)
         if L["subm"]:

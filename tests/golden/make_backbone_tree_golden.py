@@ -16,7 +16,8 @@ constructed with the arguments the REFERENCE passes.  Two fixtures (data, never 
                          stride, padding, indice_key, bias, BN eps / momentum / affine), state_dict keys +
                          shapes + dtypes, the order in which forward() calls the leaf modules, the
                          constructor's public attributes (sparse_shape, num_point_features, backbone_channels)
-  backbone_forward.npz   one small scene through the reference's VoxelResBackBone8x.forward in eval mode:
+  backbone_forward.npz   (backbone_forward_plain.npz: the same for VoxelBackBone8x)
+                         one small scene through the reference's VoxelResBackBone8x.forward in eval mode:
                          inputs (voxel features + coords), weight seed, and the five outputs
                          (encoded_spconv_tensor, x_conv1..x_conv4: indices + f32 features)
 
@@ -152,28 +153,29 @@ def main():
         entry["multi_scale_3d_strides"] = dict(bd["multi_scale_3d_strides"])
         tree[cls_name] = entry
 
-        if cls_name == "VoxelResBackBone8x":
-            got = {"out": bd["encoded_spconv_tensor"], **bd["multi_scale_3d_features"]}
-            sd = {k: t.detach().numpy() for k, t in small.state_dict().items()}
-            want = O.backbone_forward(sd, feats, coords, 1, small.sparse_shape)
-            arrays = {"voxel_features": feats, "voxel_coords": coords, "grid_size": grid,
-                      "weight_seed": np.int64(SEED_WEIGHTS), "scene": np.array([SEED_SCENE, STRIDE], np.int64),
-                      "half_range": np.float32(HALF)}
-            for k, t in got.items():
-                f, i = t.features.numpy(), t.indices.numpy()
-                assert np.array_equal(i, want[k].indices), k
-                err = np.abs(f - want[k].features).max()
-                assert err <= 1e-5 * max(1.0, np.abs(f).max()), (k, err)   # torch's BatchNorm1d vs the folded scale / shift
-                print(f"{k}: {i.shape[0]} sites x {f.shape[1]}, |reference forward - oracle.backbone_forward| max {err:.2e}")
-                arrays[k + "_indices"], arrays[k + "_features"] = i, f.astype(np.float32)
-                arrays[k + "_spatial_shape"] = np.array(t.spatial_shape, np.int64)
-            # the weights are a function of (tree, seed); a checksum guards the recipe itself
-            arrays["state_checksum"] = np.array([float(np.abs(v).astype(np.float64).sum()) for v in sd.values()])
-            np.savez_compressed(os.path.join(out_dir, "backbone_forward.npz"), **arrays)
+        # the reference's forward() output itself (over the oracle's convolution primitive), held against oracle.backbone_forward
+        res = cls_name == "VoxelResBackBone8x"
+        got = {"out": bd["encoded_spconv_tensor"], **bd["multi_scale_3d_features"]}
+        sd = {k: t.detach().numpy() for k, t in small.state_dict().items()}
+        want = O.backbone_forward(sd, feats, coords, 1, small.sparse_shape, table=None if res else O.PLAIN_BACKBONE8X)
+        arrays = {"voxel_features": feats, "voxel_coords": coords, "grid_size": grid,
+                  "weight_seed": np.int64(SEED_WEIGHTS), "scene": np.array([SEED_SCENE, STRIDE], np.int64),
+                  "half_range": np.float32(HALF)}
+        for k, t in got.items():
+            f, i = t.features.numpy(), t.indices.numpy()
+            assert np.array_equal(i, want[k].indices), k
+            err = np.abs(f - want[k].features).max()
+            assert err <= 1e-5 * max(1.0, np.abs(f).max()), (k, err)   # torch's BatchNorm1d vs the folded scale / shift
+            print(f"{cls_name} {k}: {i.shape[0]} sites x {f.shape[1]}, |reference forward - oracle.backbone_forward| max {err:.2e}")
+            arrays[k + "_indices"], arrays[k + "_features"] = i, f.astype(np.float32)
+            arrays[k + "_spatial_shape"] = np.array(t.spatial_shape, np.int64)
+        # the weights are a function of (tree, seed); a checksum guards the recipe itself
+        arrays["state_checksum"] = np.array([float(np.abs(v).astype(np.float64).sum()) for v in sd.values()])
+        np.savez_compressed(os.path.join(out_dir, "backbone_forward.npz" if res else "backbone_forward_plain.npz"), **arrays)
 
     with open(os.path.join(out_dir, "backbone_tree.json"), "w") as f:
         json.dump(tree, f, indent=1, sort_keys=True)
-    print("wrote backbone_tree.json, backbone_forward.npz")
+    print("wrote backbone_tree.json, backbone_forward.npz, backbone_forward_plain.npz")
 
 
 if __name__ == "__main__":

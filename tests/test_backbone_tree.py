@@ -27,8 +27,8 @@ TREE = json.load(open(os.path.join(HERE, "golden", "backbone_tree.json")))
 OUTPUTS = ("out", "x_conv1", "x_conv2", "x_conv3", "x_conv4")
 
 
-def _fixture():
-    return np.load(os.path.join(HERE, "golden", "backbone_forward.npz"))
+def _fixture(plain=False):
+    return np.load(os.path.join(HERE, "golden", "backbone_forward_plain.npz" if plain else "backbone_forward.npz"))
 
 
 def _describe(m):
@@ -92,10 +92,10 @@ def test_oracle_layer_table_is_the_reference_forward_order():
     assert want["multi_scale_3d_strides"] == {"x_conv1": 1, "x_conv2": 2, "x_conv3": 4, "x_conv4": 8}
 
 
-def _weights(fx, dtype="fp32"):
+def _weights(fx, dtype="fp32", plain=False):
     from findnpropagate_amd import synthetic as syn
-    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
-    net = VoxelResBackBone8x({"USE_BIAS": False, "FNP_DTYPE": dtype}, 5, fx["grid_size"])
+    from findnpropagate_amd.backbones_3d import VoxelBackBone8x, VoxelResBackBone8x
+    net = (VoxelBackBone8x if plain else VoxelResBackBone8x)({"USE_BIAS": False, "FNP_DTYPE": dtype}, 5, fx["grid_size"])
     syn.init_backbone_weights(net, int(fx["weight_seed"])).eval()
     chk = np.array([float(np.abs(v.detach().numpy()).astype(np.float64).sum()) for v in net.state_dict().values()])
     assert np.allclose(chk, fx["state_checksum"], rtol=1e-12), "weight recipe drifted from the fixture's"
@@ -112,6 +112,33 @@ def test_oracle_backbone_forward_reproduces_the_reference_forward():
         assert got[k].spatial_shape == fx[k + "_spatial_shape"].tolist()
         w = fx[k + "_features"]
         # torch's BatchNorm1d (eval) against the oracle's folded scale / shift: rounding only
+        assert np.abs(got[k].features - w).max() <= 1e-5 * max(1.0, np.abs(w).max()), k
+
+
+def test_oracle_plain_table_is_the_reference_forward_order_and_reproduces_its_forward():
+    """oracle.PLAIN_BACKBONE8X (VoxelBackBone8x, spconv_backbone.py:70-181) against the reference's own constructor, the order its
+    forward() reached the layers in, and the forward's five outputs on the fixture scene (backbone_forward_plain.npz)."""
+    want = TREE["VoxelBackBone8x"]
+    mods = {m["name"]: m for m in want["modules"]}
+    calls = want["call_order"]
+    convs = [n for n in calls if mods[n]["class"] in ("SubMConv3d", "SparseConv3d")]
+    layers = O.backbone_layers(want["ctor"]["input_channels"], 0, table=O.PLAIN_BACKBONE8X)
+    assert [L["conv"] for L in layers] == convs and len(convs) == 12
+    for L in layers:
+        m = mods[L["conv"]]
+        assert (m["in_channels"], m["out_channels"], m["kernel_size"], m["subm"], m["indice_key"]) == \
+               (L["cin"], L["cout"], L["kernel"], L["subm"], L["indice_key"]), L
+        if not L["subm"]:
+            assert m["stride"] == L["stride"] and m["padding"] == L["padding"], L
+        i = calls.index(L["conv"])
+        assert calls[i + 1] == L["bn"] and mods[calls[i + 2]]["class"] == "ReLU" and not L["residual"]
+    fx = _fixture(plain=True)
+    net = _weights(fx, plain=True)
+    sd = {k: t.detach().numpy() for k, t in net.state_dict().items()}
+    got = O.backbone_forward(sd, fx["voxel_features"], fx["voxel_coords"], 1, net.sparse_shape, table=O.PLAIN_BACKBONE8X)
+    for k in OUTPUTS:
+        assert np.array_equal(got[k].indices, fx[k + "_indices"]), k
+        w = fx[k + "_features"]
         assert np.abs(got[k].features - w).max() <= 1e-5 * max(1.0, np.abs(w).max()), k
 
 
@@ -177,3 +204,26 @@ def test_product_engines_reproduce_the_reference_forward(path):
         g, w = got[k].features.float().cpu().numpy()[go], fx[k + "_features"][wo]
         err = np.abs(g - w).max()
         assert err <= tol * max(1.0, np.abs(w).max()), (path, k, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+def test_product_plain_backbone_reproduces_the_reference_forward(dtype, tol):
+    """VoxelBackBone8x (spconv_backbone.py:70-181; module path) on the fixture's inputs against what the reference's own
+    VoxelBackBone8x.forward produced: site sets equal, features within the engine's precision."""
+    fx = _fixture(plain=True)
+    dev = torch.device("cuda", 0)
+    net = _weights(fx, dtype, plain=True).to(dev)
+    with torch.no_grad():
+        bd = net({"voxel_features": torch.from_numpy(fx["voxel_features"]).to(dev), "voxel_coords": torch.from_numpy(fx["voxel_coords"]).to(dev),
+                  "batch_size": 1})
+    got = {"out": bd["encoded_spconv_tensor"], **bd["multi_scale_3d_features"]}
+    for k in OUTPUTS:
+        gi, wi = got[k].indices.cpu().numpy(), fx[k + "_indices"]
+        s = got[k].spatial_shape
+        assert list(s) == fx[k + "_spatial_shape"].tolist()
+        key = lambda i: ((i[:, 1].astype(np.int64) * s[1]) + i[:, 2]) * s[2] + i[:, 3]
+        go, wo = np.argsort(key(gi)), np.argsort(key(wi))
+        assert np.array_equal(gi[go], wi[wo]), (dtype, k)
+        g, w = got[k].features.float().cpu().numpy()[go], fx[k + "_features"][wo]
+        assert np.abs(g - w).max() <= tol * max(1.0, np.abs(w).max()), (dtype, k, np.abs(g - w).max())
