@@ -297,7 +297,7 @@ class PermutedWeight(torch.Tensor):
 
 def pack_weight(weight, dtype, mfma_f32=False):
     """spconv 2.x layout (Cout,kD,kH,kW,Cin) -> packed (K, Cout, Cin) contiguous in `dtype`.
-    (spconv 1.x (kD,kH,kW,Cin,Cout) is converted by the module loader, see spconv/conv.py.)
+    (spconv 1.x (kD,kH,kW,Cin,Cout) is converted when a checkpoint is loaded: SparseConvolution._load_from_state_dict, spconv/conv.py.)
     mfma_f32: f32 weights of a shape the f32 MFMA kernel covers are stored with every group of 16 input channels
     transposed 4 x 4 (position 4q + r <- channel 4r + q): the layout that kernel reads without lane exchanges; the result
     is tagged (PermutedWeight) so that conv_forward passes FNP_HINT_W_PERMUTED."""

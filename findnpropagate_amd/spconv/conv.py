@@ -135,6 +135,17 @@ class SparseConvolution(SparseModule):
             self._packed[key] = hit
         return hit[1]
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Checkpoints written with spconv 1.x hold the weight as (kD, kH, kW, Cin, Cout); the reference's loader adapts them
+        (detector3d_template.py:401-433: permute(4, 0, 1, 2, 3) gives this module's (Cout, kD, kH, kW, Cin)).  A plain
+        load_state_dict() of such a checkpoint does the same here instead of failing on the shape."""
+        key = prefix + "weight"
+        w = state_dict.get(key)
+        if isinstance(w, torch.Tensor) and w.dim() == 5 and tuple(w.shape) != tuple(self.weight.shape):
+            if tuple(w.shape) == (*self.weight.shape[1:4], self.weight.shape[4], self.weight.shape[0]):
+                state_dict[key] = w.permute(4, 0, 1, 2, 3).contiguous()
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
     def forward(self, input: SparseConvTensor):
         assert isinstance(input, SparseConvTensor)
         with_grad = torch.is_grad_enabled() and (self.weight.requires_grad or input.features.requires_grad)

@@ -227,3 +227,25 @@ def test_product_plain_backbone_reproduces_the_reference_forward(dtype, tol):
         assert np.array_equal(gi[go], wi[wo]), (dtype, k)
         g, w = got[k].features.float().cpu().numpy()[go], fx[k + "_features"][wo]
         assert np.abs(g - w).max() <= tol * max(1.0, np.abs(w).max()), (dtype, k, np.abs(g - w).max())
+
+
+def test_checkpoints_in_the_spconv_1x_weight_layout_load():
+    """detector3d_template.py:401-433 adapts convolution weights saved with spconv 1.x — (kD, kH, kW, Cin, Cout) — to this layout
+    (Cout, kD, kH, kW, Cin); a plain load_state_dict() of such a checkpoint must give the same parameters
+    (SparseConvolution._load_from_state_dict), and the reference's own find_all_spconv_keys walk (spconv_utils.py:15-29:
+    isinstance(child, spconv.conv.SparseConvolution)) finds all 21 weights."""
+    from findnpropagate_amd import spconv, synthetic as syn
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    grid = np.array([64, 64, 16])
+    a = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 3)
+    sd = a.state_dict()
+    keys = [n + ".weight" for n, m in a.named_modules() if isinstance(m, spconv.conv.SparseConvolution)]
+    assert len(keys) == 21 and all(k in sd for k in keys)
+    disk = {k: v.clone() for k, v in sd.items()}
+    for k in keys:
+        disk[k] = sd[k].permute(1, 2, 3, 4, 0).contiguous()          # (Cout, kD, kH, kW, Cin) -> 1.x (kD, kH, kW, Cin, Cout)
+        assert disk[k].shape != sd[k].shape
+    b = VoxelResBackBone8x({"USE_BIAS": False}, 5, grid)
+    b.load_state_dict(disk)
+    for k, v in sd.items():
+        assert torch.equal(b.state_dict()[k], v), k
