@@ -376,6 +376,20 @@ def main():
     prof = rep_prof[mid]
     eng.profile, eng.profile_only = None, None
 
+    # Per-rank shard evidence: every rank's stage counts and a checksum of its voxel coordinates travel to
+    # rank 0 in ONE all_gather after the timed region, so that a multi-GPU run can be checked for N DISTINCT shards (rank r takes
+    # seeds r*B .. r*B + B - 1) from its single JSON line.  Not a data-path collective: the step itself exchanges nothing.
+    vc = res["voxel_coords"].to(torch.int64)
+    lin = ((vc[:, 0] * 41 + vc[:, 1]) * 1440 + vc[:, 2]) * 1440 + vc[:, 3]
+    mine = torch.tensor([int(c) for c in counts] + [int((lin * 1000003 % 2147483647).sum().item()), seeds[0], seeds[-1]], dtype=torch.int64, device=dev)
+    if dist is not None:
+        allr = torch.empty((world * mine.numel(),), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(world, -1).tolist()
+    else:
+        allr = [mine.tolist()]
+    per_rank = [{"rank": r, "seeds": [row[6], row[7]], "site_counts": row[:5], "voxel_coords_checksum": row[5]} for r, row in enumerate(allr)]
+
     out = {
         "metric": "NuScenes scenes/s (30k pts, Transfusion voxel backbone)",
         "value": world * B * args.steps / elapsed,
@@ -396,6 +410,7 @@ def main():
                    "scenes_per_step_per_gpu": B, "points_per_scene": int(pts_np.shape[0] // B),
                    "voxels_per_scene": int(counts[0] // B), "sparse_shape": [41, 1440, 1440],
                    "site_counts": [int(c) for c in counts], "weights": "seeded random init",
+                   "per_rank": per_rank, "shards_distinct": len({r["voxel_coords_checksum"] for r in per_rank}) == world,
                    "parallelism": f"scenes sharded {world}x, no data-path collective",
                    # the statistic the tile-rulebook kernels are gated on (share of 32-row groups with an escape entry, stages 2 / 3;
                    # above 0.004 a stage runs on the gather kernels) and which stages that switched off in this run
@@ -547,6 +562,12 @@ def main():
                         row[f"pipeline_{depth}_error"] = repr(e)[:200]
             sweep[str(b)] = row
         out["batch_sweep"] = sweep
+        # like-for-like with rounds 1-3 (the default went from 64 to 128 scenes per step in round 4): the same replayed
+        # step at 64 scenes per step, beside `value`
+        if B == 64:
+            out["value_at_64"] = out["value"]
+        elif "scenes_per_s_graph" in sweep.get("64", {}):
+            out["value_at_64"] = sweep["64"]["scenes_per_s_graph"]
         # The same 64-scene step with several BATCHES in flight (PointsPipeline: a hipGraph, an engine and a HIP stream per slot;
         # results identical per batch): what a server that is handed batches back to back gets out of the card — the latency-bound
         # index kernels of one batch run under the convolutions of another.  Reported beside `value`, which stays one batch at a time.

@@ -174,7 +174,8 @@ def _module_forward(self, batch_dict):
                                    spatial_shape=self.sparse_shape, batch_size=batch_size)
     # the strided layers' rulebooks are asked for ahead of the layers before them (spconv/conv.py prefetch): the first one from
     # the input coordinates right here, each further one by the strided layer before it
-    if x_in.features.is_cuda and torch.is_grad_enabled():
+    prepacked = x_in.features.is_cuda and torch.is_grad_enabled()
+    if prepacked:
         # every layer's packed weights (and its data gradient's slabs) in one launch per dtype
         from ..spconv import conv as _C
         conv0 = self.conv_input[0]
@@ -187,16 +188,19 @@ def _module_forward(self, batch_dict):
         if chain and x_in.indices.shape[0] > 0:
             chain[0].prefetch(x_in.indices, x_in.n_dev(), x_in.rank_grid(), x_in.spatial_shape, batch_size, x_in.indice_dict)
     # first conv consumes f32 point features; activations then live in `act`
-    conv0 = self.conv_input[0]
-    x = conv0(x_in)
-    x = x.replace_feature(_bn_relu(self.conv_input[1], self.conv_input[2], x, act))
-    x_conv1 = _seq_forward(self.conv1, x, act)
-    x_conv2 = _seq_forward(self.conv2, x_conv1, act)
-    x_conv3 = _seq_forward(self.conv3, x_conv2, act)
-    x_conv4 = _seq_forward(self.conv4, x_conv3, act)
-    out = _seq_forward(self.conv_out, x_conv4, act)
-    if x_in.features.is_cuda and torch.is_grad_enabled():
-        _C.end_of_backbone_forward(convs + [c for c in chain if c not in convs], x_in.indice_dict)   # (the autograd nodes hold their own slabs; nothing stale stays on the modules)
+    try:
+        conv0 = self.conv_input[0]
+        x = conv0(x_in)
+        x = x.replace_feature(_bn_relu(self.conv_input[1], self.conv_input[2], x, act))
+        x_conv1 = _seq_forward(self.conv1, x, act)
+        x_conv2 = _seq_forward(self.conv2, x_conv1, act)
+        x_conv3 = _seq_forward(self.conv3, x_conv2, act)
+        x_conv4 = _seq_forward(self.conv4, x_conv3, act)
+        out = _seq_forward(self.conv_out, x_conv4, act)
+    finally:
+        # (also when a layer raised: the autograd nodes hold their own slabs; nothing stale stays on the modules)
+        if prepacked:
+            _C.end_of_backbone_forward(convs + [c for c in chain if c not in convs], x_in.indice_dict)
     return self._pack_outputs(batch_dict, out, x_conv1, x_conv2, x_conv3, x_conv4)
 
 
@@ -348,11 +352,17 @@ class _PointsGraph:
         self.pts = torch.full((capacity, n_feat), self.FAR, dtype=torch.float32, device=device)
         self.off = torch.zeros((batch_size + 1,), dtype=torch.int32, device=device)
         self.n_prev = 0
-        self.cap_factor = engine._graph_key()
         self.prep_key = engine._prep_key
-        # warm-up on a side stream (allocations of persistent grids/workspaces, lazy kernel attributes), then capture
-        self._body(voxel_cfg)
+        # warm-up (allocations of persistent grids/workspaces, lazy kernel attributes), then capture.  The warm-up is not a frame:
+        # it must not count the tile gate's gather-kernel period down, and the key the graph is stored under is read AFTER it
+        # (a key taken before an eager warm-up that ticked the gate went stale and forced one more recapture)
+        engine._gate_hold = True
+        try:
+            self._body(voxel_cfg)
+        finally:
+            engine._gate_hold = False
         torch.cuda.synchronize(device)
+        self.cap_factor = engine._graph_key()
         self.graph = torch.cuda.CUDAGraph()
         # No cyclic garbage collection while the stream is capturing: a collection that fires inside the capture and finalises
         # an OLDER graph or its pooled tensors (a replaced _PointsGraph, another test's engine) frees device memory in the
@@ -458,6 +468,7 @@ class PointsPipeline:
     def _graph(self, d):
         e = self.engines[d]
         e.prepare()
+        e._gate_tick()        # (a replayed frame counts the tile gate's period down like an eager one)
         g = self.slots[d]
         if g is None or g.cap_factor != e._graph_key() or g.prep_key != e._prep_key:
             torch.cuda.synchronize(self.device)   # (capture: nothing else of this pipeline may be in flight)
@@ -564,8 +575,10 @@ class FusedResBackbone:
         # count comes back with the forward's one synchronisation, and a stage whose share exceeds TILE_ESC_MAX runs on the gather
         # kernels for the next TILE_REPROBE eager forwards (then the tiles are tried, and measured, again).  Single-sweep lidar:
         # ~1e-5; the 10-sweep density of transfusion_lidar.yaml: 2 % / 11 % of the groups, tiled kernels 4-8 % slower (measured).
-        self.tile_off = {}            # stage index li (0: stage 2, 1: stage 3) -> eager forwards left on the gather kernels
+        self.tile_off = {}            # stage index li (0: stage 2, 1: stage 3) -> forwards (eager OR replayed) left on the gather kernels
+        self.tile_period = {}         # li -> length of the current gather-kernel period (doubles while every re-probe fails)
         self.tile_escape_share = {}   # last measured share per stage (diagnostics; bench.py reports it)
+        self._gate_hold = False       # a _PointsGraph warm-up / capture is running: not a frame
         self.two_streams = True   # (PointsPipeline clears it for its slots when several frames are in flight: they already overlap)
         self._dirty = False      # a forward is in flight or died before its sparse clear: grids may hold stale bits
         # measurement hooks (bench.py): when `profile` is a list every conv launch is bracketed by
@@ -607,6 +620,19 @@ class FusedResBackbone:
 
     TILE_ESC_MAX = float(os.environ.get("FNP_TILE_ESC_MAX", "0.004"))
     TILE_REPROBE = int(os.environ.get("FNP_TILE_REPROBE", "64"))
+    TILE_REPROBE_MAX = int(os.environ.get("FNP_TILE_REPROBE_MAX", "4096"))
+
+    def _gate_tick(self):
+        """one frame has been issued — eagerly (_run_once), from a captured graph (run_points_graphed) or through a
+        PointsPipeline slot: count the gather-kernel period of every gated stage down.  (only eager forwards used
+        to count, so a graph user that met ONE dense frame stayed on the gather kernels for the rest of the process.)  When a
+        period ends the stage is tried on tiles again — for a captured graph that is a recapture — and measured: a stream that
+        stays dense doubles its period at every failed re-probe (64, 128, ... TILE_REPROBE_MAX frames), so the recaptures of a
+        10-sweep stream die out; a stream that went back to single sweeps returns to tiles for good."""
+        if self._gate_hold:
+            return
+        for li in list(self.tile_off):
+            self.tile_off[li] = max(0, self.tile_off[li] - 1)
 
     def _heur_key(self):
         """what a captured graph bakes in besides capacities: which tiled stages run on the gather kernels"""
@@ -627,7 +653,11 @@ class FusedResBackbone:
                 share = used / max(1.0, counts[li + 1] / 32.0)
                 self.tile_escape_share[li] = share
                 if share > self.TILE_ESC_MAX:
-                    self.tile_off[li] = self.TILE_REPROBE
+                    # first sighting: TILE_REPROBE frames on the gather kernels; a re-probe that fails again: twice the last period
+                    period = min(self.tile_period[li] * 2, self.TILE_REPROBE_MAX) if li in self.tile_period else self.TILE_REPROBE
+                    self.tile_period[li] = self.tile_off[li] = period
+                else:
+                    self.tile_period.pop(li, None)
                 continue
             if used > pool:
                 self.ell_pool[which] = max(self.ell_pool[which] * 2.0, used * 1.25 / max(cap1 * (self.cap_factor[0] if which else 1.0), 1))
@@ -784,6 +814,7 @@ class FusedResBackbone:
         assert n <= capacity
         self.prepare()
         key = (batch_size, capacity, C, str(points.device), bool(probe))
+        self._gate_tick()
         while True:
             g = self._graphs.get(key)
             if g is None or g.cap_factor != self._graph_key() or g.prep_key != self._prep_key:
@@ -841,11 +872,14 @@ class FusedResBackbone:
         # (a forward returns before the GPU has finished it — the counts leave early —: a caller that comes back on ANOTHER stream
         #  must not touch the persistent grids and workspaces before the previous forward is through)
         capturing = feats.is_cuda and torch.cuda.is_current_stream_capturing()
+        # (bf16x3 parameters are ((W_hi, W_lo, ones), None, shift) triples and a layer is several launches: the per-launch
+        #  measurement hooks and the probe's deferred launches are written for the one-launch engines)
+        assert not (self.x3 and (self.profile is not None or self.rulebook_log is not None or (probe is not None and probe.probe))), \
+            "bf16x3: profile / rulebook_log / probe graphs are not supported (time the whole forward instead: tools/bench_x3.py)"
         if feats.is_cuda and not capturing and self._last_done is not None:
             torch.cuda.current_stream(feats.device).wait_event(self._last_done)
         if not capturing:
-            for li in list(self.tile_off):      # (eager forwards count the gather-kernel period down; a captured graph keeps its choice)
-                self.tile_off[li] = max(0, self.tile_off[li] - 1)
+            self._gate_tick()      # (a captured forward is counted where it is replayed: run_points_graphed, PointsPipeline)
         m, P, act = self.m, self.prepare(), self.act
         if final_dtype not in (None, act, torch.float32):
             final_dtype = None       # (the conv epilogue writes the activation dtype or f32; anything else is cast by the caller)

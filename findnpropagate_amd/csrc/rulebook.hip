@@ -12,8 +12,8 @@
 //              grid by the inputs (atomicOr), ranked by a popcount scan, and the coordinate list
 //              is emitted in rank order — a deterministic, spatially blocked row order (spconv
 //              leaves the output order implementation-defined).
-#include "rankgrid.cuh"
-#include "tilerb.cuh"
+#include "rankgrid.h"
+#include "tilerb.h"
 
 namespace {
 
@@ -111,7 +111,7 @@ __device__ __forceinline__ unsigned long long spread16(unsigned s) {
 // wave must call it (wave-level merging: inputs in rank-grid order reach one output block from ~30 consecutive rows; the bits
 // of equal blocks are OR-ed along the wave — a lane may take in any earlier lane's bits of the same block — and the last lane
 // of each run issues the one atomic: same-address atomics serialise in L2).
-// (MarkTab, mark_put, mark_tab_init / mark_tab_flush: rankgrid.cuh — shared with the voxeliser's marking kernel)
+// (MarkTab, mark_put, mark_tab_init / mark_tab_flush: rankgrid.h — shared with the voxeliser's marking kernel)
 template <int SZ, int SY, int SX>
 __device__ __forceinline__ void mark2_row(bool valid, const int4 c, const RG &go, const Geom &ge, int lane, MarkTab *tab = nullptr) {
     long long blk0 = -1;          // block of the first outputs (corner 0,0,0) and its bits
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kThreads) void subm_nbr_row_kernel(const int *__res
     }
 }
 
-// subm_nbr_row_kernel<3, 3, 3> that also writes the TILE RULEBOOK of the table (tilerb.cuh; same records as
+// subm_nbr_row_kernel<3, 3, 3> that also writes the TILE RULEBOOK of the table (tilerb.h; same records as
 // fnp_tile_rulebook_build makes from the table afterwards, without reading the table back): the 256 rows a workgroup
 // resolves per pass are one 256-row tile or two 128-row tiles, and the entries are restated from the LDS strips the int32
 // rows are flushed from.
@@ -475,7 +475,7 @@ extern "C" int fnp_rulebook_subm_tiled(const int *coords, const int *n_rows, int
     return FNP_OK;
 }
 
-// The same two entry points for the WIDE tile rulebooks (tilerb.cuh G64W / G128W: fnp_spconv_forward_wtiled); lean != 0: the
+// The same two entry points for the WIDE tile rulebooks (tilerb.h G64W / G128W: fnp_spconv_forward_wtiled); lean != 0: the
 // int32 table receives the rows of escape tiles only.
 extern "C" int fnp_rulebook_subm_wtiled(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom, const fnp_rankgrid *grid,
                                         int *nbr, int channels, void *tile_rb, int lean, const fnp_rankgrid *mark_grid,

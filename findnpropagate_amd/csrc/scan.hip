@@ -2,7 +2,7 @@
 // first-point flags of the voxeliser (int32 scan: tile reduce -> scan of tile sums -> tile scan)
 // and the rank-grid popcount prefix, which walks the summary level so that only occupied
 // blocks are read.
-#include "rankgrid.cuh"
+#include "rankgrid.h"
 
 namespace {
 

@@ -18,7 +18,7 @@
 //   * f32 validation path on the VALU: a k-ascending, cin-ascending fmaf chain per output
 //     element, the same chain the CPU oracle evaluates, so it is bit-comparable.
 // No atomics anywhere: every output row is written once, results are run-to-run identical.
-#include "rankgrid.cuh"
+#include "rankgrid.h"
 #include <type_traits>
 #include <cstdlib>
 

@@ -21,7 +21,7 @@
 // (offset, lane group), swizzled so that the 16-byte reads of rows at different offsets spread over the banks.
 // BatchNorm(eval) scale / shift, residual and ReLU in the epilogue, as in spconv_mfma_kernel.  No atomics in the sum:
 // run-to-run identical.
-#include "rankgrid.cuh"
+#include "rankgrid.h"
 #include <type_traits>
 
 namespace {

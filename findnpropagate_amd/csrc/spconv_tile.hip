@@ -22,7 +22,7 @@
 // they are handed over through counters in LDS, not workgroup barriers (see below).
 // Products, their order (offsets ascending, one 32-wide MFMA step per offset) and the epilogue arithmetic are those of
 // spconv_mfma_kernel: the output is bit-identical (tests/test_gpu_spconv.py::test_tile_kernel_equals_gather_kernel).
-#include "tilerb.cuh"
+#include "tilerb.h"
 #include <type_traits>
 
 #ifndef FNP_NT_STORE

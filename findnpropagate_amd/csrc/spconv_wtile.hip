@@ -21,11 +21,11 @@
 //            step, between its halves, at which every wave has finished reading that slot.
 //   image    rows [tile - HALO, tile + TILE + HALO) of the input, the tile's distinct far neighbour rows (tile rulebook's
 //            far list), a row of zeros; entries are 16-bit addresses in 16-byte units with the row's rotation in the low bits
-//            (tilerb.cuh: conflict-free for ANY run of 16 consecutive image rows).  The entries themselves stay in memory: a
+//            (tilerb.h: conflict-free for ANY run of 16 consecutive image rows).  The entries themselves stay in memory: a
 //            lane needs 16 (8) bytes of them per offset and reads those three offsets ahead.
 // An entry the tile record could not hold (ESCAPE: more distinct far rows than overflow rows — arbitrary row orders) is
 // fetched through the int32 table, as in spconv_tile.hip: correct for any row order.
-#include "tilerb.cuh"
+#include "tilerb.h"
 #include <cstdlib>
 #include <type_traits>
 

@@ -12,8 +12,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // ADD: x + float(t) (a bf16 tensor: the two cross terms of a bf16x3 convolution, which need bf16 precision only), then ReLU if
 // asked, written back to y (f32) before the split.
 template <bool ADD>
-__global__ __launch_bounds__(256) void split_bf16_kernel(const float *__restrict__ x, const __bf16 *__restrict__ t, int relu,
-                                                         const int *__restrict__ n_rows, int cap_rows, int C, float *__restrict__ y,
+// (x and y are NOT __restrict__: fnp_split_bf16_add is called in place, y == x — each thread reads its float4 and then writes it)
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float *x, const __bf16 *__restrict__ t, int relu,
+                                                         const int *__restrict__ n_rows, int cap_rows, int C, float *y,
                                                          __bf16 *__restrict__ hi, __bf16 *__restrict__ lo) {
     const long long total4 = (long long)min(*n_rows, cap_rows) * C / 4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {

@@ -15,7 +15,7 @@
 //   5. per-scene max_voxels cut, then one pass per voxel writes coords, counts, the zero padded
 //      (M, max_points, C) block and the mean feature row                       [emit]
 // No sort, no hash probing, no floating-point atomics.
-#include "rankgrid.cuh"
+#include "rankgrid.h"
 
 namespace {
 
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kThreads) void vox_mark_kernel(const float *__restr
         if (z <= n) cnt[z] = 0;
         if (z == 0 && (long long)gridDim.x * kThreads <= n) cnt[n] = 0;   // (n a multiple of the workgroup size)
     }
-    __shared__ MarkTab tab;   // the marks of the workgroup's 256 points meet here first (rankgrid.cuh): one atomic per distinct block
+    __shared__ MarkTab tab;   // the marks of the workgroup's 256 points meet here first (rankgrid.h): one atomic per distinct block
     if (FNP_MARK_TAB) mark_tab_init(&tab, threadIdx.x, kThreads);
     const int i = blockIdx.x * kThreads + threadIdx.x;   // (whole waves stay: the shuffles below need them)
     const int lane = fnp_lane();

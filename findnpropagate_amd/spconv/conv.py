@@ -8,6 +8,8 @@ With grad enabled the convolution runs through `SparseConvFunction` (SURVEY.md Â
 """
 import math
 
+import threading
+
 import torch
 import torch.nn as nn
 
@@ -244,11 +246,13 @@ class SparseConvolution(SparseModule):
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(dev))
         side.wait_event(ready)
-        host = _pinned_word()     # (a word of this prefetch's own: module replicas and forwards in flight never share one)
+        slot, host = _pinned_word()     # (a word of this prefetch's own: module replicas and forwards in flight never share one)
         done = torch.cuda.Event()
         with torch.cuda.stream(side):
             host.copy_(rb.out_n, non_blocking=True)
             done.record(side)
+        with _PIN_LOCK:
+            _PIN_BUSY[slot] = done
         rb.out_n.record_stream(side)
         indice_dict[("prefetch", id(self))] = (rb, done, host, indices.data_ptr(), indices.shape[0])
 
@@ -274,18 +278,24 @@ def prepack_weights(convs_and_dtypes):
 
 PREFETCH = True   # (tests switch it off to compare with the synchronous path)
 _SIDE = {}
-_PIN_RING, _PIN_NEXT = None, [0]
+_PIN_RING, _PIN_NEXT, _PIN_LOCK = None, [0], threading.Lock()
+_PIN_BUSY = {}      # slot -> the event recorded behind the copy that last wrote it
 
 
 def _pinned_word():
-    """one int32 of pinned host memory out of a ring of 256 (a forward has at most four prefetches in flight; a word comes
-    round again after 256 of them)"""
+    """(slot, one int32 of pinned host memory) out of a ring of 256 (a forward has at most four prefetches in flight).  The
+    ring index is taken under a lock (DataParallel replicas and loader threads prefetch concurrently), and a slot that comes
+    round again waits for the copy that last wrote it â€” consumed long ago in any sane schedule; the wait makes it certain."""
     global _PIN_RING
-    if _PIN_RING is None:
-        _PIN_RING = torch.empty((256,), dtype=torch.int32, pin_memory=True)
-    i = _PIN_NEXT[0]
-    _PIN_NEXT[0] = (i + 1) % 256
-    return _PIN_RING[i:i + 1]
+    with _PIN_LOCK:
+        if _PIN_RING is None:
+            _PIN_RING = torch.empty((256,), dtype=torch.int32, pin_memory=True)
+        i = _PIN_NEXT[0]
+        _PIN_NEXT[0] = (i + 1) % 256
+        old = _PIN_BUSY.pop(i, None)
+    if old is not None:
+        old.synchronize()
+    return i, _PIN_RING[i:i + 1]
 
 
 def end_of_backbone_forward(convs, indice_dict=None):

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE ONLY (see oracle/README or DESIGN.md section 2): a numpy reading of the tile rulebook that
-fnp_tile_rulebook_build / fnp_rulebook_subm_tiled write (include/fnp.h, findnpropagate_amd/csrc/tilerb.cuh), used by
+fnp_tile_rulebook_build / fnp_rulebook_subm_tiled write (include/fnp.h, findnpropagate_amd/csrc/tilerb.h), used by
 tests/test_gpu_tile_rulebook.py to check that a tile rulebook says exactly what the (27, cap) int32 table says.
 
 The tile rulebook has no counterpart in the reference (spconv keeps indice pairs, spconv_backbone.py:12-17 call sites): it
@@ -11,7 +11,7 @@ ESCAPE = 0xFFFF
 GEOMETRY = {  # channels -> (TILE, HALO, OVF, ROW_BYTES)
     32: (256, 32, 256, 64),
     64: (128, 64, 128, 128),
-    # WIDE tiles (tilerb.cuh G64W / G128W; fnp_wtile_rulebook_build): entries in 16-byte units, window split by row mod 4
+    # WIDE tiles (tilerb.h G64W / G128W; fnp_wtile_rulebook_build): entries in 16-byte units, window split by row mod 4
     "w64": (512, 64, 256, 128),
     "w128": (256, 32, 160, 256),
 }

@@ -140,6 +140,45 @@ def test_tile_gate_switches_on_the_measured_escape_share(cuda):
     assert eng.tile_off[1] == eng.TILE_REPROBE - 1
 
 
+def test_tile_gate_reopens_for_graph_replays_and_backs_off_on_dense_streams(cuda):
+    """ADVICE r04 (medium).  A captured-graph user meets one dense frame: the gated stage's period is counted down by REPLAYED
+    frames too, the stage returns to tiles (a recapture) when the period ends and — the frames being single sweeps again — stays
+    there; on a stream that stays dense every failed re-probe doubles the period.  Same bits throughout."""
+    if S.TILE_MODE is not None:
+        pytest.skip("FNP_TILE forces the kernel")
+    net = _net(cuda, "bf16")
+    eng = net.engine()
+    eng.TILE_REPROBE = 3                      # (instance override: the class default is 64 frames)
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, syn.MAX_VOXELS_TEST)
+    p1, o1 = syn.make_batch((5,))
+    p10, o10 = syn.make_sweeps_batch((34,))
+    s_p, s_o = torch.from_numpy(p1).to(cuda), torch.from_numpy(o1).to(cuda)
+    d_p, d_o = torch.from_numpy(p10).to(cuda), torch.from_numpy(o10).to(cuda)
+    cap = 393216
+    with torch.no_grad():
+        want = {k: v.features.clone() for k, v in net.forward_points(s_p, s_o, 1, cfg).items() if k.startswith("x_conv") or k == "out"}
+        run = lambda p, o: net.forward_points_graphed(p, o, 1, cfg, capacity=cap)
+        run(s_p, s_o)
+        assert eng._heur_key() == []
+        run(d_p, d_o)                                        # the dense frame: measured on tiles, stage 3 gated
+        assert 1 in eng._heur_key() and eng.tile_off[1] == 3 and eng.tile_period[1] == 3
+        g_before = eng._graphs[(1, cap, 5, str(cuda), False)]
+        for left in (2, 1):
+            got = run(s_p, s_o)                              # replays on the gather kernels count the period down
+            assert eng.tile_off[1] == left
+        assert eng._graphs[(1, cap, 5, str(cuda), False)] is not g_before        # (one recapture, when the gate closed)
+        got = run(s_p, s_o)                                  # period over: tiles again, measured, fine
+        assert eng._heur_key() == [] and 1 not in eng.tile_period and eng.tile_escape_share[1] < eng.TILE_ESC_MAX
+        for k, w in want.items():
+            assert torch.equal(got[k].features, w), k
+        # a stream that stays dense: 3 frames gated, re-probe fails -> 6, fails again -> 12
+        periods = []
+        for _ in range(3 + 1 + 6 + 1):
+            run(d_p, d_o)
+            periods.append(eng.tile_period.get(1))
+        assert periods[0] == 3 and periods[2] == 3 and periods[3] == 6 and periods[8] == 6 and periods[9] == 12, periods
+
+
 def test_ten_sweep_scene_bf16x3_engine_with_and_without_tiles(cuda):
     """FNP_DTYPE: bf16x3 at 10-sweep density: the first forward runs stages 2-3 on the tile rulebook with a lean int32 table
     (2 % / 11 % of the 32-row groups fetch through it: the escape path of all three launches of a layer, the split epilogue

@@ -18,7 +18,7 @@ def morton3(v):
 
 
 def rank_key(idx, shape):
-    """rank-grid order of rankgrid.cuh: scene, patch (row-major), Z-order column, block bottom-to-top, bit."""
+    """rank-grid order of rankgrid.h: scene, patch (row-major), Z-order column, block bottom-to-top, bit."""
     b, z, y, x = [idx[:, i].astype(np.int64) for i in range(4)]
     D, H, W = shape
     bd, bh, bw = (D + 3) >> 2, (H + 3) >> 2, (W + 3) >> 2
