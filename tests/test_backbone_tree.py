@@ -249,3 +249,95 @@ def test_checkpoints_in_the_spconv_1x_weight_layout_load():
     b.load_state_dict(disk)
     for k, v in sd.items():
         assert torch.equal(b.state_dict()[k], v), k
+
+
+# ---- round 5: the reference's checkpoint adapter and a batch with an empty scene ------------------------------------------------
+ADAPTER = json.load(open(os.path.join(HERE, "golden", "state_dict_adapter.json")))
+
+
+def _sha(t):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(t.detach().cpu().numpy()).tobytes()).hexdigest()
+
+
+def test_load_state_dict_equals_the_reference_adapter_on_every_layout():
+    """tests/golden/state_dict_adapter.json: the reference's own `_load_state_dict` (detector3d_template.py:401-433) and its
+    find_all_spconv_keys (spconv_utils.py:15-29), RUN by tests/golden/make_backbone_extra_golden.py on checkpoints of one seeded
+    model in three convolution-weight layouts.  A plain load_state_dict() of the product's class must end with the parameters the
+    reference's adapter ended with (sha256 per key) for the 1.x and the implicit-gemm layouts, and must refuse the 2.x native
+    layout for the keys the reference refused (neither knows that layout; both raise RuntimeError)."""
+    from backbone_recipes import ADAPTER_GRID, ADAPTER_SEED, disk_layouts
+    from findnpropagate_amd import spconv, synthetic as syn
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    mk = lambda: VoxelResBackBone8x({"USE_BIAS": False}, 5, np.array(ADAPTER_GRID))
+    src = syn.init_backbone_weights(mk(), ADAPTER_SEED)
+    keys = sorted(n + ".weight" for n, m in src.named_modules() if isinstance(m, spconv.conv.SparseConvolution))
+    assert keys == ADAPTER["spconv_keys"] and len(keys) == 21
+    for name, disk in disk_layouts(src.state_dict(), keys).items():
+        want = ADAPTER["layouts"][name]
+        dst = mk()
+        if want.get("raises"):
+            with pytest.raises(RuntimeError) as e:
+                dst.load_state_dict(disk)
+            for k in want["rejected_keys"]:
+                assert k in str(e.value), (name, k)
+            square = [k for k in keys if k not in want["rejected_keys"]]
+            assert not any(("size mismatch for " + k) in str(e.value) for k in square), name
+            continue
+        dst.load_state_dict(disk)
+        got = dst.state_dict()
+        assert sorted(got) == sorted(want["sha256"]) == want["updated_keys"]
+        for k, h in want["sha256"].items():
+            assert _sha(got[k]) == h, (name, k)
+
+
+def _batch_fixture():
+    return np.load(os.path.join(HERE, "golden", "backbone_forward_batch.npz"))
+
+
+def test_batch_recipe_is_the_fixture_and_the_oracle_reproduces_the_reference_on_it():
+    """backbone_forward_batch.npz: the reference's VoxelResBackBone8x.forward on THREE scenes whose middle one is empty."""
+    from backbone_recipes import BATCH_SCENES, batch_scene
+    fx = _batch_fixture()
+    feats, coords, grid = batch_scene()
+    assert int(fx["batch_size"]) == BATCH_SCENES == 3 and set(np.unique(coords[:, 0]).tolist()) == {0, 2}
+    assert np.array_equal(feats, fx["voxel_features"]) and np.array_equal(coords, fx["voxel_coords"]) and np.array_equal(grid, fx["grid_size"])
+    net = _weights(fx)
+    sd = {k: t.detach().numpy() for k, t in net.state_dict().items()}
+    got = O.backbone_forward(sd, feats, coords, BATCH_SCENES, net.sparse_shape)
+    for k in OUTPUTS:
+        assert np.array_equal(got[k].indices, fx[k + "_indices"]), k
+        w = fx[k + "_features"]
+        assert np.abs(got[k].features - w).max() <= 1e-5 * max(1.0, np.abs(w).max()), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol,path", [("fp32", 1e-4, "engine"), ("fp32", 1e-4, "module"), ("bf16", 3e-2, "engine"), ("bf16x3", 1e-4, "engine")])
+def test_product_on_a_batch_with_an_empty_scene_equals_the_reference_forward(dtype, tol, path):
+    """the fused engines and the module path (the reference's forward() signature) on the three-scene fixture: same sites in
+    every scene — none in the empty one —, features within the engine's bound of the reference's forward"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    fx = _batch_fixture()
+    dev = torch.device("cuda", 0)
+    net = _weights(fx, dtype).to(dev)
+    B = int(fx["batch_size"])
+    bd = {"voxel_features": torch.from_numpy(fx["voxel_features"]).to(dev), "voxel_coords": torch.from_numpy(fx["voxel_coords"]).to(dev), "batch_size": B}
+    with torch.no_grad():
+        if path == "module":
+            from findnpropagate_amd.backbones_3d import spconv_backbone as sb
+            bd = sb._module_forward(net, bd)
+        else:
+            bd = net(bd)
+    got = {"out": bd["encoded_spconv_tensor"], **bd["multi_scale_3d_features"]}
+    for k in OUTPUTS:
+        assert got[k].batch_size == B
+        gi, wi = got[k].indices.cpu().numpy(), fx[k + "_indices"]
+        s = got[k].spatial_shape
+        assert list(s) == fx[k + "_spatial_shape"].tolist()
+        key = lambda i: (((i[:, 0].astype(np.int64) * s[0] + i[:, 1]) * s[1]) + i[:, 2]) * s[2] + i[:, 3]
+        go, wo = np.argsort(key(gi)), np.argsort(key(wi))
+        assert np.array_equal(gi[go], wi[wo]), (dtype, k)
+        assert 1 not in set(gi[:, 0].tolist())
+        g, w = got[k].features.float().cpu().numpy()[go], fx[k + "_features"][wo]
+        assert np.abs(g - w).max() <= tol * max(1.0, np.abs(w).max()), (dtype, path, k, np.abs(g - w).max())
