@@ -728,7 +728,7 @@ class FusedResBackbone:
             # bf16 engine's tile-rulebook / class-sorted kernels where the stage has them) chained through a bf16 residual; only the
             # main product keeps f32, and ITS epilogue adds them, applies the ReLU and writes the f32 rows with their (hi, lo) split
             # (conv_forward_split; FNP_X3_FUSED=0: f32-out gather kernel + a split pass)
-            kw = dict(ranked=True) if fast else dict(tile=False, wide=False)
+            kw = dict(ranked=True) if fast else dict(tile=False)
             t = S.conv_forward(x[1], whi, rb, n, **kw)
             t = S.conv_forward(x[0], wlo, rb, n, residual=t, out=t, **kw)
             y, hi, lo = S.conv_forward_split(x[0], whi, rb, n, scale=ones, shift=shift, residual=res, addend=t, relu=True, ranked=ranked,
@@ -737,13 +737,13 @@ class FusedResBackbone:
         if fast:
             t = S.conv_forward(x[1], whi, rb, n, ranked=True)
             t = S.conv_forward(x[0], wlo, rb, n, residual=t, ranked=True, out=t)
-            y = S.conv_forward(x[0], whi, rb, n, out_dtype=torch.float32, scale=ones, shift=shift, residual=res, relu=False, tile=False, wide=False)
+            y = S.conv_forward(x[0], whi, rb, n, out_dtype=torch.float32, scale=ones, shift=shift, residual=res, relu=False, tile=False)
             hi, lo = S.split_bf16_add(y, t, n, relu=True)
             return (hi, lo, y)
-        t = S.conv_forward(x[1], whi, rb, n, out_dtype=torch.float32, residual=res, tile=False, wide=False)
-        t = S.conv_forward(x[0], wlo, rb, n, out_dtype=torch.float32, residual=t, out=t, tile=False, wide=False)
+        t = S.conv_forward(x[1], whi, rb, n, out_dtype=torch.float32, residual=res, tile=False)
+        t = S.conv_forward(x[0], wlo, rb, n, out_dtype=torch.float32, residual=t, out=t, tile=False)
         y = S.conv_forward(x[0], whi, rb, n, out_dtype=torch.float32, scale=ones, shift=shift, residual=t, relu=True, out=t if out is None else out,
-                           tile=False, wide=False)
+                           tile=False)
         return self._split(y, n)
 
     # ---- persistent rank grids (zero between calls; cleared sparsely after use) -----------
@@ -1008,23 +1008,19 @@ class FusedResBackbone:
                 # rulebook (stage 2, 32 channels), the rulebook kernel writes it in the same pass
                 w0 = P[blk_key][0][0][0]
                 ch = int((w0[0] if isinstance(w0, tuple) else w0).shape[1])
-                # wide tiles (round 4; 64 and 128 channels from a capacity on that gives every CU several tiles): they replace the
-                # 128-row tiles of stage 3 and the class-sorted gather sweep of stage 4
-                wide = (S.wide_by_default(ch, act, caps[li + 1]) and S.wide_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
-                        and self.rulebook_log is None)
                 act_k = torch.bfloat16 if (self.x3 and X3_FAST) else act     # (bf16x3: its cross terms run on the bf16 engine's kernels)
-                srt = S.sorted_by_default(ch, ch, act_k, caps[li + 1]) and not wide
-                tiled = wide or (S.tiled_by_default(ch, act_k, caps[li + 1]) and S.tiled_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
-                                 and self.tile_off.get(li, 0) <= 0)
+                srt = S.sorted_by_default(ch, ch, act_k, caps[li + 1])
+                tiled = (S.tiled_by_default(ch, act_k, caps[li + 1]) and S.tiled_fits(caps[li + 1], ch, caps[li + 1], caps[li + 1])
+                         and self.tile_off.get(li, 0) <= 0)
                 # the SubM rulebook kernel of this stage also marks the output sites of the NEXT strided layer (the coordinates are
                 # in its registers): that layer's own marking launch goes
                 nxt = down_convs[li + 1]
                 lean = tiled and self.rulebook_log is None and (not self.x3 or (X3_FAST and X3_FUSED))   # (all four layers of the stage run tiled)
                 mark_next = (grids[li + 2], nxt.kernel_size, nxt.stride, nxt.padding) if (lean or srt) and S.MARK_FUSED else None
                 srt32 = S.f32_sorted_by_default(ch, act, caps[li + 1]) and self.rulebook_log is None and not self.x3
-                esc_ctr = self._ell_counter(("esc", li), dev) if (lean and not wide and S.TILE_MODE is None) else None
+                esc_ctr = self._ell_counter(("esc", li), dev) if (lean and S.TILE_MODE is None) else None
                 rb = S.rulebook_subm(rbs.out_indices, rbs.out_n, rbs.out_grid, 3, tile_channels=ch if tiled else None, masks=srt or srt32,
-                                     lean_table=lean, mark_next=mark_next, wide=wide, esc_counter=esc_ctr)
+                                     lean_table=lean, mark_next=mark_next, esc_counter=esc_ctr)
                 if esc_ctr is not None:
                     ell_used.append((esc_ctr, None, ("esc", li)))
                 if self.tile_off.get(li, 0) > 0:

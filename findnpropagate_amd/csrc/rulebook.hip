@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void strided_mark2_kernel(const int *__re
     // the row id and coordinates of the NEXT round are requested before this round's dependent chain
     // (occupancy-word read -> atomic -> summary atomic) is walked: two of its five memory round trips overlap
     auto fetch = [&](int it, int &row, int4 &c) {
-        const int i = (it * gridDim.x + blockIdx.x) * kThreads + threadIdx.x;
+        const int i = (it * gridDim.x + blockIdx.x) * kThreads + threadIdx.x;   // (NOT XCD-contiguous: the marking kernels' atomics ran 8-13 % slower that way, round 5)
         row = (it < nround && i < span) ? i : -1;
         if (order && row >= 0) row = order[row];
         if (!(row >= 0 && row < n)) row = -1;
@@ -272,7 +272,10 @@ __global__ __launch_bounds__(NT) void subm_nbr_row_tile_kernel(const int *__rest
     int *strip_wave = strips[threadIdx.x >> 6];
     const int n = min(*n_rows, cap), tid = threadIdx.x, lane = fnp_lane();
     tilerb::fill_lut<G>(lut, tid, NT);
-    for (int base = blockIdx.x * NT; base < n; base += gridDim.x * NT) {   // (whole workgroups stay in the loop)
+    // (XCD-contiguous workgroup order — common.h — for the 64-channel geometry only: measured -8 % there and +14 % on the 32-channel
+    //  one, twice, on rocprofv3 averages of the 128-scene step: round 5)
+    const int blk0 = G::ROWB == 128 ? (int)fnp_xcd_block() : (int)blockIdx.x;
+    for (int base = blk0 * NT; base < n; base += gridDim.x * NT) {   // (whole workgroups stay in the loop)
         const int o = base + tid;
         if (tid < TPP * G::OVF) (&table[0][0])[tid] = -1;
         if (tid < NT / 32) esc[tid] = 0;
@@ -471,40 +474,6 @@ extern "C" int fnp_rulebook_subm_tiled(const int *coords, const int *n_rows, int
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G64>), dim3(fnp_grid_for(cap, kThreads)), dim3(kThreads), 0,
                            (hipStream_t)stream, coords, n_rows, cap, fnp_rg_view(grid), nbr, (unsigned char *)tile_rb);
-    FNP_LAUNCH_CHECK();
-    return FNP_OK;
-}
-
-// The same two entry points for the WIDE tile rulebooks (tilerb.h G64W / G128W: fnp_spconv_forward_wtiled); lean != 0: the
-// int32 table receives the rows of escape tiles only.
-extern "C" int fnp_rulebook_subm_wtiled(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom, const fnp_rankgrid *grid,
-                                        int *nbr, int channels, void *tile_rb, int lean, const fnp_rankgrid *mark_grid,
-                                        const fnp_conv_geom *mark_geom, fnp_stream_t stream) {
-    if (!coords || !n_rows || cap <= 0 || !nbr || !tile_rb || !geom_ok(geom) || !fnp_rg_valid(grid)) return FNP_ERR_ARG;
-    if (!shape_is(grid, geom->in_shape) || ((uintptr_t)tile_rb & 15) || (channels != 64 && channels != 128)) return FNP_ERR_ARG;
-    for (int d = 0; d < 3; ++d)
-        if (geom->ksize[d] != 3) return FNP_ERR_ARG;
-    MarkJob mk;
-    if (!make_mark_job(grid, mark_grid, mark_geom, mk)) return FNP_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    unsigned char *t = (unsigned char *)tile_rb;
-    if (channels == 64) {
-        constexpr int NT = tilerb::G64W::TILE;   // (a workgroup pass = one tile)
-        if (lean)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G64W, true, NT>), dim3(fnp_grid_for(cap, NT)), dim3(NT), 0, s, coords, n_rows,
-                               cap, fnp_rg_view(grid), nbr, t, mk);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G64W, false, NT>), dim3(fnp_grid_for(cap, NT)), dim3(NT), 0, s, coords, n_rows,
-                               cap, fnp_rg_view(grid), nbr, t, mk);
-    } else {
-        constexpr int NT = tilerb::G128W::TILE;
-        if (lean)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G128W, true, NT>), dim3(fnp_grid_for(cap, NT)), dim3(NT), 0, s, coords, n_rows,
-                               cap, fnp_rg_view(grid), nbr, t, mk);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(subm_nbr_row_tile_kernel<tilerb::G128W, false, NT>), dim3(fnp_grid_for(cap, NT)), dim3(NT), 0, s, coords, n_rows,
-                               cap, fnp_rg_view(grid), nbr, t, mk);
-    }
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }

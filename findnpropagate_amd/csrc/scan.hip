@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kThreads) void summary_pass_kernel(RG g, long long 
                                                                 int *__restrict__ out_coords) {
     constexpr int ROUND = WPW < 4 ? WPW : 4;   // non-zero summary words visited per round
     const int lane = fnp_lane();
-    const long long U = ((long long)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    const long long U = ((long long)fnp_xcd_block() * kThreads + threadIdx.x) >> 6;
     if (U >= nunits) return;
     if (PASS == 1 && U == 0) {
         unsigned t = 0;

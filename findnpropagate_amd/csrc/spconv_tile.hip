@@ -963,27 +963,6 @@ extern "C" int fnp_debug_tile_hold(int on) {
     return FNP_OK;
 }
 
-extern "C" long long fnp_wtile_rulebook_bytes(int cap_out, int channels) {
-    if (cap_out <= 0) return 0;
-    if (channels == 64) return (long long)fnp_divup(cap_out, tilerb::G64W::TILE) * tilerb::G64W::REC;
-    if (channels == 128) return (long long)fnp_divup(cap_out, tilerb::G128W::TILE) * tilerb::G128W::REC;
-    return 0;
-}
-
-extern "C" int fnp_wtile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int channels, void *tile_rb,
-                                        fnp_stream_t stream) {
-    if (!nbr || !n_out || !tile_rb || K != kK || cap_out <= 0 || nbr_stride < cap_out || (channels != 64 && channels != 128)) return FNP_ERR_ARG;
-    if ((uintptr_t)tile_rb & 15) return FNP_ERR_ARG;
-    if (channels == 64)
-        hipLaunchKernelGGL(tile_rulebook_kernel<tilerb::G64W>, dim3(fnp_divup(cap_out, tilerb::G64W::TILE)), dim3(256), 0, (hipStream_t)stream, nbr, nbr_stride,
-                           n_out, cap_out, (unsigned char *)tile_rb);
-    else
-        hipLaunchKernelGGL(tile_rulebook_kernel<tilerb::G128W>, dim3(fnp_divup(cap_out, tilerb::G128W::TILE)), dim3(256), 0, (hipStream_t)stream, nbr, nbr_stride,
-                           n_out, cap_out, (unsigned char *)tile_rb);
-    FNP_LAUNCH_CHECK();
-    return FNP_OK;
-}
-
 extern "C" long long fnp_tile_rulebook_bytes(int cap_out, int channels) {
     if (cap_out <= 0) return 0;
     if (channels == 32) return (long long)fnp_divup(cap_out, G32::TILE) * G32::REC;

@@ -26,30 +26,6 @@ struct G64 {   // 64 channels: 128-byte rows
     // the row at slot rs stores logical chunk c (0..7) at chunk c ^ ((rs >> 1) & 7)
     __host__ __device__ static constexpr unsigned code(unsigned rs) { return rs * ROWB + (((rs >> 1) & 7u) << 4); }
 };
-// WIDE tiles (spconv_wtile.hip, round 4): a wave owns 64 rows x 64 output channels, so that a weight fragment read from LDS
-// serves four 16-row blocks instead of two and a row fragment four channel blocks.  An entry is the image row's address in
-// 16-BYTE UNITS with the row's ROTATION in its low bits: logical chunk c of the row at slot rs sits at unit
-// rs * CH + ((c + rot(rs)) & (CH - 1)), rot(rs) = 2 rs mod CH (64 channels: rs & 6).  With a rotation by twice the slot, the 16
-// lanes a ds_read_b128 serves together — rows s .. s+3 and s+12 .. s+15 of one chunk with rows s+4 .. s+11 of the next — fall
-// into 16 different 16-byte bank groups for ANY 16 consecutive slots s .. s+15, not only for runs that start at a multiple of
-// 16 (an XOR swizzle's condition; neighbour runs start anywhere).  A lane owns rows 4 l15 + mb of its wave's 64, whose
-// neighbours are rows of one residue mod 4 (a lane owns rows SPLIT l15 + mb, SPLIT = 8 or 4 blocks per wave): the window
-// keeps the residues in separate parts.  The entries are not part of the image (the convolution's lanes read them from
-// memory, three offsets ahead).  Far rows per tile on the synthetic scenes (tools/tile_locality_stats.py): 512 rows with a
-// +-64 window 70 on average, 174 at the 99th percentile, 192 at most; 256 rows with +-32: 59 / 139 / 151.
-struct G64W {   // 64 channels: 128-byte rows; a wave owns 128 rows (8 blocks) x 64 output channels, 4 waves, one workgroup per CU
-    static constexpr int TILE = FNP_WTILE64_ROWS, HALO = 64, WIN = TILE + 2 * HALO, OVF = 256, ZERO = WIN + OVF, ROWB = 128, SPLIT = 8, CH = 8;
-    static constexpr int REC_FAR = kK * TILE * 2, REC_ESC = REC_FAR + OVF * 4, REC = REC_ESC + 16;
-    __host__ __device__ static constexpr unsigned code(unsigned rs) { return rs * CH + (rs & 6u); }
-};
-struct G128W {   // 128 channels: 256-byte rows; a wave owns 64 rows (4 blocks) x 128 output channels, 4 waves, one workgroup per CU
-    static constexpr int TILE = FNP_WTILE128_ROWS, HALO = 32, WIN = TILE + 2 * HALO, OVF = 160, ZERO = WIN + OVF, ROWB = 256, SPLIT = 4, CH = 16;
-    static constexpr int REC_FAR = kK * TILE * 2, REC_ESC = REC_FAR + OVF * 4, REC = REC_ESC + 16;
-    __host__ __device__ static constexpr unsigned code(unsigned rs) { return rs * CH + ((2u * rs) & 15u); }
-};
-static_assert(G64W::REC == FNP_WTILE64_RECORD_BYTES && G64W::REC % 16 == 0 && G64W::ZERO * G64W::CH + G64W::CH < 0xFFFF, "wide 64-channel tile record");
-static_assert(G128W::REC == FNP_WTILE128_RECORD_BYTES && G128W::REC % 16 == 0 && G128W::ZERO * G128W::CH + G128W::CH < 0xFFFF, "wide 128-channel tile record");
-static_assert((G64W::WIN / G64W::SPLIT) % 16 == 0 && (G128W::WIN / G128W::SPLIT) % 16 == 0 && G64W::TILE / 32 <= 16 && G128W::TILE / 32 <= 16, "window quarters; escape flags fit the record's 16 bytes");
 static_assert(G32::REC == FNP_TILE_RECORD_BYTES && G32::REC % 16 == 0 && G32::ZERO * G32::ROWB + 48 < 0xFFFF, "32-channel tile record");
 static_assert(G64::REC == FNP_TILE64_RECORD_BYTES && G64::REC % 16 == 0 && G64::ZERO * G64::ROWB + 112 < 0xFFFF, "64-channel tile record");
 static_assert(G32::HALO % 32 == 0 && (G32::WIN / 2) % 4 == 0 && G64::HALO % 32 == 0 && (G64::WIN / 2) % 8 == 0, "window halves keep the swizzle period");
@@ -58,8 +34,7 @@ template <typename G> __host__ __device__ constexpr unsigned win_slot(unsigned d
 // into one long cluster of the linear-probing table (with id & (OVF - 1) the 64-channel build spent 0.12 ms in probes)
 template <typename G> __host__ __device__ constexpr unsigned far_hash(int id) {
     const unsigned h = (unsigned)id * 0x9E3779B1u;
-    if constexpr ((G::OVF & (G::OVF - 1)) == 0) return h >> (32 - (G::OVF == 256 ? 8 : G::OVF == 128 ? 7 : 6));
-    else return ((h >> 16) * (unsigned)G::OVF) >> 16;   // (any table size)
+    return h >> (32 - (G::OVF == 256 ? 8 : G::OVF == 128 ? 7 : 6));
 }
 template <typename G> __host__ __device__ constexpr unsigned far_next(unsigned h) { return h + 1 == (unsigned)G::OVF ? 0u : h + 1; }
 static_assert((G32::OVF == 256 || G32::OVF == 128) && G64::OVF == 128, "far_hash knows these table sizes");

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(kThreads) void vox_mark_kernel(const float *__restr
     }
     __shared__ MarkTab tab;   // the marks of the workgroup's 256 points meet here first (rankgrid.h): one atomic per distinct block
     if (FNP_MARK_TAB) mark_tab_init(&tab, threadIdx.x, kThreads);
-    const int i = blockIdx.x * kThreads + threadIdx.x;   // (whole waves stay: the shuffles below need them)
+    const int i = blockIdx.x * kThreads + threadIdx.x;   // (whole waves stay: the shuffles below need them.  Plain workgroup order: XCD-contiguous
+                                                         //  runs — common.h — made this kernel's atomics 26 % slower, round 5)
     const int lane = fnp_lane();
     long long blk = -1;
     unsigned long long m = 0ull;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(kThreads) void vox_crowded_insert_kernel(int n, int
 // flag[i] = point i is the FIRST point of its cell (the smallest index among the cell's kept points)
 __global__ __launch_bounds__(kThreads) void vox_flag_kernel(int n, int maxp, const int *__restrict__ rank,
                                                             const int *__restrict__ top, const int *__restrict__ cnt, int *__restrict__ flag) {
-    const int i = blockIdx.x * kThreads + threadIdx.x;
+    const int i = fnp_xcd_block() * kThreads + threadIdx.x;
     if (i >= n) return;
     const int r = rank[i];
     int f = 0;
@@ -243,7 +244,13 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
     if (n_cells && blockIdx.x == 0 && threadIdx.x == 0) *n_cells = ns;
     // ranks beyond the occupied cells map to no row (consumers walk perm[0 .. cap))
     for (int r = ns + blockIdx.x * kThreads + threadIdx.x; r < cap; r += gridDim.x * kThreads) perm[r] = -1;
-    for (int r = blockIdx.x * kThreads + threadIdx.x; r < ns; r += gridDim.x * kThreads) {
+    // Every XCD takes ONE contiguous eighth of the ranks (ranks run scene by scene): the cell -> voxel-row scatter below is random
+    // inside a scene — rank order is spatial, row order first-come — but touches that scene's ~2 MB of points, codes, first-come
+    // ranks, coordinates and means only, which one 4 MB L2 holds.  With interleaved workgroups every one of those lines went
+    // through all eight L2s (418 MB of HBM traffic per 64-scene launch against ~165 MB of tensors, round 3's PMC).
+    const long long lb = fnp_xcd_block(), nchunk = (ns + kThreads - 1) / kThreads;      // balanced runs of whole 256-rank chunks
+    const int r_begin = (int)(nchunk * lb / gridDim.x) * kThreads, r_end = min(ns, (int)(nchunk * (lb + 1) / gridDim.x) * kThreads);
+    for (int r = r_begin + threadIdx.x; r < r_end; r += kThreads) {
         const int *slots = top + (size_t)r * maxp;
         // the cell's kept points: min(cnt, max_points) slots in arrival order (a crowded cell: already ascending); they are
         // consumed in ASCENDING index order below — next = the smallest index above the previous one — so that sums and the
@@ -285,7 +292,27 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
         num_points[id] = np;
         const float norm = (float)(np < 1 ? 1 : np);
         // per channel the sum runs in ascending point order, like sum(dim=1) over the sorted block
-        if (C <= 8) {
+        if (C == 5 || C == 4) {
+            // nuScenes / KITTI point rows (x y z intensity [t]) as ONE 16-byte access + one dword instead of five dword accesses:
+            // this kernel is bound by the NUMBER of scattered requests it puts through L2 (~22 per voxel before, round 5), not by
+            // bytes.  Rows are 4-byte aligned only: f4u carries that alignment (global memory takes dword-aligned wide accesses).
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            f4u s4 = {0.f, 0.f, 0.f, 0.f};
+            float s1f = 0.f;
+            int pi = p0;
+            for (int j = 0; j < np; ++j) {
+                const float *pr = pts + (size_t)pi * C;
+                const f4u v4 = *reinterpret_cast<const f4u *>(pr);
+                const float v1 = C == 5 ? pr[4] : 0.f;
+                if (j + 1 < np) pi = next_above(pi);   // (the slots are in L1: the search runs under the point's loads)
+                s4 += v4;
+                s1f += v1;
+            }
+            float *mo = mean + (size_t)id * C;
+            f4u m4 = {s4[0] / norm, s4[1] / norm, s4[2] / norm, s4[3] / norm};
+            *reinterpret_cast<f4u *>(mo) = m4;
+            if (C == 5) mo[4] = s1f / norm;
+        } else if (C <= 8) {
             float s8[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) s8[c] = 0.f;
@@ -474,7 +501,7 @@ struct ClearJobs { ClearJob j[8]; };
 __global__ __launch_bounds__(kThreads) void rg_clear_multi_kernel(ClearJobs jobs) {
     const ClearJob &J = jobs.j[blockIdx.y];
     const int n = min(*J.n_rows, J.cap);
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+    for (int i = fnp_xcd_block() * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         const int4 c = reinterpret_cast<const int4 *>(J.coords)[i];
         if (!coord_ok(J.g.d, c)) continue;
         const long long blk = rg_block_of(J.g.d, c.x, c.y, c.z, c.w);

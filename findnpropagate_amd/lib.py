@@ -130,10 +130,6 @@ SIGNATURES = {
     "fnp_rulebook_strided_premarked": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), POINTER(RankGridC),
                                                P, P, c_int, P, P, c_int64, P]),
     "fnp_spconv_forward_tiled": (c_int, [P, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
-    "fnp_wtile_rulebook_bytes": (c_int64, [c_int, c_int]),
-    "fnp_wtile_rulebook_build": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P]),
-    "fnp_rulebook_subm_wtiled": (c_int, [P, P, c_int, POINTER(ConvGeom), POINTER(RankGridC), P, c_int, P, c_int, POINTER(RankGridC), POINTER(ConvGeom), P]),
-    "fnp_spconv_forward_wtiled": (c_int, [P, c_int, c_int, P, P, P, c_int, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     "fnp_split_bf16": (c_int, [P, P, c_int, c_int, P, P, P]),
     "fnp_split_bf16_add": (c_int, [P, P, c_int, P, c_int, c_int, P, P, P, P]),
     "fnp_spconv_forward_split": (c_int, [P, c_int, c_int, P, P, c_int, c_int, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),

@@ -192,7 +192,7 @@ def clear_grids(jobs):
 
 
 # --------------------------------------------------------------------------------- rulebooks
-def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None, masks=False, lean_table=False, mark_next=None, wide=False, esc_counter=None):
+def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None, masks=False, lean_table=False, mark_next=None, esc_counter=None):
     """tile_channels (32 or 64, 3x3x3 only): also write the tile rulebook the `tile_channels`-channel layers of this rulebook
     run on (conv_forward's tiled path finds it with the rulebook), in the same pass.
     masks (3x3x3 only): also write the per-row neighbour masks (`rb._rowmask`) the class sort of the 128-channel layers starts from.
@@ -200,7 +200,6 @@ def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None, masks=False, 
     entries) — for a caller that runs nothing but conv_forward's tiled path on this rulebook (`rb._lean` is set: conv_forward
     refuses any other kernel on it).
     esc_counter (with lean_table): a (1,) int32 device counter that receives += the number of 32-row groups with an escape entry.
-    wide (with tile_channels 64 or 128): the WIDE tile rulebook (fnp_rulebook_subm_wtiled; conv_forward's wide-tile path).
     mark_next (with lean_table or masks): (out_grid, ksize, stride, padding) of the strided convolution that consumes these rows —
     the kernel marks its output sites in out_grid (all zero) on the way; rulebook_strided(..., premarked=True) then skips its
     own marking launch.  `rb._marked_next` says whether it was done."""
@@ -217,16 +216,6 @@ def rulebook_subm(indices, n_dev, grid, ksize, tile_channels=None, masks=False, 
             mg = out_grid.c(with_perm=False)
         else:
             mgeom = None
-    if tile_channels and wide and K == 27:
-        t = torch.empty((L.fnp_wtile_rulebook_bytes(cap, tile_channels),), dtype=torch.uint8, device=indices.device)
-        rc = L.fnp_rulebook_subm_wtiled(_l.ptr(indices), _l.ptr(n_dev), cap, geom, grid.c(), _l.ptr(nbr), tile_channels, _l.ptr(t), int(bool(lean_table)),
-                                        mg if lean_table else None, mgeom if lean_table else None, _l.stream())
-        _l.check(rc, "fnp_rulebook_subm_wtiled")
-        rb = Rulebook(nbr=nbr, K=K, cap_out=cap, geom=geom)
-        rb._tile_rb = {("w", tile_channels): t}
-        rb._lean = bool(lean_table)
-        rb._marked_next = bool(lean_table and mg is not None)
-        return rb
     if tile_channels and K == 27 and os.environ.get("FNP_TILE_FUSED", "1") != "0":   # (0: development A/B — the stand-alone build on first use)
         t = torch.empty((L.fnp_tile_rulebook_bytes(cap, tile_channels),), dtype=torch.uint8, device=indices.device)
         if lean_table:
@@ -363,41 +352,21 @@ HINT_W_PERMUTED = 4    # fnp.h FNP_HINT_W_PERMUTED
 TILE_MODE = {"0": False, "1": True}.get(os.environ.get("FNP_TILE", ""))
 
 
-def tile_rulebook(rb, n_out_dev, channels, wide=False):
-    """The tile rulebook of a 3x3x3 rulebook for `channels`-channel layers (fnp_tile_rulebook_build; wide: fnp_wtile_rulebook_build),
+def tile_rulebook(rb, n_out_dev, channels):
+    """The tile rulebook of a 3x3x3 rulebook for `channels`-channel layers (fnp_tile_rulebook_build),
     built on first use and kept with it: valid as long as rb.nbr and the row count are (a Rulebook object is never rewritten in place)."""
     cache = rb.__dict__.setdefault("_tile_rb", {})
-    key = ("w", channels) if wide else channels
+    key = channels
     t = cache.get(key)
     if t is None:
         L = _l.load()
         if getattr(rb, "_lean", False):
             raise _l.FnpError("this rulebook's int32 table holds the rows of escape tiles only: no other tile rulebook can be made from it")
-        nbytes, build = (L.fnp_wtile_rulebook_bytes, L.fnp_wtile_rulebook_build) if wide else (L.fnp_tile_rulebook_bytes, L.fnp_tile_rulebook_build)
-        t = torch.empty((nbytes(rb.cap_out, channels),), dtype=torch.uint8, device=rb.nbr.device)
-        rc = build(_l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, _l.ptr(n_out_dev), rb.cap_out, channels, _l.ptr(t), _l.stream())
-        _l.check(rc, "fnp_wtile_rulebook_build" if wide else "fnp_tile_rulebook_build")
+        t = torch.empty((L.fnp_tile_rulebook_bytes(rb.cap_out, channels),), dtype=torch.uint8, device=rb.nbr.device)
+        rc = L.fnp_tile_rulebook_build(_l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, _l.ptr(n_out_dev), rb.cap_out, channels, _l.ptr(t), _l.stream())
+        _l.check(rc, "fnp_tile_rulebook_build")
         cache[key] = t
     return t
-
-
-# WIDE tiles (fnp_spconv_forward_wtiled, round 4): one wave per SIMD owning 128 x 64 / 64 x 128 outputs in the whole 512-register
-# file.  Built, bit-identical, and SLOWER than the kernels it was meant to replace in every form measured (DESIGN.md section 5,
-# round 4): it stays selectable (FNP_WTILE=1, or wide=True per call) and tested, and is never taken by default.
-WIDE_CHANNELS = (64, 128)
-WIDE_MODE = {"0": False, "1": True}.get(os.environ.get("FNP_WTILE", ""))
-WIDE_MIN_ROWS = {64: int(os.environ.get("FNP_WTILE64_MIN_ROWS", str(1 << 62))), 128: int(os.environ.get("FNP_WTILE128_MIN_ROWS", str(1 << 62)))}
-
-
-def wide_by_default(channels, dtype, cap):
-    if channels not in WIDE_CHANNELS or dtype not in (torch.bfloat16, torch.float16):
-        return False
-    return bool(WIDE_MODE) if WIDE_MODE is not None else cap >= WIDE_MIN_ROWS[channels]
-
-
-def wide_fits(n_in_rows, channels, nbr_stride, cap_out):
-    rb_bytes = int(_l.load().fnp_wtile_rulebook_bytes(cap_out, channels))
-    return n_in_rows * channels * 2 < 0x7fffffff and 27 * nbr_stride * 4 < 0x7fffffff and rb_bytes < 0x7fffffff
 
 
 TILED_CHANNELS = (32, 64)   # channel counts fnp_spconv_forward_tiled covers
@@ -544,7 +513,7 @@ def classsort_f32(rb, n_out_dev, channels):
 
 
 def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, shift=None, residual=None, relu=False,
-                 out=None, ranked=False, valu=False, tile=None, wide=None):
+                 out=None, ranked=False, valu=False, tile=None):
     """feat_out (cap_out, Cout) = act(conv * scale + shift + residual).  No host sync.
     ranked: input and output rows are both in rank-grid order (performance hint only).
     valu: f32 only — the thread-per-element chain instead of the f32 MFMA kernel (same bits).
@@ -567,19 +536,6 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
         assert residual.dtype == out.dtype and residual.shape[1] == Cout and residual.is_contiguous()
     if scale is not None:
         assert scale.dtype == torch.float32 and shift.dtype == torch.float32
-    # wide: True / False forces / forbids the wide-tile kernel of the 64 -> 64 and 128 -> 128 layers (None: ranked tensors from
-    # WIDE_MIN_ROWS rows of capacity on, or a rulebook that carries its wide tile rulebook; same bits either way)
-    has_wide = ("w", Cin) in getattr(rb, "_tile_rb", {})
-    if wide is None:
-        wide = WIDE_MODE if WIDE_MODE is not None else (True if (has_wide and tile is None) else None)
-    if (K == 27 and Cin == Cout and Cin in WIDE_CHANNELS and feat_in.dtype in (torch.bfloat16, torch.float16) and out.dtype == feat_in.dtype
-            and (wide or (wide is None and tile is None and ranked and wide_by_default(Cin, feat_in.dtype, cap_out)))
-            and wide_fits(feat_in.shape[0], Cin, rb.nbr.shape[1], cap_out)):
-        rc = L.fnp_spconv_forward_wtiled(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed),
-                                         _l.ptr(tile_rulebook(rb, n_out_dev, Cin, wide=True)), _l.ptr(rb.nbr), rb.nbr.shape[1], _l.ptr(n_out_dev), cap_out,
-                                         _l.ptr(out), _l.ptr(scale), _l.ptr(shift), _l.ptr(residual), int(bool(relu)), Cin, Cout, _l.stream())
-        _l.check(rc, "fnp_spconv_forward_wtiled")
-        return out
     if (K == 27 and Cin == Cout and Cin in TILED_CHANNELS and feat_in.dtype in (torch.bfloat16, torch.float16) and out.dtype == feat_in.dtype
             and (tile or (tile is None and ranked and tiled_by_default(Cin, feat_in.dtype, cap_out)))
             and tiled_fits(feat_in.shape[0], Cin, rb.nbr.shape[1], cap_out)):

@@ -364,7 +364,7 @@ class SparseInverseConv3d(SparseConvolution):
         if nbr_t is None or nbr_t.shape[1] != cap_in:
             nbr_t = rb._nbr_t = S.rulebook_transpose(rb, rb.out_n, cap_in)
         rbt = S.Rulebook(nbr=nbr_t, K=rb.K, cap_out=cap_in, geom=rb.geom)
-        out_feats = S.conv_forward(feats, self.packed_weight(feats.dtype), rbt, n_in_dev, tile=False, wide=False)[: in_idx.shape[0]]
+        out_feats = S.conv_forward(feats, self.packed_weight(feats.dtype), rbt, n_in_dev, tile=False)[: in_idx.shape[0]]
         if self.bias is not None:
             out_feats = out_feats + self.bias.to(out_feats.dtype)
         return SparseConvTensor(out_feats, in_idx, in_shape, input.batch_size, input.grid, input.voxel_num, input.indice_dict,

@@ -156,6 +156,31 @@ def init_backbone_weights(module, seed=0):
     return module
 
 
+def calibrate_batchnorm(module, batch_dict):
+    """Give a seeded backbone the BatchNorm statistics of a TRAINED one: one forward in train mode with momentum 1 over
+    `batch_dict` (voxel_features, voxel_coords, batch_size — device tensors), so that every running_mean / running_var is the
+    statistic of the rows that layer actually sees and every stage output is O(1) in eval mode, as SURVEY.md Appendix A.6 describes
+    the reference's activations ("values of O(1) after BN").  The seeded statistics of init_backbone_weights leave the kaiming
+    weights' growth in (feature scales of 200-300 at the last stages): fine for relative error bounds, useless for BASELINE.json's
+    ABSOLUTE 1e-4.  Returns the module in eval mode."""
+    import torch
+
+    bns = [m for m in module.modules() if isinstance(m, torch.nn.BatchNorm1d)]
+    old = [m.momentum for m in bns]
+    was_training = module.training
+    try:
+        for m in bns:
+            m.momentum = 1.0
+        module.train()
+        with torch.no_grad():
+            module(dict(batch_dict))
+    finally:
+        for m, mom in zip(bns, old):
+            m.momentum = mom
+        module.train(was_training)
+    return module.eval()
+
+
 # ------------------------------------------------------------------------------------------
 # Cameras and 2D detections for the Greedy Box Seeker (SURVEY.md §8d)
 # ------------------------------------------------------------------------------------------

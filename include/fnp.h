@@ -279,10 +279,6 @@ int fnp_spconv_forward(const void *feat_in, int in_dtype, int n_in_rows, const v
 #define FNP_TILE_RECORD_BYTES 14864
 #define FNP_TILE64_ROWS 128          /* 64 channels */
 #define FNP_TILE64_RECORD_BYTES 7440
-#define FNP_WTILE64_ROWS 512         /* wide tiles (fnp_spconv_forward_wtiled): 64 channels */
-#define FNP_WTILE64_RECORD_BYTES 28688
-#define FNP_WTILE128_ROWS 256        /* wide tiles: 128 channels */
-#define FNP_WTILE128_RECORD_BYTES 14480
 /* Diagnostic: the 32-channel kernel hands tile images between its producer and consumer waves through counters in LDS; a
  * wait that times out (2^20 polls, tens of milliseconds; never, unless that protocol is broken) ends the workgroup with
  * wrong output and counts here.  fnp_spconv_tiled_aborts synchronises the device (>= 0, or a negative error code);
@@ -330,30 +326,6 @@ int fnp_spconv_forward_tiled(const void *feat_in, int dtype, int n_in_rows, cons
                              const int *n_out, int cap_out, void *feat_out,
                              const float *scale, const float *shift, const void *residual, int relu,
                              int Cin, int Cout, fnp_stream_t stream);
-
-/* WIDE TILES (ABI 10) for the ranked 16-bit 64 -> 64 and 128 -> 128 SubM layers of 3x3x3 kernels (stages 3 and 4 of
- * VoxelResBackBone8x, spconv_backbone.py:212-224) at batch sizes that fill the card: the same tile-rulebook idea with tiles of
- * FNP_WTILE64_ROWS / FNP_WTILE128_ROWS output rows and every wave owning 64 rows x 64 output channels (a weight fragment
- * read from LDS then serves four 16-row blocks, a row fragment four channel blocks: 2/3 of the LDS operand bytes per flop of
- * fnp_spconv_forward_tiled, half its barriers and weight-slab bytes per row).  Records are laid out like
- * fnp_tile_rulebook_build's (27 x TILE 16-bit entries | 256 / 160 far-row ids | escape flags per 32 rows) with entries in 16-byte
- * units, FNP_WTILE64_RECORD_BYTES / FNP_WTILE128_RECORD_BYTES per tile.  fnp_spconv_forward_wtiled is bit-identical to
- * fnp_spconv_forward on the int32 table for ANY row order (entries a record cannot hold are fetched through `nbr`).
- *   fnp_wtile_rulebook_build   from the (27, cap) table
- *   fnp_rulebook_subm_wtiled   fnp_rulebook_subm that writes the wide tile rulebook in the same pass; lean != 0: the int32 table
- *                              receives the rows of escape tiles only (see fnp_rulebook_subm_tiled_lean); mark_grid / mark_geom as there
- * channels = Cin = Cout = 64 or 128, K = 27, dtype FNP_BF16 or FNP_F16; FNP_ERR_ARG otherwise and beyond 32-bit byte offsets. */
-long long fnp_wtile_rulebook_bytes(int cap_out, int channels);
-int fnp_wtile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int channels,
-                             void *tile_rb, fnp_stream_t stream);
-int fnp_rulebook_subm_wtiled(const int *coords, const int *n_rows, int cap, const fnp_conv_geom *geom,
-                             const fnp_rankgrid *grid, int *nbr, int channels, void *tile_rb, int lean,
-                             const fnp_rankgrid *mark_grid, const fnp_conv_geom *mark_geom, fnp_stream_t stream);
-int fnp_spconv_forward_wtiled(const void *feat_in, int dtype, int n_in_rows, const void *weight,
-                              const void *tile_rb, const int *nbr, int nbr_stride,
-                              const int *n_out, int cap_out, void *feat_out,
-                              const float *scale, const float *shift, const void *residual, int relu,
-                              int Cin, int Cout, fnp_stream_t stream);
 
 /* f32 rows -> two bf16 tensors hi = bf16(x), lo = bf16(x - hi) (ABI 10): hi + lo equals x to 2^-17 of |x|.  The activation
  * format of the fused backbone's "bf16x3" precision (FNP_DTYPE: bf16x3): every convolution is three fnp_spconv_forward launches

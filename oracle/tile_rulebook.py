@@ -11,14 +11,7 @@ ESCAPE = 0xFFFF
 GEOMETRY = {  # channels -> (TILE, HALO, OVF, ROW_BYTES)
     32: (256, 32, 256, 64),
     64: (128, 64, 128, 128),
-    # WIDE tiles (tilerb.h G64W / G128W; fnp_wtile_rulebook_build): entries in 16-byte units, window split by row mod 4
-    "w64": (512, 64, 256, 128),
-    "w128": (256, 32, 160, 256),
 }
-
-
-def is_wide(channels):
-    return isinstance(channels, str)
 
 
 def record_bytes(channels):
@@ -27,23 +20,18 @@ def record_bytes(channels):
 
 
 def swizzle(channels, rs):
-    """Swizzle bits of the image row at slot rs: byte-address bits 4.. (XOR swizzle), or for the wide geometries the rotation in
-    16-byte units (entry low bits)."""
+    """Swizzle bits of the image row at slot rs: byte-address bits 4.. (XOR swizzle)."""
     if channels == 32:
         return ((-(rs >> 2)) & 3) << 4
-    if channels == 64:
-        return ((rs >> 1) & 7) << 4
-    if channels == "w64":
-        return rs & 6
-    return (2 * rs) & 15
+    return ((rs >> 1) & 7) << 4
 
 
 def decode(tile_rb, n, channels):
     """tile_rb: uint8 array; returns (nbr (27, n) int64 with -2 where the entry is an escape, escape flags (tiles, TILE//32))."""
     tile, halo, ovf, rowb = GEOMETRY[channels]
     win, zero, rec = tile + 2 * halo, tile + 2 * halo + ovf, record_bytes(channels)
-    unit = rowb // 16 if is_wide(channels) else rowb       # what one image row spans in the entry's unit
-    split = {"w64": 8, "w128": 4}.get(channels, 2)
+    unit = rowb       # what one image row spans in the entry's unit
+    split = 2
     ntiles = (n + tile - 1) // tile
     recs = np.asarray(tile_rb[: ntiles * rec], dtype=np.uint8).reshape(ntiles, rec)
     codes = recs[:, : K * tile * 2].copy().view(np.uint16).reshape(ntiles, K, tile).astype(np.int64)

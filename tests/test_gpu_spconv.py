@@ -641,41 +641,6 @@ def test_tile_kernel_equals_gather_kernel(cuda, rng, n, order, dtype, C):
         S.conv_forward(x, wp, rb2, n_dev, ranked=True, tile=False)
 
 
-@pytest.mark.parametrize("C", [64, 128])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("n,order", [(1, "random"), (200, "random"), (513, "sorted"), (5000, "random"), (5000, "sorted"), (40000, "sorted")])
-def test_wide_tile_kernel_equals_gather_kernel(cuda, rng, n, order, dtype, C):
-    """The wide-tile kernel of the ranked 64 -> 64 and 128 -> 128 layers (spconv_wtile.hip: 512- / 256-row tiles, a wave owns
-    64 rows x 64 output channels, the weights of a 64-wide input-channel half per step through a two-slot LDS ring) against
-    spconv_mfma_kernel: same products, same order, bit-identical output, for any row order (random: the escape path carries the
-    layer), with the tile rulebook made from the table and by the rulebook kernel itself (full table and lean)."""
-    B, shape = 2, [9, 40, 41] if n <= 5000 else [21, 80, 80]
-    feats, idx = _random_sparse(rng, B, shape, n, C)
-    if order == "sorted":
-        idx = idx[np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))]
-    d_idx = torch.from_numpy(idx).to(cuda)
-    n_dev = S.device_scalar(n, cuda)
-    rb = S.rulebook_subm(d_idx, n_dev, S.build_grid(d_idx, n_dev, B, shape), 3)
-    wp = S.pack_weight(torch.from_numpy((rng.standard_normal((C, 3, 3, 3, C)) * 0.1).astype(np.float32)).to(cuda), dtype)
-    x = torch.from_numpy(feats).to(cuda).to(dtype)
-    sc = torch.from_numpy(rng.uniform(0.5, 1.5, C).astype(np.float32)).to(cuda)
-    sh = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).to(cuda)
-    res = torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32)).to(cuda).to(dtype)
-    for residual, scale, relu in ((None, sc, True), (res, sc, True), (res, None, False)):
-        shift = sh if scale is not None else None
-        a = S.conv_forward(x, wp, rb, n_dev, scale=scale, shift=shift, residual=residual, relu=relu, ranked=False, tile=False, wide=False)
-        b = S.conv_forward(x, wp, rb, n_dev, scale=scale, shift=shift, residual=residual, relu=relu, ranked=True, wide=True)
-        assert torch.equal(a[:n], b[:n]), (residual is not None, scale is not None)
-    grid2 = S.build_grid(d_idx, n_dev, B, shape)
-    want = S.conv_forward(x, wp, rb, n_dev, scale=sc, shift=sh, residual=res, relu=True, ranked=False, tile=False, wide=False)
-    for lean in (False, True):
-        rb2 = S.rulebook_subm(d_idx, n_dev, grid2, 3, tile_channels=C, lean_table=lean, wide=True)
-        d = S.conv_forward(x, wp, rb2, n_dev, scale=sc, shift=sh, residual=res, relu=True, ranked=True)   # (the rulebook carries its wide tiles)
-        assert torch.equal(d[:n], want[:n]), lean
-    with pytest.raises(S._l.FnpError, match="escape tiles only"):
-        S.conv_forward(x, wp, rb2, n_dev, ranked=True, tile=False, wide=False)
-
-
 def test_bf16x3_engine_is_f32_grade_on_the_bf16_matrix_pipe(cuda, oracle):
     """FNP_DTYPE: bf16x3 — activations as f32 rows + their split x = hi + lo into two bf16 tensors (fnp_split_bf16), weights (with
     the BatchNorm scale folded in) as W_hi + W_lo, every convolution three launches of the bf16 MFMA kernels with f32 outputs
@@ -741,7 +706,7 @@ def test_split_epilogue_equals_convolution_then_split_pass(cuda, rng, cin, cout,
     add = torch.from_numpy((rng.standard_normal((n, cout)) * 0.01).astype(np.float32)).to(cuda).to(dtype)
     tiled = cin == cout and cin in (32, 64)
     for residual, addend, relu in ((res, add, True), (None, add, True), (res, None, True), (None, None, False)):
-        y0 = S.conv_forward(x, wp, rb, n_dev, out_dtype=torch.float32, scale=ones, shift=sh, residual=residual, relu=False, tile=False, wide=False)
+        y0 = S.conv_forward(x, wp, rb, n_dev, out_dtype=torch.float32, scale=ones, shift=sh, residual=residual, relu=False, tile=False)
         if addend is not None:
             if dtype == torch.bfloat16:
                 hi0, lo0 = S.split_bf16_add(y0, addend, n_dev, relu=relu)

@@ -206,3 +206,118 @@ def test_ten_sweep_scene_bf16x3_engine_with_and_without_tiles(cuda):
             err = float((got[name].features - w).abs().max())
             assert err <= 3e-5 * scale, (name, err, scale)
     assert _l.load().fnp_spconv_tiled_aborts() == aborts0
+
+
+@pytest.mark.parametrize("mode,cin,cout,s,p", [("subm", 16, 16, 1, 1), ("strided", 16, 32, 2, 1), ("subm", 64, 64, 1, 1)])
+def test_backward_on_a_ten_sweep_scene(cuda, mode, cin, cout, s, p):
+    """a26 at the density transfusion_lidar.yaml trains on (MAX_SWEEPS 10; MAX_NUMBER_OF_VOXELS 120 k in training,
+    transfusion_lidar.yaml:54-59 — the cap fires on this scene): data and weight gradients of a SubM and a strided layer on the
+    voxel coordinates of ONE 10-sweep scene at the full 41 x 1440 x 1440 range (the 64 -> 64 layer on that scene's stage-3 sites),
+    fp16 — the reference's AMP dtype — against the oracle's conv_backward."""
+    from findnpropagate_amd import spconv
+    rng = np.random.default_rng(11)
+    pts, off = syn.make_sweeps_batch((36,))
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, 120000)
+    vox = S.voxelize(torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda), 1, cfg)
+    n = int(vox["n"].item())
+    assert n == 120000, "the training cap must fire"
+    idx, shape = vox["coords"][:n].cpu().numpy(), list(GRID)
+    if cin == 64:                                  # the stage-3 sites of the scene (two stride-2 layers down)
+        for _ in range(2):
+            idx, shape, _, _, _ = O.rulebook_strided(idx, shape, 3, 2, 1)
+        shape = [int(v) for v in shape]
+    n = idx.shape[0]
+    td = torch.float16
+    feats = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).to(td).float().numpy()
+    kk, ss, pp = [3] * 3, [s] * 3, [p] * 3
+    conv = (spconv.SubMConv3d(cin, cout, kk, padding=[1, 1, 1], bias=False, indice_key="a") if mode == "subm"
+            else spconv.SparseConv3d(cin, cout, kk, stride=ss, padding=pp, bias=False)).to(cuda)
+    w = conv.weight.detach().to(td).float().cpu().numpy()
+    x = torch.from_numpy(feats).to(cuda).to(td).requires_grad_(True)
+    out = conv(spconv.SparseConvTensor(x, torch.from_numpy(idx).to(cuda), shape, 1))
+    oi = out.indices.cpu().numpy()
+    dy = torch.from_numpy(rng.standard_normal((oi.shape[0], cout)).astype(np.float32)).to(td).float().numpy()
+    (out.features.float() * torch.from_numpy(dy).to(cuda)).sum().backward()
+    if mode == "subm":
+        pin, pout, pnum = O.rulebook_subm(idx, shape, kk)
+        order = np.arange(n)
+    else:
+        o_idx, o_shape, pin, pout, pnum = O.rulebook_strided(idx, shape, kk, ss, pp)
+        assert np.array_equal(np.sort(_key(oi, o_shape)), np.sort(_key(o_idx, o_shape)))       # site set at the full range
+        lut = {int(v): i for i, v in enumerate(_key(oi, o_shape))}
+        order = np.array([lut[int(v)] for v in _key(o_idx, o_shape)])
+    dx_w, dw_w = O.conv_backward(feats, w, pin, pout, pnum, dy[order])
+    for got, want in ((x.grad.float().cpu().numpy(), dx_w), (conv.weight.grad.float().cpu().numpy(), dw_w)):
+        scale = max(float(np.abs(want).max()), 1e-6)
+        assert np.abs(got - want).max() <= 4e-3 * scale, (mode, cin, np.abs(got - want).max(), scale)
+
+
+def test_amp_training_step_at_the_shipped_configuration(cuda):
+    """BATCH_SIZE_PER_GPU 4 x MAX_SWEEPS 10 under AMP (transfusion_lidar.yaml:147, nuscenes_dataset.yaml:5, train_utils.py:135-176) is
+    what tools/bench_train.py --sweeps 10 --batch 4 --amp times; here ONE such scene through the same step: the training voxel
+    cap fires, the step is not skipped (finite unscaled gradients), every parameter moves, site sets equal the oracle's."""
+    net = _net(cuda, "bf16").train()
+    pts, off = syn.make_sweeps_batch((37,))
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, 120000)
+    vox = S.voxelize(torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda), 1, cfg)
+    n = int(vox["n"].item())
+    assert n == 120000
+    bd = {"voxel_features": vox["mean"][:n], "voxel_coords": vox["coords"][:n].float(), "batch_size": 1}
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10)
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    opt.zero_grad()
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = net(bd)
+        loss = (out["encoded_spconv_tensor"].features.float() ** 2).mean()
+    scaler.scale(loss).backward()
+    scaler.unscale_(opt)
+    norm = torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0)
+    s0 = scaler.get_scale()
+    scaler.step(opt)
+    scaler.update()
+    assert torch.isfinite(loss) and torch.isfinite(norm) and scaler.get_scale() == s0, "the step was skipped"
+    moved = [k for k, v in net.named_parameters() if not torch.equal(v.detach(), before[k])]
+    assert len(moved) == len(before), sorted(set(before) - set(moved))[:5]
+    res = {"out": out["encoded_spconv_tensor"], **out["multi_scale_3d_features"]}
+    _check_sites(res, vox["coords"][:n].cpu().numpy(), 1)
+
+
+@pytest.mark.parametrize("scene", ["single_sweep_x2", "ten_sweeps"])
+def test_bf16x3_meets_the_absolute_1e4_on_calibrated_weights(cuda, scene):
+    """BASELINE.json: "box regressions within 1e-4 fp32" — an ABSOLUTE bound on f32 features of the magnitude a trained network
+    has.  The seeded kaiming weights blow the activations up (scales of 200-300 at the last stages), where only a relative bound
+    means anything (test_bf16x3_engine_is_f32_grade...: 3e-5 of scale).  Here the BatchNorm statistics are CALIBRATED on the input
+    (synthetic.calibrate_batchnorm: one train-mode forward with momentum 1, as a trained network's statistics fit its data:
+    SURVEY Appendix A.6 'values of O(1) after BN'), every stage output is O(1), and the bf16x3 engine must be within 1e-4 ABSOLUTE
+    of the f32 engine — which is the CPU oracle bit for bit (test_fused_backbone_f32_is_the_oracle_bit_for_bit) — at all five
+    outputs: two full-grid 30 k-point scenes, and one 10-sweep scene (first forward on the tile rulebooks, second — the gate has
+    switched — on the gather kernels)."""
+    if scene == "ten_sweeps":
+        pts, off = syn.make_sweeps_batch((38,))
+    else:
+        pts, off = syn.make_batch((40, 41))
+    B = len(off) - 1
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, syn.MAX_VOXELS_TEST)
+    d_p, d_o = torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda)
+    ref = _net(cuda, "fp32")
+    vox = S.voxelize(d_p, d_o, B, cfg)
+    n = int(vox["n"].item())
+    syn.calibrate_batchnorm(ref, {"voxel_features": vox["mean"][:n], "voxel_coords": vox["coords"][:n].float(), "batch_size": B})
+    x3 = _net(cuda, "bf16x3")
+    x3.load_state_dict(ref.state_dict())
+    x3.eval()
+    with torch.no_grad():
+        want = ref.forward_points(d_p, d_o, B, cfg)
+        runs = [x3.forward_points(d_p, d_o, B, cfg) for _ in range(2 if scene == "ten_sweeps" else 1)]
+    worst, scales = {}, {}
+    for name in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out"):
+        w = want[name].features
+        rms = float(w.float().pow(2).mean().sqrt())
+        assert 0.02 < rms < 5.0, (name, rms, "calibration should leave O(1) features")
+        scales[name] = (round(rms, 3), round(float(w.abs().max()), 1))
+        for got in runs:
+            assert torch.equal(got[name].indices, want[name].indices), name
+            worst[name] = max(worst.get(name, 0.0), float((got[name].features - w).abs().max()))
+    print(scene, "bf16x3 max |err| absolute per output:", {k: f"{v:.2e}" for k, v in worst.items()}, "(rms, max |feature|):", scales)
+    assert max(worst.values()) <= 1e-4, worst

@@ -29,20 +29,19 @@ def _sites(rng, B, shape, n, order):
     return np.stack([b, z, y, x], 1).astype(np.int32)
 
 
-@pytest.mark.parametrize("channels", [32, 64, "w64", "w128"])
+@pytest.mark.parametrize("channels", [32, 64])
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("n,order", [(1, "sorted"), (255, "sorted"), (3000, "random"), (20000, "sorted"), (20000, "random")])
 def test_tile_rulebook_restates_the_table(cuda, n, order, fused, channels):
-    wide = TR.is_wide(channels)
-    ch = int(channels[1:]) if wide else channels
-    rng = np.random.default_rng(n + (7 if fused else 0) + ch + (1000 if wide else 0))
+    ch = channels
+    rng = np.random.default_rng(n + (7 if fused else 0) + ch)
     aborts0 = _l.load().fnp_spconv_tiled_aborts()   # (library-wide counter: another test raises it on purpose)
     B, shape = 2, [11, 60, 61]
     idx = torch.from_numpy(_sites(rng, B, shape, n, order)).to(cuda)
     n_dev = S.device_scalar(n, cuda)
     grid = S.build_grid(idx, n_dev, B, shape)
-    rb = S.rulebook_subm(idx, n_dev, grid, 3, tile_channels=ch if fused else None, wide=wide)
-    tile_rb = S.tile_rulebook(rb, n_dev, ch, wide=wide)
+    rb = S.rulebook_subm(idx, n_dev, grid, 3, tile_channels=ch if fused else None)
+    tile_rb = S.tile_rulebook(rb, n_dev, ch)
     assert tile_rb.numel() == TR.record_bytes(channels) * ((rb.cap_out + TR.GEOMETRY[channels][0] - 1) // TR.GEOMETRY[channels][0])
     got, esc = TR.decode(tile_rb.cpu().numpy(), n, channels)
     want = rb.nbr[:, :n].cpu().numpy().astype(np.int64)

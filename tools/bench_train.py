@@ -10,12 +10,16 @@ from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4); ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--sweeps", type=int, default=1, help="10: the density transfusion_lidar.yaml trains on (nuscenes_dataset.yaml:5 MAX_SWEEPS 10): ~300 k points, ~150 k voxels per scene")
+ap.add_argument("--amp", action="store_true", help="the reference's AMP recipe (tools/train_utils/train_utils.py:135-176): autocast(fp16) around the forward, "
+                "GradScaler, unscale_, clip_grad_norm_(10), scaler.step / update")
 args = ap.parse_args()
 dev = torch.device("cuda", 0); B = args.batch
 grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
 net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False, "FNP_DTYPE": args.dtype}, 5, grid), 0).to(dev)
-pts, off = syn.make_batch(list(range(B)))
-cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+pts, off = syn.make_sweeps_batch(list(range(B)), args.sweeps) if args.sweeps > 1 else syn.make_batch(list(range(B)))
+# (transfusion_lidar.yaml:54-59: MAX_NUMBER_OF_VOXELS 120 k train / 160 k test; the 10-sweep scenes hold ~150 k cells: the training cap fires)
+cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 120000 if args.sweeps > 1 else 160000)
 vox = S.voxelize(torch.from_numpy(pts).to(dev), torch.from_numpy(off).to(dev), B, cfg)
 n = int(vox["n"].item())
 bd = lambda: {"voxel_features": vox["mean"][:n], "voxel_coords": vox["coords"][:n].float(), "batch_size": B}
@@ -37,9 +41,20 @@ def timed(fn, reps):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
+scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 12) if args.amp else None
+
 def step(all_outputs=True):
     opt.zero_grad(set_to_none=True)
-    loss = fwd(all_outputs); loss.backward(); opt.step()
+    if scaler is None:
+        loss = fwd(all_outputs); loss.backward(); opt.step()
+        return
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss = fwd(all_outputs)
+    scaler.scale(loss).backward()
+    scaler.unscale_(opt)
+    torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0)      # optim_cfg.GRAD_NORM_CLIP of the nuScenes configs
+    scaler.step(opt)
+    scaler.update()
 
 net.train()
 ms_step = timed(step, args.reps)
@@ -58,7 +73,8 @@ with torch.no_grad():
 net.eval()
 with torch.no_grad():
     ms_fwd_eval = timed(lambda: net(bd()), args.reps)   # fused inference path
-print(json.dumps({"batch": B, "voxels": n, "dtype": args.dtype, "train_step_ms": round(ms_step, 2),
+print(json.dumps({"batch": B, "sweeps": args.sweeps, "amp": bool(args.amp), "points": int(pts.shape[0]), "voxels": n, "dtype": "fp16 autocast" if args.amp else args.dtype,
+                  "train_step_ms": round(ms_step, 2),
                   "train_step_ms_loss_on_encoded_tensor_only": round(ms_step_enc, 2), "stand_in_loss_alone_ms": round(ms_loss, 2),
                   "module_forward_ms": round(ms_fwd_train, 2),
                   "fused_eval_forward_ms": round(ms_fwd_eval, 2), "scenes_per_s_train": round(B / ms_step * 1e3, 1)}))
