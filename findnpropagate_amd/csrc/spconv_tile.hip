@@ -117,8 +117,14 @@ __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restric
 #ifndef FNP_TILE64_SCHED
 #define FNP_TILE64_SCHED 1
 #endif
+#ifndef FNP_TILE64_WDEPTH
+#define FNP_TILE64_WDEPTH 2   // weight slabs in flight in registers (64-channel kernel)
+#endif
 #ifndef FNP_TILE64_SPREAD
-#define FNP_TILE64_SPREAD 1
+#define FNP_TILE64_SPREAD 2   // (1: one piece per offset from the sweep's second offset on — round 4; 2: two per offset behind the last slab requests — round 5)
+#endif
+#ifndef FNP_TILE32_NPW
+#define FNP_TILE32_NPW 8   // producer waves of the 32-channel kernel
 #endif
 #ifndef FNP_TILE_PSLEEP
 #define FNP_TILE_PSLEEP 8
@@ -168,10 +174,17 @@ __device__ unsigned long long g_tile_stamps[4][8];   // [role][phase] sums, [2 +
 __device__ unsigned g_tile_aborts;   // hand-over waits that timed out, since the library was loaded (never, unless the protocol is broken)
 __device__ int g_tile_hold;          // test hook (fnp_debug_tile_hold): producers never publish an image, so every consumer wait times out
 
-// Geometry: 8 consumer waves x 32 rows.  Consumer wave w owns tile rows [32 w, 32 w + 32); its MFMA column l15 of block mb
-// is row 32 w + 2 l15 + mb, so the two entries of a lane sit in one 32-bit word of the natural [offset][row] table.
-// Neighbours of such a column set are rows of ONE parity, so the window image keeps even and odd rows in separate halves:
-// what a fragment read touches is then 16 consecutive 64-byte rows, as in a dense tile.
+// Geometry: NCW = 16 / MB consumer waves x (16 MB) rows, MB = FNP_TILE32_MB = 2 as shipped: consumer wave w owns tile rows
+// [32 w, 32 w + 32); its MFMA column l15 of block mb is row 32 w + MB l15 + mb, so the MB entries of a lane sit in one 32-bit (MB = 4:
+// 64-bit) word of the natural [offset][row] table.  Neighbours of such a column set are rows of ONE residue mod MB, so the window
+// image keeps the residues in separate parts (tilerb.h SPLIT): what a fragment read touches is then 16 consecutive 64-byte rows, as
+// in a dense tile.
+// MB = 4 (round 5; four consumer waves x 64 rows, 768 threads, 166 registers): a weight fragment read from LDS serves four row
+// blocks instead of two — 6.5 LDS reads per 8 MFMAs instead of 4.5 per 4, -28 % of the array cycles per flop, the remedy if the LDS
+// array (SQ_LDS_IDX_ACTIVE = 0.87 of the busy CU cycles, r04 PMC) were what bounds the kernel.  Bit-identical and SLOWER: 0.304
+// against 0.289 ms per launch at 128 scenes, 0.159 against 0.152 at 64 (tools/ab_tiled.py, interleaved in one process; four
+// producer waves instead of eight: 0.304 / 0.164) — ONE consumer wave per SIMD has nobody to issue into its waits, which costs more
+// than the array cycles saved.  Kept as a build switch with the numbers.
 // X3 (fnp_spconv_forward_tiled_split, the bf16x3 engine's main product): the epilogue keeps f32 — f32 residual in, a 16-bit addend
 // (the two cross terms) joined before the ReLU, f32 rows out AND their (hi, lo) 16-bit split, the next layer's operands.  The
 // kernel's own y / residual are unused then.
@@ -209,7 +222,7 @@ __device__ __forceinline__ void x3_store(const X3Args &a, size_t elem, float (&v
 }
 
 template <typename TAct, bool X3 = false>
-__global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__restrict__ x, int x_bytes, const TAct *__restrict__ w,
+__global__ __launch_bounds__((16 / FNP_TILE32_MB + FNP_TILE32_NPW) * 64, (16 / FNP_TILE32_MB + FNP_TILE32_NPW) / 4) void spconv_tile32_kernel(const TAct *__restrict__ x, int x_bytes, const TAct *__restrict__ w,
                                                                  const unsigned char *__restrict__ tile_rb, int rb_bytes,
                                                                  const int *__restrict__ nbr, int nbr_stride,
                                                                  const int *__restrict__ n_out, int cap, TAct *__restrict__ y,
@@ -217,7 +230,8 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
                                                                  const TAct *__restrict__ residual, int relu, X3Args x3) {
     using frag8 = typename V16<TAct>::v8;
     using act4 = typename V16<TAct>::v4;
-    constexpr int MB = 2, NCW = 8, NPW = 8, NT = 1024, PT = NPW * 64, NB = kC / 16;
+    constexpr int MB = FNP_TILE32_MB, NCW = 16 / MB, NPW = FNP_TILE32_NPW, NT = (NCW + NPW) * 64, PT = NPW * 64, NB = kC / 16;
+    static_assert(MB == 2 || MB == 4, "consumer tile");
     constexpr int NWL = (kWin * kCH + PT - 1) / PT;          // window chunks per producer thread
     constexpr int NCL = (kRbBytes / 16 + PT - 1) / PT;       // entry-table chunks per producer thread
     constexpr int NGL = kOvf / NPW / 16;                     // overflow-row loads per producer thread (4 lanes per row)
@@ -230,8 +244,8 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
     // Hand-over counters (no workgroup barrier after the prologue: a barrier per tile made every wave wait for the slowest
     // one of either role, and the fill and drain of each wave's pipeline fell on the same moment for all of them).  Each
     // counts WAVES that completed an event and only grows; i = tile number inside the workgroup's run, image i & 1:
-    //   READY[i & 1]  producer waves that finished writing the image     consumers of tile i wait for 8 (i / 2 + 1)
-    //   FREED[i & 1]  consumer waves that finished reading the image     producers of tile i wait for 8 (i / 2)
+    //   READY[i & 1]  producer waves that finished writing the image     consumers of tile i wait for NPW (i / 2 + 1)
+    //   FREED[i & 1]  consumer waves that finished reading the image     producers of tile i wait for NCW (i / 2)
     // A wait that outlasts kSpinLimit polls (tens of milliseconds; a hand-over takes microseconds) raises ABORT, which ends
     // every wave of the workgroup — wrong output instead of a hung GPU — and counts in g_tile_aborts, which the host layer
     // reads with its per-forward counts (fnp_spconv_tiled_aborts_copy) and turns into an error.
@@ -329,7 +343,7 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
 #pragma unroll
             for (int j = 0; j < NWL; ++j)
                 if (ptid + j * PT < kWin * kCH) *reinterpret_cast<u32x4 *>(img + win_dst[j]) = pwin[j];
-            if (ptid < 8) esc_flags[image * NCW + ptid] = (FNP_TILE_ABLATE & 1) ? 0 : (int)pesc;
+            if (ptid < 8) esc_flags[image * 8 + ptid] = (FNP_TILE_ABLATE & 1) ? 0 : (int)pesc;   // (per 32-row group)
         };
         // Iteration i: write tile i + 1 (requested last iteration) into its image as soon as the consumers have left it,
         // request tile i + 2 (its far-row ids were requested last iteration), request the far-row ids of tile i + 3.
@@ -341,7 +355,7 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
         FNP_STAMP_DECL;
         for (int i = -1; i + 1 < nt; ++i) {
             const int t = t_begin + i, p = (i + 1) & 1;
-            if (!wait_for(FREED + p, 8 * ((i + 1) / 2))) break;
+            if (!wait_for(FREED + p, NCW * ((i + 1) / 2))) break;
             FNP_STAMP(5);
             if (!(FNP_TILE_ABLATE & 4) || i < 1) put_tile(img0 + p * kImgBytes, p);
             if (!hold) signal(READY + p);
@@ -358,7 +372,7 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
 
     // ---------------------------------------------------------------------- consumer waves
     const int aoff = wpos(l15, q);
-    const int rloc = wave * 32 + 2 * l15;            // this lane's row of block 0 inside the tile (block 1: the next row)
+    const int rloc = wave * (16 * MB) + MB * l15;    // this lane's row of block 0 inside the tile (block mb: mb rows further)
     const unsigned qx = (unsigned)q << 4;
     const int poff = (q & 1) * 32 + (q >> 1) * 16;   // epilogue: this lane's 16 bytes of a row
     float sc[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, sh[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -377,10 +391,12 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
     for (int t = t_begin; t < t_end; ++t) {
         const int tile_base = t * kTile, row_end = min(n, tile_base + kTile);
         const int image = (t - t_begin) & 1;
-        if (!wait_for(READY + image, 8 * ((t - t_begin) / 2 + 1))) break;
+        if (!wait_for(READY + image, NPW * ((t - t_begin) / 2 + 1))) break;
         FNP_STAMP(2);
         const unsigned char *img = img0 + image * kImgBytes;
-        const unsigned *rb32 = reinterpret_cast<const unsigned *>(img + kXBytes) + wave * 16 + l15;   // both blocks' entries
+        // the MB entries of a lane's rows are MB consecutive 16-bit words of the [offset][row] table
+        using ent_t = typename std::conditional<MB == 4, unsigned long long, unsigned>::type;
+        const ent_t *rbE = reinterpret_cast<const ent_t *>(img + kXBytes) + wave * 16 + l15;
         // residual rows requested now, used after the sweep
         uint4 rv[MB];
 #pragma unroll
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        auto entry = [&](int k) -> unsigned { return rb32[(k < kK ? k : kK - 1) * (kTile / 2)]; };
+        auto entry = [&](int k) -> ent_t { return rbE[(k < kK ? k : kK - 1) * (kTile / MB)]; };
         auto weights = [&](int k, frag8 (&wa)[NB]) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -405,10 +421,10 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
         // The sweep: weights one offset ahead, fragments two, entries four.  ESC: this wave's entries may hold escapes.
         auto sweep = [&](auto esc_tag) {
             constexpr bool ESC = decltype(esc_tag)::value;
-            auto fragments = [&](unsigned e, int k, u32x4 (&xv)[MB]) {
+            auto fragments = [&](ent_t e, int k, u32x4 (&xv)[MB]) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    const unsigned em = mb ? e >> 16 : e & 0xffffu;
+                    const unsigned em = (unsigned)(e >> (16 * mb)) & 0xffffu;
                     if constexpr (ESC) {
                         if (__ballot(em == kEscape) != 0ull) {
                             // more far rows than overflow slots: this fragment comes from memory
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
             };
             // LDS reads run ahead of the matrix work: weights DW offsets, fragments DX, entries DX + 2
             constexpr int DW = FNP_TILE_DW, DX = FNP_TILE_DX;
-            unsigned en[2];
+            ent_t en[2];
             frag8 wa[DW + 1][NB];
             u32x4 xf[DX + 1][MB];
 #pragma unroll
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
 #pragma unroll
             for (int k = 0; k < ((FNP_TILE_ABLATE & 2) ? 0 : kK); ++k) {
                 if (!(FNP_TILE_ABLATE & 16)) weights(k + DW, wa[(k + DW) % (DW + 1)]);
-                const unsigned e_new = (FNP_TILE_ABLATE & 32) ? en[0] : entry(k + DX + 2);
+                const ent_t e_new = (FNP_TILE_ABLATE & 32) ? en[0] : entry(k + DX + 2);
                 if (k + DX < kK && !(FNP_TILE_ABLATE & 32)) fragments(en[(k + DX) & 1], k + DX, xf[(k + DX) % (DX + 1)]);
                 if constexpr (!ESC && FNP_TILE_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -452,7 +468,20 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
                     }
                 }
                 if constexpr (!ESC && FNP_TILE_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!ESC && FNP_TILE_SCHED != 0) {
+                if constexpr (!ESC && FNP_TILE_SCHED != 0 && MB == 4) {
+                    // one iteration = 8 MFMAs with the 7 LDS reads (2 weight fragments, 4 row fragments, the entry word) and their
+                    // address arithmetic spread between them, one read per MFMA: the ONE consumer wave of a SIMD has nobody to
+                    // fill its gaps, and reads bunched together queue up in the LDS array (measured on the 64-channel kernel, round 5)
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);   // (nothing moves between iterations: the read-ahead distances stand)
+                }
+                if constexpr (!ESC && FNP_TILE_SCHED != 0 && MB == 2) {
                     // one iteration = 4 MFMAs with the 5 LDS reads and their address arithmetic spread between them: the two
                     // consumer waves of a SIMD then keep both pipes busy instead of bursting into each in turn
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
@@ -470,7 +499,10 @@ __global__ __launch_bounds__(1024, 4) void spconv_tile32_kernel(const TAct *__re
                 en[(k + DX) & 1] = e_new;
             }
         };
-        if (esc_flags[image * NCW + wave]) sweep(std::true_type{});
+        bool any_esc = false;
+#pragma unroll
+        for (int g = 0; g < MB / 2; ++g) any_esc |= esc_flags[image * 8 + wave * (MB / 2) + g] != 0;   // (flags per 32-row group)
+        if (any_esc) sweep(std::true_type{});
         else sweep(std::false_type{});
         FNP_STAMP(0);
 
@@ -659,13 +691,20 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
         // offset k, so a wave leaves the barrier with everything its next 16 MFMAs need in registers; slab k + 2 is stored
         // (slot k & 1, whose fragments were read an offset ago) during offset k, requested from L2 an offset before that.
         // Slabs 0 - 2 are requested before the image is written: they land meanwhile.
-        u32x4 wreg[2][NSL], wslab[2][NSL];   // wslab[k & 1]: slab k + 2 on its way to LDS
+        constexpr int WD = FNP_TILE64_WDEPTH;   // slabs on their way to LDS in registers (slab j in wslab[j % WD])
+        u32x4 wreg[2][NSL], wslab[WD][NSL];
+        if (FNP_TILE_ABLATE & 2048) {
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) wslab[1 % WD][j] = u32x4{0u, 0u, 0u, 0u};
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < NSL; ++j) wreg[h][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)h * (C * C * 2), 0);
 #pragma unroll
-        for (int j = 0; j < NSL; ++j) wslab[0][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, 2u * (C * C * 2), 0);
+        for (int sl = 2; sl <= WD; ++sl)
+#pragma unroll
+            for (int j = 0; j < NSL; ++j) wslab[sl % WD][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)sl * (C * C * 2), 0);
         FNP_STAMP(0);   // (slab requests)
         __syncthreads();   // every wave has left the previous tile's image and slabs
         FNP_STAMP(1);   // (barrier: the slowest wave's epilogue)
@@ -686,7 +725,12 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const unsigned *rb32 = reinterpret_cast<const unsigned *>(img + XB) + wave * 16 + l15;   // both blocks' entries
-        auto entry = [&](int k) -> unsigned { return rb32[(k < kK ? k : kK - 1) * (G::TILE / 2)]; };
+        // (FNP_TILE_ABLATE & 1024, timing probe, wrong results: every entry names the row of zeros — all 16 lanes of a read group then
+        //  share one address, a broadcast — i.e. the sweep with its B-fragment reads free of bank conflicts)
+        auto entry = [&](int k) -> unsigned {
+            const unsigned e = rb32[(k < kK ? k : kK - 1) * (G::TILE / 2)];
+            return (FNP_TILE_ABLATE & 1024) ? ((e & 0u) | (G::code(G::ZERO) * 0x10001u)) : e;
+        };
         uint4 rv[MB][NB / 2];   // residual rows: requested a few offsets before the sweep ends
         auto req_residual = [&]() {
 #pragma unroll
@@ -747,12 +791,27 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
             __syncthreads();   // slab 0's fragments are read: offset 0 may store slab 2 over it
 #pragma unroll
             for (int k = 0; k < ((FNP_TILE_ABLATE & 2) ? 0 : kK); ++k) {
-                if (k + 3 < kK && !(FNP_TILE_ABLATE & 128)) {
+                if (k + WD + 1 < kK && !(FNP_TILE_ABLATE & (128 | 2048))) {   // (2048: probe — the slabs are stored but not loaded)
 #pragma unroll
                     for (int j = 0; j < NSL; ++j)
-                        wslab[(k + 1) & 1][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)(k + 3) * (C * C * 2), 0);
+                        wslab[(k + 1) % WD][j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(tid + j * NT) * 16u, (unsigned)(k + WD + 1) * (C * C * 2), 0);
                 }
-                if (FNP_TILE64_SPREAD && k >= 1 && k <= NPIECE) req_piece(t + 1, k - 1);
+                if (FNP_TILE64_SPREAD == 1 && k >= 1 && k <= NPIECE) req_piece(t + 1, k - 1);
+                if (FNP_TILE64_SPREAD == 2) {
+                    // LATE PIECES (round 5).  The image pieces are the only loads of the sweep that go to HBM (~2 us); issued one per
+                    // offset from the second offset on they sat, in the wave's in-order memory queue, IN FRONT of every weight-slab
+                    // load of offsets 2-15 — L2 hits that then returned with the HBM latency of the piece ahead of them (probes at
+                    // 128 scenes: no slab loads -12 % of the launch, no slab stores -5 %).  Now two per offset in the LAST seven
+                    // offsets, behind the sweep's last slab requests; the epilogue and the other workgroup of the CU cover their
+                    // latency, and the 56 prefetch registers are free for most of the sweep (256 registers with 2 spilt -> 243, none):
+                    // 0.610 -> 0.593 ms per launch at 128 scenes, 0.313 -> 0.301 at 64, 50.2 -> 48.3 us at 8 (tools/ab_tiled.py,
+                    // interleaved; bit-identical).  A third slab in flight on top (FNP_TILE64_WDEPTH 3) adds nothing (0.592 / 0.305).
+                    constexpr int K0 = kK - (NPIECE + 1) / 2;
+                    if (k >= K0) {
+                        req_piece(t + 1, 2 * (k - K0));
+                        if (2 * (k - K0) + 1 < NPIECE) req_piece(t + 1, 2 * (k - K0) + 1);
+                    }
+                }
                 if (k == kK - 6) req_residual();
                 const unsigned e_new = entry(k + 3);
                 if (k + 1 < kK) {
@@ -780,10 +839,11 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 en[(k + 1) & 1] = e_new;
+                if ((FNP_TILE_ABLATE & 4096) && k + 2 < kK) asm volatile("" ::"v"(wslab[(k + 2) % WD][0]), "v"(wslab[(k + 2) % WD][NSL - 1]));
                 if (k + 1 < kK) {
-                    if (k + 2 < kK && !(FNP_TILE_ABLATE & 128)) {
+                    if (k + 2 < kK && !(FNP_TILE_ABLATE & (128 | 4096))) {   // (4096: probe — the slabs are loaded but not stored)
 #pragma unroll
-                        for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[(k & 1) * SLABC + st_pos + j * NT]) = wslab[k & 1][j];
+                        for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[(k & 1) * SLABC + st_pos + j * NT]) = wslab[(k + 2) % WD][j];
                     }
                     if (!(FNP_TILE_ABLATE & 256)) __syncthreads();
                 }
@@ -900,7 +960,7 @@ int launch_tile32(const void *x, long long x_bytes, const void *w, const void *t
     }
     const int tiles = fnp_divup(cap, kTile);
     const int grid = tiles < 256 ? tiles : 256;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), kLds, s, (const TAct *)x, (int)x_bytes, (const TAct *)w, (const unsigned char *)tile_rb, (int)rb_bytes,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3((16 / FNP_TILE32_MB + FNP_TILE32_NPW) * 64), kLds, s, (const TAct *)x, (int)x_bytes, (const TAct *)w, (const unsigned char *)tile_rb, (int)rb_bytes,
                        nbr, nbr_stride, n_out, cap, (TAct *)y, scale, shift, (const TAct *)residual, relu, x3);
     FNP_LAUNCH_CHECK();
     return FNP_OK;

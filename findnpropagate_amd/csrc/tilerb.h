@@ -4,6 +4,10 @@
 #pragma once
 #include "common.h"
 
+#ifndef FNP_TILE32_MB
+#define FNP_TILE32_MB 2   // (4: four consumer waves x 64 rows — built, bit-identical, 5 % slower: round 5, spconv_tile.hip)
+#endif
+
 namespace tilerb {
 
 constexpr int kK = 27;                  // 3x3x3 kernels only
@@ -15,7 +19,10 @@ constexpr unsigned kEscape = 0xFFFFu;   // entry: not in the tile image — fetc
 // 16 consecutive image rows), OVF overflow rows (far neighbours, one slot per distinct row), one row of zeros.
 struct G32 {   // 32 channels: 64-byte rows.  (window +-64 with 128 overflow rows fits LDS too and was slower: 0.20 vs 0.18 ms per
                // layer, rulebook pass 0.27 vs 0.20 ms — 39 distinct far rows crowd a 128-slot table)
-    static constexpr int TILE = FNP_TILE_ROWS, HALO = 32, WIN = TILE + 2 * HALO, OVF = 256, ZERO = WIN + OVF, ROWB = 64, SPLIT = 2;
+    // SPLIT = 16-row blocks a consumer wave of spconv_tile32_kernel owns (FNP_TILE32_MB): its MFMA column l15 of block mb is tile row
+    // SPLIT l15 + mb of the wave's rows, so the neighbours of one block are rows of ONE residue mod SPLIT: the window keeps the
+    // residues in separate parts, and what a fragment read touches is 16 consecutive image rows.
+    static constexpr int TILE = FNP_TILE_ROWS, HALO = 32, WIN = TILE + 2 * HALO, OVF = 256, ZERO = WIN + OVF, ROWB = 64, SPLIT = FNP_TILE32_MB;
     static constexpr int REC_FAR = kK * TILE * 2, REC_ESC = REC_FAR + OVF * 4, REC = REC_ESC + 16;
     // the row at slot rs stores logical chunk c (0..3) at chunk c ^ (-(rs >> 2) & 3)
     __host__ __device__ static constexpr unsigned code(unsigned rs) { return rs * ROWB + (((0u - (rs >> 2)) & 3u) << 4); }
@@ -28,7 +35,7 @@ struct G64 {   // 64 channels: 128-byte rows
 };
 static_assert(G32::REC == FNP_TILE_RECORD_BYTES && G32::REC % 16 == 0 && G32::ZERO * G32::ROWB + 48 < 0xFFFF, "32-channel tile record");
 static_assert(G64::REC == FNP_TILE64_RECORD_BYTES && G64::REC % 16 == 0 && G64::ZERO * G64::ROWB + 112 < 0xFFFF, "64-channel tile record");
-static_assert(G32::HALO % 32 == 0 && (G32::WIN / 2) % 4 == 0 && G64::HALO % 32 == 0 && (G64::WIN / 2) % 8 == 0, "window halves keep the swizzle period");
+static_assert(G32::HALO % 32 == 0 && (G32::WIN / G32::SPLIT) % 4 == 0 && G64::HALO % 32 == 0 && (G64::WIN / 2) % 8 == 0, "window parts keep the swizzle period");
 template <typename G> __host__ __device__ constexpr unsigned win_slot(unsigned d) { return (d % (unsigned)G::SPLIT) * (G::WIN / G::SPLIT) + d / (unsigned)G::SPLIT; }
 // first slot a far row probes: multiplicative, so that the runs of consecutive row ids far neighbours come in do not pile up
 // into one long cluster of the linear-probing table (with id & (OVF - 1) the 64-channel build spent 0.12 ms in probes)

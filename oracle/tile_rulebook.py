@@ -31,7 +31,7 @@ def decode(tile_rb, n, channels):
     tile, halo, ovf, rowb = GEOMETRY[channels]
     win, zero, rec = tile + 2 * halo, tile + 2 * halo + ovf, record_bytes(channels)
     unit = rowb       # what one image row spans in the entry's unit
-    split = 2
+    split = 2      # tilerb.h G32::SPLIT (= FNP_TILE32_MB, 2 as shipped) / G64::SPLIT: window rows kept apart by residue
     ntiles = (n + tile - 1) // tile
     recs = np.asarray(tile_rb[: ntiles * rec], dtype=np.uint8).reshape(ntiles, rec)
     codes = recs[:, : K * tile * 2].copy().view(np.uint16).reshape(ntiles, K, tile).astype(np.int64)

@@ -49,13 +49,21 @@ for tag, rb, n_dev in log:
     w = (torch.randn((K, cout, cin), device=dev) * 0.05).to(torch.bfloat16)
     sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
     resid = torch.randn((rb.cap_out, cout), device=dev).to(torch.bfloat16)
-    trb = S.tile_rulebook(rb, n_dev, cin)
+    # every library restates the table into ITS tile rulebook (a build may change the tile geometry: FNP_TILE32_MB)
+    trbs = {}
+    for name, L in libs.items():
+        L.fnp_tile_rulebook_bytes.restype = ctypes.c_longlong
+        nb = L.fnp_tile_rulebook_bytes(ctypes.c_int(rb.cap_out), ctypes.c_int(cin))
+        trbs[name] = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        rc = L.fnp_tile_rulebook_build(P(rb.nbr.data_ptr()), ctypes.c_int(rb.nbr.shape[1]), ctypes.c_int(27), P(n_dev.data_ptr()), ctypes.c_int(rb.cap_out),
+                                       ctypes.c_int(cin), P(trbs[name].data_ptr()), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        assert rc == 0, (name, rc)
     outs = {k: torch.zeros((rb.cap_out, cout), dtype=torch.bfloat16, device=dev) for k in libs}
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def launch(name):
         rc = libs[name].fnp_spconv_forward_tiled(P(x.data_ptr()), ctypes.c_int(_l.dtype_code(x)), ctypes.c_int(x.shape[0]), P(w.data_ptr()),
-                                                 P(trb.data_ptr()), P(rb.nbr.data_ptr()), ctypes.c_int(rb.nbr.shape[1]), P(n_dev.data_ptr()),
+                                                 P(trbs[name].data_ptr()), P(rb.nbr.data_ptr()), ctypes.c_int(rb.nbr.shape[1]), P(n_dev.data_ptr()),
                                                  ctypes.c_int(rb.cap_out), P(outs[name].data_ptr()), P(sc.data_ptr()), P(sh.data_ptr()),
                                                  P(resid.data_ptr()), ctypes.c_int(1), ctypes.c_int(cin), ctypes.c_int(cout), stream)
         assert rc == 0, (name, rc)
