@@ -434,6 +434,13 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
     auto win_sw = [](unsigned d) -> unsigned { return CH == 4 ? ((0u - (d >> 2)) & 3u) : ((d >> 1) & 7u); };
 
     constexpr bool PAIR = Cfg::PAIR;
+#ifndef FNP_SWEEP_PRIO
+#define FNP_SWEEP_PRIO 0
+#endif
+#ifndef FNP_GPAIR
+#define FNP_GPAIR 1   // (round 5: 128 -> 128 class-sorted 0.765 -> 0.751 ms per launch at 128 scenes, 0.397 -> 0.390 at 64, conv_out -5 %; bit-identical)
+#endif
+    constexpr bool GPAIR = FNP_GPAIR && !WIN && KS % 2 == 0 && PFK == 1;
 #ifdef FNP_KLIM   // timing probe only (results are wrong): sweep the first FNP_KLIM offsets
     const int K = KVOL > 0 ? (Cfg::KEFF < FNP_KLIM ? Cfg::KEFF : FNP_KLIM) : Krt;
 #else
@@ -607,7 +614,10 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
             else return i;
         };
         auto ent_raw = [&](int k, int mb) -> int {
-            if constexpr (SORTED) return nbr[(size_t)koff(k) * nbr_stride + prow[mb]];
+            if constexpr (SORTED) {
+                if (FNP_ABLATE & 512) return prow[mb] + koff(k) - 13;   // (probe: no rulebook loads)
+                return nbr[(size_t)koff(k) * nbr_stride + prow[mb]];
+            }
             else return nbr_raw(k, row0 + mb * 16 + l15, row_end);
         };
         auto ent_at = [&](int k, int mb) -> int {
@@ -769,6 +779,9 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
             }
         }
         FNP_MS(2);
+#if FNP_SWEEP_PRIO
+        __builtin_amdgcn_s_setprio(FNP_SWEEP_PRIO);   // (probe: a sweeping workgroup's waves ahead of those of a workgroup in its prologue / epilogue)
+#endif
         for (int k0 = 0; k0 < Kt; k0 += PFK) {
 #pragma unroll
             for (int u = 0; u < PFK; ++u) {
@@ -873,10 +886,24 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
                     }
                     // (4) the registers are free again: request the fragments of offset k + PFK (the
                     //     rulebook entry was loaded two rounds ago; validity is decided here)
+                    if constexpr (GPAIR) {
+                        // (FNP_GPAIR: the two 64-byte halves of a 128-byte line requested back to back — behind the odd step — so that
+                        //  the second half finds the line in L1 instead of fetching it from L2 again)
+                        if (ks & 1) {
+#pragma unroll
+                            for (int mb = 0; mb < MBT; ++mb) {
+                                const bool ok = live(k + PFK) && (row0 + mb * 16 + l15 < row_end);
+                                const unsigned ro = row_off(ok ? rawq[u][mb] : -1);
+                                xb[u][ks - 1][mb] = gather(ro, ks - 1);
+                                xb[u][ks][mb] = gather(ro, ks);
+                            }
+                        }
+                    } else {
 #pragma unroll
                     for (int mb = 0; mb < MBT; ++mb) {
                         const bool ok = live(k + PFK) && (row0 + mb * 16 + l15 < row_end);
                         xb[u][ks][mb] = gather(WIN ? row_off_w(ok ? rawq[u][mb] : -1, wlo) : row_off(ok ? rawq[u][mb] : -1), ks);
+                    }
                     }
                     __builtin_amdgcn_sched_barrier(0);  // keep the steps in program order
                 }
@@ -908,6 +935,9 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
             }
         }
 #undef FNP_LDS_POS
+#if FNP_SWEEP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if constexpr (NPF > 0) {
 #pragma unroll
             for (int j = 0; j < NPF; ++j) asm volatile("" ::"v"(pfv[j]));

@@ -117,6 +117,21 @@ __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restric
 #ifndef FNP_TILE64_SCHED
 #define FNP_TILE64_SCHED 1
 #endif
+#ifndef FNP_TILE64_RESK
+#define FNP_TILE64_RESK 6   // residual rows are requested this many offsets before the sweep ends
+#endif
+#ifndef FNP_TILE32_PRIO
+#define FNP_TILE32_PRIO 0
+#endif
+// wave priority during the 64-channel kernel's offset sweep (round 5).  The two workgroups of a CU share its SIMDs wave by wave;
+// when one of them is between two sweeps — image and slab stores, residual loads, the epilogue's arithmetic and row stores — its
+// instructions compete at equal priority with the other one's matrix and LDS-read stream, which is what bounds the launch.  With
+// the sweep at priority 2 (the rest at 0): 0.607 -> 0.577 ms per launch at 128 scenes (-4.9 %; priority 1 / 3: 0.579 / 0.577;
+// tools/ab_tiled.py, interleaved, bit-identical).  The same switch on the 32-channel kernel's consumer waves (against its producer
+// waves) and on the gather kernels' sweeps measured within +-0.5 %: not taken there.
+#ifndef FNP_TILE64_PRIO
+#define FNP_TILE64_PRIO 2
+#endif
 #ifndef FNP_TILE64_WDEPTH
 #define FNP_TILE64_WDEPTH 2   // weight slabs in flight in registers (64-channel kernel)
 #endif
@@ -386,6 +401,9 @@ __global__ __launch_bounds__((16 / FNP_TILE32_MB + FNP_TILE32_NPW) * 64, (16 / F
             }
     }
     __syncthreads();   // weights, zero rows, counters
+#if FNP_TILE32_PRIO
+    __builtin_amdgcn_s_setprio(FNP_TILE32_PRIO);   // (the consumer waves — matrix work and LDS reads — ahead of the producers' data movement)
+#endif
     if ((FNP_TILE_SCHED == 2 || FNP_TILE_SCHED == 3) && wave >= 4) __builtin_amdgcn_s_sleep(4);
     FNP_STAMP_DECL;
     for (int t = t_begin; t < t_end; ++t) {
@@ -812,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
                         if (2 * (k - K0) + 1 < NPIECE) req_piece(t + 1, 2 * (k - K0) + 1);
                     }
                 }
-                if (k == kK - 6) req_residual();
+                if (k == kK - FNP_TILE64_RESK) req_residual();
                 const unsigned e_new = entry(k + 3);
                 if (k + 1 < kK) {
                     fragments(en[(k + 1) & 1], k + 1, xf[(k + 1) & 1]);
@@ -849,8 +867,14 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
                 }
             }
         };
+#if FNP_TILE64_PRIO
+        __builtin_amdgcn_s_setprio(FNP_TILE64_PRIO);   // (the sweeping workgroup's waves ahead of the other workgroup's staging / epilogue waves)
+#endif
         if (esc_flags[wave]) sweep(std::true_type{});
         else sweep(std::false_type{});
+#if FNP_TILE64_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         FNP_STAMP(4);   // (sweep)
 
         // epilogue: the arithmetic of spconv_mfma_kernel (scale / shift, residual, ReLU, one rounding), 16 bytes per lane

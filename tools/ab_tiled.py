@@ -36,6 +36,7 @@ for v in [v for v in args.variants.split(",") if v]:
     libs[v] = ctypes.CDLL(path)
 for L in libs.values():
     L.fnp_spconv_forward_tiled.restype = ctypes.c_int
+    L.fnp_spconv_forward_sorted.restype = ctypes.c_int
 P = ctypes.c_void_p
 want = [int(c) for c in args.channels.split(",")]
 seen = set()
@@ -45,6 +46,43 @@ for tag, rb, n_dev in log:
         continue
     seen.add(cin)
     n = int(n_dev.item())
+    if cin == 128:    # the class-sorted sweep of stage 4 (fnp_spconv_forward_sorted): same harness, the shipped library's class order
+        x = torch.randn((rb.cap_out, cin), device=dev).to(torch.bfloat16)
+        w = (torch.randn((K, cout, cin), device=dev) * 0.05).to(torch.bfloat16)
+        sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
+        resid = torch.randn((rb.cap_out, cout), device=dev).to(torch.bfloat16)
+        rb.__dict__.pop("_sorted", None)
+        S.classsort(rb, n_dev, 128)
+        perm, bmask = rb._sorted
+        outs = {k: torch.zeros((rb.cap_out, cout), dtype=torch.bfloat16, device=dev) for k in libs}
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+        def launch(name):
+            rc = libs[name].fnp_spconv_forward_sorted(P(x.data_ptr()), ctypes.c_int(_l.dtype_code(x)), ctypes.c_int(x.shape[0]), P(w.data_ptr()),
+                                                      P(rb.nbr.data_ptr()), ctypes.c_int(rb.nbr.shape[1]), P(perm.data_ptr()), P(bmask.data_ptr()),
+                                                      P(n_dev.data_ptr()), ctypes.c_int(rb.cap_out), P(outs[name].data_ptr()), P(sc.data_ptr()),
+                                                      P(sh.data_ptr()), P(resid.data_ptr()), ctypes.c_int(1), ctypes.c_int(cin), ctypes.c_int(cout), stream)
+            assert rc == 0, (name, rc)
+
+        for name in libs:
+            for _ in range(3):
+                launch(name)
+        torch.cuda.synchronize()
+        equal = {name: bool(torch.equal(outs[name][:n], outs["main"][:n])) for name in libs}
+        times = {name: [] for name in libs}
+        for _ in range(args.rounds):
+            for name in libs:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    launch(name)
+                e1.record()
+                torch.cuda.synchronize()
+                times[name].append(e0.elapsed_time(e1) / args.reps)
+        print(json.dumps({"channels": cin, "kernel": "sorted", "rows": n, "scenes": B,
+                          "ms_per_launch_median": {k: round(float(np.median(v)), 4) for k, v in times.items()},
+                          "ms_all_rounds": {k: [round(t, 4) for t in v] for k, v in times.items()}, "bit_identical_to_main": equal}), flush=True)
+        continue
     x = torch.randn((rb.cap_out, cin), device=dev).to(torch.bfloat16)
     w = (torch.randn((K, cout, cin), device=dev) * 0.05).to(torch.bfloat16)
     sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
