@@ -435,6 +435,9 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
     auto win_sw = [](unsigned d) -> unsigned { return CH == 4 ? ((0u - (d >> 2)) & 3u) : ((d >> 1) & 7u); };
 
     constexpr bool PAIR = Cfg::PAIR;
+#ifndef FNP_CONV_PRIO
+#define FNP_CONV_PRIO 0
+#endif
 #ifndef FNP_SWEEP_PRIO
 #define FNP_SWEEP_PRIO 0
 #endif
@@ -446,6 +449,9 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
     const int K = KVOL > 0 ? (Cfg::KEFF < FNP_KLIM ? Cfg::KEFF : FNP_KLIM) : Krt;
 #else
     const int K = KVOL > 0 ? Cfg::KEFF : Krt;   // (PAIR: offset pairs)
+#endif
+#if FNP_CONV_PRIO
+    __builtin_amdgcn_s_setprio(FNP_CONV_PRIO);   // (probe: convolution waves ahead of the index kernels that share the CUs in the replayed step)
 #endif
     const int n = min(*n_out, cap);
     const int tid = threadIdx.x;

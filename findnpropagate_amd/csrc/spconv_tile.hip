@@ -120,6 +120,9 @@ __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restric
 #ifndef FNP_TILE64_RESK
 #define FNP_TILE64_RESK 6   // residual rows are requested this many offsets before the sweep ends
 #endif
+#ifndef FNP_CONV_PRIO
+#define FNP_CONV_PRIO 0
+#endif
 #ifndef FNP_TILE32_PRIO
 #define FNP_TILE32_PRIO 0
 #endif
@@ -287,6 +290,9 @@ __global__ __launch_bounds__((16 / FNP_TILE32_MB + FNP_TILE32_NPW) * 64, (16 / F
         if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&cnt[which], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
+#if FNP_CONV_PRIO
+    __builtin_amdgcn_s_setprio(FNP_CONV_PRIO);   // (probe: convolution waves ahead of the index kernels that share the CUs in the replayed step)
+#endif
     const int n = min(*n_out, cap);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
@@ -614,6 +620,9 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
     unsigned char *const img = smem + 2 * SLABC * 16;
     int *const esc_flags = reinterpret_cast<int *>(img + XB + EB);
 
+#if FNP_CONV_PRIO
+    __builtin_amdgcn_s_setprio(FNP_CONV_PRIO);   // (probe: convolution waves ahead of the index kernels that share the CUs in the replayed step)
+#endif
     const int n = min(*n_out, cap);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, x_bytes, 0x00020000);
@@ -731,10 +740,13 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[h * SLABC + st_pos + j * NT]) = wreg[h][j];
+        // (the far-row ids of the NEXT tile pass through LDS here, under the same barrier as the image: their readers — the overflow
+        //  pieces requested late in this sweep — come behind it, their previous readers finished before the barrier above; round 5:
+        //  one workgroup barrier per tile less)
+        if (FNP_TILE64_SPREAD && tid < G::OVF) id_lds[tid] = t + 1 < t_end ? far_id : -1;
         __syncthreads();
         FNP_STAMP(2);   // (image + slabs 0, 1 -> LDS, barrier)
-        if (FNP_TILE64_SPREAD) req_ids(t + 1);   // (the image's loads follow piece by piece inside the sweep)
-        else req_tile(t + 1);   // (one more barrier inside: the ids' pass through LDS)
+        if (!FNP_TILE64_SPREAD) req_tile(t + 1);   // (one more barrier inside: the ids' pass through LDS)
         req_far_ids(t + 2);
         FNP_STAMP(3);   // (next tile requested)
         f32x4 acc[NB][MB];
@@ -873,7 +885,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
         if (esc_flags[wave]) sweep(std::true_type{});
         else sweep(std::false_type{});
 #if FNP_TILE64_PRIO
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(FNP_CONV_PRIO);
 #endif
         FNP_STAMP(4);   // (sweep)
 
