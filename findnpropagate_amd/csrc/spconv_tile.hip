@@ -138,6 +138,9 @@ __global__ __launch_bounds__(256) void tile_rulebook_kernel(const int *__restric
 #ifndef FNP_TILE64_WDEPTH
 #define FNP_TILE64_WDEPTH 2   // weight slabs in flight in registers (64-channel kernel)
 #endif
+#ifndef FNP_TILE64_STORE_AT
+#define FNP_TILE64_STORE_AT 6
+#endif
 #ifndef FNP_TILE64_SPREAD
 #define FNP_TILE64_SPREAD 2   // (1: one piece per offset from the sweep's second offset on — round 4; 2: two per offset behind the last slab requests — round 5)
 #endif
@@ -776,6 +779,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
         if (FNP_TILE_ABLATE & 2) req_residual();
         auto sweep = [&](auto esc_tag) {
             constexpr bool ESC = decltype(esc_tag)::value;
+            constexpr bool kStoreEarly = !ESC && FNP_TILE64_SCHED == 2;
             // fragments of one offset: [ks][mb]; lane (l15, q) takes chunk 4 ks + q of its row
             auto fragments = [&](unsigned e, int k, u32x4 (&xv)[KS][MB]) {
 #pragma unroll
@@ -848,6 +852,10 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
                     fragments(en[(k + 1) & 1], k + 1, xf[(k + 1) & 1]);
                     weights(k + 1, wa[(k + 1) & 1]);
                 }
+                if (kStoreEarly && k + 2 < kK && !(FNP_TILE_ABLATE & (128 | 4096))) {
+#pragma unroll
+                    for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[(k & 1) * SLABC + st_pos + j * NT]) = wslab[(k + 2) % WD][j];
+                }
                 // the 12 LDS reads of offset k + 1 interleaved with the 16 MFMAs of offset k and nothing moved across: left to
                 // itself the scheduler sinks every read to just before its first use and the wave waits for LDS four times an offset
 #pragma unroll
@@ -864,6 +872,11 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
                         __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // VALU (fragment addresses)
+                        // (SCHED 2, measured and NOT taken: the slab stores in the middle of the block instead of behind its last MFMA, so that
+                        //  the barrier's LDS drain finds them done — legal at any point of offset k, slot k & 1 was last read during offset
+                        //  k - 1.  0.555 -> 0.587 ms per launch at 128 scenes behind MFMA 6; with a third slab in flight 0.566 / 0.559 /
+                        //  0.579 behind MFMA 6 / 9 / 2: the stores are cheapest where nothing else wants the LDS, at the end.  Round 5)
+                        if (FNP_TILE64_SCHED == 2 && i == FNP_TILE64_STORE_AT) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -871,7 +884,7 @@ __global__ __launch_bounds__(256, 2) void spconv_tile64_kernel(const TAct *__res
                 en[(k + 1) & 1] = e_new;
                 if ((FNP_TILE_ABLATE & 4096) && k + 2 < kK) asm volatile("" ::"v"(wslab[(k + 2) % WD][0]), "v"(wslab[(k + 2) % WD][NSL - 1]));
                 if (k + 1 < kK) {
-                    if (k + 2 < kK && !(FNP_TILE_ABLATE & (128 | 4096))) {   // (4096: probe — the slabs are loaded but not stored)
+                    if (!kStoreEarly && k + 2 < kK && !(FNP_TILE_ABLATE & (128 | 4096))) {   // (4096: probe — the slabs are loaded but not stored)
 #pragma unroll
                         for (int j = 0; j < NSL; ++j) *reinterpret_cast<u32x4 *>(&wl[(k & 1) * SLABC + st_pos + j * NT]) = wslab[(k + 2) % WD][j];
                     }
