@@ -210,12 +210,21 @@ __global__ __launch_bounds__(64) void aligned_overlap_kernel(const float *__rest
 
 // Suppression mask, same layout as the reference: mask[i * col_blocks + cb] bit j set iff
 // box (cb*64 + j) comes after i and IoU > thresh.  grid (col_blocks, col_blocks), one wave each.
+// BATCHED form (counts != nullptr; round 5: the per-class NMS of multi_classes_nms, model_nms_utils.py:30-66, as ONE launch pair):
+// blockIdx.z = list, list z holds counts[z] <= cap boxes at boxes + z * cap * 7 and its mask at mask + z * cap * ceil(cap / 64);
+// tiles beyond a list's own count leave at once.
 template <bool ROTATED>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ boxes, int n, float thresh,
-                                                      unsigned long long *__restrict__ mask) {
+                                                      unsigned long long *__restrict__ mask, const int *__restrict__ counts = nullptr, int cap = 0) {
     __shared__ RBox cols[ROTATED ? 64 : 1];
     __shared__ float cols_raw[64 * 7];
     const int rb = blockIdx.y, cb = blockIdx.x;
+    if (counts) {
+        n = min(counts[blockIdx.z], cap);
+        boxes += (size_t)blockIdx.z * cap * 7;
+        mask += (size_t)blockIdx.z * cap * ((cap + 63) / 64);
+        if (rb * 64 >= n || cb * 64 >= n) return;   // (whole workgroup)
+    }
     const int col_blocks = (n + 63) / 64;
     const int row_size = min(n - rb * 64, 64), col_size = min(n - cb * 64, 64);
     const int lane = threadIdx.x;
@@ -252,9 +261,20 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ 
 // Greedy sweep in ONE wave (iou3d_nms.cpp:139-155 on the device).
 constexpr int kMaxColBlocks = 1024;  // up to 65536 boxes
 __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long *__restrict__ mask, int n,
-                                                       int64_t *__restrict__ keep, int *__restrict__ num_keep) {
+                                                       int64_t *__restrict__ keep, int *__restrict__ num_keep,
+                                                       const int *__restrict__ counts = nullptr, int cap = 0) {
     __shared__ unsigned long long remv[kMaxColBlocks];
     const int lane = threadIdx.x;
+    if (counts) {   // (batched: blockIdx.x = list; see nms_mask_kernel)
+        n = min(counts[blockIdx.x], cap);
+        mask += (size_t)blockIdx.x * cap * ((cap + 63) / 64);
+        keep += (size_t)blockIdx.x * cap;
+        num_keep += blockIdx.x;
+        if (n <= 0) {
+            if (lane == 0) *num_keep = 0;
+            return;
+        }
+    }
     const int col_blocks = (n + 63) / 64;
     for (int j = lane; j < col_blocks; j += 64) remv[j] = 0;
     __syncthreads();
@@ -453,6 +473,32 @@ extern "C" int fnp_recall_counters(const float *preds, int pred_stride, int max_
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
+// Several score-sorted box lists at once (the classes of multi_classes_nms): list z = counts[z] boxes (a DEVICE array: the counts
+// come out of a score threshold) in a (lists, cap, 7) tensor; keep (lists, cap) int64, num_keep (lists) int32.  Two launches, no
+// host synchronisation; per list the result of fnp_nms_rotated / fnp_nms_normal on its first counts[z] boxes.
+extern "C" int64_t fnp_nms_batched_workspace_bytes(int lists, int cap) {
+    const int64_t cb = (cap + 63) / 64;
+    return (int64_t)(lists > 0 ? lists : 1) * (cap > 0 ? cap : 1) * (cb > 0 ? cb : 1) * 8;
+}
+extern "C" int fnp_nms_batched(const float *boxes, const int *counts, int lists, int cap, float thresh, int rotated, void *ws, int64_t *keep,
+                               int *num_keep, fnp_stream_t s) {
+    if (lists < 0 || cap < 0 || !num_keep) return FNP_ERR_ARG;
+    if (lists == 0) return FNP_OK;
+    if (!counts || (cap > 0 && (!boxes || !ws || !keep))) return FNP_ERR_ARG;
+    const int cb = (cap + 63) / 64;
+    if (cb > kMaxColBlocks || lists > 65535) return FNP_ERR_ARG;
+    if (cap > 0) {
+        if (rotated)
+            hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(cb, cb, lists), dim3(64), 0, (hipStream_t)s, boxes, 0, thresh, (unsigned long long *)ws, counts, cap);
+        else
+            hipLaunchKernelGGL(nms_mask_kernel<false>, dim3(cb, cb, lists), dim3(64), 0, (hipStream_t)s, boxes, 0, thresh, (unsigned long long *)ws, counts, cap);
+        FNP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(lists), dim3(64), 0, (hipStream_t)s, (const unsigned long long *)ws, 0, keep, num_keep, counts, cap);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
 extern "C" int64_t fnp_nms_workspace_bytes(int n) {
     const int64_t cb = (n + 63) / 64;
     return (int64_t)(n > 0 ? n : 1) * (cb > 0 ? cb : 1) * 8;

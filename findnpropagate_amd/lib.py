@@ -102,6 +102,8 @@ SIGNATURES = {
     "fnp_nms_workspace_bytes": (c_int64, [c_int]),
     "fnp_nms_rotated": (c_int, [P, c_int, c_float, P, P, P, P]),
     "fnp_nms_normal": (c_int, [P, c_int, c_float, P, P, P, P]),
+    "fnp_nms_batched_workspace_bytes": (c_int64, [c_int, c_int]),
+    "fnp_nms_batched": (c_int, [P, P, c_int, c_int, c_float, c_int, P, P, P, P]),
     "fnp_rankgrid_num_blocks": (c_int64, [c_int, c_int, c_int, c_int]),
     "fnp_rankgrid_num_summary": (c_int64, [c_int, c_int, c_int, c_int]),
     "fnp_rankgrid_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),

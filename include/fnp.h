@@ -122,6 +122,13 @@ int fnp_nms_rotated(const float *boxes, int num_boxes, float thresh, void *works
                     int64_t *keep, int *num_keep, fnp_stream_t stream);
 int fnp_nms_normal(const float *boxes, int num_boxes, float thresh, void *workspace,
                    int64_t *keep, int *num_keep, fnp_stream_t stream);
+/* (ABI 12) Several score-sorted lists in one launch pair — the per-class NMS of multi_classes_nms (model_nms_utils.py:30-66): list z holds
+ * counts[z] (a DEVICE array, each <= cap) boxes at boxes + z * cap * 7; keep (lists, cap) int64 and num_keep (lists) int32 receive,
+ * per list, what fnp_nms_rotated (rotated != 0) / fnp_nms_normal gives for its first counts[z] boxes.  workspace:
+ * fnp_nms_batched_workspace_bytes(lists, cap).  No host synchronisation. */
+int64_t fnp_nms_batched_workspace_bytes(int lists, int cap);
+int fnp_nms_batched(const float *boxes, const int *counts, int lists, int cap, float thresh, int rotated, void *workspace,
+                    int64_t *keep, int *num_keep, fnp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Rank grid — the voxel index behind voxelisation and rulebook building.  A grid of

@@ -99,3 +99,31 @@ def test_boxes_aligned_iou3d(cuda, rng):
     assert got.shape == (200, 1)
     assert torch.equal(got[:, 0], torch.diagonal(U.boxes_iou3d_gpu(ta, tb)))     # same device function, same bits
     assert (got[:100] > 0.2).any() and U.boxes_aligned_iou3d_gpu(ta[:0], tb[:0]).shape == (0, 1)
+
+
+@pytest.mark.parametrize("rotated", [True, False])
+def test_batched_nms_equals_the_single_list_entry_points(cuda, rng, rotated):
+    """fnp_nms_batched (round 5: all classes of multi_classes_nms in one launch pair, counts on the device) against
+    fnp_nms_rotated / fnp_nms_normal list by list: lists of 0, 1, 63, 64, 65 and 300 boxes in one (lists, cap, 7) tensor."""
+    from findnpropagate_amd import lib as _l
+    from findnpropagate_amd.iou3d_nms import iou3d_nms_cuda as C
+    L = _l.load()
+    counts = [0, 1, 63, 64, 65, 300]
+    cap = 320
+    boxes = torch.zeros((len(counts), cap, 7), device=cuda)
+    for z, c in enumerate(counts):
+        if c:
+            boxes[z, :c] = torch.from_numpy(syn.random_boxes(rng, c, centre_range=6.0)).to(cuda)
+        boxes[z, c:] = 1.0e6        # garbage beyond a list's count must never be read as a box
+    d_counts = torch.tensor(counts, dtype=torch.int32, device=cuda)
+    ws = torch.empty((int(L.fnp_nms_batched_workspace_bytes(len(counts), cap)),), dtype=torch.uint8, device=cuda)
+    keep = torch.full((len(counts), cap), -1, dtype=torch.int64, device=cuda)
+    num = torch.full((len(counts),), -1, dtype=torch.int32, device=cuda)
+    rc = L.fnp_nms_batched(_l.ptr(boxes), _l.ptr(d_counts), len(counts), cap, 0.25, int(rotated), _l.ptr(ws), _l.ptr(keep), _l.ptr(num), _l.stream())
+    assert rc == 0
+    for z, c in enumerate(counts):
+        k1, n1 = C._nms_device(boxes[z, :c].contiguous(), 0.25, rotated)
+        m = int(n1.item())
+        assert int(num[z].item()) == m, (z, c)
+        assert torch.equal(keep[z, :m], k1[:m]), (z, c)
+    assert 0 < int(num[5].item()) < 300
