@@ -45,6 +45,7 @@ __device__ __forceinline__ int fnp_lane() { return threadIdx.x & 63; }
 #ifndef FNP_XCD_SWZ
 #define FNP_XCD_SWZ 1
 #endif
+// (restated and checked on the host: tests/test_host_logic_r5.py)
 __device__ __forceinline__ unsigned fnp_xcd_block() {
     const unsigned G = gridDim.x, b = blockIdx.x;
     if (!FNP_XCD_SWZ || G < 16u) return b;
