@@ -314,7 +314,6 @@ struct FusedRb {
 struct SortedRb {
     const int *perm;
     const unsigned *blockmask;
-    int pos_table;   // the table passed as `nbr` is in POSITION order (fnp_rulebook_permute_table): entry (k, position), not (k, row)
 };
 
 // f32 outputs only (the bf16x3 engine's main product, fnp_spconv_forward_split): a 16-bit addend (its two cross terms, which need
@@ -623,9 +622,9 @@ __global__ __launch_bounds__((NwOf<CIN, COUT, NWO>::value * 64), (MfmaOcc<CIN, C
         auto ent_raw = [&](int k, int mb) -> int {
             if constexpr (SORTED) {
                 if (FNP_ABLATE & 512) return prow[mb] + koff(k) - 13;   // (probe: no rulebook loads)
-                if (FNP_ABLATE & 2048) return nbr[(size_t)koff(k) * nbr_stride + min(row0 + mb * 16 + l15, row_end - 1)];   // (probe, wrong results: entries read in POSITION order — coalesced)
-                // (position-ordered table: the 16 lanes of a block read 64 contiguous bytes instead of 16 scattered words)
-                if (srb.pos_table) return nbr[(size_t)koff(k) * nbr_stride + min(row0 + mb * 16 + l15, row_end - 1)];
+                // (round 5, measured and removed: a copy of the table in PROCESSING order — one 64-byte read per block and offset instead of 16
+                //  scattered words through perm — takes 3.4 % off this launch and costs its own permute pass, 61 us per 128-scene step for
+                //  4 x 25 us: +0.6 % / -0.3 % end to end at 64 / 128 scenes, a wash)
                 return nbr[(size_t)koff(k) * nbr_stride + prow[mb]];
             }
             else return nbr_raw(k, row0 + mb * 16 + l15, row_end);
@@ -1233,7 +1232,7 @@ int launch_mfma_k(const void *x, int x_bytes, const void *w, const int *nbr, int
         if (!frb_in) return FNP_ERR_ARG;
         frb = *frb_in;
     }
-    SortedRb srb{nullptr, nullptr, 0};
+    SortedRb srb{nullptr, nullptr};
     if (SORTED && !grid_only) {
         if (!srb_in || !srb_in->perm || !srb_in->blockmask) return FNP_ERR_ARG;
         srb = *srb_in;
@@ -1643,41 +1642,16 @@ extern "C" int fnp_rulebook_classsort(const int *nbr, int nbr_stride, int K, con
     return FNP_OK;
 }
 
-// nbr_pos[k][position] = nbr[k][perm[position]]: the table of a class-sorted rulebook restated in PROCESSING order, once per forward
-// (four convolutions read it).  The sorted sweep fetched its entries through perm — per 16-row block and offset 16 scattered 4-byte
-// reads of a table that has long left the caches, a fifth of the address work of the launch's vector-memory instructions; from the
-// position-ordered table the same entries are one 64-byte read.
-__global__ __launch_bounds__(256) void permute_table_kernel(const int *__restrict__ nbr, int nbr_stride, const int *__restrict__ perm,
-                                                            const int *__restrict__ n_out, int cap, int *__restrict__ out) {
-    const int n = min(*n_out, cap);
-    for (int p = fnp_xcd_block() * 256 + threadIdx.x; p < n; p += gridDim.x * 256) {
-        const int r = perm[p];
-        int v[27];
-#pragma unroll
-        for (int k = 0; k < 27; ++k) v[k] = nbr[(size_t)k * nbr_stride + r];
-#pragma unroll
-        for (int k = 0; k < 27; ++k) out[(size_t)k * nbr_stride + p] = v[k];
-    }
-}
-
-extern "C" int fnp_rulebook_permute_table(const int *nbr, int nbr_stride, int K, const int *perm, const int *n_out, int cap_out, int *nbr_pos,
-                                          fnp_stream_t stream) {
-    if (!nbr || !perm || !n_out || !nbr_pos || K != 27 || cap_out <= 0 || nbr_stride < cap_out) return FNP_ERR_ARG;
-    hipLaunchKernelGGL(permute_table_kernel, dim3(fnp_grid_for(cap_out, 256)), dim3(256), 0, (hipStream_t)stream, nbr, nbr_stride, perm, n_out, cap_out, nbr_pos);
-    FNP_LAUNCH_CHECK();
-    return FNP_OK;
-}
-
-static int sorted_forward(const void *feat_in, int dtype, int n_in_rows, const void *weight, const int *nbr, int nbr_stride,
-                          const int *perm, const unsigned *blockmask, const int *n_out, int cap_out, void *feat_out,
-                          const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
-                          fnp_stream_t stream, int pos_table) {
+extern "C" int fnp_spconv_forward_sorted(const void *feat_in, int dtype, int n_in_rows, const void *weight, const int *nbr, int nbr_stride,
+                                         const int *perm, const unsigned *blockmask, const int *n_out, int cap_out, void *feat_out,
+                                         const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
+                                         fnp_stream_t stream) {
     if (!feat_in || !weight || !nbr || !perm || !blockmask || !n_out || !feat_out || cap_out <= 0 || nbr_stride < cap_out || n_in_rows <= 0)
         return FNP_ERR_ARG;
     if ((scale == nullptr) != (shift == nullptr) || Cin != 128 || Cout != 128) return FNP_ERR_ARG;
     const long long xb = (long long)n_in_rows * Cin * 2;
     if (xb >= 0x7fffffffll) return FNP_ERR_ARG;
-    const SortedRb srb{perm, blockmask, pos_table};
+    const SortedRb srb{perm, blockmask};
     if (dtype == FNP_BF16)
         return launch_mfma_k<128, 128, 27, false, __bf16, false, __bf16, true>(feat_in, (int)xb, weight, nbr, nbr_stride, 27, n_out, cap_out, feat_out, scale,
                                                                                 shift, residual, relu, 0, (hipStream_t)stream, nullptr, &srb);
@@ -1685,22 +1659,6 @@ static int sorted_forward(const void *feat_in, int dtype, int n_in_rows, const v
         return launch_mfma_k<128, 128, 27, false, _Float16, false, _Float16, true>(feat_in, (int)xb, weight, nbr, nbr_stride, 27, n_out, cap_out, feat_out,
                                                                                     scale, shift, residual, relu, 0, (hipStream_t)stream, nullptr, &srb);
     return FNP_ERR_ARG;
-}
-
-extern "C" int fnp_spconv_forward_sorted(const void *feat_in, int dtype, int n_in_rows, const void *weight, const int *nbr, int nbr_stride,
-                                         const int *perm, const unsigned *blockmask, const int *n_out, int cap_out, void *feat_out,
-                                         const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
-                                         fnp_stream_t stream) {
-    return sorted_forward(feat_in, dtype, n_in_rows, weight, nbr, nbr_stride, perm, blockmask, n_out, cap_out, feat_out, scale, shift, residual, relu, Cin,
-                          Cout, stream, 0);
-}
-// the same with `nbr_pos` = fnp_rulebook_permute_table's output in the place of the table
-extern "C" int fnp_spconv_forward_sorted_pos(const void *feat_in, int dtype, int n_in_rows, const void *weight, const int *nbr_pos, int nbr_stride,
-                                             const int *perm, const unsigned *blockmask, const int *n_out, int cap_out, void *feat_out,
-                                             const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
-                                             fnp_stream_t stream) {
-    return sorted_forward(feat_in, dtype, n_in_rows, weight, nbr_pos, nbr_stride, perm, blockmask, n_out, cap_out, feat_out, scale, shift, residual, relu,
-                          Cin, Cout, stream, 1);
 }
 
 extern "C" int fnp_spconv_forward_sorted_split(const void *feat_in, int dtype, int n_in_rows, const void *weight, const int *nbr, int nbr_stride,
@@ -1722,7 +1680,7 @@ extern "C" int fnp_spconv_forward_sorted_split(const void *feat_in, int dtype, i
     launch_mfma_k<128, 128, 27, false, float, false, __bf16, true>(nullptr, 0, nullptr, nullptr, cap_out, 27, n_out, cap_out, nullptr, nullptr, nullptr, nullptr,
                                                                    0, 0, s, nullptr, nullptr, &g32);
     if (g16 != g32) return FNP_ERR_ARG;
-    const SortedRb srb{perm, blockmask, 0};
+    const SortedRb srb{perm, blockmask};
     const SplitOut so{addend, out_hi, out_lo, relu};
     if (dtype == FNP_BF16)
         return launch_mfma_k<128, 128, 27, false, float, false, __bf16, true>(feat_in, (int)xb, weight, nbr, nbr_stride, 27, n_out, cap_out, feat_out, scale, shift,

@@ -147,8 +147,6 @@ SIGNATURES = {
     "fnp_rulebook_classsort_f32": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "fnp_spconv_forward_f32_sorted": (c_int, [P, c_int, P, P, c_int, P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "fnp_spconv_forward_sorted": (c_int, [P, c_int, c_int, P, P, c_int, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
-    "fnp_spconv_forward_sorted_pos": (c_int, [P, c_int, c_int, P, P, c_int, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
-    "fnp_rulebook_permute_table": (c_int, [P, c_int, c_int, P, P, c_int, P, P]),
     "fnp_boxseeker_workspace_bytes": (c_int64, [c_int, c_int]),
     "fnp_seeker_prepare_matrices": (c_int, [P, P, P, P, P, c_int, P, P, P]),
     "fnp_host_enumerate_frustums": (c_int, [P, P, P, P, P, c_int, c_int, POINTER(c_int), c_int, c_float, c_float, P, c_int]),

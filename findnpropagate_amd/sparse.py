@@ -456,7 +456,6 @@ MARK_FUSED = os.environ.get("FNP_MARK_FUSED", "0") == "1"
 SORTED_SHAPES = {(128, 128)}   # (Cin, Cout) fnp_spconv_forward_sorted covers
 # the class-sorted sweep pays from a few scenes on (one more small kernel per forward against ~20 % of four sweeps); 0 / 1 force it
 SORT_MODE = {"0": False, "1": True}.get(os.environ.get("FNP_SORT", ""))
-SORT_POS = os.environ.get("FNP_SORT_POS", "1") != "0"   # the sorted sweeps read a position-ordered copy of the table (0: through perm)
 SORT_MIN_ROWS = 131072   # (row CAPACITY of the stage: a one-scene hipGraph has 65,536; from ~4 scenes on the sort pays)
 
 
@@ -483,13 +482,6 @@ def classsort(rb, n_out_dev, channels=128):
                                   _l.ptr(perm), _l.ptr(blockmask), _l.ptr(ws), 0 if ws is None else ws.numel(), _l.stream())
     _l.check(rc, "fnp_rulebook_classsort")
     rb._sorted = (perm, blockmask)
-    if SORT_POS and not getattr(rb, "_lean", False):
-        # the table once more, in processing order (fnp_rulebook_permute_table): the four sorted sweeps then read their entries
-        # coalesced instead of through perm (round 5)
-        nbr_pos = torch.empty_like(rb.nbr)
-        rc = L.fnp_rulebook_permute_table(_l.ptr(rb.nbr), rb.nbr.shape[1], rb.K, _l.ptr(perm), _l.ptr(n_out_dev), rb.cap_out, _l.ptr(nbr_pos), _l.stream())
-        _l.check(rc, "fnp_rulebook_permute_table")
-        rb._sorted = (perm, blockmask, nbr_pos)
     if rowmask is None:
         rb._rowmask = ws.view(torch.int32)
     return rb
@@ -560,11 +552,9 @@ def conv_forward(feat_in, w_packed, rb, n_out_dev, out_dtype=None, scale=None, s
     srt = getattr(rb, "_sorted", None)
     if (srt is not None and K == 27 and (Cin, Cout) in SORTED_SHAPES and feat_in.dtype in (torch.bfloat16, torch.float16)
             and out.dtype == feat_in.dtype and feat_in.shape[0] * Cin * 2 < 0x7fffffff):
-        pos = srt[2] if len(srt) > 2 else None
-        fn = L.fnp_spconv_forward_sorted if pos is None else L.fnp_spconv_forward_sorted_pos
-        rc = fn(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed), _l.ptr(rb.nbr if pos is None else pos),
-                rb.nbr.shape[1], _l.ptr(srt[0]), _l.ptr(srt[1]), _l.ptr(n_out_dev), cap_out, _l.ptr(out),
-                _l.ptr(scale), _l.ptr(shift), _l.ptr(residual), int(bool(relu)), Cin, Cout, _l.stream())
+        rc = L.fnp_spconv_forward_sorted(_l.ptr(feat_in), _l.dtype_code(feat_in), feat_in.shape[0], _l.ptr(w_packed), _l.ptr(rb.nbr),
+                                         rb.nbr.shape[1], _l.ptr(srt[0]), _l.ptr(srt[1]), _l.ptr(n_out_dev), cap_out, _l.ptr(out),
+                                         _l.ptr(scale), _l.ptr(shift), _l.ptr(residual), int(bool(relu)), Cin, Cout, _l.stream())
         _l.check(rc, "fnp_spconv_forward_sorted")
         return out
     pf = (getattr(rb, "_perm_f32", None) or {}).get(Cin)

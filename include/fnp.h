@@ -433,16 +433,6 @@ int fnp_spconv_forward_sorted(const void *feat_in, int dtype, int n_in_rows, con
                               const int *perm, const unsigned *blockmask, const int *n_out, int cap_out, void *feat_out,
                               const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
                               fnp_stream_t stream);
-/* (ABI 12) The table of a class-sorted rulebook in PROCESSING order, nbr_pos[k][position] = nbr[k][perm[position]] ((27, nbr_stride)
- * int32 like nbr; positions >= *n_out untouched), made once per forward; fnp_spconv_forward_sorted_pos is
- * fnp_spconv_forward_sorted reading its entries from it — per 16-row block and offset one 64-byte read instead of 16 scattered
- * 4-byte reads through perm.  Same values. */
-int fnp_rulebook_permute_table(const int *nbr, int nbr_stride, int K, const int *perm, const int *n_out, int cap_out, int *nbr_pos,
-                               fnp_stream_t stream);
-int fnp_spconv_forward_sorted_pos(const void *feat_in, int dtype, int n_in_rows, const void *weight, const int *nbr_pos, int nbr_stride,
-                                  const int *perm, const unsigned *blockmask, const int *n_out, int cap_out, void *feat_out,
-                                  const float *scale, const float *shift, const void *residual, int relu, int Cin, int Cout,
-                                  fnp_stream_t stream);
 
 /* The f32 engine's form of the class sort (the f32 3x3x3 SubM layers, 16 / 32 / 64 / 128 channels, run on v_mfma_f32_16x16x4_f32
  * and are bound by the matrix pipe; the kernel skips the MFMAs of a (16-row block, offset) pair without any neighbour).

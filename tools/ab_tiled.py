@@ -54,17 +54,12 @@ for tag, rb, n_dev in log:
         rb.__dict__.pop("_sorted", None)
         S.classsort(rb, n_dev, 128)
         perm, bmask = rb._sorted[:2]
-        nbr_pos = rb._sorted[2] if len(rb._sorted) > 2 else None
-        if nbr_pos is not None:
-            libs["pos"] = libs["main"]          # the shipped library reading the position-ordered table (fnp_spconv_forward_sorted_pos)
-            libs["main"].fnp_spconv_forward_sorted_pos.restype = ctypes.c_int
         outs = {k: torch.zeros((rb.cap_out, cout), dtype=torch.bfloat16, device=dev) for k in libs}
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
         def launch(name):
-            fn = libs[name].fnp_spconv_forward_sorted_pos if name == "pos" else libs[name].fnp_spconv_forward_sorted
-            rc = fn(P(x.data_ptr()), ctypes.c_int(_l.dtype_code(x)), ctypes.c_int(x.shape[0]), P(w.data_ptr()),
-                                                      P((nbr_pos if name == "pos" else rb.nbr).data_ptr()), ctypes.c_int(rb.nbr.shape[1]), P(perm.data_ptr()), P(bmask.data_ptr()),
+            rc = libs[name].fnp_spconv_forward_sorted(P(x.data_ptr()), ctypes.c_int(_l.dtype_code(x)), ctypes.c_int(x.shape[0]), P(w.data_ptr()),
+                                                      P(rb.nbr.data_ptr()), ctypes.c_int(rb.nbr.shape[1]), P(perm.data_ptr()), P(bmask.data_ptr()),
                                                       P(n_dev.data_ptr()), ctypes.c_int(rb.cap_out), P(outs[name].data_ptr()), P(sc.data_ptr()),
                                                       P(sh.data_ptr()), P(resid.data_ptr()), ctypes.c_int(1), ctypes.c_int(cin), ctypes.c_int(cout), stream)
             assert rc == 0, (name, rc)
