@@ -174,53 +174,63 @@ __device__ __forceinline__ int rg_lookup(const RG &g, int b, int z, int y, int x
 // per lane, four offsets (4 x 256 contiguous bytes) per wave instruction instead of one: the 4-byte form was
 // bound by the number of store instructions, not by bytes.
 // mask_out (optional): bit k = the row has a neighbour at offset k (K <= 32).
-template <int KZ, int KY, int KX>
+// DEFER (default): all K ranks are formed first and the permutation loads of a stage-1 grid leave together (the record builders, the
+// plain table kernels, the in-kernel rulebooks of the strided convolutions: -13 ... -24 % / -15 % / -2 ... -3 %).  DEFER = false: every
+// entry leaves for the strip as soon as it is known — the tile-rulebook kernels, where 27 live ranks cost a wave per SIMD (+5 ... +7 %)
+// and the grids carry no permutation.
+template <int KZ, int KY, int KX, bool DEFER = true>
 __device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, int lox, int *strip, int sstride, unsigned *mask_out = nullptr) {   // (strip: LDS shared by the lanes of a wave - no __restrict__)
-    unsigned msk = 0u;
+    // Round 5: BRANCH-FREE.  The first form tested every entry under three nested `if`s and, for a grid with a rank -> row
+    // permutation (stage 1), loaded perm[rank] inside the innermost one: hipcc turned that into ~200 exec-mask branches per row and,
+    // worse, a load + s_waitcnt vmcnt(0) PER ENTRY — 27 serial memory round trips per row in the stage-1 record builders.  Now every
+    // rank is computed unconditionally (bit arithmetic on words already in registers), absent entries are selected to -1, and the
+    // permutation loads of all K entries are issued together behind ONE uniform branch.
     const int bz0 = loz >> 2, by0 = loy >> 2, bx0 = lox >> 2;   // (arithmetic shift: -1 -> block -1, outside)
     unsigned long long w[2][2][2];
     unsigned base[2][2][2];
 #pragma unroll
-    for (int cz = 0; cz < 2; ++cz)
+    for (int cy = 0; cy < 2; ++cy)
 #pragma unroll
-        for (int cy = 0; cy < 2; ++cy)
+        for (int cx = 0; cx < 2; ++cx) {
+            const int by = by0 + cy, bx = bx0 + cx;
+            const bool need_yx = (cy == 0 || ((loy + KY - 1) >> 2) != by0) && (cx == 0 || ((lox + KX - 1) >> 2) != bx0);
+            const bool in_yx = by >= 0 && by < g.d.bh && bx >= 0 && bx < g.d.bw;
+            // the blocks of a column are numbered bottom to top: one column base, + bz
+            const unsigned col = (rg_morton3((unsigned)by & 7u) << 1) | rg_morton3((unsigned)bx & 7u);
+            const long long colbase = ((((long long)b * g.d.th + (by >> 3)) * g.d.tw + (bx >> 3)) * 64 + col) * g.d.bd;
 #pragma unroll
-            for (int cx = 0; cx < 2; ++cx) {
-                const int bz = bz0 + cz, by = by0 + cy, bx = bx0 + cx;
-                const bool need = (cz == 0 || ((loz + KZ - 1) >> 2) != bz0) && (cy == 0 || ((loy + KY - 1) >> 2) != by0) &&
-                                  (cx == 0 || ((lox + KX - 1) >> 2) != bx0);
-                const bool in = bz >= 0 && bz < g.d.bd && by >= 0 && by < g.d.bh && bx >= 0 && bx < g.d.bw;
+            for (int cz = 0; cz < 2; ++cz) {
+                const int bz = bz0 + cz;
+                const bool need = need_yx && (cz == 0 || ((loz + KZ - 1) >> 2) != bz0);
+                const bool in = in_yx && bz >= 0 && bz < g.d.bd;
                 unsigned long long ww = 0ull;
                 unsigned bb = 0u;
                 if (need && in) {
-                    const long long blk = rg_block_of(g.d, b, bz << 2, by << 2, bx << 2);
-                    ww = g.bits[blk];
-                    bb = g.base[blk];   // (defined only where ww != 0; unused otherwise)
+                    ww = g.bits[colbase + bz];
+                    bb = g.base[colbase + bz];   // (defined only where ww != 0; unused otherwise)
                 }
                 w[cz][cy][cx] = ww;
                 base[cz][cy][cx] = bb;
             }
+        }
+    constexpr int K = KZ * KY * KX;
+    unsigned msk = 0u;
+    int rk[DEFER ? K : 1];
 #pragma unroll
     for (int jz = 0; jz < KZ; ++jz) {
         const int z = loz + jz;
         const bool cz = (z >> 2) != bz0;
         const bool vz = z >= 0 && z < g.d.D;
-        unsigned long long wz[2][2];
-        unsigned bsz[2][2];
-#pragma unroll
-        for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-            for (int cx = 0; cx < 2; ++cx) {
-                wz[cy][cx] = cz ? w[1][cy][cx] : w[0][cy][cx];
-                bsz[cy][cx] = cz ? base[1][cy][cx] : base[0][cy][cx];
-            }
 #pragma unroll
         for (int jy = 0; jy < KY; ++jy) {
             const int y = loy + jy;
             const bool cy = (y >> 2) != by0;
             const bool vy = vz && y >= 0 && y < g.d.H;
-            const unsigned long long wy0 = cy ? wz[1][0] : wz[0][0], wy1 = cy ? wz[1][1] : wz[0][1];
-            const unsigned by0v = cy ? bsz[1][0] : bsz[0][0], by1v = cy ? bsz[1][1] : bsz[0][1];
+            const unsigned long long wy0 = cz ? (cy ? w[1][1][0] : w[1][0][0]) : (cy ? w[0][1][0] : w[0][0][0]);
+            const unsigned long long wy1 = cz ? (cy ? w[1][1][1] : w[1][0][1]) : (cy ? w[0][1][1] : w[0][0][1]);
+            const unsigned by0v = cz ? (cy ? base[1][1][0] : base[1][0][0]) : (cy ? base[0][1][0] : base[0][0][0]);
+            const unsigned by1v = cz ? (cy ? base[1][1][1] : base[1][0][1]) : (cy ? base[0][1][1] : base[0][0][1]);
+            const int line = ((z & 3) << 4) | ((y & 3) << 2);
 #pragma unroll
             for (int jx = 0; jx < KX; ++jx) {
                 const int x = lox + jx;
@@ -228,15 +238,33 @@ __device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, in
                 const bool v = vy && x >= 0 && x < g.d.W;
                 const unsigned long long ww = cx ? wy1 : wy0;
                 const unsigned bb = cx ? by1v : by0v;
-                const int bit = rg_bit_of(z, y, x);
-                int r = -1;
-                if (v && ((ww >> bit) & 1ull)) {
-                    r = (int)bb + __popcll(ww & ((1ull << bit) - 1ull));
-                    if (g.perm) r = g.perm[r];
+                const int bit = line | (x & 3);
+                const bool hit = v && ((ww >> bit) & 1ull);
+                const int r = (int)bb + __popcll(ww & ((1ull << bit) - 1ull));
+                const int e = (jz * KY + jy) * KX + jx;
+                if constexpr (DEFER) {
+                    rk[e] = hit ? r : -1;
+                } else {
+                    int rr = hit ? r : -1;
+                    if (g.perm && hit) rr = g.perm[r];
+                    strip[e * sstride] = rr;
+                    if (mask_out && hit) msk |= 1u << (e & 31);
                 }
-                strip[((jz * KY + jy) * KX + jx) * sstride] = r;
-                if (mask_out && r >= 0) msk |= 1u << (((jz * KY + jy) * KX + jx) & 31);
             }
+        }
+    }
+    if constexpr (DEFER) {
+        if (g.perm) {   // (uniform) rank -> row: all K loads in flight together
+            int pr[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) pr[k] = g.perm[rk[k] < 0 ? 0 : rk[k]];
+#pragma unroll
+            for (int k = 0; k < K; ++k) rk[k] = rk[k] < 0 ? -1 : pr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            strip[k * sstride] = rk[k];
+            if (mask_out && rk[k] >= 0) msk |= 1u << (k & 31);
         }
     }
     if (mask_out) *mask_out = msk;

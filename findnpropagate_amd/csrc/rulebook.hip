@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NT) void subm_nbr_row_tile_kernel(const int *__rest
         if (mk.on) mark_job_row(mk, o < n, cm, lane);
         if (o < n) {
             const int4 c = cm;
-            nbr_row<3, 3, 3>(g, c.x, c.y - 1, c.z - 1, c.w - 1, strip_wave + lane, 64);
+            nbr_row<3, 3, 3, false>(g, c.x, c.y - 1, c.z - 1, c.w - 1, strip_wave + lane, 64);
         }
         if constexpr (!LEAN) nbr_flush<K>(strip_wave, base + (tid & ~63), n, cap, nbr);
         __syncthreads();   // empty tables
