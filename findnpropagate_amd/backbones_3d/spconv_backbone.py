@@ -170,6 +170,12 @@ def _module_forward(self, batch_dict):
     voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords']
     batch_size = batch_dict['batch_size']
     act = self._act_dtype()
+    if torch.is_autocast_enabled() and voxel_features.is_cuda:
+        # under torch.cuda.amp (tools/train_utils/train_utils.py:172) the reference's activations ARE the autocast dtype from
+        # layer to layer: spconv's convolutions write fp16, nn.BatchNorm1d / ReLU keep the dtype they are given.  Same here —
+        # and the fused BatchNorm kernels then run (round 5: with `act` left at FNP_DTYPE every layer went conv fp16 -> torch
+        # batch_norm in f32 -> bf16 -> fp16 again, 8 of the 19.5 ms of the step at the shipped configuration)
+        act = torch.get_autocast_dtype('cuda')
     x_in = spconv.SparseConvTensor(features=voxel_features.float().contiguous(), indices=voxel_coords.int().contiguous(),
                                    spatial_shape=self.sparse_shape, batch_size=batch_size)
     # the strided layers' rulebooks are asked for ahead of the layers before them (spconv/conv.py prefetch): the first one from

@@ -208,7 +208,8 @@ def test_ten_sweep_scene_bf16x3_engine_with_and_without_tiles(cuda):
     assert _l.load().fnp_spconv_tiled_aborts() == aborts0
 
 
-@pytest.mark.parametrize("mode,cin,cout,s,p", [("subm", 16, 16, 1, 1), ("strided", 16, 32, 2, 1), ("subm", 64, 64, 1, 1)])
+@pytest.mark.parametrize("mode,cin,cout,s,p", [("subm", 16, 16, 1, 1), ("strided", 16, 32, 2, 1), ("subm", 64, 64, 1, 1),
+                                               ("subm", 5, 16, 1, 1)])   # (5 -> 16: conv_input, zero-padded to the 16 -> 16 MFMA kernels)
 def test_backward_on_a_ten_sweep_scene(cuda, mode, cin, cout, s, p):
     """a26 at the density transfusion_lidar.yaml trains on (MAX_SWEEPS 10; MAX_NUMBER_OF_VOXELS 120 k in training,
     transfusion_lidar.yaml:54-59 — the cap fires on this scene): data and weight gradients of a SubM and a strided layer on the
@@ -252,10 +253,15 @@ def test_backward_on_a_ten_sweep_scene(cuda, mode, cin, cout, s, p):
         assert np.abs(got - want).max() <= 4e-3 * scale, (mode, cin, np.abs(got - want).max(), scale)
 
 
-def test_amp_training_step_at_the_shipped_configuration(cuda):
+def test_amp_training_step_at_the_shipped_configuration(cuda, monkeypatch):
     """BATCH_SIZE_PER_GPU 4 x MAX_SWEEPS 10 under AMP (transfusion_lidar.yaml:147, nuscenes_dataset.yaml:5, train_utils.py:135-176) is
     what tools/bench_train.py --sweeps 10 --batch 4 --amp times; here ONE such scene through the same step: the training voxel
-    cap fires, the step is not skipped (finite unscaled gradients), every parameter moves, site sets equal the oracle's."""
+    cap fires, the step is not skipped (finite unscaled gradients), every parameter moves, site sets equal the oracle's.
+    Every BatchNorm of the step runs on the library's fused kernels in the autocast dtype (torch's batch_norm is made to raise:
+    until round 5 the activations were cast fp16 -> f32 -> bf16 -> fp16 around a torch batch_norm per layer)."""
+    def _no_torch_bn(*a, **k):
+        raise AssertionError("torch batch_norm ran inside the AMP step")
+    monkeypatch.setattr(torch.nn.functional, "batch_norm", _no_torch_bn)
     net = _net(cuda, "bf16").train()
     pts, off = syn.make_sweeps_batch((37,))
     cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, 120000)
@@ -281,6 +287,30 @@ def test_amp_training_step_at_the_shipped_configuration(cuda):
     assert len(moved) == len(before), sorted(set(before) - set(moved))[:5]
     res = {"out": out["encoded_spconv_tensor"], **out["multi_scale_3d_features"]}
     _check_sites(res, vox["coords"][:n].cpu().numpy(), 1)
+
+
+def test_amp_module_forward_equals_the_fp16_module_forward(cuda):
+    """Under autocast(fp16) the module path keeps its activations in fp16 from layer to layer, as spconv + nn.BatchNorm1d do in
+    the reference's AMP step: its outputs are those of the same network built with FNP_DTYPE fp16 and run without autocast
+    (same kernels, same order), up to conv_input, which autocast runs in fp16 and the fp16 network in f32."""
+    pts, off = syn.make_batch((3, 4))
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, syn.MAX_POINTS_PER_VOXEL, 160000)
+    vox = S.voxelize(torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda), 2, cfg)
+    n = int(vox["n"].item())
+    bd = lambda: {"voxel_features": vox["mean"][:n], "voxel_coords": vox["coords"][:n].float(), "batch_size": 2}
+    a_net, b_net = _net(cuda, "bf16").train(), _net(cuda, "fp16").train()
+    b_net.load_state_dict(a_net.state_dict())
+    with torch.autocast("cuda", dtype=torch.float16):
+        a = a_net(bd())
+    b = b_net(bd())
+    for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4"):
+        fa, fb = a["multi_scale_3d_features"][k].features.float(), b["multi_scale_3d_features"][k].features.float()
+        assert torch.equal(a["multi_scale_3d_features"][k].indices, b["multi_scale_3d_features"][k].indices)
+        scale = float(fb.abs().max())
+        assert float((fa - fb).abs().max()) <= 2e-2 * scale, (k, float((fa - fb).abs().max()), scale)
+    for (ka, pa), (kb, pb) in zip(a_net.named_buffers(), b_net.named_buffers()):      # running statistics advanced alike
+        if ka.endswith("running_mean"):
+            assert torch.allclose(pa, pb, rtol=2e-2, atol=2e-3), ka
 
 
 @pytest.mark.parametrize("scene", ["single_sweep_x2", "ten_sweeps"])
