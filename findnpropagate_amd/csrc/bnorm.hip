@@ -61,17 +61,34 @@ template <typename T> __device__ __forceinline__ void store8(T *p, const float (
 
 // Statistics pass.  MODE 0 (forward): a = x, b = x * x.  MODE 1 (backward): a = g, b = g * xhat.
 // part[(wg * C + c) * 2 + {0, 1}] = the workgroup's sums for channel c (f64).
+// Round 5: kStatThreads = 512 threads per workgroup instead of 256 (one workgroup per CU either way — the number of partials the
+// finishing launch adds stays 256 — but 8 waves per CU with U x 1-3 16-byte loads in flight each instead of 4), and the sums of a
+// wave meet through lane shuffles (an xor tree over the lanes that hold the same channels: a fixed order) before ONE line per wave
+// goes to LDS.  Same-process A/B (tools/ab_bnorm.py, forward / backward of one layer = statistics + finish + apply, bf16 rows of the
+// four stages at 16 scenes): 22.8 / 44.4 / 51.0 / 44.0 -> 21.5 / 39.5 / 43.2 / 38.4 us forward, 29.5 / 62.4 / 71.1 / 60.8 -> 27.1 /
+// 55.8 / 63.0 / 54.0 us backward, every output bit-identical (1,024 threads: the 16-channel stage slower than before, the rest
+// as 512).
+#ifndef FNP_BN_STAT_THREADS
+#define FNP_BN_STAT_THREADS 512
+#endif
+constexpr int kStatThreads = FNP_BN_STAT_THREADS;
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return __hiloint2double(hi, lo);
+}
 template <typename T, int MODE>
-__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T *__restrict__ x, const T *__restrict__ dy,
-                                                            const T *__restrict__ y, const int *__restrict__ n_rows, int cap,
-                                                            int C, const float *__restrict__ mean,
-                                                            const float *__restrict__ invstd, int relu,
-                                                            double *__restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char fnp_bn_smem[];
-    double *red = reinterpret_cast<double *>(fnp_bn_smem);      // [kThreads][16]
+__global__ __launch_bounds__(kStatThreads) void bn_stats_kernel(const T *__restrict__ x, const T *__restrict__ dy,
+                                                                const T *__restrict__ y, const int *__restrict__ n_rows, int cap,
+                                                                int C, const float *__restrict__ mean,
+                                                                const float *__restrict__ invstd, int relu,
+                                                                double *__restrict__ part) {
+    constexpr int NW = kStatThreads / 64;
+    __shared__ double red[NW][32][16];          // [wave][channel group (<= 32: C <= 256)][8 sums a, 8 sums b]
     const int n = min(*n_rows, cap);
-    const int tpr = C / 8;                     // threads per row
-    const int rows_per_iter = kThreads / tpr;
+    const int tpr = C / 8;                     // threads per row (a power of two, <= 32)
+    const int rows_per_iter = kStatThreads / tpr;
     const int cg = threadIdx.x % tpr, rl = threadIdx.x / tpr;
     double sa[8], sb[8];
 #pragma unroll
@@ -87,9 +104,8 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T *__restrict_
     // contiguous row range per workgroup (so that the partial order is a function of n and the grid only)
     const long long per = ((long long)n + gridDim.x - 1) / gridDim.x;
     const long long r0 = per * blockIdx.x, r1 = min((long long)n, r0 + per);
-    // U rows per trip: their loads (U, 2 U or 3 U of 16 bytes) are all requested before the first is used (one workgroup per CU:
-    // a wave that waits for one row at a time spends the pass waiting); the sums stay in row order
-    constexpr int U = FNP_BN_UNROLL;
+    // U rows per trip: their loads (U, 2 U or 3 U of 16 bytes) are all requested before the first is used; the sums stay in row order
+    constexpr int U = MODE == 1 ? (FNP_BN_UNROLL + 1) / 2 : FNP_BN_UNROLL;   // (backward: three tensors per row, 128 registers at 16 waves per CU)
     for (long long r = r0 + rl; r < r1; r += (long long)U * rows_per_iter) {
         float xv[U][8], gv[U][8], yv[U][8];
 #pragma unroll
@@ -127,26 +143,30 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T *__restrict_
             }
         }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        red[threadIdx.x * 16 + j] = sa[j];
-        red[threadIdx.x * 16 + 8 + j] = sb[j];
-    }
-    __syncthreads();
-    // threads of one channel group sit tpr apart: fixed-order tree over the row lanes
-    for (int s = rows_per_iter / 2; s > 0; s >>= 1) {
-        if (rl < s) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) red[threadIdx.x * 16 + j] += red[(threadIdx.x + s * tpr) * 16 + j];
-        }
-        __syncthreads();
-    }
-    if (rl == 0) {
+    // lanes l, l + tpr, l + 2 tpr, ... of a wave hold the same channels: xor tree over them (tpr <= 32 divides 64)
+    for (int m = 32; m >= tpr; m >>= 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            part[((size_t)blockIdx.x * C + cg * 8 + j) * 2] = red[threadIdx.x * 16 + j];
-            part[((size_t)blockIdx.x * C + cg * 8 + j) * 2 + 1] = red[threadIdx.x * 16 + 8 + j];
+            sa[j] += shfl_xor_f64(sa[j], m);
+            sb[j] += shfl_xor_f64(sb[j], m);
         }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < tpr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[wave][lane][j] = sa[j];
+            red[wave][lane][8 + j] = sb[j];
+        }
+    }
+    __syncthreads();
+    // thread (channel group g, slot j of 16) adds the waves' lines in wave order
+    if ((int)threadIdx.x < tpr * 16) {
+        const int g = threadIdx.x >> 4, j = threadIdx.x & 15;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][g][j];
+        part[((size_t)blockIdx.x * C + g * 8 + (j & 7)) * 2 + (j >> 3)] = v;
     }
 }
 
@@ -259,7 +279,7 @@ __global__ __launch_bounds__(kThreads) void bn_backward_apply_kernel(const T *__
 }
 
 int stats_grid(int cap, int C) {
-    const int rows_per_iter = kThreads / (C / 8);
+    const int rows_per_iter = kStatThreads / (C / 8);
     int g = fnp_divup(cap, rows_per_iter * 8);
     if (g > kMaxParts) g = kMaxParts;
     if (g < 1) g = 1;
@@ -271,7 +291,7 @@ int run_forward(const void *x, const int *n_rows, int cap, int C, const float *g
                 float momentum, float eps, const void *residual, int relu, void *y, float *save_mean, float *save_invstd,
                 void *ws, hipStream_t s, long long *nbt) {
     const int g = stats_grid(cap, C);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_stats_kernel<T, 0>), dim3(g), dim3(kThreads), kThreads * 16 * sizeof(double), s,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_stats_kernel<T, 0>), dim3(g), dim3(kStatThreads), 0, s,
                        (const T *)x, (const T *)nullptr, (const T *)nullptr, n_rows, cap, C, (const float *)nullptr,
                        (const float *)nullptr, 0, (double *)ws);
     FNP_LAUNCH_CHECK();
@@ -289,7 +309,7 @@ int run_backward(const void *dy, const void *x, const void *y, const int *n_rows
                  const float *save_mean, const float *save_invstd, int relu, void *dx, void *dres, float *dgamma, float *dbeta,
                  void *ws, hipStream_t s) {
     const int g = stats_grid(cap, C);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_stats_kernel<T, 1>), dim3(g), dim3(kThreads), kThreads * 16 * sizeof(double), s,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(bn_stats_kernel<T, 1>), dim3(g), dim3(kStatThreads), 0, s,
                        (const T *)x, (const T *)dy, (const T *)y, n_rows, cap, C, save_mean, save_invstd, relu, (double *)ws);
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_finish_kernel, dim3(C <= kFinC ? 1 : C / kFinC), dim3(kThreads), 0, s, (const double *)ws, g, C, n_rows, cap, 1, 0.f, 0.f, dbeta,
