@@ -216,31 +216,50 @@ __device__ __forceinline__ void nbr_row(const RG &g, int b, int loz, int loy, in
     constexpr int K = KZ * KY * KX;
     unsigned msk = 0u;
     int rk[DEFER ? K : 1];
+    // A LINE of the block (fixed z, y) is a nibble of its word; the KX cells of a row's line lie in the nibbles of the two x-adjacent
+    // words: one byte `lb` (cell lox - (lox & 3) + i at bit i).  Per line: the byte and the two "cells before the line" prefixes
+    // (a 64-bit mask and popcount each); per entry a 32-bit and / popcount / select (round 5, after the branch-free form: the 27
+    // entries each built their own 64-bit mask and popcount — ~22 vector instructions per entry, 7 now).
+    const int px0 = lox & 3;
+    unsigned bitx[KX], mA[KX];
+    bool selx[KX], vx[KX];
+#pragma unroll
+    for (int jx = 0; jx < KX; ++jx) {
+        const int pj = px0 + jx, x = lox + jx;             // position in the byte: 0 .. 3 + KX - 1
+        selx[jx] = pj >= 4;                                // the cell lies in the second word
+        bitx[jx] = 1u << pj;
+        mA[jx] = selx[jx] ? ((bitx[jx] - 1u) & 0xF0u) : (bitx[jx] - 1u);   // the cells of ITS nibble before it
+        vx[jx] = x >= 0 && x < g.d.W;
+    }
 #pragma unroll
     for (int jz = 0; jz < KZ; ++jz) {
         const int z = loz + jz;
         const bool cz = (z >> 2) != bz0;
         const bool vz = z >= 0 && z < g.d.D;
+        unsigned long long wz[2][2];
+        unsigned bzv[2][2];
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+                wz[cy][cx] = cz ? w[1][cy][cx] : w[0][cy][cx];
+                bzv[cy][cx] = cz ? base[1][cy][cx] : base[0][cy][cx];
+            }
 #pragma unroll
         for (int jy = 0; jy < KY; ++jy) {
             const int y = loy + jy;
             const bool cy = (y >> 2) != by0;
             const bool vy = vz && y >= 0 && y < g.d.H;
-            const unsigned long long wy0 = cz ? (cy ? w[1][1][0] : w[1][0][0]) : (cy ? w[0][1][0] : w[0][0][0]);
-            const unsigned long long wy1 = cz ? (cy ? w[1][1][1] : w[1][0][1]) : (cy ? w[0][1][1] : w[0][0][1]);
-            const unsigned by0v = cz ? (cy ? base[1][1][0] : base[1][0][0]) : (cy ? base[0][1][0] : base[0][0][0]);
-            const unsigned by1v = cz ? (cy ? base[1][1][1] : base[1][0][1]) : (cy ? base[0][1][1] : base[0][0][1]);
+            const unsigned long long wy0 = cy ? wz[1][0] : wz[0][0], wy1 = cy ? wz[1][1] : wz[0][1];
+            const unsigned by0v = cy ? bzv[1][0] : bzv[0][0], by1v = cy ? bzv[1][1] : bzv[0][1];
             const int line = ((z & 3) << 4) | ((y & 3) << 2);
+            const unsigned long long below = (1ull << line) - 1ull;
+            const unsigned pre0 = by0v + (unsigned)__popcll(wy0 & below), pre1 = by1v + (unsigned)__popcll(wy1 & below);
+            const unsigned lb = ((unsigned)(wy0 >> line) & 0xFu) | (((unsigned)(wy1 >> line) & 0xFu) << 4);
 #pragma unroll
             for (int jx = 0; jx < KX; ++jx) {
-                const int x = lox + jx;
-                const bool cx = (x >> 2) != bx0;
-                const bool v = vy && x >= 0 && x < g.d.W;
-                const unsigned long long ww = cx ? wy1 : wy0;
-                const unsigned bb = cx ? by1v : by0v;
-                const int bit = line | (x & 3);
-                const bool hit = v && ((ww >> bit) & 1ull);
-                const int r = (int)bb + __popcll(ww & ((1ull << bit) - 1ull));
+                const bool hit = vy && vx[jx] && (lb & bitx[jx]) != 0u;
+                const int r = (int)((selx[jx] ? pre1 : pre0) + (unsigned)__popc(lb & mA[jx]));
                 const int e = (jz * KY + jy) * KX + jx;
                 if constexpr (DEFER) {
                     rk[e] = hit ? r : -1;

@@ -203,7 +203,10 @@ struct MfmaCfg {
     static constexpr int LDS_BYTES = (ALLK ? KEFF : WPAIR ? 4 : 2) * SLAB * 16;
     static constexpr int KS = (CIN + 31) / 32;            // 32-wide K steps of the MFMA
     // gather prefetch distance in kernel offsets: 16 gathers in flight per wave
-    static constexpr int PFK = ALLK ? (KS == 1 ? 4 : 2) : 1;
+#ifndef FNP_PFK128
+#define FNP_PFK128 1   // (probe, round 5: fragments of the 128 -> 128 sweep requested TWO offsets ahead)
+#endif
+    static constexpr int PFK = ALLK ? (KS == 1 ? 4 : 2) : (CIN == 128 && COUT == 128 && KVOL == 27) ? FNP_PFK128 : 1;
     // feature window (WIN kernels, 32/64-channel layers): rows [tile - WH, tile + rows + WH) of the
     // input tensor are staged in LDS once per tile; WZERO bytes of zeros follow them
 #ifndef FNP_WH32

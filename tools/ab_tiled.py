@@ -15,6 +15,7 @@ from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64); ap.add_argument("--variants", default=""); ap.add_argument("--channels", default="64,32")
 ap.add_argument("--rounds", type=int, default=5); ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--plain128", action="store_true", help="channels 128: fnp_spconv_forward (row order) instead of the class-sorted sweep")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 B = args.batch
@@ -64,6 +65,16 @@ for tag, rb, n_dev in log:
                                                       P(sh.data_ptr()), P(resid.data_ptr()), ctypes.c_int(1), ctypes.c_int(cin), ctypes.c_int(cout), stream)
             assert rc == 0, (name, rc)
 
+        if args.plain128:     # the row-order sweep of the same table (fnp_spconv_forward) instead of the class-sorted one
+            for L in libs.values():
+                L.fnp_spconv_forward.restype = ctypes.c_int
+
+            def launch(name):
+                rc = libs[name].fnp_spconv_forward(P(x.data_ptr()), ctypes.c_int(_l.dtype_code(x)), ctypes.c_int(x.shape[0]), P(w.data_ptr()), P(rb.nbr.data_ptr()),
+                                                   ctypes.c_int(rb.nbr.shape[1]), ctypes.c_int(27), P(n_dev.data_ptr()), ctypes.c_int(rb.cap_out), P(outs[name].data_ptr()),
+                                                   ctypes.c_int(_l.dtype_code(x)), P(sc.data_ptr()), P(sh.data_ptr()), P(resid.data_ptr()), ctypes.c_int(1), ctypes.c_int(0),
+                                                   ctypes.c_int(cin), ctypes.c_int(cout), stream)
+                assert rc == 0, (name, rc)
         for name in libs:
             for _ in range(3):
                 launch(name)
@@ -79,7 +90,7 @@ for tag, rb, n_dev in log:
                 e1.record()
                 torch.cuda.synchronize()
                 times[name].append(e0.elapsed_time(e1) / args.reps)
-        print(json.dumps({"channels": cin, "kernel": "sorted", "rows": n, "scenes": B,
+        print(json.dumps({"channels": cin, "kernel": "plain" if args.plain128 else "sorted", "rows": n, "scenes": B,
                           "ms_per_launch_median": {k: round(float(np.median(v)), 4) for k, v in times.items()},
                           "ms_all_rounds": {k: [round(t, 4) for t in v] for k, v in times.items()}, "bit_identical_to_main": equal}), flush=True)
         continue
