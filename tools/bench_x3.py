@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Secondary measurement: the 1e-4-grade engine on the bf16 matrix pipe (FNP_DTYPE: bf16x3 — features and weights split into two
+"""Secondary measurement: the f32-GRADE engine on the bf16 matrix pipe — ~2e-5 of the feature scale, NOT BASELINE.json's absolute 1e-4
+(1.8e-3 absolute at features of 65) — (FNP_DTYPE: bf16x3 — features and weights split into two
 bf16 terms, three bf16 MFMA products per term pair, f32 accumulate and f32 activations between layers) — scenes/s at B scenes
 per step, and its largest absolute deviation from the f32 engine (which is the CPU oracle bit for bit) at the five outputs."""
 import argparse, json, os, sys, time
