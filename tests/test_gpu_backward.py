@@ -198,7 +198,8 @@ def test_ddp_wraps_the_backbone(cuda, rng):
 
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("bf16", 2e-2), ("fp16", 3e-3)])
-@pytest.mark.parametrize("C,n,with_res", [(16, 2, False), (32, 777, True), (64, 20000, True), (128, 5001, False)])
+@pytest.mark.parametrize("C,n,with_res", [(16, 2, False), (32, 777, True), (64, 20000, True), (128, 5001, False),
+                                          (8, 100, False), (256, 3001, True), (16, 70001, True)])   # (8 / 256: one / 32 threads per row in the statistics pass)
 def test_fused_bn_relu_residual_matches_torch(cuda, rng, dtype, tol, C, n, with_res):
     """spconv/norm.bn_act (csrc/bnorm.hip) == nn.BatchNorm1d(train) -> (+ residual) -> ReLU evaluated by torch in f32 on
     the same stored values: output, input / residual / affine gradients, running statistics, num_batches_tracked;
@@ -241,8 +242,16 @@ def test_fused_bn_relu_residual_matches_torch(cuda, rng, dtype, tol, C, n, with_
     assert ((dx_a[:n].float() - x.grad).abs() * sure).max() <= tol * scale(x.grad) + 2.0 * float((~sure).sum()) / n * scale(dy.float())
     if with_res:
         assert ((dr_a[:n].float() - r.grad).abs() * sure).max() <= tol * scale(r.grad)
-    assert (bn_a.weight.grad - bn_b.weight.grad).abs().max() <= max(tol, 1e-4) * scale(bn_b.weight.grad)
-    assert (bn_a.bias.grad - bn_b.bias.grad).abs().max() <= max(tol, 1e-4) * scale(bn_b.bias.grad)
+    # (an element whose ReLU fell on the other side carries its whole dy, and dy * xhat, into the affine gradients of its channel:
+    #  with 70 k rows one such element is likely; the allowance is exactly those elements' contribution)
+    flip = ((y_a[:n].float() > 0) != (y_t.detach() > 0)) & ~sure
+    xd = x.detach()
+    xhat = (xd - xd.mean(0)) / torch.sqrt(xd.var(0, unbiased=False) + bn_b.eps)
+    slack_b = (flip * dy[:n].float().abs()).sum(0) * 1.01
+    slack_g = (flip * (dy[:n].float() * xhat).abs()).sum(0) * 1.01
+    assert ((bn_a.weight.grad - bn_b.weight.grad).abs() <= max(tol, 1e-4) * scale(bn_b.weight.grad) + slack_g).all()
+    assert ((bn_a.bias.grad - bn_b.bias.grad).abs() <= max(tol, 1e-4) * scale(bn_b.bias.grad) + slack_b).all()
+    assert int(flip.sum()) <= 3
     assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-6)
     assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-5, atol=1e-6)
     assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 1
