@@ -615,7 +615,7 @@ def main():
             "train_step": ([py, os.path.join(T, "bench_train.py"), "--batch", "16"], 240),
             # the step transfusion_lidar.yaml actually runs per GPU (BATCH_SIZE_PER_GPU 4, :147; MAX_SWEEPS 10, nuscenes_dataset.yaml:5; AMP,
             # train_utils.py:135-176): four 10-sweep scenes under autocast(fp16) + GradScaler + clip_grad_norm_
-            "train_step_cfg": ([py, os.path.join(T, "bench_train.py"), "--batch", "4", "--sweeps", "10", "--amp", "--reps", "4"], 240),
+            "train_step_cfg": ([py, os.path.join(T, "bench_train.py"), "--batch", "4", "--sweeps", "10", "--amp", "--reps", "6"], 240),
             "first_bev_block": ([py, os.path.join(T, "bench_bev.py"), "--batch", "16"], 240),
             # the density transfusion_lidar.yaml feeds the backbone (nuscenes_dataset.yaml:5 MAX_SWEEPS 10): emulated 10-sweep scenes
             "ten_sweep": ([py, os.path.join(T, "bench_sweeps.py"), "--batch", "8"], 240),

@@ -8,7 +8,7 @@ import numpy as np, torch
 from findnpropagate_amd import sparse as S, synthetic as syn
 from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
 
-ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4); ap.add_argument("--reps", type=int, default=5)
+ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=4); ap.add_argument("--reps", type=int, default=7)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--sweeps", type=int, default=1, help="10: the density transfusion_lidar.yaml trains on (nuscenes_dataset.yaml:5 MAX_SWEEPS 10): ~300 k points, ~150 k voxels per scene")
 ap.add_argument("--amp", action="store_true", help="the reference's AMP recipe (tools/train_utils/train_utils.py:135-176): autocast(fp16) around the forward, "
@@ -34,12 +34,15 @@ def fwd(all_outputs=True):
     return sum((t.features.float() ** 2).mean() for t in ts)
 
 def timed(fn, reps):
+    # MEDIAN of the steps' own durations (events around every step, steps issued back to back): one step in a few dozen stalls for
+    # 50-100 ms on this pool (allocator growth, a host hiccup) and would otherwise decide the mean of five
     for _ in range(2): fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); e0.record()
-    for _ in range(reps): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    torch.cuda.synchronize(); evs[0].record()
+    for i in range(reps):
+        fn(); evs[i + 1].record()
+    torch.cuda.synchronize()
+    return float(np.median([evs[i].elapsed_time(evs[i + 1]) for i in range(reps)]))
 
 scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 12) if args.amp else None
 
