@@ -72,6 +72,9 @@ template <typename T> __device__ __forceinline__ void store8(T *p, const float (
 #define FNP_BN_STAT_THREADS 512
 #endif
 constexpr int kStatThreads = FNP_BN_STAT_THREADS;
+// whole waves; 32 lanes per row at most (C <= 256) must fit a wave-aligned workgroup; red[NW][32][16] f64 is 4 KB per wave of
+// static LDS: 1,024 threads sit exactly on the 64 KB limit
+static_assert(kStatThreads % 64 == 0 && kStatThreads >= 64 && kStatThreads <= 1024, "FNP_BN_STAT_THREADS: a multiple of 64 in [64, 1024]");
 __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __shfl_xor(lo, m);
@@ -160,9 +163,11 @@ __global__ __launch_bounds__(kStatThreads) void bn_stats_kernel(const T *__restr
         }
     }
     __syncthreads();
-    // thread (channel group g, slot j of 16) adds the waves' lines in wave order
-    if ((int)threadIdx.x < tpr * 16) {
-        const int g = threadIdx.x >> 4, j = threadIdx.x & 15;
+    // slot (channel group g, sum j of 16) adds the waves' lines in wave order; a strided loop over the tpr * 16 <= 512 slots, so that
+    // any workgroup size of the FNP_BN_STAT_THREADS switch writes every partial (with `threadIdx.x < tpr * 16` a
+    // 256-thread build left the partials of channel groups 16-31 of a 256-channel layer unwritten)
+    for (int slot = threadIdx.x; slot < tpr * 16; slot += kStatThreads) {
+        const int g = slot >> 4, j = slot & 15;
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += red[w][g][j];

@@ -42,16 +42,10 @@ __device__ __forceinline__ int fnp_lane() { return threadIdx.x & 63; }
 // at 128 scenes (rocprofv3 averages of two builds on one box, round 5): vox_emit -6 %, vox_flag -13 %, the 64-channel tile-rulebook
 // kernel -8 %, the small-grid prefix pass -13 %, the sparse clear -4 %; every kernel whose time is ATOMICS got slower (vox_mark
 // +26 %, strided_mark2 +8 / +13 %, vox_insert +4 %) and keeps the interleaved order.  The whole step did not move (+-0.3 %).
-#ifndef FNP_XCD_SWZ
-#define FNP_XCD_SWZ 1
+#include "xcdmap.h"   // fnp_xcd_map(G, b): plain C++, compiled by the host test as it stands
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned fnp_xcd_block() { return fnp_xcd_map(gridDim.x, blockIdx.x); }
 #endif
-// (restated and checked on the host: tests/test_host_logic_r5.py)
-__device__ __forceinline__ unsigned fnp_xcd_block() {
-    const unsigned G = gridDim.x, b = blockIdx.x;
-    if (!FNP_XCD_SWZ || G < 16u) return b;
-    const unsigned per = G >> 3, rem = G & 7u, x = b & 7u, sl = b >> 3;
-    return (x < rem ? x * (per + 1u) : rem * (per + 1u) + (x - rem) * per) + sl;
-}
 
 
 // Fill `count` 32-bit words at a 4-byte aligned address with `value`.  The library never issues hipMemsetAsync on a path a

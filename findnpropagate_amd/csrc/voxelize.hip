@@ -523,8 +523,9 @@ extern "C" int fnp_rankgrid_clear_multi(int count, const int *const *coords, con
         jobs.j[i].g = fnp_rg_view(&grids[i]);
         if (caps[i] > cap_max) cap_max = caps[i];
     }
-    hipLaunchKernelGGL(rg_clear_multi_kernel, dim3(fnp_grid_for(cap_max, kThreads, 512), count), dim3(kThreads), 0,
-                       (hipStream_t)stream, jobs);
+    // (gridDim.x a multiple of 8: fnp_xcd_block()'s one-run-per-XCD property on a 2-D grid needs it — common.h)
+    const int gx = (fnp_grid_for(cap_max, kThreads, 512) + 7) & ~7;
+    hipLaunchKernelGGL(rg_clear_multi_kernel, dim3(gx, count), dim3(kThreads), 0, (hipStream_t)stream, jobs);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }

@@ -53,13 +53,20 @@ def multi_classes_nms(cls_scores, box_preds, nms_config, score_thresh=None):
     _l.require_device(cls_scores, box_preds)
     rotated = {"nms_gpu": 1, "nms_normal_gpu": 0}[_cfg(nms_config, "NMS_TYPE")]
     per_class = cls_scores.t().float()                                        # (num_class, N)
-    if score_thresh is not None:
-        per_class = torch.where(per_class >= score_thresh, per_class, per_class.new_full((), float("-inf")))
+    # which boxes take part is an explicit mask, not a sentinel score (with -inf as the sentinel a genuine -inf score
+    # was dropped when no threshold is given, and a NaN score — first in a descending sort, never counted — pushed valid boxes off
+    # the counted prefix).  A NaN never passes a threshold (`>=` is false, as in the reference's mask); without a threshold every
+    # box takes part, NaN ones last.
+    valid = (per_class >= score_thresh) if score_thresh is not None else torch.ones_like(per_class, dtype=torch.bool)
+    key = torch.where(valid & ~torch.isnan(per_class), per_class, per_class.new_full((), float("-inf")))
     cap = min(int(_cfg(nms_config, "NMS_PRE_MAXSIZE")), n)
-    # (a STABLE descending sort, not top-k: equal scores keep their index order whatever the backend's top-k does)
-    top_scores, top_idx = torch.sort(per_class, dim=1, descending=True, stable=True)
-    top_scores, top_idx = top_scores[:, :cap], top_idx[:, :cap]
-    counts = (top_scores > float("-inf")).sum(dim=1).to(torch.int32)         # boxes of each class that passed the threshold
+    # (a STABLE descending sort, not top-k: equal scores keep their index order whatever the backend's top-k does.  Boxes that do
+    #  not take part sort behind every box that does: the sort key of an invalid box is -inf AND it is ordered after the valid -inf
+    #  ones by sorting on (invalid, -key) — one stable sort on the validity after the stable sort on the score)
+    _, idx1 = torch.sort(key, dim=1, descending=True, stable=True)
+    _, idx2 = torch.sort((~valid).gather(1, idx1).to(torch.uint8), dim=1, stable=True)
+    top_idx = idx1.gather(1, idx2)[:, :cap]
+    counts = valid.sum(dim=1).clamp(max=cap).to(torch.int32)                  # boxes of each class that take part (<= cap)
     boxes = box_preds[top_idx.reshape(-1), 0:7].float().contiguous()          # (num_class * cap, 7)
     L = _l.load()
     ws = torch.empty((max(int(L.fnp_nms_batched_workspace_bytes(num_class, cap)), 8),), dtype=torch.uint8, device=dev)

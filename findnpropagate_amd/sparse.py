@@ -713,6 +713,17 @@ WGRAD_PAIR_SHAPES = {(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128)
 WGRAD_PAIRS = os.environ.get("FNP_WGRAD_PAIRS", "1") == "1"
 
 
+def mfma_pad_channels(cin, cout):
+    """Input channels a 16-bit training layer of `cin` < 16 channels is zero-padded to so that its forward AND its weight gradient
+    run on the matrix kernels (SPLIT_SHAPES = the shapes the 16-bit matrix kernel covers, WGRAD_PAIR_SHAPES those of the MFMA
+    weight gradient), or 0 when no such shape exists / none is needed: conv_input (4 / 5 -> 16, and 4 / 5 -> 32 of a wider first
+    layer) -> 16."""
+    if (cin, cout) in SPLIT_SHAPES and (cin, cout) in WGRAD_PAIR_SHAPES:
+        return 0
+    fits = sorted(ci for (ci, co) in SPLIT_SHAPES & WGRAD_PAIR_SHAPES if co == cout and ci >= cin)
+    return fits[0] if fits else 0
+
+
 def rulebook_pairs(rb, n_out_dev, rows=None):
     """Pair lists of a rulebook (fnp_rulebook_pairs), kept with it (`rb._pairs` = (pair_o, pair_i, pair_count)): per kernel
     offset the output rows that have a neighbour there, ascending, and those neighbours.  Built once per rulebook and

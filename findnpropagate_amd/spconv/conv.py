@@ -137,6 +137,13 @@ class SparseConvolution(SparseModule):
             self._packed[key] = hit
         return hit[1]
 
+    def pad_channels(self, dtype):
+        """zero channels appended to the input of a 16-bit TRAINING forward so that the layer runs on the MFMA kernels (0: none)"""
+        if dtype not in (torch.float16, torch.bfloat16) or self.in_channels >= 16 or not kvol_is_27(self.kernel_size):
+            return 0
+        to = S.mfma_pad_channels(self.in_channels, self.out_channels)
+        return to - self.in_channels if to else 0
+
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         """Checkpoints written with spconv 1.x hold the weight as (kD, kH, kW, Cin, Cout); the reference's loader adapts them
         (detector3d_template.py:401-433: permute(4, 0, 1, 2, 3) gives this module's (Cout, kD, kH, kW, Cin)).  A plain
@@ -169,8 +176,9 @@ class SparseConvolution(SparseModule):
         # and the weight are zero-padded to 16 channels and the layer runs on the MFMA kernels, forward and weight gradient (the
         # padding's own backward slices the gradient back) — the thread-per-element kernels these shapes otherwise take cost
         # 0.34 + 0.39 ms per step at the shipped training configuration, the 16 -> 16 MFMA ones 0.03 + 0.05
-        pad_c = 16 - self.in_channels if (with_grad and feats.is_cuda and feats.dtype in (torch.float16, torch.bfloat16)
-                                          and self.in_channels < 16 and self.out_channels == 16) else 0
+        # (which layers: derived from the channel pairs the matrix kernels cover — sparse.mfma_pad_channels —, not a literal 16 -> 16:
+        #  a 4 / 5 -> 32 first layer pads to 16 -> 32 the same way)
+        pad_c = self.pad_channels(feats.dtype) if (with_grad and feats.is_cuda) else 0
         weight = self.weight
         if pad_c:
             feats = torch.nn.functional.pad(feats, (0, pad_c))
@@ -279,6 +287,8 @@ def prepack_weights(convs_and_dtypes):
         w = conv.weight
         if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
             continue
+        if conv.pad_channels(dtype):
+            continue    # (its forward pads features and weight and packs the padded weight itself: a pack of the bare one is dead work)
         odd = all(int(v) & 1 for v in conv.kernel_size)
         groups.setdefault(dtype, []).append((conv, 2 if (conv.subm and odd) else 3))
     for dtype, items in groups.items():

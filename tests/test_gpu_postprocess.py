@@ -67,6 +67,38 @@ def test_class_agnostic_and_multi_class_nms(cuda, oracle, rng, nms_type, score_t
     assert np.array_equal(pb.cpu().numpy(), np.concatenate(wb))
 
 
+@pytest.mark.parametrize("score_thresh", [None, 0.35])
+def test_multi_class_nms_with_minus_inf_and_nan_scores(cuda, oracle, rng, score_thresh):
+    """which boxes take part is a mask, not a -inf sentinel.  Without a threshold the reference keeps every box
+    (model_nms_utils.py:38-45: the mask exists only `if score_thresh is not None`), a genuine -inf score included; NaN scores
+    never pass a threshold and must not push valid boxes off the list handed to the NMS."""
+    from findnpropagate_amd.model_utils import model_nms_utils as M
+    n = 120
+    boxes = syn.random_boxes(rng, n, centre_range=40.0)          # spread out: nearly everything survives the NMS
+    boxes9 = np.concatenate([boxes, rng.normal(size=(n, 2)).astype(np.float32)], 1)
+    s0 = rng.permutation(n).astype(np.float32) / n
+    s1 = s0.copy()
+    s1[[3, 50]] = -np.inf
+    s2 = s0.copy()
+    s2[[7, 8, 90]] = np.nan
+    cls = np.stack([s0, s1, s2], 1)
+    cfg = {"NMS_TYPE": "nms_normal_gpu", "NMS_THRESH": 0.2, "NMS_PRE_MAXSIZE": 200, "NMS_POST_MAXSIZE": 200}
+    ps, pl, pb = M.multi_classes_nms(torch.from_numpy(cls).to(cuda), torch.from_numpy(boxes9).to(cuda), cfg, score_thresh)
+    ps, pl = ps.cpu().numpy(), pl.cpu().numpy()
+    # class 0 (clean scores) is the oracle's; the other two classes: the same boxes minus those that cannot take part
+    w0, _ = oracle.class_agnostic_nms(s0, boxes9, "nms_normal_gpu", 0.2, 200, 200, score_thresh)
+    assert np.array_equal(ps[pl == 0], s0[w0])
+    if score_thresh is None:
+        # every box takes part: -inf ones are kept (last), NaN ones too, and no valid box is cut off
+        assert (pl == 1).sum() >= (pl == 0).sum() - 2 and np.isneginf(ps[pl == 1]).sum() == 2
+        valid2 = ps[pl == 2][~np.isnan(ps[pl == 2])]
+        assert len(valid2) >= (pl == 0).sum() - 3 and np.all(np.diff(valid2) <= 0)
+    else:
+        assert not np.isinf(ps).any() and not np.isnan(ps).any() and (ps >= score_thresh).all()
+        w2, _ = oracle.class_agnostic_nms(np.where(np.isnan(s2), np.float32(-1.0), s2), boxes9, "nms_normal_gpu", 0.2, 200, 200, score_thresh)
+        assert np.array_equal(ps[pl == 2], s2[w2])
+
+
 def test_recall_counter_vector_on_record_rows(cuda, oracle, rng):
     """The extraction pipeline's form: predictions are the strided body rows of a (K_MAX + 1, 9) record, the live-row
     count is a device float (the record header), counters accumulate on the device; a zero row in the MIDDLE of the

@@ -3,19 +3,42 @@ import numpy as np
 import pytest
 
 
-def xcd_block(b, G):
-    """findnpropagate_amd/csrc/common.h fnp_xcd_block(): the logical block of hardware workgroup b of a G-workgroup launch."""
-    if G < 16:
-        return b
-    per, rem, x, sl = G >> 3, G & 7, b & 7, b >> 3
-    return (x * (per + 1) if x < rem else rem * (per + 1) + (x - rem) * per) + sl
+_XCD_SRC = r"""
+#include <cstdio>
+#include <cstdlib>
+#include "xcdmap.h"
+int main(int argc, char **argv) {
+    for (int a = 1; a < argc; ++a) {
+        const unsigned G = (unsigned)atoi(argv[a]);
+        for (unsigned b = 0; b < G; ++b) printf("%u ", fnp_xcd_map(G, b));
+        printf("\n");
+    }
+    return 0;
+}
+"""
+_XCD_GS = [1, 7, 15, 16, 17, 23, 64, 255, 256, 257, 2047, 2048]
 
 
-@pytest.mark.parametrize("G", [1, 7, 15, 16, 17, 23, 64, 255, 256, 257, 2047, 2048])
-def test_xcd_contiguous_workgroup_order_is_a_bijection_with_one_run_per_xcd(G):
+@pytest.fixture(scope="module")
+def xcd_tables(tmp_path_factory):
+    """fnp_xcd_map AS SHIPPED (findnpropagate_amd/csrc/xcdmap.h, the function fnp_xcd_block() calls on the device), compiled for
+    the host with g++ and run for every grid size of the test: {G: [logical block of hardware workgroup b]}"""
+    import os
+    import subprocess
+    d = tmp_path_factory.mktemp("xcd")
+    src, exe = d / "xcd.cpp", d / "xcd"
+    src.write_text(_XCD_SRC)
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "findnpropagate_amd", "csrc")
+    subprocess.run(["g++", "-O1", "-std=c++17", f"-I{inc}", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)] + [str(g) for g in _XCD_GS], check=True, capture_output=True, text=True).stdout
+    return {g: [int(v) for v in line.split()] for g, line in zip(_XCD_GS, out.splitlines())}
+
+
+@pytest.mark.parametrize("G", _XCD_GS)
+def test_xcd_contiguous_workgroup_order_is_a_bijection_with_one_run_per_xcd(G, xcd_tables):
     """Workgroup b runs on XCD b & 7; the renumbering must hit every logical block exactly once (results cannot change) and
     give every XCD ONE contiguous run of logical blocks (that is what it is for)."""
-    lb = np.array([xcd_block(b, G) for b in range(G)])
+    lb = np.array(xcd_tables[G])
     assert np.array_equal(np.sort(lb), np.arange(G))
     if G >= 16:
         for x in range(8):
