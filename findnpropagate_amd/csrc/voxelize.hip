@@ -291,14 +291,20 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
         reinterpret_cast<int4 *>(coords)[id] = make_int4(bb, z, y, x);
         num_points[id] = np;
         const float norm = (float)(np < 1 ? 1 : np);
-        // per channel the sum runs in ascending point order, like sum(dim=1) over the sorted block
-        if (C == 5 || C == 4) {
+        // Per channel the kept points meet in the order torch's CPU `voxels.sum(dim=1)` adds the slots of the (M, max_points, C) block
+        // (mean_vfe.py:26; round 6: held to the reference's own class bit for bit, tests/golden/meanvfe_golden.npz).  That order
+        // is cascade_sum's (aten/src/ATen/native/cpu/SumKernel.cpp, restated in oracle/fnp_oracle.c orc_mean_vfe): for C < 8 the
+        // columns 0 .. 4 * (C / 4) - 1 in slot order, the C % 4 columns left over — t of a 5-feature nuScenes point — as FOUR
+        // interleaved partial sums (slot j to partial j & 3 for j < 4 * (P / 4)), partial 0 then takes the P % 4 tail slots and
+        // the partials 1, 2, 3; blocks of 16 slots cascade through accumulator levels (P >= 16 only).  Padding slots are zeros.
+        if ((C == 5 || C == 4) && maxp < 16) {
             // nuScenes / KITTI point rows (x y z intensity [t]) as ONE 16-byte access + one dword instead of five dword accesses:
             // this kernel is bound by the NUMBER of scattered requests it puts through L2 (~22 per voxel before, round 5), not by
             // bytes.  Rows are 4-byte aligned only: f4u carries that alignment (global memory takes dword-aligned wide accesses).
             typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
             f4u s4 = {0.f, 0.f, 0.f, 0.f};
-            float s1f = 0.f;
+            float part[4] = {0.f, 0.f, 0.f, 0.f}, tl[3] = {0.f, 0.f, 0.f};
+            const int P4 = maxp & ~3;
             int pi = p0;
             for (int j = 0; j < np; ++j) {
                 const float *pr = pts + (size_t)pi * C;
@@ -306,36 +312,87 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
                 const float v1 = C == 5 ? pr[4] : 0.f;
                 if (j + 1 < np) pi = next_above(pi);   // (the slots are in L1: the search runs under the point's loads)
                 s4 += v4;
-                s1f += v1;
+                // (register selects, no indexed array: a partial is never -0.0, so the + 0.f of the other three is exact)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) part[k] += (j < P4 && (j & 3) == k) ? v1 : 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) tl[k] = (j == P4 + k) ? v1 : tl[k];
             }
             float *mo = mean + (size_t)id * C;
             f4u m4 = {s4[0] / norm, s4[1] / norm, s4[2] / norm, s4[3] / norm};
             *reinterpret_cast<f4u *>(mo) = m4;
-            if (C == 5) mo[4] = s1f / norm;
-        } else if (C <= 8) {
-            float s8[8];
+            if (C == 5) {
+                float s1f = part[0];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) s8[c] = 0.f;
-            int pi = p0;
-            for (int j = 0; j < np; ++j) {
-                const float *pr = pts + (size_t)pi * C;
-                float v8[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v8[c] = c < C ? pr[c] : 0.f;
-                if (j + 1 < np) pi = next_above(pi);   // (the slots are in L1: the search runs under the point's loads)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) s8[c] += v8[c];
+                for (int k = 0; k < 3; ++k) s1f += (P4 + k < maxp) ? tl[k] : 0.f;
+                s1f += part[1];
+                s1f += part[2];
+                s1f += part[3];
+                mo[4] = s1f / norm;
             }
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (c < C) mean[(size_t)id * C + c] = s8[c] / norm;
         } else {
+            // any other shape: column by column with the cascade written out (a pass over the voxel's points per column)
             for (int c = 0; c < C; ++c) {
-                float sacc = 0.f;
+                const bool ilp = C < 8 && c >= (C / 4) * 4;           // a left-over column: four interleaved partials
+                const int nsum = ilp ? 4 : 1, size = ilp ? maxp / 4 : maxp;
+                int lp = 0;
+                while ((1 << lp) < size) ++lp;
+                lp = C >= 8 ? 30 : max(4, lp / 4);                       // (C >= 8: slot order, as the oracle — torch's form depends on the host ISA)
+                const int mask = (1 << lp) - 1;
+                float acc[4][4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int l = 0; l < 4; ++l) acc[k][l] = 0.f;
+                float tail = 0.f;
+                bool tail_started = false;
                 int pi = p0;
-                for (int j = 0; j < np; ++j) {
-                    sacc += pts[(size_t)pi * C + c];
+                for (int j = 0; j < maxp; ++j) {                         // every slot, the zero padding included (it moves the cascade's levels)
+                    const float v = j < np ? pts[(size_t)pi * C + c] : 0.f;
                     if (j + 1 < np) pi = next_above(pi);
+                    if (j < size * nsum) {
+                        const int e = j / nsum + 1;                      // elements this partial holds after the add
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (k != (ilp ? (j & 3) : 0)) continue;
+                            acc[k][0] += v;
+                            if ((e & mask) == 0) {
+#pragma unroll
+                                for (int l = 1; l < 4; ++l) {
+                                    acc[k][l] += acc[k][l - 1];
+                                    acc[k][l - 1] = 0.f;
+                                    if ((e & (mask << (l * lp))) != 0) break;
+                                }
+                            }
+                        }
+                    } else {                                             // the P % 4 tail slots of a left-over column go to partial 0
+                        if (!tail_started) {
+#pragma unroll
+                            for (int l = 1; l < 4; ++l) acc[0][0] += acc[0][l];
+                            tail = acc[0][0];
+                            tail_started = true;
+                        }
+                        tail += v;
+                    }
+                }
+                float sacc;
+                if (ilp) {
+                    if (!tail_started) {
+#pragma unroll
+                        for (int l = 1; l < 4; ++l) acc[0][0] += acc[0][l];
+                        tail = acc[0][0];
+                    }
+                    sacc = tail;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) {
+#pragma unroll
+                        for (int l = 1; l < 4; ++l) acc[k][0] += acc[k][l];
+                        sacc += acc[k][0];
+                    }
+                } else {
+#pragma unroll
+                    for (int l = 1; l < 4; ++l) acc[0][0] += acc[0][l];
+                    sacc = acc[0][0];
                 }
                 mean[(size_t)id * C + c] = sacc / norm;
             }

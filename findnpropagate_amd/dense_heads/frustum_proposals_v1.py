@@ -361,6 +361,11 @@ class FrustumProposerOG(nn.Module):
                              _l.ptr(dbg.get('npts')), _l.ptr(dbg.get('frust')), _l.ptr(dbg.get('cand')),
                              _l.ptr(dbg.get('iou')), _l.ptr(dbg.get('count')), _l.ptr(dbg.get('valid')), _l.stream())
         _l.check(rc, "fnp_boxseeker")
+        if debug:
+            # the lidar-frame points of every frustum as the kernel counted them (second half of its workspace: (F, stride, 3) f32,
+            # the first npts[f] rows of frustum f) — what the reference hands to points_in_boxes_gpu per candidate (:812-815,930-932)
+            stride = max(max_pts, 1)
+            dbg['points_xyz'] = ws[F * stride * 12: 2 * F * stride * 12].view(torch.float32).view(F, stride, 3)
         out_count = out_valid
         if TK > 1:   # row form (device ops, no sync): one row per (frustum, rank), valid while rank < the frustum's box count
             out_valid = (torch.arange(TK, device=dev, dtype=torch.int32)[None, :] < out_count[:, None]).to(torch.int32).reshape(-1)

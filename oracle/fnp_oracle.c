@@ -352,14 +352,68 @@ ORC_API int orc_voxelize(const float *points, int n, int C, const float *range_m
     return voxel_num;
 }
 
-/* MeanVFE.forward, pcdet/models/backbones_3d/vfe/mean_vfe.py:25-29: sum over the max_points
- * slots (zero padded) in slot order, divided by clamp_min(num_points, 1). */
+/* MeanVFE.forward, pcdet/models/backbones_3d/vfe/mean_vfe.py:25-29: `voxels.sum(dim=1) / clamp_min(num_points, 1)`.
+ *
+ * The ORDER in which the <= max_points addends of a column meet is torch's (round 6: tests/golden/meanvfe_golden.npz, written by the
+ * reference's own class on the CPU, showed that a plain slot-order sum differs from it in the last bit of the LAST column of
+ * 5-feature points — the time lag of multi-sweep nuScenes points; single-sweep scenes have t = 0 and never showed it).  torch's CPU
+ * `sum` of a float tensor is cascade_sum (aten/src/ATen/native/cpu/SumKernel.cpp; torch 2.10 installed here, the kernel has had this
+ * form since 1.7).  For a contiguous (M, P, C) tensor reduced over dim 1 the 2-D loop it sees is size0 = P (the reduced dimension,
+ * stride C) x size1 = C (stride 1); with C < 8 = Vec<float>::size() of the narrowest vector build, neither vectorised form applies
+ * and it runs scalar_outer_sum:
+ *     columns 0 .. 4 * (C / 4) - 1, four at a time: multi_row_sum  — every column on its own, slots in order, cascaded through four
+ *                                                     accumulator levels in blocks of 2^max(4, ceil_log2(P) / 4) slots;
+ *     the C % 4 columns left over, one at a time:   row_sum        — FOUR interleaved partial sums (slot j goes to partial j & 3
+ *                                                     for j < 4 * (P / 4), each partial a multi_row_sum over its P / 4 slots), then
+ *                                                     partial 0 takes the P % 4 tail slots, then partials 1, 2, 3.
+ * With P = 10, C = 5 (transfusion_lidar.yaml): x y z intensity in slot order, t = ((((t0 + t4) + t8) + t9) + (t1 + t5)) + (t2 + t6))
+ * + (t3 + t7).  C >= 8 columns take torch's vectorised forms, whose grouping depends on the host's vector ISA (AVX2 / AVX-512): not
+ * restated — such inputs are summed in slot order here (they are not on the path: nuScenes 5, KITTI 4 features). */
+static int orc_ceil_log2(int64_t x) {
+    int l = 0;
+    while (((int64_t)1 << l) < x) ++l;
+    return l;
+}
+/* multi_row_sum for one column: elements e = 0 .. size - 1 at base[e * stride] */
+static float orc_cascade_sum(const float *base, int64_t stride, int64_t size) {
+    const int levels = 4;
+    int lp = orc_ceil_log2(size) / levels;
+    if (lp < 4) lp = 4;
+    const int64_t step = (int64_t)1 << lp, mask = step - 1;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int64_t i = 0;
+    while (i + step <= size) {
+        for (int64_t j = 0; j < step; ++j, ++i) acc[0] += base[i * stride];
+        for (int j = 1; j < levels; ++j) {
+            acc[j] += acc[j - 1];
+            acc[j - 1] = 0.f;
+            if ((i & (mask << (j * lp))) != 0) break;
+        }
+    }
+    for (; i < size; ++i) acc[0] += base[i * stride];
+    for (int j = 1; j < levels; ++j) acc[0] += acc[j];
+    return acc[0];
+}
 ORC_API void orc_mean_vfe(const float *voxels, const int *num_points, int M, int max_points, int C, float *out) {
+    const int P = max_points, c4 = C < 8 ? (C / 4) * 4 : C;
     for (int v = 0; v < M; ++v) {
-        float norm = (float)(num_points[v] < 1 ? 1 : num_points[v]);
+        const float norm = (float)(num_points[v] < 1 ? 1 : num_points[v]);
+        const float *row = voxels + (size_t)v * P * C;
         for (int c = 0; c < C; ++c) {
-            float s = 0.f;
-            for (int p = 0; p < max_points; ++p) s += voxels[((size_t)v * max_points + p) * C + c];
+            float s;
+            if (C >= 8) {                       /* (outside the restated domain: slot order) */
+                s = 0.f;
+                for (int p = 0; p < P; ++p) s += row[(size_t)p * C + c];
+            } else if (c < c4) {
+                s = orc_cascade_sum(row + c, C, P);
+            } else {                            /* row_sum: ilp_factor 4 */
+                const int ilp = P / 4;
+                float part[4];
+                for (int k = 0; k < 4; ++k) part[k] = orc_cascade_sum(row + (size_t)k * C + c, (int64_t)4 * C, ilp);
+                for (int p = ilp * 4; p < P; ++p) part[0] += row[(size_t)p * C + c];
+                for (int k = 1; k < 4; ++k) part[0] += part[k];
+                s = part[0];
+            }
             out[(size_t)v * C + c] = s / norm;
         }
     }

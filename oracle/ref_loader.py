@@ -36,3 +36,18 @@ def iou3d_gpu_lib():
     import torch  # noqa: F401
 
     return ctypes.CDLL(path)
+
+
+def pib_gpu_lib():
+    """The reference's point-in-box device code (roiaware_pool3d_kernel.cu:16-36,313-336, extracted by line range at build time)
+    compiled by hipcc for gfx950 behind ref_pib_gpu.hip's launcher (needs a GPU to call):
+    ref_points_in_boxes(B, T, M, boxes (B,T,7), pts (B,M,3), box_idx_of_points (B,M) prefilled -1, stream)."""
+    path = os.path.join(_REF, "libref_pib_gpu.so")
+    if not os.path.exists(path):
+        return None
+    import torch  # noqa: F401
+
+    lib = ctypes.CDLL(path)
+    lib.ref_points_in_boxes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ref_points_in_boxes.restype = ctypes.c_int
+    return lib

@@ -11,6 +11,11 @@ For every frustum that yields a box the implementation under test reports which 
   * the returned box equals the reference's own box of THAT candidate (the row it handed to points_in_boxes_gpu)
     in all 7 components to BOX_ATOL;
   * when the reference's top score is unique beyond tol the box therefore equals the reference's output box.
+What the count allowance is (round 6): NOT a tolerance between two point-in-box implementations — on the GPU box every
+per-candidate count of the kernel is held to the reference's own points_in_boxes kernel with array_equal
+(tests/test_gpu_boxseeker.py _counts_equal_the_reference_kernel, oracle/_ref/libref_pib_gpu.so) — but between the kernel's run and
+the FIXTURE's run of the reference, whose candidate boxes equal the kernel's to 1e-4, not bit for bit (torch f32 vs the kernel's
+f32 arithmetic), so a point within that distance of a face may fall on the other side.
 Exact ties (yaw 0 vs pi footprints, the six identical depth samples of a collapsed frustum) are the only freedom left:
 the reference's own unstable sort (iou3d_nms_utils.py:146) decides them.
 """

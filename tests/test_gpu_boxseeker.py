@@ -62,6 +62,26 @@ def _chosen(dbg, scene=None):
     return out
 
 
+def _counts_equal_the_reference_kernel(dbg):
+    """Every per-candidate point count of the kernel against the REFERENCE's own points_in_boxes kernel (roiaware_pool3d_kernel.cu
+    compiled by hipcc, oracle/_ref/libref_pib_gpu.so) run per candidate as the reference's loop does (:930-932), on the kernel's
+    own frustum points and candidate boxes: identical inputs, same GPU, same ocml -> equal counts, no face-grazing allowance."""
+    import ref_pib
+    ref = ref_pib.lib_or_none()
+    if ref is None:
+        return 0
+    valid, count, npts = dbg["valid"].cpu().numpy(), dbg["count"].cpu().numpy(), dbg["npts"].cpu().numpy()
+    checked = 0
+    for f in range(valid.shape[0]):
+        ids = np.nonzero(valid[f] == 2)[0]
+        if npts[f] == 0 or len(ids) == 0:
+            continue
+        want = ref_pib.counts(ref, dbg["points_xyz"][f, :int(npts[f])], dbg["cand"][f][torch.from_numpy(ids).to(dbg["cand"].device)])
+        assert np.array_equal(count[f][ids], want.cpu().numpy()), f"frustum {f}"
+        checked += len(ids)
+    return checked
+
+
 @pytest.mark.parametrize("seed", list(range(18)))
 def test_matches_reference_golden(cuda, seed):
     """18 scenes run through the reference's own get_proposals (identity and non-identity lidar_aug_matrix incl. a flip,
@@ -91,8 +111,11 @@ def test_matches_reference_golden(cuda, seed):
     counts = dbg["count"].cpu().numpy()[scored]
     want = d["pib_count"]
     assert counts.shape == want.shape, "same candidates survive max_dist and min_cam_iou"
+    # (against the FIXTURE the counts may differ by a face-grazing point: the reference run counted inside ITS candidate boxes, which
+    #  equal the kernel's to 1e-4, not bit for bit, and with the libm stand-in of make_boxseeker_golden.py)
     assert (counts != want).mean() < 0.01 and np.abs(counts - want).max() <= 2
     np.testing.assert_allclose(dbg["cand"].cpu().numpy()[scored], d["pib_box"], rtol=0, atol=BOX_ATOL)
+    _counts_equal_the_reference_kernel(dbg)
     # 2D IoUs of the distance-valid candidates, per calc_iou call
     ious = dbg["iou"].cpu().numpy()
     k = 0
@@ -164,6 +187,7 @@ def test_option_variants_match_reference_golden(cuda, seed):
         np.testing.assert_allclose(out_score[f][: n_out[f]], ref_sel, rtol=2e-2 if occl else 0, atol=1e-4 + 2.0 / max(float(ref_counts.max()), 1.0))
         k += 1
     assert pos == d["pib_box"].shape[0] and k == len(ws)
+    _counts_equal_the_reference_kernel(r["dbg"])
 
 
 @pytest.mark.parametrize("seed", [0, 4, 14, 15])

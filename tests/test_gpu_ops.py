@@ -37,15 +37,39 @@ def test_points_in_boxes_gpu_bit_exact(cuda, oracle, rng):
         bx = boxes[b, 0]
         pts[b, 0] = [bx[0] + bx[3] / 2, bx[1], bx[2]]
         pts[b, 1] = [bx[0], bx[1], bx[2] + bx[5] / 2]
-    got = U.points_in_boxes_gpu(torch.from_numpy(pts).to(cuda), torch.from_numpy(boxes).to(cuda)).cpu().numpy()
+    d_pts, d_boxes = torch.from_numpy(pts).to(cuda), torch.from_numpy(boxes).to(cuda)
+    got = U.points_in_boxes_gpu(d_pts, d_boxes).cpu().numpy()
+    assert (got >= 0).sum() > 100 and got.dtype == np.int32
+    import ref_pib
+    ref = ref_pib.lib_or_none()
+    if ref is not None:
+        # the reference's OWN kernel on this GPU (roiaware_pool3d_kernel.cu:16-36,313-336 compiled by hipcc): bit-exact, no allowance
+        assert np.array_equal(got, ref_pib.points_in_boxes(ref, d_boxes, d_pts).cpu().numpy())
+        return
+    # without it (oracle/_ref not built): the libm oracle, where only face-grazing pairs may differ (ocml vs glibc cos / sin)
     want = oracle.points_in_boxes(pts, boxes)
     diff = got != want
-    if diff.any():  # only face-grazing pairs may differ (different libm); none expected in practice
+    if diff.any():
         for b in range(B):
             near = _boundary_mask(pts[b], boxes[b], 1e-5).any(0)
             assert not (diff[b] & ~near).any()
     assert diff.sum() <= 2
-    assert (got >= 0).sum() > 100 and got.dtype == np.int32
+
+
+def test_reference_point_in_box_kernel_is_the_checker_when_the_reference_build_travelled(cuda):
+    """oracle/_ref is built in the container (where /root/reference is) and travels with the snapshot: when the reference's iou3d
+    build is there, its point-in-box build must be too — otherwise the array_equal checks above silently fall back to the libm
+    oracle and its face-grazing allowance."""
+    import os
+    import ref_pib
+    ref_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    if not os.path.exists(os.path.join(ref_dir, "libref_iou3d_gpu.so")):
+        pytest.skip("oracle/_ref not built")
+    lib = ref_pib.lib_or_none()
+    assert lib is not None, "oracle/_ref/libref_pib_gpu.so missing: run `make -C oracle ref` where /root/reference is"
+    boxes = torch.tensor([[[0.0, 0.0, 0.0, 4.0, 2.0, 1.5, 0.3]]], device=cuda)
+    pts = torch.tensor([[[0.5, 0.2, 0.0], [3.0, 0.0, 0.0], [0.0, 0.0, 0.76]]], device=cuda)
+    assert ref_pib.points_in_boxes(lib, boxes, pts).cpu().tolist() == [[0, -1, -1]]
 
 
 def test_points_in_boxes_empty_and_large_T(cuda, oracle, rng):
@@ -68,9 +92,14 @@ def test_points_in_boxes_count_and_dense(cuda, oracle, rng):
     boxes[:, 3:6] *= 1.5
     pts = rng.uniform(-8, 8, size=(3001, 3)).astype(np.float32)
     cnt = U.points_in_boxes_count(torch.from_numpy(pts).to(cuda), torch.from_numpy(boxes).to(cuda)).cpu().numpy()
-    want = oracle.points_in_boxes_count(pts, boxes)
-    assert np.abs(cnt - want).max() <= 1 and (cnt != want).sum() <= 1
     assert cnt.sum() > 0
+    import ref_pib
+    ref = ref_pib.lib_or_none()
+    if ref is not None:   # the reference kernel, one box per launch like the Box Seeker's loop (:930-932): equal counts, no allowance
+        assert np.array_equal(cnt, ref_pib.counts(ref, torch.from_numpy(pts).to(cuda), torch.from_numpy(boxes).to(cuda)).cpu().numpy())
+    else:                 # libm oracle: a face-grazing point may flip
+        want = oracle.points_in_boxes_count(pts, boxes)
+        assert np.abs(cnt - want).max() <= 1 and (cnt != want).sum() <= 1
     # per-candidate loop of the reference (one launch each) gives the same counts
     d_pts, d_boxes = torch.from_numpy(pts).to(cuda), torch.from_numpy(boxes).to(cuda)
     loop = [int((U.points_in_boxes_gpu(d_pts[None], d_boxes[[i]][None]) >= 0).sum()) for i in range(0, 60, 7)]

@@ -493,6 +493,44 @@ def test_points_pipeline_equals_eager_frame_by_frame(cuda, depth):
 
 
 @pytest.mark.gpu
+def test_batch_path_with_two_batches_in_flight_equals_forward_points(cuda):
+    """forward_points_iter (round 6: the batch path's default — two batches in flight) and the PROBE form of the pipeline that
+    bench.py times (every slot a two-graph capture, the four 128 -> 128 launches between event pairs on the slot's stream):
+    batch by batch the tensors of forward_points."""
+    from findnpropagate_amd import sparse as S, synthetic as syn
+    from findnpropagate_amd.backbones_3d import VoxelResBackBone8x
+    grid = np.round((np.array(syn.POINT_CLOUD_RANGE[3:]) - np.array(syn.POINT_CLOUD_RANGE[:3])) / np.array(syn.VOXEL_SIZE)).astype(int)
+    net = syn.init_backbone_weights(VoxelResBackBone8x({"USE_BIAS": False}, 5, grid), 0).to(cuda).eval()
+    cfg = S.make_voxel_cfg(syn.VOXEL_SIZE, syn.POINT_CLOUD_RANGE, 5, 10, 160000)
+    batches, want = [], []
+    for seeds in ([0, 1], [2, 3], [4, 5], [6, 7], [8, 9]):
+        pts, off = syn.make_batch(seeds)
+        pts, off = torch.from_numpy(pts).to(cuda), torch.from_numpy(off).to(cuda)
+        batches.append((pts, off))
+        with torch.no_grad():
+            w = net.forward_points(pts, off, 2, cfg)
+        want.append({k: (w[k].features.clone(), w[k].indices.clone()) for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out")} | {"counts": w["counts"]})
+    keys = ("x_conv1", "x_conv2", "x_conv3", "x_conv4", "out")
+    with torch.no_grad():
+        n = 0
+        for i, got in enumerate(net.forward_points_iter(iter(batches), 2, cfg)):
+            assert got["counts"] == want[i]["counts"], i
+            for k in keys:
+                assert torch.equal(got[k].features, want[i][k][0]) and torch.equal(got[k].indices, want[i][k][1]), (i, k)
+            n += 1
+        assert n == len(batches)
+        pipe = net.points_pipeline(2, cfg, depth=2, capacity=131072, probe=True)
+        pipe.profile = []
+        for i, got in enumerate(pipe.map(batches)):
+            assert got["counts"] == want[i]["counts"], i
+            for k in keys:
+                assert torch.equal(got[k].features, want[i][k][0]) and torch.equal(got[k].indices, want[i][k][1]), (i, k)
+        torch.cuda.synchronize()
+        assert len(pipe.profile) == 4 * len(batches) and all(t[:3] == (128, 128, 27) for t, _, _ in pipe.profile)
+        assert all(e0.elapsed_time(e1) > 0 for _, e0, e1 in pipe.profile)
+
+
+@pytest.mark.gpu
 def test_capacity_overflow_regrows_eager_and_graphed(cuda):
     """Stage capacities that are too small are detected after the step (true counts live on the device),
     grown, the persistent grids wiped, and the step repeated — eager and hipGraph paths, same results."""

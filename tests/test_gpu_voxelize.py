@@ -107,3 +107,35 @@ def test_rerun_is_deterministic(cuda):
     b, _ = _run(scenes, args, cuda)
     for k in a:
         assert np.array_equal(a[k], b[k])
+
+
+def test_fused_mean_equals_the_reference_meanvfe_fixture(cuda, oracle):
+    """tests/golden/meanvfe_golden.npz: MeanVFE.forward of the reference's own class (mean_vfe.py:14-31, torch CPU) on the voxel
+    block of a scene whose time column is that of a ten-sweep aggregation.  The voxeliser's fused mean (vox_emit_kernel) must be
+    that tensor bit for bit — which it is only in torch's summation order (163 rows of this fixture differ in a slot-order sum)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "meanvfe_golden.npz"))
+    n_scene = int(d["n_scene_voxels"])
+    args = (syn.VOXEL_SIZE, [float(v) for v in d["range"]], 5, 10, 160000)
+    got, n = _run([d["points"]], args, cuda)
+    assert n == n_scene
+    assert np.array_equal(got["voxels"], d["voxels"][:n_scene]) and np.array_equal(got["num_points"], d["num_points"][:n_scene])
+    assert np.array_equal(got["mean"], d["mean"][:n_scene])
+    seq = np.zeros((n_scene, 5), np.float32)
+    for p in range(10):
+        seq = (seq + d["voxels"][:n_scene, p]).astype(np.float32)
+    assert (seq / np.maximum(d["num_points"][:n_scene], 1)[:, None].astype(np.float32) != got["mean"]).any(), "the fixture tells the two orders apart"
+
+
+@pytest.mark.parametrize("C,max_points", [(4, 10), (5, 5), (6, 10), (7, 12), (5, 20), (4, 35), (3, 10), (8, 10)])
+def test_fused_mean_in_torchs_summation_order_for_other_shapes(cuda, oracle, rng, C, max_points):
+    """The generic path of vox_emit_kernel (any feature count, max_points >= 16: the cascade's accumulator levels) against
+    oracle.mean_vfe, which tests/test_meanvfe_golden.py holds to torch's own CPU sum(dim=1) for the same shapes."""
+    p = rng.uniform(-3, 3, size=(20000, C)).astype(np.float32)
+    p[:, 2] = rng.uniform(-1.2, 1.2, size=p.shape[0])
+    p[:, 3:] = (rng.normal(size=(p.shape[0], C - 3)) * rng.choice([1e-3, 1.0, 100.0], size=(p.shape[0], C - 3))).astype(np.float32)
+    args = ([0.5, 0.5, 0.5], [-2.5, -2.5, -1.0, 2.5, 2.5, 1.0], C, max_points, 100000)
+    got, n = _run([p], args, cuda)
+    c, num, vox, mean = _oracle([p], args, oracle)
+    assert n == c.shape[0] and num.max() == max_points
+    assert np.array_equal(got["voxels"], vox) and np.array_equal(got["mean"], mean)
