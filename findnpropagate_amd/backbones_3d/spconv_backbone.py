@@ -321,10 +321,10 @@ class VoxelResBackBone8x(_BackboneBase):
         capacity: point capacity of the graph (default: N rounded up to 64 Ki)."""
         return self.engine().run_points_graphed(points, batch_offsets, batch_size, voxel_cfg, capacity, probe=probe)
 
-    def points_pipeline(self, batch_size, voxel_cfg, depth=2, capacity=65536, n_feat=5, probe=False):
+    def points_pipeline(self, batch_size, voxel_cfg, depth=2, capacity=65536, n_feat=5, probe=False, serial_convs=None):
         """forward_points_graphed for frames that arrive one at a time, `depth` of them in flight on their own HIP streams
         (PointsPipeline: submit / result / map).  Same results; the frame rate of a one-scene stream roughly doubles."""
-        return PointsPipeline(self, batch_size, voxel_cfg, depth=depth, capacity=capacity, n_feat=n_feat, probe=probe)
+        return PointsPipeline(self, batch_size, voxel_cfg, depth=depth, capacity=capacity, n_feat=n_feat, probe=probe, serial_convs=serial_convs)
 
     def forward_points_iter(self, batches, batch_size, voxel_cfg, depth=2, capacity=None):
         """THE BATCH PATH for a caller that has more than one batch to run (an extraction or evaluation loop, a server): an iterator
@@ -359,7 +359,7 @@ class _PointsGraph:
     """Static inputs + captured forward of one (batch_size, point capacity) configuration."""
     FAR = 1.0e9   # padding points: outside every range, dropped by the voxeliser
 
-    def __init__(self, engine, capacity, n_feat, batch_size, voxel_cfg, device, probe=False):
+    def __init__(self, engine, capacity, n_feat, batch_size, voxel_cfg, device, probe=False, split_index=False):
         # probe: the forward is captured as TWO graphs with the launches of the last SubM stage (the four 128 -> 128
         # convolutions of VoxelResBackBone8x: the step's dominant kernel) left out between them; replay() issues those as plain
         # launches, each bracketed with a pair of timing events when asked to.  A measurement device (bench.py: the step replayed
@@ -368,6 +368,11 @@ class _PointsGraph:
         # Every capture is TWO graphs, cut where the counts are final (in front of the last SubM stage): replay() copies them to
         # pinned memory between the two and records counts_event there, so the host sizes the outputs while the second graph
         # still runs (done_event marks its end).
+        # split_index (round 6, PointsPipeline's serial-convolution mode): the voxeliser and the whole index chain — everything that
+        # reads coordinates only — are a graph of their own (graph_i) in front of the other two, so that replay() can issue them on the
+        # slot's stream while every slot's convolutions go, in submission order, through ONE stream shared by the pipeline: batch
+        # i + 1's latency-bound index kernels run under batch i's convolutions, and two convolutions never share the CUs.
+        self.split_index, self.graph_i, self._index_cut = bool(split_index), None, False
         self.probe, self.deferred, self.graph_b = bool(probe), [], None
         self.counts_dev, self.counts_pin = None, None
         self.counts_event, self.done_event = torch.cuda.Event(), torch.cuda.Event()
@@ -399,28 +404,44 @@ class _PointsGraph:
         gc.disable()
         try:
             self.graph_b = torch.cuda.CUDAGraph()
-            self._ctx = torch.cuda.graph(self.graph)
+            if self.split_index:
+                self.graph_i = torch.cuda.CUDAGraph()
+                self._ctx = torch.cuda.graph(self.graph_i)
+            else:
+                self._ctx = torch.cuda.graph(self.graph)
             self._ctx.__enter__()
             try:
                 self.vox, self.res = self._body(voxel_cfg)   # (the engine calls counts_ready() where the first graph ends)
             finally:
                 self._ctx.__exit__(None, None, None)
             assert self.counts_dev is not None and (self.deferred or not self.probe), "the engine did not reach its cut"
+            assert self._index_cut or not self.split_index, "the engine did not cut behind its index chain"
         finally:
             if gc_was_on:
                 gc.enable()
+
+    def index_ready(self):
+        """called by the engine between its index chain and its first convolution (split_index captures only; the chain must be on
+        the capture stream itself: no second branch): ends graph_i, begins the first convolution graph in the same pool"""
+        if not self.split_index or self._index_cut:
+            return
+        self._index_cut = True
+        self._ctx.__exit__(None, None, None)
+        self._ctx = torch.cuda.graph(self.graph, pool=self.graph_i.pool())
+        self._ctx.__enter__()
 
     def counts_ready(self, counts_dev):
         """called by the engine where the counts are final (every forked stream rejoined): ends the first graph's capture and
         begins the second's on the same capture stream and memory pool"""
         self.counts_dev = counts_dev
         self._ctx.__exit__(None, None, None)
-        self._ctx = torch.cuda.graph(self.graph_b, pool=self.graph.pool())
+        self._ctx = torch.cuda.graph(self.graph_b, pool=(self.graph_i if self.split_index else self.graph).pool())
         self._ctx.__enter__()
 
-    def replay(self, profile=None):
+    def replay(self, profile=None, conv_stream=None):
         """one forward.  probe graphs: first half, the deferred launches (each between two timing events appended to `profile`
-        as (tag, start, end) when a list is given), second half"""
+        as (tag, start, end) when a list is given), second half.  conv_stream (split_index captures): the stream the convolution
+        graphs and everything behind them are issued on; the index graph goes to the current stream."""
         cur = torch.cuda.current_stream(self.pts.device)
         if self._replayed:   # (the previous replay may have been issued on another stream: the buffers are shared)
             cur.wait_event(self.done_event)
@@ -428,6 +449,18 @@ class _PointsGraph:
         if self.engine._last_done is not None and self.engine._last_done is not self.done_event:
             cur.wait_event(self.engine._last_done)
         self._replayed = True
+        if self.split_index:
+            self.graph_i.replay()
+            if conv_stream is not None and conv_stream != cur:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                conv_stream.wait_event(ev)
+                with torch.cuda.stream(conv_stream):
+                    self._replay_convs(profile)
+                return
+        self._replay_convs(profile)
+
+    def _replay_convs(self, profile):
         self.graph.replay()
         if self.counts_pin is None:
             self.counts_pin = torch.empty((16,), dtype=torch.int32, pin_memory=True)
@@ -473,7 +506,7 @@ class PointsPipeline:
     multiplies.  Results are the graphed path's, bit for bit.  The returned tensors are views of the slot's static buffers:
     valid until `depth` more frames have been submitted."""
 
-    def __init__(self, module, batch_size, voxel_cfg, depth=2, capacity=65536, n_feat=5, device=None, probe=False):
+    def __init__(self, module, batch_size, voxel_cfg, depth=2, capacity=65536, n_feat=5, device=None, probe=False, serial_convs=None):
         # probe: every slot's capture is the two-graph PROBE form of _PointsGraph (the launches of the last SubM stage issued as plain
         # launches between the two graphs); with `self.profile` a list each of them is bracketed by a pair of timing events on the
         # slot's stream, (tag, start, end) appended — how bench.py times the dominant kernel inside its pipelined timed region
@@ -489,6 +522,26 @@ class PointsPipeline:
             e.two_streams = self.depth == 1 or os.environ.get("FNP_PIPE_TWO", "0") == "1"
 
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.depth)]
+        # SERIAL CONVOLUTIONS (round 6).  With `depth` whole forwards in flight on `depth` streams the hardware interleaves them as
+        # it likes: two 128 -> 128 launches share the CUs and each takes 1.8x as long (0.78 -> 1.37 ms at 128 scenes).  The gain of
+        # the pipeline is elsewhere — a batch's voxeliser and index chain (latency- and atomics-bound, ~2 ms of a 10 ms step, a few
+        # waves per CU) running under ANOTHER batch's convolutions — so each slot's capture is cut behind its index chain
+        # (_PointsGraph split_index): the index graph goes to the slot's stream, the convolution graphs of ALL slots to one
+        # stream in submission order.  Default: on for batches of >= 8 scenes (convolutions that fill the chip); a one-scene
+        # stream, whose convolutions leave most CUs idle, keeps the free-for-all.  FNP_PIPE_SERIAL=0 / 1 forces.
+        # Measured at 128 scenes (one box, bench.py): one batch at a time 12.50 k scenes/s; serial, two / three in flight 12.79-13.07 /
+        # 12.84-13.04 k with the dominant kernel at 0.76-0.78 ms; free-for-all 13.10-13.12 / 13.42 k with it at 1.37 ms.  A kernel
+        # trace of the serial form (tools/pipe_trace.sh) shows a gapless convolution chain (0.24 ms of gaps per step) whose early
+        # layers run slower under the other batch's index kernels (16 -> 16 123 -> 195 us, 16 -> 32 244 -> 406, 32 -> 64 390 -> 570,
+        # tile32 263 -> 340; the wide layers within 3 %): 8.76 ms of convolutions take 9.53.  Starting a batch's index chain only
+        # where the batch before it reaches its 128 -> 128 launches (so that it meets matrix-bound kernels only) is WORSE, 12.2 k:
+        # those launches hold every CU's registers and LDS, the index kernels crawl (5 ms of kernel time) and the chain waits 1.7 ms.
+        env = {"0": False, "1": True}.get(os.environ.get("FNP_PIPE_SERIAL", ""))
+        self.serial_convs = self.depth > 1 and (bool(serial_convs) if serial_convs is not None else env if env is not None else self.batch_size >= 8)
+        self.conv_stream = torch.cuda.Stream(self.device) if self.serial_convs else None
+        if self.serial_convs:
+            for e in self.engines:
+                e.two_streams = False      # (the index chain must sit on the capture stream itself: it becomes a graph of its own)
         self.slots = [None] * self.depth      # _PointsGraph per slot, captured on first use
         self.pending = []                     # (slot, event, host counts, inputs) in submission order
         self.next_slot = 0
@@ -500,7 +553,7 @@ class PointsPipeline:
         g = self.slots[d]
         if g is None or g.cap_factor != e._graph_key() or g.prep_key != e._prep_key:
             torch.cuda.synchronize(self.device)   # (capture: nothing else of this pipeline may be in flight)
-            g = _PointsGraph(e, self.capacity, self.n_feat, self.batch_size, self.cfg, self.device, probe=self.probe)
+            g = _PointsGraph(e, self.capacity, self.n_feat, self.batch_size, self.cfg, self.device, probe=self.probe, split_index=self.serial_convs)
             self.slots[d] = g
         return g
 
@@ -521,7 +574,8 @@ class PointsPipeline:
                 g.pts[n:g.n_prev].fill_(_PointsGraph.FAR)
             g.n_prev = n
             g.off.copy_(batch_offsets, non_blocking=True)
-            g.replay(self.profile if self.probe else None)    # (copies the counts to pinned memory between its two graphs; done_event at the end)
+            # (copies the counts to pinned memory between its two convolution graphs; done_event at the end)
+            g.replay(self.profile if self.probe else None, conv_stream=self.conv_stream)
         points.record_stream(st)
         batch_offsets.record_stream(st)
         self.pending.append((d, None, (points, batch_offsets)))
@@ -1066,6 +1120,9 @@ class FusedResBackbone:
                                      out_grid=grids[4], premarked=premarked)
 
         # ---- convolutions -----------------------------------------------------------------------------------------------
+        if probe is not None and getattr(probe, "split_index", False):
+            assert not two, "a split capture keeps its index chain on the capture stream"
+            probe.index_ready()      # (_PointsGraph: the voxeliser + index chain are a graph of their own)
         joined = [False]
 
         def ready(i):

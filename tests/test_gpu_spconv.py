@@ -519,15 +519,21 @@ def test_batch_path_with_two_batches_in_flight_equals_forward_points(cuda):
                 assert torch.equal(got[k].features, want[i][k][0]) and torch.equal(got[k].indices, want[i][k][1]), (i, k)
             n += 1
         assert n == len(batches)
-        pipe = net.points_pipeline(2, cfg, depth=2, capacity=131072, probe=True)
-        pipe.profile = []
-        for i, got in enumerate(pipe.map(batches)):
-            assert got["counts"] == want[i]["counts"], i
-            for k in keys:
-                assert torch.equal(got[k].features, want[i][k][0]) and torch.equal(got[k].indices, want[i][k][1]), (i, k)
-        torch.cuda.synchronize()
-        assert len(pipe.profile) == 4 * len(batches) and all(t[:3] == (128, 128, 27) for t, _, _ in pipe.profile)
-        assert all(e0.elapsed_time(e1) > 0 for _, e0, e1 in pipe.profile)
+        # serial_convs: every slot's capture cut behind its index chain, the convolution graphs of all slots on one stream (the
+        # default from 8 scenes per batch on); False: whole forwards in flight side by side
+        for serial, depth in ((True, 2), (False, 2), (True, 3)):
+            pipe = net.points_pipeline(2, cfg, depth=depth, capacity=131072, probe=True, serial_convs=serial)
+            assert pipe.serial_convs == serial
+            pipe.profile = []
+            for rep in range(2):
+                for i, got in enumerate(pipe.map(batches)):
+                    assert got["counts"] == want[i]["counts"], (serial, i)
+                    for k in keys:
+                        assert torch.equal(got[k].features, want[i][k][0]) and torch.equal(got[k].indices, want[i][k][1]), (serial, i, k)
+            torch.cuda.synchronize()
+            assert len(pipe.profile) == 2 * 4 * len(batches) and all(t[:3] == (128, 128, 27) for t, _, _ in pipe.profile)
+            assert all(e0.elapsed_time(e1) > 0 for _, e0, e1 in pipe.profile)
+            del pipe
 
 
 @pytest.mark.gpu
