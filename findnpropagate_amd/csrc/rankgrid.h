@@ -14,6 +14,7 @@
 // (the voxeliser's first-come order).
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 struct RankGridDims {
     int B, D, H, W;       // cells
@@ -41,10 +42,29 @@ struct RG {
     unsigned long long *summ;
     int *perm;
     long long nblk, nsum;
+    // counted marks (round 6; fnp.h fnp_rankgrid.counters): cells per UNIT of `wpw` summary words, per group of 64 units, per chunk
+    // of 1024 units, laid out cnt[nunits] | gtot[ngroups] | ctot[nchunks]; nullptr = not counted (the prefix counts by itself)
+    unsigned *ctr;
+    int wpw;
+    long long nunits;
+    int ctr_levels;   // 1: the marks count per unit only (the totals kernel stays), 3: per unit, group and chunk (development)
 };
+
+// summary words per unit of the rank prefix (scan.hip): 64 for the large ~98 % empty grids, 8 / 1 for the small dense ones.  The
+// marking kernels and the prefix pass must agree on it: it is a function of the grid's size alone.
+__host__ __device__ inline int fnp_rg_wpw(long long nsum) { return nsum >= (1ll << 18) ? 64 : nsum >= (1ll << 15) ? 8 : 1; }
+__host__ __device__ inline long long fnp_rg_counter_words(long long nsum) {
+    const long long nunits = (nsum + fnp_rg_wpw(nsum) - 1) / fnp_rg_wpw(nsum);
+    return nunits + ((nunits + 63) >> 6) + ((nunits + 1023) >> 10);
+}
 
 inline bool fnp_rg_valid(const fnp_rankgrid *g, bool need_perm = false) {
     return g && g->B > 0 && g->D > 0 && g->H > 0 && g->W > 0 && g->bits && g->base && g->summary && (!need_perm || g->perm);
+}
+
+inline int fnp_count_levels() {
+    static const int v = [] { const char *e = getenv("FNP_COUNT_LEVELS"); return (e && e[0] == '3') ? 3 : 1; }();
+    return v;
 }
 
 inline RG fnp_rg_view(const fnp_rankgrid *g) {
@@ -56,6 +76,10 @@ inline RG fnp_rg_view(const fnp_rankgrid *g) {
     r.perm = g->perm;
     r.nblk = fnp_num_blocks(r.d);
     r.nsum = (r.nblk + 63) >> 6;
+    r.ctr = (unsigned *)g->counters;
+    r.wpw = fnp_rg_wpw(r.nsum);
+    r.nunits = (r.nsum + r.wpw - 1) / r.wpw;
+    r.ctr_levels = fnp_count_levels();
     return r;
 }
 
@@ -94,13 +118,34 @@ __device__ __forceinline__ void rg_decode(const RankGridDims &g, long long blk, 
 // 0 -> non-zero and publishes the block in the summary level.  (Measured: publishing from every thread
 // that reads the summary bit as unset — two independent no-return atomics instead of a dependent pair —
 // is 2.5x slower; same-address atomics serialise in L2.)
-__device__ __forceinline__ void rg_mark_mask(const RG &g, long long blk, unsigned long long m) {
-    if ((g.bits[blk] & m) == m) return;
+// Returns the number of cells this call newly set (every bit goes 0 -> 1 exactly once, in exactly one call: the returns of all
+// calls of a build add up to the number of occupied cells).
+__device__ __forceinline__ int rg_mark_mask(const RG &g, long long blk, unsigned long long m) {
+    if ((g.bits[blk] & m) == m) return 0;
     const unsigned long long old = atomicOr(&g.bits[blk], m);
     if (old == 0ull) atomicOr(&g.summ[blk >> 6], 1ull << (blk & 63));
+    return __popcll(m & ~old);
 }
 __device__ __forceinline__ void rg_mark(const RG &g, long long blk, int bit) { rg_mark_mask(g, blk, 1ull << bit); }
 
+// COUNTED MARKS (round 6).  The rank prefix used to open with a pass of its own that counted the occupied cells per unit (scan.hip
+// PASS 0: 32 us on the stage-1 and stage-2 grids of a 128-scene batch, five launches per forward) and a totals kernel over those
+// counts (five more).  The marking kernels know what they set: rg_mark_mask returns the new cells of a call, a workgroup adds them
+// up per unit in a small LDS table (its 256 rows are a compact patch: 1-3 units of the large grids, a dozen of the small ones) and
+// issues one atomicAdd per unit, per group of 64 units and per chunk of 1024 units it touched — a few hundred adds per counter
+// word over a launch.  The prefix is then ONE launch (scan.hip PASS 1 reading these counters).
+constexpr int kCntTab = 32;
+struct CntTab {
+    unsigned key[kCntTab];   // unit id + 1, 0 = free
+    unsigned val[kCntTab];
+};
+__device__ __forceinline__ void rg_count_global(const RG &g, unsigned U, unsigned inc) {
+    atomicAdd(&g.ctr[U], inc);
+    if (g.ctr_levels >= 3) {
+        atomicAdd(&g.ctr[g.nunits + (U >> 6)], inc);
+        atomicAdd(&g.ctr[g.nunits + ((g.nunits + 63) >> 6) + (U >> 10)], inc);
+    }
+}
 // Workgroup-level merging of the marks (round 3).  The marking kernels spend three quarters of their time in the atomics
 // themselves — read-modify-writes of words of a zeroed, sparse grid that miss L2 (1.4 M misses for 1.05 M atomics per
 // launch; a probe that finds every bit already set runs in 25 of 100 us, and fire-and-forget atomics take as long as returning
@@ -112,13 +157,29 @@ constexpr int kMarkTabLog = 9, kMarkTab = 1 << kMarkTabLog;
 struct MarkTab {
     unsigned long long key[kMarkTab];   // block id, ~0 = free
     unsigned long long val[kMarkTab];
+    CntTab cnt;                         // new cells per unit (counted marks, below mark_tab_flush)
 };
 #ifndef FNP_MARK_TAB
 #define FNP_MARK_TAB 1
 #endif
+__device__ __forceinline__ void rg_count_put(MarkTab *tab, const RG &g, long long blk, int inc) {
+    if (!g.ctr || inc <= 0) return;
+    const unsigned U = (unsigned)((blk >> 6) / g.wpw);
+    unsigned h = (U * 0x9E3779B1u) >> 27;
+    for (int probe = 0; probe < 4; ++probe) {
+        const unsigned old = atomicCAS(&tab->cnt.key[h], 0u, U + 1u);
+        if (old == 0u || old == U + 1u) {
+            atomicAdd(&tab->cnt.val[h], (unsigned)inc);
+            return;
+        }
+        h = (h + 1) & (unsigned)(kCntTab - 1);
+    }
+    rg_count_global(g, U, (unsigned)inc);   // (a crowded table: straight to memory)
+}
 __device__ __forceinline__ void mark_put(MarkTab *tab, const RG &go, long long blk, unsigned long long m) {
     if (!FNP_MARK_TAB || !tab) {
-        rg_mark_mask(go, blk, m);
+        const int inc = rg_mark_mask(go, blk, m);
+        if (go.ctr && inc > 0) rg_count_global(go, (unsigned)((blk >> 6) / go.wpw), (unsigned)inc);
         return;
     }
     unsigned h = ((unsigned)blk * 0x9E3779B1u) >> (32 - kMarkTabLog);
@@ -130,7 +191,11 @@ __device__ __forceinline__ void mark_put(MarkTab *tab, const RG &go, long long b
         }
         h = (h + 1) & (unsigned)(kMarkTab - 1);
     }
-    rg_mark_mask(go, blk, m);   // (a crowded table: straight to memory)
+    // (a crowded table: straight to memory, the count too.  Not through rg_count_put: with a second inlined copy of its LDS
+    //  compare-and-swap loop behind this function's null test of `tab`, hipcc 7.2 fails in instruction selection —
+    //  "V_CMP_NE_U32_e32 0, $src_shared_base: Operand has incorrect register class")
+    const int inc = rg_mark_mask(go, blk, m);
+    if (go.ctr && inc > 0) rg_count_global(go, (unsigned)((blk >> 6) / go.wpw), (unsigned)inc);
 }
 // every thread of the workgroup: empty the table / write its blocks out and empty it (barriers inside)
 __device__ __forceinline__ void mark_tab_init(MarkTab *tab, int tid, int nthreads) {
@@ -138,6 +203,7 @@ __device__ __forceinline__ void mark_tab_init(MarkTab *tab, int tid, int nthread
         tab->key[i] = ~0ull;
         tab->val[i] = 0ull;
     }
+    if (tid < kCntTab) tab->cnt.key[tid] = tab->cnt.val[tid] = 0u;
     __syncthreads();
 }
 __device__ __forceinline__ void mark_tab_flush(MarkTab *tab, const RG &go, int tid, int nthreads) {
@@ -145,12 +211,19 @@ __device__ __forceinline__ void mark_tab_flush(MarkTab *tab, const RG &go, int t
     for (int i = tid; i < kMarkTab; i += nthreads) {
         const unsigned long long k = tab->key[i];
         if (k != ~0ull) {
-            rg_mark_mask(go, (long long)k, tab->val[i]);
+            rg_count_put(tab, go, (long long)k, rg_mark_mask(go, (long long)k, tab->val[i]));
             tab->key[i] = ~0ull;
             tab->val[i] = 0ull;
         }
     }
     __syncthreads();
+    if (go.ctr) {   // (uniform) the workgroup's new cells per unit: one add per unit, group and chunk
+        if (tid < kCntTab && tab->cnt.key[tid] != 0u) {
+            rg_count_global(go, tab->cnt.key[tid] - 1u, tab->cnt.val[tid]);
+            tab->cnt.key[tid] = tab->cnt.val[tid] = 0u;
+        }
+        __syncthreads();
+    }
 }
 
 
@@ -325,6 +398,7 @@ int int32(const int *in, long long n, int *out, int *total, void *ws, hipStream_
 long long workspace_bytes(long long n);
 // base[w] for every occupied block of the grid, *total = number of occupied cells.  With out_coords the
 // (b, z, y, x) of every occupied cell is written at its rank (rows >= cap_out dropped) in the same sweep.
-int rank_grid(const RG &g, int *total, void *ws, hipStream_t s, int *out_coords = nullptr, int cap_out = 0);
+// counted: the grid's counters (g.ctr) hold the cells per unit / group / chunk already (counted marks): one launch instead of three.
+int rank_grid(const RG &g, int *total, void *ws, hipStream_t s, int *out_coords = nullptr, int cap_out = 0, bool counted = false);
 long long rank_grid_workspace_bytes(long long nsum);
 }  // namespace fnp_scan

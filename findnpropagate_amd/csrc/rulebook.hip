@@ -403,6 +403,7 @@ static bool make_mark_job(const fnp_rankgrid *rows_grid, const fnp_rankgrid *mar
     }
     mk.go = fnp_rg_view(mark_grid);
     mk.go.perm = nullptr;
+    mk.go.ctr = nullptr;   // (marks carried by a rulebook kernel are not counted: fnp_rulebook_strided_premarked ranks with the three-launch prefix)
     mk.ge = to_geom(mark_geom);
     const int *st = mark_geom->stride;
     mk.on = (st[0] == 2 && st[1] == 2 && st[2] == 2) ? 1 : (st[0] == 2 && st[1] == 1 && st[2] == 1) ? 2 : 3;
@@ -520,6 +521,10 @@ static int rulebook_strided_impl(const int *in_coords, const int *n_in, int cap_
 
     bool two = true;   // at most two outputs per input cell and axis
     for (int d = 0; d < 3; ++d) two = two && (ge.k[d] + ge.s[d] - 1) / ge.s[d] <= 2;
+    // counted marks (rankgrid.h): the closed-form marking kernels add the cells they set to the output grid's counters and the
+    // prefix is one launch; the generic marking loop and marks carried by a rulebook kernel leave the counting to the prefix
+    const bool counted = go.ctr != nullptr && two && !premarked;
+    if (!counted) go.ctr = nullptr;
     const dim3 mgrid(fnp_grid_for(cap_in, kThreads));
     if (premarked) {
         // (the output sites were marked by the kernel that built the rulebook of the input rows: fnp_rulebook_subm_masked /
@@ -533,7 +538,7 @@ static int rulebook_strided_impl(const int *in_coords, const int *n_in, int cap_
     else
         hipLaunchKernelGGL(strided_mark_kernel, mgrid, dim3(kThreads), 0, s, in_coords, n_in, cap_in, go, ge);
     FNP_LAUNCH_CHECK();
-    int rc = fnp_scan::rank_grid(go, n_out, workspace, s, out_coords, cap_out);   // ranks + coordinates in rank order
+    int rc = fnp_scan::rank_grid(go, n_out, workspace, s, out_coords, cap_out, counted);   // ranks + coordinates in rank order
     if (rc) return rc;
     if (!nbr) return FNP_OK;   // grid + coordinates only (the convolution resolves its neighbours itself)
     const dim3 rgrid(fnp_grid_for(cap_out, kThreads));

@@ -259,7 +259,7 @@ long long rank_grid_workspace_bytes(long long nsum) {
     return ((nsum * 4 + 255) & ~255ll) + (((ngroups + nchunks) * 4 + 255) & ~255ll) + 256;
 }
 template <int WPW>
-static int rank_grid_w(const RG &g, int *total, void *ws, hipStream_t s, int *out_coords, int cap_out) {
+static int rank_grid_w(const RG &g, int *total, void *ws, hipStream_t s, int *out_coords, int cap_out, bool counted) {
     const long long nunits = (g.nsum + WPW - 1) / WPW;
     const long long ngroups = (nunits + 63) >> 6, nchunks = (nunits + 1023) >> 10;
     if (nchunks > 0x7fffffffll) return FNP_ERR_ARG;
@@ -267,6 +267,18 @@ static int rank_grid_w(const RG &g, int *total, void *ws, hipStream_t s, int *ou
     unsigned *gtot = (unsigned *)((char *)ws + ((nunits * 4 + 255) & ~255ll));
     unsigned *ctot = gtot + ngroups;
     const int grid = fnp_divup(nunits * 64, kThreads);
+    if (counted) {   // the marking kernels counted (rankgrid.h): cnt | gtot | ctot are the grid's own, the prefix pass is all there is
+        if (!g.ctr || g.wpw != WPW || g.nunits != nunits) return FNP_ERR_ARG;
+        if (g.ctr_levels < 3) {   // units counted by the marks, groups and chunks by the totals kernel (into the grid's own counter words)
+            hipLaunchKernelGGL(rank_totals_kernel, dim3((unsigned)nchunks), dim3(kThreads), 0, s, (const unsigned *)g.ctr, nunits, g.ctr + nunits,
+                               g.ctr + nunits + ngroups);
+            FNP_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(summary_pass_kernel<1, WPW>), dim3(grid), dim3(kThreads), 0, s, g, nunits, g.ctr,
+                           (const unsigned *)(g.ctr + nunits), (const unsigned *)(g.ctr + nunits + ngroups), (int)nchunks, total, cap_out, out_coords);
+        FNP_LAUNCH_CHECK();
+        return FNP_OK;
+    }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(summary_pass_kernel<0, WPW>), dim3(grid), dim3(kThreads), 0, s, g, nunits, cnt,
                        (const unsigned *)nullptr, (const unsigned *)nullptr, (int)nchunks, total, 0, (int *)nullptr);
     FNP_LAUNCH_CHECK();
@@ -277,13 +289,20 @@ static int rank_grid_w(const RG &g, int *total, void *ws, hipStream_t s, int *ou
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
-int rank_grid(const RG &g, int *total, void *ws, hipStream_t s, int *out_coords, int cap_out) {
-    // the split only changes who computes what, never the ranks
-    if (g.nsum >= (1ll << 18)) return rank_grid_w<64>(g, total, ws, s, out_coords, cap_out);
-    if (g.nsum >= (1ll << 15)) return rank_grid_w<8>(g, total, ws, s, out_coords, cap_out);
-    return rank_grid_w<1>(g, total, ws, s, out_coords, cap_out);
+int rank_grid(const RG &g, int *total, void *ws, hipStream_t s, int *out_coords, int cap_out, bool counted) {
+    // the split only changes who computes what, never the ranks (fnp_rg_wpw: the marking kernels count per the same units)
+    const int wpw = fnp_rg_wpw(g.nsum);
+    if (wpw == 64) return rank_grid_w<64>(g, total, ws, s, out_coords, cap_out, counted);
+    if (wpw == 8) return rank_grid_w<8>(g, total, ws, s, out_coords, cap_out, counted);
+    return rank_grid_w<1>(g, total, ws, s, out_coords, cap_out, counted);
 }
 }  // namespace fnp_scan
+
+extern "C" int64_t fnp_rankgrid_counter_words(int B, int D, int H, int W) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const long long nblk = fnp_num_blocks(fnp_make_dims(B, D, H, W));
+    return fnp_rg_counter_words((nblk + 63) >> 6) + 64;
+}
 
 extern "C" int64_t fnp_rankgrid_workspace_bytes(int B, int D, int H, int W) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;

@@ -413,6 +413,13 @@ __device__ __forceinline__ bool coord_ok(const RankGridDims &g, const int4 &c) {
     return c.x >= 0 && c.x < g.B && c.y >= 0 && c.y < g.D && c.z >= 0 && c.z < g.H && c.w >= 0 && c.w < g.W;
 }
 
+// the counters of the counted marks (rankgrid.h) go back to zero with the grid: a dense loop over a few thousand words
+__device__ __forceinline__ void rg_zero_counters(const RG &g, long long first, long long stride) {
+    if (!g.ctr) return;
+    const long long words = fnp_rg_counter_words(g.nsum);
+    for (long long i = first; i < words; i += stride) g.ctr[i] = 0u;
+}
+
 template <bool CLEAR>
 __global__ __launch_bounds__(kThreads) void rg_mark_coords_kernel(const int *__restrict__ coords,
                                                                   const int *__restrict__ n_rows, int cap, RG g) {
@@ -428,6 +435,7 @@ __global__ __launch_bounds__(kThreads) void rg_mark_coords_kernel(const int *__r
             rg_mark(g, blk, rg_bit_of(c.y, c.z, c.w));
         }
     }
+    if (CLEAR) rg_zero_counters(g, (long long)blockIdx.x * kThreads + threadIdx.x, (long long)gridDim.x * kThreads);
 }
 
 __global__ __launch_bounds__(kThreads) void rg_perm_kernel(const int *__restrict__ coords, const int *__restrict__ n_rows,
@@ -492,7 +500,7 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
     //  min(cnt, max_points) slots are written before they are read)
     hipLaunchKernelGGL(vox_mark_kernel, dim3(pgrid), dim3(kThreads), 0, s, points, n, C, batch_offsets, B, *cfg, g, w.code, w.cnt);
     FNP_LAUNCH_CHECK();
-    int rc = fnp_scan::rank_grid(g, w.n_sorted, w.scan_ws, s);
+    int rc = fnp_scan::rank_grid(g, w.n_sorted, w.scan_ws, s, nullptr, 0, g.ctr != nullptr);   // (vox_mark_kernel counted its marks)
     if (rc) return rc;
     hipLaunchKernelGGL(vox_insert_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, n,
                        (const unsigned long long *)g.bits, (const unsigned *)g.base, w.code, w.rank, w.top, w.cnt, w.cnt + n, w.flag);
@@ -524,7 +532,7 @@ extern "C" int fnp_rankgrid_build(const int *coords, const int *n_rows, int cap,
     const int blocks = fnp_grid_for(cap, kThreads);
     hipLaunchKernelGGL(rg_mark_coords_kernel<false>, dim3(blocks), dim3(kThreads), 0, s, coords, n_rows, cap, g);
     FNP_LAUNCH_CHECK();
-    int rc = fnp_scan::rank_grid(g, total, scan_ws, s);
+    int rc = fnp_scan::rank_grid(g, total, scan_ws, s);   // (rg_mark_coords_kernel does not count: three-launch prefix; the counters stay zero)
     if (rc) return rc;
     if (g.perm) {
         {
@@ -565,6 +573,7 @@ __global__ __launch_bounds__(kThreads) void rg_clear_multi_kernel(ClearJobs jobs
         J.g.bits[blk] = 0ull;
         J.g.summ[blk >> 6] = 0ull;
     }
+    rg_zero_counters(J.g, blockIdx.x * kThreads + threadIdx.x, gridDim.x * kThreads);
 }
 
 extern "C" int fnp_rankgrid_clear_multi(int count, const int *const *coords, const int *const *n_rows, const int *caps,
@@ -583,6 +592,52 @@ extern "C" int fnp_rankgrid_clear_multi(int count, const int *const *coords, con
     // (gridDim.x a multiple of 8: fnp_xcd_block()'s one-run-per-XCD property on a 2-D grid needs it — common.h)
     const int gx = (fnp_grid_for(cap_max, kThreads, 512) + 7) & ~7;
     hipLaunchKernelGGL(rg_clear_multi_kernel, dim3(gx, count), dim3(kThreads), 0, (hipStream_t)stream, jobs);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
+// SUMMARY-DRIVEN CLEAR (round 6).  The row form above reads every coordinate row of every stage (5.8 M rows, 93 MB at 128 scenes)
+// and zeroes the occupancy word and the summary word of each — 7 rows per occupied block, 11.6 M scattered stores, 79 us.  The
+// summary level already names the occupied blocks: a wave per 64 summary words reads them (27 MB for the five grids of a 128-scene
+// batch, coalesced), and for every non-zero word the lanes whose bit is set zero their block's occupancy word; the summary word
+// goes last.  ~0.8 M stores instead of 11.6 M — and it needs no coordinate list: cells of voxels dropped by max_voxels and sites
+// beyond a stage's row capacity (which the row form could not see: the engine wiped the whole grid after an overflow) go too.
+__device__ __forceinline__ unsigned long long clr_readlane64(unsigned long long v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__global__ __launch_bounds__(kThreads) void rg_clear_summary_kernel(ClearJobs jobs) {
+    const RG &g = jobs.j[blockIdx.y].g;
+    const int lane = fnp_lane();
+    const long long nunits = (g.nsum + 63) >> 6, wstride = (long long)gridDim.x * (kThreads / 64);
+    for (long long U = (long long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); U < nunits; U += wstride) {
+        const long long S0 = U * 64;
+        const unsigned long long sw = (S0 + lane < g.nsum) ? g.summ[S0 + lane] : 0ull;
+        unsigned long long todo = __ballot(sw != 0ull);
+        if (todo == 0ull) continue;   // (uniform)
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const unsigned long long swj = clr_readlane64(sw, j);
+            if ((swj >> lane) & 1ull) g.bits[(S0 + j) * 64 + lane] = 0ull;
+        }
+        if (sw != 0ull) g.summ[S0 + lane] = 0ull;
+    }
+    rg_zero_counters(g, (long long)blockIdx.x * kThreads + threadIdx.x, (long long)gridDim.x * kThreads);
+}
+
+extern "C" int fnp_rankgrid_clear_summary(int count, const fnp_rankgrid *grids, fnp_stream_t stream) {
+    if (count <= 0 || count > 8 || !grids) return FNP_ERR_ARG;
+    ClearJobs jobs{};
+    long long units_max = 1;
+    for (int i = 0; i < count; ++i) {
+        if (!fnp_rg_valid(&grids[i])) return FNP_ERR_ARG;
+        jobs.j[i].g = fnp_rg_view(&grids[i]);
+        const long long u = (jobs.j[i].g.nsum + 63) >> 6;
+        if (u > units_max) units_max = u;
+    }
+    const int gx = (fnp_grid_for(units_max, kThreads / 64, 2048) + 7) & ~7;
+    hipLaunchKernelGGL(rg_clear_summary_kernel, dim3(gx, count), dim3(kThreads), 0, (hipStream_t)stream, jobs);
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }

@@ -46,7 +46,7 @@ class RankGridC(ctypes.Structure):
 
     _fields_ = [
         ("B", c_int), ("D", c_int), ("H", c_int), ("W", c_int),
-        ("bits", c_void_p), ("base", c_void_p), ("summary", c_void_p), ("perm", c_void_p),
+        ("bits", c_void_p), ("base", c_void_p), ("summary", c_void_p), ("perm", c_void_p), ("counters", c_void_p),
     ]
 
 
@@ -106,10 +106,12 @@ SIGNATURES = {
     "fnp_nms_batched": (c_int, [P, P, c_int, c_int, c_float, c_int, P, P, P, P]),
     "fnp_rankgrid_num_blocks": (c_int64, [c_int, c_int, c_int, c_int]),
     "fnp_rankgrid_num_summary": (c_int64, [c_int, c_int, c_int, c_int]),
+    "fnp_rankgrid_counter_words": (c_int64, [c_int, c_int, c_int, c_int]),
     "fnp_rankgrid_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "fnp_rankgrid_build": (c_int, [P, P, c_int, POINTER(RankGridC), P, c_int64, P]),
     "fnp_rankgrid_clear": (c_int, [P, P, c_int, POINTER(RankGridC), P]),
     "fnp_rankgrid_clear_multi": (c_int, [c_int, P, P, P, P, P]),
+    "fnp_rankgrid_clear_summary": (c_int, [c_int, c_void_p, c_void_p]),
     "fnp_voxelize_workspace_bytes": (c_int64, [c_int64, POINTER(VoxelCfg), POINTER(RankGridC)]),
     "fnp_voxelize": (c_int, [P, c_int, P, POINTER(VoxelCfg), POINTER(RankGridC), P, c_int64,
                              P, P, P, P, P, P, c_int, P]),

@@ -36,6 +36,7 @@ class RankGrid:
     perm: Optional[torch.Tensor]  # (cap,) int32 or None (rows already in rank order)
     batch_size: int
     shape: List[int]              # [D, H, W]
+    counters: Optional[torch.Tensor] = None   # (fnp_rankgrid_counter_words,) int32, zero between builds: the counted marks (fnp.h)
 
     def c(self, with_perm=True):
         """struct fnp_rankgrid for the ABI."""
@@ -43,11 +44,14 @@ class RankGrid:
         g.B, g.D, g.H, g.W = self.batch_size, self.shape[0], self.shape[1], self.shape[2]
         g.bits, g.base, g.summary = self.bits.data_ptr(), self.base.data_ptr(), self.summary.data_ptr()
         g.perm = self.perm.data_ptr() if (with_perm and self.perm is not None) else None
+        g.counters = self.counters.data_ptr() if (self.counters is not None and COUNTED_MARKS) else None
         return g
 
     def zero_(self):
         self.bits.zero_()
         self.summary.zero_()
+        if self.counters is not None:
+            self.counters.zero_()
 
 
 @dataclass
@@ -63,6 +67,11 @@ class Rulebook:
     in_grid: Optional[RankGrid] = None           # strided, nbr is None: the grid the convolution looks its inputs up in
 
 
+# counted marks (round 6, fnp.h fnp_rankgrid.counters): the marking kernels count the cells they set and the rank prefix is one
+# launch instead of three.  FNP_COUNTED_MARKS=0: the three-launch prefix (development A/B; same grids, same ranks)
+COUNTED_MARKS = os.environ.get("FNP_COUNTED_MARKS", "1") != "0"
+
+
 def num_blocks(batch_size, shape):
     return int(_l.load().fnp_rankgrid_num_blocks(batch_size, *shape))
 
@@ -74,7 +83,8 @@ def alloc_grid(batch_size, shape, device, with_perm_cap=None):
     base = torch.empty((nblk,), dtype=torch.int32, device=device)
     summary = torch.zeros(((nblk + 63) // 64,), dtype=torch.int64, device=device)
     perm = torch.empty((with_perm_cap,), dtype=torch.int32, device=device) if with_perm_cap else None
-    return RankGrid(bits, base, summary, perm, batch_size, [int(v) for v in shape])
+    counters = torch.zeros((int(_l.load().fnp_rankgrid_counter_words(batch_size, *shape)),), dtype=torch.int32, device=device)
+    return RankGrid(bits, base, summary, perm, batch_size, [int(v) for v in shape], counters)
 
 
 def make_geom(ksize, stride, padding, in_shape, out_shape=None):
@@ -177,10 +187,20 @@ def clear_grid(grid, indices, n_dev):
     _l.check(rc, "fnp_rankgrid_clear")
 
 
+# the clear of the fused engine's persistent grids walks their summary level (fnp_rankgrid_clear_summary: 79 -> ~25 us at 128 scenes,
+# and nothing a coordinate list could miss); FNP_CLEAR_ROWS=1: the row form of rounds 1-5 (development A/B)
+CLEAR_BY_SUMMARY = os.environ.get("FNP_CLEAR_ROWS", "0") != "1"
+
+
 def clear_grids(jobs):
     """clear_grid for several grids in ONE launch.  jobs: list of (grid, indices, n_dev), at most 8."""
     L = _l.load()
     k = len(jobs)
+    if CLEAR_BY_SUMMARY:
+        grids = (_l.RankGridC * k)(*[g.c() for g, _, _ in jobs])
+        rc = L.fnp_rankgrid_clear_summary(k, ctypes.cast(grids, ctypes.c_void_p), _l.stream())
+        _l.check(rc, "fnp_rankgrid_clear_summary")
+        return
     P = ctypes.c_void_p * k
     coords = P(*[_l.ptr(idx) for _, idx, _ in jobs])
     rows = P(*[_l.ptr(n) for _, _, n in jobs])

@@ -146,10 +146,15 @@ typedef struct fnp_rankgrid {
     uint32_t *base;     /* (nblk)  exclusive popcount prefix, defined where bits != 0 */
     uint64_t *summary;  /* (nsum)  bit j of word i set iff bits[64*i + j] != 0; zero before a build */
     int *perm;          /* (cap)   rank -> row, or NULL when rows are stored in rank order */
+    uint32_t *counters; /* (ABI 13, nullable) fnp_rankgrid_counter_words() words, ALL ZERO before a build: the marking kernels of
+                         * fnp_voxelize / fnp_rulebook_strided add the cells they set to per-unit / per-group / per-chunk counters
+                         * here (one atomic per workgroup and counter), and the rank prefix is ONE launch instead of three (count
+                         * pass, totals, prefix pass).  The fnp_rankgrid_clear* calls zero them again.  NULL: the three-launch prefix. */
 } fnp_rankgrid;
 
 int64_t fnp_rankgrid_num_blocks(int B, int D, int H, int W);   /* nblk */
 int64_t fnp_rankgrid_num_summary(int B, int D, int H, int W);  /* nsum = ceil(nblk / 64) */
+int64_t fnp_rankgrid_counter_words(int B, int D, int H, int W); /* (ABI 13) uint32 words of fnp_rankgrid.counters */
 int64_t fnp_rankgrid_workspace_bytes(int B, int D, int H, int W);
 
 /* Index an existing coordinate list (N,4) [b,z,y,x] (e.g. a SparseConvTensor built from user
@@ -164,6 +169,10 @@ int fnp_rankgrid_clear(const int *coords, const int *n_rows, int cap, const fnp_
 /* fnp_rankgrid_clear for up to 8 grids in one launch (HOST arrays of `count` device pointers / capacities / grids). */
 int fnp_rankgrid_clear_multi(int count, const int *const *coords, const int *const *n_rows, const int *caps,
                              const fnp_rankgrid *grids, fnp_stream_t stream);
+
+/* (ABI 13) Zero up to 8 grids through their SUMMARY level in one launch: every occupancy word a summary bit names, the summary
+ * words, the counters.  No coordinate list: whatever was marked goes (cells of dropped voxels and of rows beyond a capacity too). */
+int fnp_rankgrid_clear_summary(int count, const fnp_rankgrid *grids, fnp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Voxelisation + MeanVFE — replaces spconv.utils.Point2VoxelCPU3d.point_to_voxel as called
