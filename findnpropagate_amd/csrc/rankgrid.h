@@ -52,9 +52,12 @@ struct RG {
 
 // summary words per unit of the rank prefix (scan.hip): 64 for the large ~98 % empty grids, 8 / 1 for the small dense ones.  The
 // marking kernels and the prefix pass must agree on it: it is a function of the grid's size alone.
-__host__ __device__ inline int fnp_rg_wpw(long long nsum) { return nsum >= (1ll << 18) ? 64 : nsum >= (1ll << 15) ? 8 : 1; }
+// (round 6: 16 instead of 64 for the large grids — with the count pass gone the prefix pass is alone, and 4 x the waves with a
+//  quarter of the serial rounds each take it from 87 to 72 us per large grid at 128 scenes; 8: 66 us, but +3 us on the marks)
+__host__ __device__ inline int fnp_rg_wpw(long long nsum) { return nsum >= (1ll << 18) ? 16 : nsum >= (1ll << 15) ? 8 : 1; }
+// (allocation: sized for the finest split a grid of this size may be given — 8 summary words per unit from 2^15 words on, else 1)
 __host__ __device__ inline long long fnp_rg_counter_words(long long nsum) {
-    const long long nunits = (nsum + fnp_rg_wpw(nsum) - 1) / fnp_rg_wpw(nsum);
+    const long long nunits = nsum >= (1ll << 15) ? (nsum + 7) / 8 : nsum;
     return nunits + ((nunits + 63) >> 6) + ((nunits + 1023) >> 10);
 }
 
@@ -78,6 +81,10 @@ inline RG fnp_rg_view(const fnp_rankgrid *g) {
     r.nsum = (r.nblk + 63) >> 6;
     r.ctr = (unsigned *)g->counters;
     r.wpw = fnp_rg_wpw(r.nsum);
+    {   // development: FNP_WPW_BIG=8 / 16 / 64 — the unit size of the large grids
+        static const int big = [] { const char *e = getenv("FNP_WPW_BIG"); return e ? atoi(e) : 0; }();
+        if (big > 0 && r.wpw == 16) r.wpw = big;
+    }
     r.nunits = (r.nsum + r.wpw - 1) / r.wpw;
     r.ctr_levels = fnp_count_levels();
     return r;

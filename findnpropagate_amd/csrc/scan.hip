@@ -291,8 +291,9 @@ static int rank_grid_w(const RG &g, int *total, void *ws, hipStream_t s, int *ou
 }
 int rank_grid(const RG &g, int *total, void *ws, hipStream_t s, int *out_coords, int cap_out, bool counted) {
     // the split only changes who computes what, never the ranks (fnp_rg_wpw: the marking kernels count per the same units)
-    const int wpw = fnp_rg_wpw(g.nsum);
+    const int wpw = g.wpw;
     if (wpw == 64) return rank_grid_w<64>(g, total, ws, s, out_coords, cap_out, counted);
+    if (wpw == 16) return rank_grid_w<16>(g, total, ws, s, out_coords, cap_out, counted);
     if (wpw == 8) return rank_grid_w<8>(g, total, ws, s, out_coords, cap_out, counted);
     return rank_grid_w<1>(g, total, ws, s, out_coords, cap_out, counted);
 }

@@ -228,6 +228,155 @@ __global__ __launch_bounds__(64) void vox_scene_kernel(const int *__restrict__ b
     }
 }
 
+// The points a cell keeps: min(cnt, max_points) slots in arrival order (a crowded cell: already ascending); they are consumed in
+// ASCENDING index order — next = the smallest index above the previous one — so that sums and the (M, max_points, C) block come
+// out as from a sorted list.
+struct CellPts {
+    const int *slots;
+    int np, s0, s1;
+    __device__ __forceinline__ int next_above(int prev) const {
+        if (np <= 2) {
+            const int a = s0, b = np == 2 ? s1 : kSentinel;
+            const int lo = a < b ? a : b, hi = a < b ? b : a;
+            return lo > prev ? lo : hi;
+        }
+        int m = kSentinel;
+        for (int j = 0; j < np; ++j) {
+            const int v = slots[j];
+            m = (v > prev && v < m) ? v : m;
+        }
+        return m;
+    }
+};
+
+// one voxel row: coordinates, point count, mean feature row (MeanVFE) and, when asked for, the zero padded (max_points, C) block
+__device__ __forceinline__ void vox_write_row(const float *__restrict__ pts, int C, int maxp, const CellPts &cp, int p0, int r, int id,
+                                              int bb, int z, int y, int x, int *__restrict__ perm, int *__restrict__ coords,
+                                              int *__restrict__ num_points, float *__restrict__ mean, float *__restrict__ voxels) {
+    const int np = cp.np;
+    auto next_above = [&](int prev) -> int { return cp.next_above(prev); };
+    perm[r] = id;
+    reinterpret_cast<int4 *>(coords)[id] = make_int4(bb, z, y, x);
+    num_points[id] = np;
+    const float norm = (float)(np < 1 ? 1 : np);
+    // Per channel the kept points meet in the order torch's CPU `voxels.sum(dim=1)` adds the slots of the (M, max_points, C) block
+    // (mean_vfe.py:26; round 6: held to the reference's own class bit for bit, tests/golden/meanvfe_golden.npz).  That order
+    // is cascade_sum's (aten/src/ATen/native/cpu/SumKernel.cpp, restated in oracle/fnp_oracle.c orc_mean_vfe): for C < 8 the
+    // columns 0 .. 4 * (C / 4) - 1 in slot order, the C % 4 columns left over — t of a 5-feature nuScenes point — as FOUR
+    // interleaved partial sums (slot j to partial j & 3 for j < 4 * (P / 4)), partial 0 then takes the P % 4 tail slots and
+    // the partials 1, 2, 3; blocks of 16 slots cascade through accumulator levels (P >= 16 only).  Padding slots are zeros.
+    if ((C == 5 || C == 4) && maxp < 16) {
+        // nuScenes / KITTI point rows (x y z intensity [t]) as ONE 16-byte access + one dword instead of five dword accesses:
+        // this kernel is bound by the NUMBER of scattered requests it puts through L2 (~22 per voxel before, round 5), not by
+        // bytes.  Rows are 4-byte aligned only: f4u carries that alignment (global memory takes dword-aligned wide accesses).
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        f4u s4 = {0.f, 0.f, 0.f, 0.f};
+        float part[4] = {0.f, 0.f, 0.f, 0.f}, tl[3] = {0.f, 0.f, 0.f};
+        const int P4 = maxp & ~3;
+        int pi = p0;
+        for (int j = 0; j < np; ++j) {
+            const float *pr = pts + (size_t)pi * C;
+            const f4u v4 = *reinterpret_cast<const f4u *>(pr);
+            const float v1 = C == 5 ? pr[4] : 0.f;
+            if (j + 1 < np) pi = next_above(pi);   // (the slots are in L1: the search runs under the point's loads)
+            s4 += v4;
+            // (register selects, no indexed array: a partial is never -0.0, so the + 0.f of the other three is exact)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) part[k] += (j < P4 && (j & 3) == k) ? v1 : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tl[k] = (j == P4 + k) ? v1 : tl[k];
+        }
+        float *mo = mean + (size_t)id * C;
+        f4u m4 = {s4[0] / norm, s4[1] / norm, s4[2] / norm, s4[3] / norm};
+        *reinterpret_cast<f4u *>(mo) = m4;
+        if (C == 5) {
+            float s1f = part[0];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s1f += (P4 + k < maxp) ? tl[k] : 0.f;
+            s1f += part[1];
+            s1f += part[2];
+            s1f += part[3];
+            mo[4] = s1f / norm;
+        }
+    } else {
+        // any other shape: column by column with the cascade written out (a pass over the voxel's points per column)
+        for (int c = 0; c < C; ++c) {
+            const bool ilp = C < 8 && c >= (C / 4) * 4;           // a left-over column: four interleaved partials
+            const int nsum = ilp ? 4 : 1, size = ilp ? maxp / 4 : maxp;
+            int lp = 0;
+            while ((1 << lp) < size) ++lp;
+            lp = C >= 8 ? 30 : max(4, lp / 4);                       // (C >= 8: slot order, as the oracle — torch's form depends on the host ISA)
+            const int mask = (1 << lp) - 1;
+            float acc[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int l = 0; l < 4; ++l) acc[k][l] = 0.f;
+            float tail = 0.f;
+            bool tail_started = false;
+            int pi = p0;
+            for (int j = 0; j < maxp; ++j) {                         // every slot, the zero padding included (it moves the cascade's levels)
+                const float v = j < np ? pts[(size_t)pi * C + c] : 0.f;
+                if (j + 1 < np) pi = next_above(pi);
+                if (j < size * nsum) {
+                    const int e = j / nsum + 1;                      // elements this partial holds after the add
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (k != (ilp ? (j & 3) : 0)) continue;
+                        acc[k][0] += v;
+                        if ((e & mask) == 0) {
+#pragma unroll
+                            for (int l = 1; l < 4; ++l) {
+                                acc[k][l] += acc[k][l - 1];
+                                acc[k][l - 1] = 0.f;
+                                if ((e & (mask << (l * lp))) != 0) break;
+                            }
+                        }
+                    }
+                } else {                                             // the P % 4 tail slots of a left-over column go to partial 0
+                    if (!tail_started) {
+#pragma unroll
+                        for (int l = 1; l < 4; ++l) acc[0][0] += acc[0][l];
+                        tail = acc[0][0];
+                        tail_started = true;
+                    }
+                    tail += v;
+                }
+            }
+            float sacc;
+            if (ilp) {
+                if (!tail_started) {
+#pragma unroll
+                    for (int l = 1; l < 4; ++l) acc[0][0] += acc[0][l];
+                    tail = acc[0][0];
+                }
+                sacc = tail;
+#pragma unroll
+                for (int k = 1; k < 4; ++k) {
+#pragma unroll
+                    for (int l = 1; l < 4; ++l) acc[k][0] += acc[k][l];
+                    sacc += acc[k][0];
+                }
+            } else {
+#pragma unroll
+                for (int l = 1; l < 4; ++l) acc[0][0] += acc[0][l];
+                sacc = acc[0][0];
+            }
+            mean[(size_t)id * C + c] = sacc / norm;
+        }
+    }
+    if (voxels) {
+        float *v = voxels + (size_t)id * maxp * C;
+        int pi = p0;
+        for (int j = 0; j < maxp; ++j) {
+            for (int c = 0; c < C; ++c) v[j * C + c] = j < np ? pts[(size_t)pi * C + c] : 0.f;
+            if (j + 1 < np) pi = next_above(pi);
+        }
+    }
+}
+
+// CELL form (rounds 1-5; FNP_VOX_EMIT=cell): a thread per occupied cell in RANK order.  Everything behind the cell's slot list is a
+// scattered access: code and first-come rank of its first point, its points' rows, and the voxel row it writes (first-come order).
 __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restrict__ pts, int C, int maxp,
                                                             const int *__restrict__ boff, int B, int max_voxels,
                                                             RankGridDims g, const long long *__restrict__ code,
@@ -251,26 +400,13 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
     const long long lb = fnp_xcd_block(), nchunk = (ns + kThreads - 1) / kThreads;      // balanced runs of whole 256-rank chunks
     const int r_begin = (int)(nchunk * lb / gridDim.x) * kThreads, r_end = min(ns, (int)(nchunk * (lb + 1) / gridDim.x) * kThreads);
     for (int r = r_begin + threadIdx.x; r < r_end; r += kThreads) {
-        const int *slots = top + (size_t)r * maxp;
-        // the cell's kept points: min(cnt, max_points) slots in arrival order (a crowded cell: already ascending); they are
-        // consumed in ASCENDING index order below — next = the smallest index above the previous one — so that sums and the
-        // (M, max_points, C) block come out as from a sorted list
-        const int cn = cnt[r], s0 = slots[0], s1 = maxp > 1 ? slots[1] : kSentinel;   // (independent loads: most cells hold one or two points)
-        const int np = min(cn, maxp);
-        auto next_above = [&](int prev) -> int {
-            if (np <= 2) {
-                const int a = s0, b = np == 2 ? s1 : kSentinel;
-                const int lo = a < b ? a : b, hi = a < b ? b : a;
-                return lo > prev ? lo : hi;
-            }
-            int m = kSentinel;
-            for (int j = 0; j < np; ++j) {
-                const int v = slots[j];
-                m = (v > prev && v < m) ? v : m;
-            }
-            return m;
-        };
-        const int p0 = next_above(-1);
+        CellPts cp;
+        cp.slots = top + (size_t)r * maxp;
+        const int cn = cnt[r];
+        cp.s0 = cp.slots[0];
+        cp.s1 = maxp > 1 ? cp.slots[1] : kSentinel;   // (independent loads: most cells hold one or two points)
+        cp.np = min(cn, maxp);
+        const int p0 = cp.next_above(-1);
         // the scene of the cell is in its block number: no search in the batch offsets
         const long long cd = code[p0];
         int bb, z, y, x;
@@ -287,125 +423,60 @@ __global__ __launch_bounds__(kThreads) void vox_emit_kernel(const float *__restr
             }
             continue;
         }
-        perm[r] = id;
-        reinterpret_cast<int4 *>(coords)[id] = make_int4(bb, z, y, x);
-        num_points[id] = np;
-        const float norm = (float)(np < 1 ? 1 : np);
-        // Per channel the kept points meet in the order torch's CPU `voxels.sum(dim=1)` adds the slots of the (M, max_points, C) block
-        // (mean_vfe.py:26; round 6: held to the reference's own class bit for bit, tests/golden/meanvfe_golden.npz).  That order
-        // is cascade_sum's (aten/src/ATen/native/cpu/SumKernel.cpp, restated in oracle/fnp_oracle.c orc_mean_vfe): for C < 8 the
-        // columns 0 .. 4 * (C / 4) - 1 in slot order, the C % 4 columns left over — t of a 5-feature nuScenes point — as FOUR
-        // interleaved partial sums (slot j to partial j & 3 for j < 4 * (P / 4)), partial 0 then takes the P % 4 tail slots and
-        // the partials 1, 2, 3; blocks of 16 slots cascade through accumulator levels (P >= 16 only).  Padding slots are zeros.
-        if ((C == 5 || C == 4) && maxp < 16) {
-            // nuScenes / KITTI point rows (x y z intensity [t]) as ONE 16-byte access + one dword instead of five dword accesses:
-            // this kernel is bound by the NUMBER of scattered requests it puts through L2 (~22 per voxel before, round 5), not by
-            // bytes.  Rows are 4-byte aligned only: f4u carries that alignment (global memory takes dword-aligned wide accesses).
-            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-            f4u s4 = {0.f, 0.f, 0.f, 0.f};
-            float part[4] = {0.f, 0.f, 0.f, 0.f}, tl[3] = {0.f, 0.f, 0.f};
-            const int P4 = maxp & ~3;
-            int pi = p0;
-            for (int j = 0; j < np; ++j) {
-                const float *pr = pts + (size_t)pi * C;
-                const f4u v4 = *reinterpret_cast<const f4u *>(pr);
-                const float v1 = C == 5 ? pr[4] : 0.f;
-                if (j + 1 < np) pi = next_above(pi);   // (the slots are in L1: the search runs under the point's loads)
-                s4 += v4;
-                // (register selects, no indexed array: a partial is never -0.0, so the + 0.f of the other three is exact)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) part[k] += (j < P4 && (j & 3) == k) ? v1 : 0.f;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) tl[k] = (j == P4 + k) ? v1 : tl[k];
-            }
-            float *mo = mean + (size_t)id * C;
-            f4u m4 = {s4[0] / norm, s4[1] / norm, s4[2] / norm, s4[3] / norm};
-            *reinterpret_cast<f4u *>(mo) = m4;
-            if (C == 5) {
-                float s1f = part[0];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) s1f += (P4 + k < maxp) ? tl[k] : 0.f;
-                s1f += part[1];
-                s1f += part[2];
-                s1f += part[3];
-                mo[4] = s1f / norm;
-            }
-        } else {
-            // any other shape: column by column with the cascade written out (a pass over the voxel's points per column)
-            for (int c = 0; c < C; ++c) {
-                const bool ilp = C < 8 && c >= (C / 4) * 4;           // a left-over column: four interleaved partials
-                const int nsum = ilp ? 4 : 1, size = ilp ? maxp / 4 : maxp;
-                int lp = 0;
-                while ((1 << lp) < size) ++lp;
-                lp = C >= 8 ? 30 : max(4, lp / 4);                       // (C >= 8: slot order, as the oracle — torch's form depends on the host ISA)
-                const int mask = (1 << lp) - 1;
-                float acc[4][4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int l = 0; l < 4; ++l) acc[k][l] = 0.f;
-                float tail = 0.f;
-                bool tail_started = false;
-                int pi = p0;
-                for (int j = 0; j < maxp; ++j) {                         // every slot, the zero padding included (it moves the cascade's levels)
-                    const float v = j < np ? pts[(size_t)pi * C + c] : 0.f;
-                    if (j + 1 < np) pi = next_above(pi);
-                    if (j < size * nsum) {
-                        const int e = j / nsum + 1;                      // elements this partial holds after the add
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            if (k != (ilp ? (j & 3) : 0)) continue;
-                            acc[k][0] += v;
-                            if ((e & mask) == 0) {
-#pragma unroll
-                                for (int l = 1; l < 4; ++l) {
-                                    acc[k][l] += acc[k][l - 1];
-                                    acc[k][l - 1] = 0.f;
-                                    if ((e & (mask << (l * lp))) != 0) break;
-                                }
-                            }
-                        }
-                    } else {                                             // the P % 4 tail slots of a left-over column go to partial 0
-                        if (!tail_started) {
-#pragma unroll
-                            for (int l = 1; l < 4; ++l) acc[0][0] += acc[0][l];
-                            tail = acc[0][0];
-                            tail_started = true;
-                        }
-                        tail += v;
-                    }
-                }
-                float sacc;
-                if (ilp) {
-                    if (!tail_started) {
-#pragma unroll
-                        for (int l = 1; l < 4; ++l) acc[0][0] += acc[0][l];
-                        tail = acc[0][0];
-                    }
-                    sacc = tail;
-#pragma unroll
-                    for (int k = 1; k < 4; ++k) {
-#pragma unroll
-                        for (int l = 1; l < 4; ++l) acc[k][0] += acc[k][l];
-                        sacc += acc[k][0];
-                    }
-                } else {
-#pragma unroll
-                    for (int l = 1; l < 4; ++l) acc[0][0] += acc[0][l];
-                    sacc = acc[0][0];
-                }
-                mean[(size_t)id * C + c] = sacc / norm;
-            }
-        }
-        if (voxels) {
-            float *v = voxels + (size_t)id * maxp * C;
-            int pi = p0;
-            for (int j = 0; j < maxp; ++j) {
-                for (int c = 0; c < C; ++c) v[j * C + c] = j < np ? pts[(size_t)pi * C + c] : 0.f;
-                if (j + 1 < np) pi = next_above(pi);
-            }
-        }
+        vox_write_row(pts, C, maxp, cp, p0, r, id, bb, z, y, x, perm, coords, num_points, mean, voxels);
     }
+}
+
+// POINT form (round 6, default): a thread per POINT in point order; the thread of a cell's FIRST point (fc[i + 1] != fc[i]) writes
+// the voxel.  Point rows, codes, ranks and first-come ranks are then read coalesced, and the voxel rows — first-come order IS point
+// order — are written nearly coalesced: consecutive first points own consecutive rows.  What stays scattered is what is keyed by
+// the cell: its point count, its slot list when it holds more than one point (and those points' rows), and perm[rank].  The cell
+// form paid ~9 scattered accesses per voxel (it is bound by their number, not by bytes: round 5), this one 2-4.
+__global__ __launch_bounds__(kThreads) void vox_emit_points_kernel(const float *__restrict__ pts, int n, int C, int maxp,
+                                                                   const int *__restrict__ boff, int B, int max_voxels,
+                                                                   RankGridDims g, const long long *__restrict__ code,
+                                                                   const int *__restrict__ rank, const int *__restrict__ top,
+                                                                   const int *__restrict__ cnt, const int *__restrict__ fc,
+                                                                   const int *__restrict__ n_first, const int *__restrict__ scene,
+                                                                   const int *__restrict__ n_sorted, int cap,
+                                                                   int *__restrict__ perm, int *__restrict__ coords,
+                                                                   int *__restrict__ num_points, float *__restrict__ mean,
+                                                                   float *__restrict__ voxels, int *__restrict__ n_cells,
+                                                                   int *__restrict__ n_dropped) {
+    const int ns = min(*n_sorted, cap);
+    const int *fc_start = scene;
+    const int *out_base = scene + (B + 1);
+    if (n_cells && blockIdx.x == 0 && threadIdx.x == 0) *n_cells = ns;
+    for (int r = ns + blockIdx.x * kThreads + threadIdx.x; r < cap; r += gridDim.x * kThreads) perm[r] = -1;
+    const int i = (int)fnp_xcd_block() * kThreads + threadIdx.x;   // (one eighth of the points — whole scenes' worth — per XCD)
+    if (i >= n) return;
+    const int r = rank[i];
+    if (r < 0) return;
+    const int f0 = fc[i], f1 = i + 1 < n ? fc[i + 1] : *n_first;
+    if (f1 == f0) return;                                          // not its cell's first point
+    const long long cd = code[i];
+    int bb, z, y, x;
+    rg_decode(g, cd >> 6, (int)(cd & 63), bb, z, y, x);
+    const int srank = f0 - fc_start[bb];
+    const int id = out_base[bb] + srank;
+    if (srank >= max_voxels || id >= cap) {
+        perm[r] = -1;
+        if (n_cells) {
+            const int t = out_base[B] + atomicAdd(n_dropped, 1);
+            if (t < cap) reinterpret_cast<int4 *>(coords)[t] = make_int4(bb, z, y, x);
+        }
+        return;
+    }
+    CellPts cp;
+    cp.slots = top + (size_t)r * maxp;
+    cp.np = min(cnt[r], maxp);
+    cp.s0 = i;                     // (a one-point cell reads no slot at all)
+    cp.s1 = kSentinel;
+    if (cp.np == 2) {              // the other point of a two-point cell: whichever slot is not i
+        const int a = cp.slots[0], b = cp.slots[1];
+        cp.s1 = a == i ? b : a;
+    }
+    vox_write_row(pts, C, maxp, cp, i, r, id, bb, z, y, x, perm, coords, num_points, mean, voxels);
 }
 
 // ---- rank grid from an explicit coordinate list ---------------------------------------------
@@ -416,7 +487,7 @@ __device__ __forceinline__ bool coord_ok(const RankGridDims &g, const int4 &c) {
 // the counters of the counted marks (rankgrid.h) go back to zero with the grid: a dense loop over a few thousand words
 __device__ __forceinline__ void rg_zero_counters(const RG &g, long long first, long long stride) {
     if (!g.ctr) return;
-    const long long words = fnp_rg_counter_words(g.nsum);
+    const long long words = g.nunits + ((g.nunits + 63) >> 6) + ((g.nunits + 1023) >> 10);   // (the words this grid's unit size uses)
     for (long long i = first; i < words; i += stride) g.ctr[i] = 0u;
 }
 
@@ -514,9 +585,15 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
     hipLaunchKernelGGL(vox_scene_kernel, dim3(1), dim3(64), 0, s, batch_offsets, B, n, w.flag, w.n_first,
                        cfg->max_voxels, cap, w.scene, n_voxels);
     FNP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(vox_emit_kernel, dim3(fnp_grid_for(n, kThreads)), dim3(kThreads), 0, s, points, C, maxp,
-                       batch_offsets, B, cfg->max_voxels, g.d, w.code, w.top, (const int *)w.cnt, w.flag, w.scene, w.n_sorted, n,
-                       g.perm, coords, num_points, mean_feats, voxels, n_cells, w.scene + 2 * (B + 1));
+    static const bool cell_form = [] { const char *e = getenv("FNP_VOX_EMIT"); return e && e[0] == 'c'; }();   // (development A/B)
+    if (cell_form)
+        hipLaunchKernelGGL(vox_emit_kernel, dim3(fnp_grid_for(n, kThreads)), dim3(kThreads), 0, s, points, C, maxp,
+                           batch_offsets, B, cfg->max_voxels, g.d, w.code, w.top, (const int *)w.cnt, w.flag, w.scene, w.n_sorted, n,
+                           g.perm, coords, num_points, mean_feats, voxels, n_cells, w.scene + 2 * (B + 1));
+    else
+        hipLaunchKernelGGL(vox_emit_points_kernel, dim3(pgrid), dim3(kThreads), 0, s, points, n, C, maxp, batch_offsets, B, cfg->max_voxels,
+                           g.d, w.code, (const int *)w.rank, w.top, (const int *)w.cnt, w.flag, (const int *)w.n_first, w.scene, w.n_sorted, n,
+                           g.perm, coords, num_points, mean_feats, voxels, n_cells, w.scene + 2 * (B + 1));
     FNP_LAUNCH_CHECK();
     return FNP_OK;
 }
