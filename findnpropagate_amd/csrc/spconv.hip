@@ -1415,290 +1415,6 @@ __global__ __launch_bounds__(kSortThreads) void classsort_place_kernel(const uns
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// ROWS128 (round 6): the class-sorted 128 -> 128 sweep with its feature rows fetched as WHOLE ROWS by LDS-DMA.
-//
-// What the gather-only probe says (tools/gather_probe.py on the real stage-4 rulebook of a 128-scene batch):
-// the fragment-shaped gathers of spconv_mfma_kernel — a wave instruction = 16 rows x 64 bytes, i.e. 16 half-line touches, four
-// instructions per row — run at 6.5-7.3 TB/s (25-29 GB/s per CU) in EVERY row order, 0.56-0.63 ms per launch against the kernel's
-// 0.76-0.78; the same rows fetched four WHOLE rows per wave instruction (16 lanes x 16 B contiguous per row: two full 128-byte lines
-// per row, 8 line touches per instruction) run at 8.9-10.2 TB/s, 0.40-0.46 ms, and 0.43-0.50 through an LDS transpose into the
-// fragment layout.  The address path is paced by line touches, not bytes (MI355X_MICROARCH.md says the same of a GEMM's x operand:
-// full-line staging + LDS-DMA against fragment-shaped loads, TA_BUSY 2x at identical traffic).
-//
-// So: per kernel offset a wave fetches the 48 neighbour rows of its 48 positions with 12 global_load_lds_dwordx4 (four rows each)
-// into a wave-private 12-KB LDS strip — no staging registers — and reads its twelve B fragments from there (ds_read_b128, XOR
-// swizzle applied on the SOURCE address: the DMA writes lane-linearly); absent neighbours fetch a row of zeros.  The weight slab of
-// the next offset comes by LDS-DMA too (4 instructions per wave).  Everything an offset needs is requested at the top of the offset
-// before it and waited for at the barrier between the two (vmcnt(0) + s_barrier: one offset of matrix work — 96 MFMAs per wave —
-// to land in), so there is exactly one buffer of everything: 64 KB of slabs + 96 KB of strips = the CU's 160 KB; BatchNorm scale /
-// shift are read from memory in the epilogue (11 tiles per CU and launch: nothing), the epilogue's transpose strips alias the row
-// strips.  Rulebook entries: lane (r4, c) holds the entry of position 12 r4 + c and hands it to the 16 lanes that fetch the row with
-// a DPP row broadcast (no LDS permute, no 12 loads per lane).  Same matrix instructions on the same operand values in the same
-// order as spconv_mfma_kernel<128, 128, 3, 27, ..., SORTED>: bit-identical (tests/test_gpu_spconv.py
-// test_class_sorted_sweep_equals_plain_sweep).  Tiles, rounds and the slot rotation are that kernel's (the class sort's perm and
-// blockmask were made for them).
-// ------------------------------------------------------------------------------------------
-__device__ uint4 g_rows128_zero[16];   // 256 bytes of zeros: the row an absent neighbour fetches
-
-template <int I> __device__ __forceinline__ int fnp_row_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + I, 0xf, 0xf, false); }
-template <int I, int N, typename F> __device__ __forceinline__ void fnp_static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        fnp_static_for<I + 1, N>(f);
-    }
-}
-typedef __attribute__((address_space(1))) const void *fnp_gptr;
-typedef __attribute__((address_space(3))) void *fnp_lptr;
-
-#ifndef FNP_R128_ABLATE
-#define FNP_R128_ABLATE 0   // development timing probes (wrong results): 1 = no MFMA, 2 = no slab DMA, 4 = no row DMA, 8 = no fragment reads
-#endif
-constexpr int kR128NW = 8, kR128MB = 3, kR128NT = kR128NW * 64, kR128Slab = 128 * 16;            // chunks per slab
-constexpr int kR128Strip = kR128MB * 16 * 256, kR128Lds = 2 * kR128Slab * 16 + kR128NW * kR128Strip;   // 160 KB
-static_assert(kR128Lds == 160 * 1024, "slabs + strips fill the CU's LDS exactly");
-
-template <typename TAct>
-__global__ __launch_bounds__(kR128NT, 2) void spconv_rows128_kernel(const TAct *__restrict__ x, const TAct *__restrict__ w, const int *__restrict__ nbr,
-                                                                    int nbr_stride, const int *__restrict__ n_out, int cap, TAct *__restrict__ y,
-                                                                    const float *__restrict__ scale, const float *__restrict__ shift,
-                                                                    const TAct *__restrict__ residual, int relu, SortedRb srb) {
-    using bf16x8 = typename Vec16<TAct>::v8;
-    using bf16x4 = typename Vec16<TAct>::v4;
-    constexpr int C = 128, NB = 8, NBH = 4, KS = 4, NW = kR128NW, MB = kR128MB, ROWS_PER_WG = NW * MB * 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char fnp_smem[];
-    uint4 *const wl = reinterpret_cast<uint4 *>(fnp_smem);
-    const int n = min(*n_out, cap);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, q = lane >> 4;     // fragment roles: column (site) l15, k-chunk q
-    const int c16 = lane & 15, r4 = lane >> 4;    // fetch roles: 16-byte chunk c16 of the row this 16-lane group fetches
-    unsigned char *const strip = fnp_smem + 2 * kR128Slab * 16 + wave * kR128Strip;
-
-    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const XcdRows xr = fnp_xcd_rows(n, G, xcd);
-    const int row_begin = xr.X0, row_end = xr.X1, xslots = xr.S;
-    if (row_begin >= row_end) return;
-
-    int aoff[KS];   // A fragments: slab row (output channel) nb * 16 + l15, chunk 4 ks + q at position chunk ^ (row & 15)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) aoff[ks] = l15 * 16 + ((ks * 4 + q) ^ l15);
-    // weight slab by LDS-DMA: wave-instruction j of this wave fills LDS chunks [(j * 8 + wave) * 64, + 64) = four slab rows; the lane's
-    // chunk sits at position pos of row wr and must hold logical chunk pos ^ (wr & 15): the swizzle is applied to the SOURCE
-    unsigned wsrc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int pch = (j * 8 + wave) * 64 + lane, wr = pch >> 4, pos = pch & 15;
-        wsrc[j] = (unsigned)(wr * 16 + (pos ^ (wr & 15))) * 16u;
-    }
-    auto dma_slab = [&](int koffset, int ring) {
-        const unsigned char *wk = reinterpret_cast<const unsigned char *>(w) + (size_t)koffset * (C * C * 2);
-        if (FNP_R128_ABLATE & 2) return;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((fnp_gptr)(wk + wsrc[j]), (fnp_lptr)(wl + ring * kR128Slab + (j * 8 + wave) * 64), 16, 0, 0);
-    };
-
-    auto run_tile = [&](auto mbt_tag, const int tile_base) __attribute__((always_inline)) {
-        constexpr int MBT = decltype(mbt_tag)::value, NI = MBT * 4;   // NI wave-instructions of four rows fetch the wave's MBT * 16 rows
-        const int row0 = tile_base + wave * (MBT * 16);
-        // the offsets this tile sweeps (as spconv_mfma_kernel's SORTED form: the union of the tile's block masks, in every wave)
-        int Kt, kl = 0;
-        {
-            const int nbt = min(NW * MBT, (row_end - tile_base + 15) >> 4);
-            unsigned m = lane < nbt ? srb.blockmask[(tile_base >> 4) + lane] : 0u;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) m |= (unsigned)__shfl_xor((int)m, d);
-            m = (unsigned)__builtin_amdgcn_readfirstlane((int)m) & 0x7ffffffu;
-            if (m == 0u) m = 1u << 13;
-            Kt = __popc(m);
-            int cnt = 0;
-#pragma unroll
-            for (int pbit = 0; pbit < 27; ++pbit) {
-                if ((m >> pbit) & 1u) {
-                    if (lane >= cnt) kl = pbit;
-                    ++cnt;
-                }
-            }
-        }
-        auto koff = [&](int i) -> int { return __builtin_amdgcn_readlane(kl, i < Kt ? i : Kt - 1); };
-        // position of the wave's tile whose ENTRY this lane holds: NI * r4 + c16 (c16 < NI); the row behind it
-        const int epos = row0 + NI * r4 + c16;
-        const bool ehas = c16 < NI && epos < row_end;
-        const int erow = srb.perm[min(epos, row_end - 1)];
-        auto entry = [&](int i) -> int {   // (raw: validated where it is consumed, after the barrier that waits for it)
-            return nbr[(size_t)koff(i) * nbr_stride + erow];
-        };
-        // fetch the rows of sweep step `i` (entries e): instruction ii brings the rows of positions NI * r + ii (r = 0..3) to strip
-        // slots 4 ii + r; the lane's 16 bytes are chunk c16 ^ (position & 15) of its row
-        auto dma_rows = [&](int e) {
-            if (FNP_R128_ABLATE & 4) return;
-            fnp_static_for<0, NI>([&](auto ic) {
-                constexpr int ii = decltype(ic)::value;
-                const int er = fnp_row_bcast<ii>(ehas ? e : -1);
-                const int pos = NI * r4 + ii;
-                const unsigned char *src = er >= 0 ? reinterpret_cast<const unsigned char *>(x) + (size_t)er * 256 + (size_t)((c16 ^ (pos & 15)) << 4)
-                                                   : reinterpret_cast<const unsigned char *>(g_rows128_zero) + (c16 << 4);
-                __builtin_amdgcn_global_load_lds((fnp_gptr)src, (fnp_lptr)(strip + ii * 1024), 16, 0, 0);
-            });
-        };
-        // B fragment addresses: position p = mb * 16 + l15 -> slot 4 (p % NI) + p / NI, chunk 4 ks + q at position chunk ^ (p & 15) = ^ l15
-        unsigned boff[MBT];
-#pragma unroll
-        for (int mb = 0; mb < MBT; ++mb) {
-            const int pp = mb * 16 + l15;
-            boff[mb] = (unsigned)(4 * (pp % NI) + pp / NI) * 256u;
-        }
-
-        f32x4 acc[NB][MBT];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int mb = 0; mb < MBT; ++mb) acc[nb][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-        // prologue: rows and slab of step 0, entries of step 1
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the epilogue of the previous tile is done with this strip
-        {
-            const int e0 = entry(0);
-            dma_rows(e0);
-        }
-        dma_slab(koff(0), 0);
-        int e_next = entry(1);
-        __syncthreads();   // (vmcnt(0) + barrier: rows, slab 0 and the entries have landed, everywhere)
-        for (int k = 0; k < Kt; ++k) {
-            // this step's twelve B fragments leave the strip first: it is refilled right behind them
-            bf16x8 xb[KS][MBT];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int mb = 0; mb < MBT; ++mb) {
-                    u32x4 t = u32x4{(unsigned)k, 0u, 0u, 0u};
-                    if (!(FNP_R128_ABLATE & 8)) t = *reinterpret_cast<const u32x4 *>(strip + boff[mb] + ((unsigned)((ks * 4 + q) ^ l15) << 4));
-                    xb[ks][mb] = *reinterpret_cast<const bf16x8 *>(&t);
-                }
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the fragments are in registers
-            __builtin_amdgcn_sched_barrier(0);
-            int e_after = 0;
-            if (k + 1 < Kt) {   // (uniform) everything step k + 1 needs, one step of matrix work ahead
-                dma_rows(e_next);
-                dma_slab(koff(k + 1), (k + 1) & 1);
-                e_after = entry(k + 2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const uint4 *wk = wl + (k & 1) * kR128Slab;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-                for (int h = 0; h < NB; h += NBH) {
-                    bf16x8 wa[NBH];
-#pragma unroll
-                    for (int j = 0; j < NBH; ++j) {
-                        const uint4 t = wk[aoff[ks] + (h + j) * 256];
-                        wa[j] = *reinterpret_cast<const bf16x8 *>(&t);
-                    }
-#pragma unroll
-                    for (int mb = 0; mb < MBT; ++mb)
-#pragma unroll
-                        for (int j = 0; j < NBH; ++j) {
-                            if (FNP_R128_ABLATE & 1) asm volatile("" ::"v"(wa[j]), "v"(xb[ks][mb]));
-                            else acc[h + j][mb] = mfma16(wa[j], xb[ks][mb], acc[h + j][mb]);
-                        }
-                }
-            }
-            e_next = e_after;
-            __syncthreads();   // vmcnt(0) + barrier: step k + 1's rows, slab and entries are in; every wave is done with slab k & 1
-        }
-
-        // epilogue (spconv_mfma_kernel's wide form: a 16-site block transposed through the wave's strip, 16 bytes per lane over whole rows)
-        constexpr int EH = 16, LPR = C / 8, SPI = 64 / LPR, NRD = EH / SPI, ES = C * 2 + 16;
-        unsigned char *const eb = strip;
-        const int wsite = lane / LPR, wchunk = lane % LPR;
-        u32x4 rs_all[MBT][NRD];
-        int orow[MBT][NRD];
-#pragma unroll
-        for (int mb = 0; mb < MBT; ++mb)
-#pragma unroll
-            for (int i = 0; i < NRD; ++i) {
-                const int r = row0 + mb * 16 + i * SPI + wsite;
-                orow[mb][i] = srb.perm[r < row_end ? r : row_end - 1];
-            }
-        if (residual) {
-#pragma unroll
-            for (int mb = 0; mb < MBT; ++mb)
-#pragma unroll
-                for (int i = 0; i < NRD; ++i) {
-                    const int r = row0 + mb * 16 + i * SPI + wsite;
-                    rs_all[mb][i] = u32x4{0u, 0u, 0u, 0u};
-                    if (r < row_end) rs_all[mb][i] = *reinterpret_cast<const u32x4 *>(residual + (size_t)orow[mb][i] * C + wchunk * 8);
-                }
-        }
-#pragma unroll
-        for (int mb = 0; mb < MBT; ++mb) {
-            const int rb = row0 + mb * 16;
-            if (residual) {
-#pragma unroll
-                for (int i = 0; i < NRD; ++i) *reinterpret_cast<u32x4 *>(eb + (i * SPI + wsite) * ES + wchunk * 16) = rs_all[mb][i];
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int c0 = nb * 16 + q * 4;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[nb][mb][j];
-                if (scale) {
-                    const float4 s4 = *reinterpret_cast<const float4 *>(scale + c0);
-                    const float4 h4 = *reinterpret_cast<const float4 *>(shift + c0);
-                    v[0] = v[0] * s4.x + h4.x; v[1] = v[1] * s4.y + h4.y; v[2] = v[2] * s4.z + h4.z; v[3] = v[3] * s4.w + h4.w;
-                }
-                bf16x4 *slotp = reinterpret_cast<bf16x4 *>(eb + l15 * ES + c0 * 2);
-                if (residual) {
-                    const bf16x4 t = *slotp;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] + (float)t[j];
-                }
-                if (relu) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.f ? 0.f : v[j];
-                }
-                *slotp = bf16x4{(TAct)v[0], (TAct)v[1], (TAct)v[2], (TAct)v[3]};
-            }
-#pragma unroll
-            for (int i = 0; i < NRD; ++i) {
-                const int r = rb + i * SPI + wsite;
-                const u32x4 t = *reinterpret_cast<const u32x4 *>(eb + (i * SPI + wsite) * ES + wchunk * 16);
-                if (r < row_end) *reinterpret_cast<u32x4 *>(y + (size_t)orow[mb][i] * C + wchunk * 8) = t;
-            }
-        }
-    };
-
-    // tiles of this slot: its tile of every full round of the XCD group (rotated, see spconv_mfma_kernel), then its share of the partial round
-    const int round_rows = xslots * ROWS_PER_WG;
-    const int full = (row_end - row_begin) / round_rows;
-    const int left0 = row_begin + full * round_rows;
-    int tper = fnp_tail_blocks(row_end - left0, xslots, NW);
-    const int tail_base = left0 + slot * (NW * tper * 16);
-    if (tail_base >= row_end) tper = 0;
-    const int rot = (xslots * 3 + 4) >> 3;
-    for (int t = 0; t < full; ++t) run_tile(std::integral_constant<int, MB>{}, row_begin + t * round_rows + ((slot + t * rot) % xslots) * ROWS_PER_WG);
-    if (tper == 3) run_tile(std::integral_constant<int, 3>{}, tail_base);
-    if (tper == 2) run_tile(std::integral_constant<int, 2>{}, tail_base);
-    if (tper == 1) run_tile(std::integral_constant<int, 1>{}, tail_base);
-}
-
-template <typename TAct>
-int launch_rows128(const void *x, const void *w, const int *nbr, int nbr_stride, const int *n_out, int cap, void *y, const float *scale,
-                   const float *shift, const void *residual, int relu, const SortedRb &srb, int grid, hipStream_t s) {
-    auto kern = spconv_rows128_kernel<TAct>;
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kR128Lds) != hipSuccess) return FNP_ERR_HIP;
-        raised = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kR128NT), kR128Lds, s, (const TAct *)x, (const TAct *)w, nbr, nbr_stride, n_out, cap, (TAct *)y, scale, shift,
-                       (const TAct *)residual, relu, srb);
-    FNP_LAUNCH_CHECK();
-    return FNP_OK;
-}
-
 template <typename TAct, typename TOut>
 int dispatch_16(const void *x, long long n_in, const void *w, const int *nbr, int nbr_stride, int K, const int *n_out, int cap,
                   void *y, const float *scale, const float *shift, const void *residual, int relu, int hints, int Cin,
@@ -1939,18 +1655,6 @@ extern "C" int fnp_spconv_forward_sorted(const void *feat_in, int dtype, int n_i
     const long long xb = (long long)n_in_rows * Cin * 2;
     if (xb >= 0x7fffffffll) return FNP_ERR_ARG;
     const SortedRb srb{perm, blockmask};
-    // ROWS128 (round 6): whole-row fetches by LDS-DMA, on the same tiles (the grid the class sort was made for).  FNP_ROWS128=0: the
-    // fragment-shaped gathers of rounds 3-5 (development A/B; bit-identical).  Full tiles only need >= one row per workgroup: same grid rule.
-    static const bool rows128 = [] { const char *e = getenv("FNP_ROWS128"); return !(e && e[0] == '0'); }();
-    if (rows128 && (dtype == FNP_BF16 || dtype == FNP_F16)) {
-        int grid = 0;
-        const int rc = launch_mfma_k<128, 128, 27, false, __bf16, false, __bf16, true>(nullptr, 0, nullptr, nullptr, cap_out, 27, n_out, cap_out, nullptr, nullptr,
-                                                                                        nullptr, nullptr, 0, 0, (hipStream_t)stream, nullptr, nullptr, &grid);
-        if (rc != FNP_OK) return rc;
-        if (dtype == FNP_BF16)
-            return launch_rows128<__bf16>(feat_in, weight, nbr, nbr_stride, n_out, cap_out, feat_out, scale, shift, residual, relu, srb, grid, (hipStream_t)stream);
-        return launch_rows128<_Float16>(feat_in, weight, nbr, nbr_stride, n_out, cap_out, feat_out, scale, shift, residual, relu, srb, grid, (hipStream_t)stream);
-    }
     if (dtype == FNP_BF16)
         return launch_mfma_k<128, 128, 27, false, __bf16, false, __bf16, true>(feat_in, (int)xb, weight, nbr, nbr_stride, 27, n_out, cap_out, feat_out, scale,
                                                                                 shift, residual, relu, 0, (hipStream_t)stream, nullptr, &srb);
