@@ -14,7 +14,6 @@
 //              leaves the output order implementation-defined).
 #include "rankgrid.h"
 #include "tilerb.h"
-#include <cstdlib>
 
 namespace {
 
@@ -203,234 +202,6 @@ __global__ __launch_bounds__(kThreads) void strided_mark2_kernel(const int *__re
         fetch(it + 1, row_n, c_n);
         mark2_row<SZ, SY, SX>(row >= 0, c, go, ge, lane, FNP_MARK_TAB ? &tab : nullptr);
         if (FNP_MARK_TAB) mark_tab_flush(&tab, go, threadIdx.x, kThreads);   // (the passes of a workgroup lie far apart: nothing to merge across them)
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// STRIDED SITE GENERATION WITHOUT ATOMICS (round 6).  The marking kernels above are a SCATTER: every input row
-// ORs its <= 8 output cells into the output grid — device-scope atomics on words of a zeroed sparse grid (0.33 M per launch after the
-// wave- and workgroup-level merges, three quarters of the kernels' 75-80 us).  But an output occupancy word is a pure function of
-// <= 27 input occupancy words: out(o) = OR over the kernel of in(o s - p + kappa), i.e. per axis a dilation by the kernel followed by
-// keeping every s-th cell, and the three axes separate.  GATHER form: one workgroup per output PATCH (8 x 8 block columns: the unit
-// the blocks are numbered by, so its 64 bd blocks are consecutive block ids and own whole summary words); it
-//   1. reads the summary words of the <= 9 input patches its outputs can draw from (<= 99 words) and leaves if all are zero;
-//   2. stages the occupancy words of the input block region (<= 17 x 17 columns x bd_in) in LDS, touching memory only where a
-//      summary bit is set (a grid that carries a rank -> row permutation — stage 1 — drops the cells whose voxel fell to the
-//      max_voxels cut: perm < 0);
-//   3. a thread per output block combines its <= 3 x 3 x 3 staged words with shifts and masks (x, then y, then z: ~450 bit
-//      operations), masks the cells beyond the output shape, and STORES the word — every word has exactly one writer —, a ballot
-//      over the wave's 64 consecutive blocks is the summary word, and the wave adds its cell count to the prefix unit's counter
-//      (counted marks, rankgrid.h: one atomic per wave that found anything).
-// Same grid, same ranks, same coordinates as the marking form (every test of the strided rulebooks runs on it unchanged);
-// FNP_STRIDED_GEN=0 keeps the marking kernels (development A/B).
-struct AxisGen {
-    int s, b0add, nblk;       // first input block of output block B: B * s + b0add; input blocks per output block (1..3)
-    unsigned m[4][3];         // m[j][d]: the cells (4-bit set) of input block d that feed output cell j
-};
-struct GenGeom { AxisGen a[3]; };   // z, y, x
-
-static AxisGen make_axis_gen(int k, int s, int p) {
-    AxisGen g;
-    g.s = s;
-    g.b0add = -((p + 3) / 4);                 // floor(-p / 4)
-    const int off = -p - 4 * g.b0add;         // first input cell of output cell 0, relative to input block b0
-    g.nblk = (off + 3 * s + k - 1) / 4 + 1;
-    for (int j = 0; j < 4; ++j)
-        for (int d = 0; d < 3; ++d) {
-            unsigned m = 0u;
-            for (int t = 0; t < 4; ++t) {
-                const int c = 4 * d + t;
-                if (c >= off + j * s && c <= off + j * s + k - 1) m |= 1u << t;
-            }
-            g.m[j][d] = m;
-        }
-    return g;
-}
-
-__device__ __forceinline__ long long rg_block_id(const RankGridDims &g, int b, int bz, int by, int bx) {
-    const unsigned col = (rg_morton3((unsigned)by & 7u) << 1) | rg_morton3((unsigned)bx & 7u);
-    return ((((long long)b * g.th + (by >> 3)) * g.tw + (bx >> 3)) * 64 + col) * g.bd + bz;
-}
-
-constexpr int kGenMaxCols = 17, kGenMaxBd = 12, kGenStage = kGenMaxCols * kGenMaxCols * kGenMaxBd;
-
-__global__ __launch_bounds__(kThreads) void strided_gen_kernel(RG gi, RG go, GenGeom gg) {
-    __shared__ unsigned long long stage[kGenStage];
-    __shared__ unsigned long long sumw[9 * kGenMaxBd + 1];
-    __shared__ unsigned short colmask[kGenMaxCols * kGenMaxCols];
-    __shared__ int any_s;
-    const int tid = threadIdx.x, lane = fnp_lane();
-    // output patch (b, ty, tx)
-    int pidx = blockIdx.x;
-    const int tx = pidx % go.d.tw; pidx /= go.d.tw;
-    const int ty = pidx % go.d.th; pidx /= go.d.th;
-    const int b = pidx;
-    const AxisGen &az = gg.a[0], &ay = gg.a[1], &ax = gg.a[2];
-    // input block region of the patch
-    const int by_lo = 8 * ty * ay.s + ay.b0add, ny = 7 * ay.s + ay.nblk;
-    const int bx_lo = 8 * tx * ax.s + ax.b0add, nx = 7 * ax.s + ax.nblk;
-    const int bz_lo = max(0, az.b0add), bz_hi = min(gi.d.bd - 1, (go.d.bd - 1) * az.s + az.b0add + az.nblk - 1), nz = bz_hi - bz_lo + 1;
-    // 1. summary words of the input patches the region touches
-    const int pty_lo = by_lo >> 3, ptx_lo = bx_lo >> 3;                 // (arithmetic shift: -1 for the fringe row above patch 0)
-    const int npy = ((by_lo + ny - 1) >> 3) - pty_lo + 1, npx = ((bx_lo + nx - 1) >> 3) - ptx_lo + 1;   // <= 3 each
-    const int bdi = gi.d.bd;
-    if (tid == 0) any_s = 0;
-    __syncthreads();
-    bool any = false;
-    for (int i = tid; i < npy * npx * bdi; i += kThreads) {
-        const int j = i % bdi, pp = i / bdi, py = pty_lo + pp / npx, px = ptx_lo + pp % npx;
-        unsigned long long v = 0ull;
-        if (py >= 0 && py < gi.d.th && px >= 0 && px < gi.d.tw) v = gi.summ[(((long long)b * gi.d.th + py) * gi.d.tw + px) * bdi + j];
-        sumw[(pp / npx * 3 + pp % npx) * kGenMaxBd + j] = v;
-        any = any || v != 0ull;
-    }
-    if (any) any_s = 1;
-    __syncthreads();
-    if (!any_s) return;   // (whole workgroup)
-    // 2. per staged block COLUMN the occupancy of its nz blocks (a bit field of the summary words: the blocks of a column are
-    //    consecutive), then the occupancy words of the occupied blocks only — a patch region is ~3,000 blocks of which a few dozen
-    //    are occupied: neither the staging nor the gather below may cost per block of the region
-    const unsigned zfield = (1u << nz) - 1u;
-    for (int c = tid; c < ny * nx; c += kThreads) {
-        const int cy = c / nx, cx = c - cy * nx, by = by_lo + cy, bx = bx_lo + cx;
-        unsigned cm = 0u;
-        if (by >= 0 && by < gi.d.bh && bx >= 0 && bx < gi.d.bw) {
-            const unsigned col = (rg_morton3((unsigned)by & 7u) << 1) | rg_morton3((unsigned)bx & 7u);
-            const int first = (int)col * bdi + bz_lo;                      // first staged block of the column, inside its patch
-            const unsigned long long *sp = sumw + (((by >> 3) - pty_lo) * 3 + ((bx >> 3) - ptx_lo)) * kGenMaxBd + (first >> 6);
-            unsigned long long f = sp[0] >> (first & 63);
-            if ((first & 63) + nz > 64) f |= sp[1] << (64 - (first & 63));   // (the field straddles two summary words; sp[1] exists: first + nz <= 64 bdi)
-            cm = (unsigned)f & zfield;
-        }
-        colmask[c] = (unsigned short)cm;
-        unsigned m = cm;
-        while (m) {
-            const int cz = __builtin_ctz(m);
-            m &= m - 1u;
-            const long long blk = rg_block_id(gi.d, b, bz_lo + cz, by, bx);
-            unsigned long long w = gi.bits[blk];
-            if (gi.perm) {   // (uniform) stage 1: a cell whose voxel was dropped by the max_voxels cut is not an input site
-                const unsigned base = gi.base[blk];
-                unsigned long long mm = w;
-                int rk = 0;
-                while (mm) {
-                    const int bit = __builtin_ctzll(mm);
-                    mm &= mm - 1ull;
-                    if (gi.perm[base + rk] < 0) w &= ~(1ull << bit);
-                    ++rk;
-                }
-            }
-            stage[c * nz + cz] = w;
-        }
-    }
-    __syncthreads();
-    // 3. a thread per output block of the patch
-    const int nbo = 64 * go.d.bd;
-    const long long patch_base = ((((long long)b * go.d.th + ty) * go.d.tw + tx) * 64) * go.d.bd;
-    for (int t0 = 0; t0 < nbo; t0 += kThreads) {   // (whole waves: nbo is a multiple of 64)
-        const int t = t0 + tid;
-        unsigned long long out = 0ull;
-        if (t < nbo) {
-            const int col = t / go.d.bd, bzo = t - col * go.d.bd;
-            const int cyo = (int)rg_unmorton3((unsigned)col >> 1), cxo = (int)rg_unmorton3((unsigned)col);
-            const int Byo = 8 * ty + cyo, Bxo = 8 * tx + cxo;
-            const int iy0 = cyo * ay.s, ix0 = cxo * ax.s, iz0 = bzo * az.s + az.b0add - bz_lo;   // staged coordinates of the first input block
-            // the staged z indices this output block draws from, as a bit window; its <= 3 x 3 columns' occupancy inside it
-            unsigned zwin = 0u;
-            for (int dz = 0; dz < az.nblk; ++dz)
-                if (iz0 + dz >= 0 && iz0 + dz < nz) zwin |= 1u << (iz0 + dz);
-            unsigned cmk[3][3];
-            unsigned anyocc = 0u;
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    cmk[dy][dx] = (dy < ay.nblk && dx < ax.nblk) ? ((unsigned)colmask[(iy0 + dy) * nx + ix0 + dx] & zwin) : 0u;
-                    anyocc |= cmk[dy][dx];
-                }
-            if (anyocc && Byo < go.d.bh && Bxo < go.d.bw) {
-                unsigned long long Yw[3] = {0ull, 0ull, 0ull};
-                for (int dz = 0; dz < az.nblk; ++dz) {
-                    const int cz = iz0 + dz;
-                    if (cz < 0 || cz >= nz || !((anyocc >> cz) & 1u)) continue;
-                    unsigned long long Xw[3] = {0ull, 0ull, 0ull};
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        unsigned long long w[3] = {0ull, 0ull, 0ull};
-                        bool some = false;
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx)
-                            if ((cmk[dy][dx] >> cz) & 1u) {
-                                w[dx] = stage[((iy0 + dy) * nx + ix0 + dx) * nz + cz];
-                                some = true;
-                            }
-                        if (!some) continue;
-                        unsigned long long X = 0ull;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            unsigned long long acc = 0ull;
-#pragma unroll
-                            for (int d = 0; d < 3; ++d) {
-                                const unsigned mm = ax.m[j][d];
-                                if (mm) {
-                                    unsigned long long q = w[d] & (0x1111111111111111ull * mm);
-                                    q |= q >> 1;
-                                    q |= q >> 2;
-                                    acc |= q;
-                                }
-                            }
-                            X |= (acc & 0x1111111111111111ull) << j;
-                        }
-                        Xw[dy] = X;
-                    }
-                    unsigned long long Y = 0ull;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        unsigned long long acc = 0ull;
-#pragma unroll
-                        for (int d = 0; d < 3; ++d) {
-                            const unsigned mm = ay.m[j][d];
-#pragma unroll
-                            for (int tt = 0; tt < 4; ++tt)
-                                if ((mm >> tt) & 1u) acc |= (Xw[d] >> (4 * tt)) & 0x000F000F000F000Full;
-                        }
-                        Y |= acc << (4 * j);
-                    }
-                    Yw[dz] = Y;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    unsigned long long acc = 0ull;
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        const unsigned mm = az.m[j][d];
-#pragma unroll
-                        for (int tt = 0; tt < 4; ++tt)
-                            if ((mm >> tt) & 1u) acc |= (Yw[d] >> (16 * tt)) & 0xFFFFull;
-                    }
-                    out |= acc << (16 * j);
-                }
-                // cells beyond the output shape
-                const unsigned vz = (unsigned)min(4, max(0, go.d.D - 4 * bzo)), vy = (unsigned)min(4, max(0, go.d.H - 4 * Byo)),
-                               vx = (unsigned)min(4, max(0, go.d.W - 4 * Bxo));
-                const unsigned long long mx = (1ull << vx) - 1ull, mline = mx * 0x1111ull & ((1ull << (4 * vy)) - 1ull);
-                unsigned long long mall = 0ull;
-                for (unsigned zz = 0; zz < vz; ++zz) mall |= mline << (16 * zz);
-                out &= mall;
-            }
-        }
-        const unsigned long long ball = __ballot(out != 0ull);
-        if (ball) {   // (wave-uniform)
-            const long long blk = patch_base + t;
-            if (out) go.bits[blk] = out;
-            unsigned c = (unsigned)__popcll(out);
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
-            if (lane == 0) {
-                go.summ[(patch_base + t0 + (tid & ~63)) >> 6] = ball;
-                if (go.ctr) rg_count_global(go, (unsigned)(((patch_base + t0 + (tid & ~63)) >> 6) / go.wpw), c);
-            }
-        }
     }
 }
 
@@ -755,21 +526,6 @@ static int rulebook_strided_impl(const int *in_coords, const int *n_in, int cap_
     const bool counted = go.ctr != nullptr && two && !premarked;
     if (!counted) go.ctr = nullptr;
     const dim3 mgrid(fnp_grid_for(cap_in, kThreads));
-    // gather form (strided_gen_kernel): needs the counters (it counts per wave), at most two outputs per input cell and axis, and
-    // patch / block-column counts its LDS stage was sized for
-    static const bool gen_on = [] { const char *e = getenv("FNP_STRIDED_GEN"); return !(e && e[0] == '0'); }();
-    bool gen = gen_on && counted && gi.d.bd <= kGenMaxBd;
-    GenGeom gg;
-    if (gen) {
-        for (int d = 0; d < 3; ++d) {
-            gg.a[d] = make_axis_gen(ge.k[d], ge.s[d], ge.p[d]);
-            gen = gen && gg.a[d].nblk <= 3 && 7 * ge.s[d] + gg.a[d].nblk <= kGenMaxCols && ge.s[d] <= 2;
-        }
-        gen = gen && (long long)go.d.B * go.d.th * go.d.tw < 0x7fffffffll;
-    }
-    if (gen) {
-        hipLaunchKernelGGL(strided_gen_kernel, dim3((unsigned)(go.d.B * go.d.th * go.d.tw)), dim3(kThreads), 0, s, gi, go, gg);
-    } else
     if (premarked) {
         // (the output sites were marked by the kernel that built the rulebook of the input rows: fnp_rulebook_subm_masked /
         //  fnp_rulebook_subm_tiled_lean with mark_grid = out_grid, mark_geom = geom)
