@@ -535,7 +535,7 @@ def main():
         # gfx950 FETCH_SIZE x2 correction applied: profiles/r0N_pmc_traffic_<dtype>_b<B>.json); null when no profile of
         # this kernel at this batch size is committed
         traffic, traffic_src = None, None
-        for name in (f"r05_pmc_traffic_{args.dtype}_b{B}.json", f"r04_pmc_traffic_{args.dtype}_b{B}.json", f"r03_pmc_traffic_{args.dtype}_b{B}.json", f"r02_pmc_traffic_{args.dtype}_b{B}.json",
+        for name in (f"r06_pmc_traffic_{args.dtype}_b{B}.json", f"r05_pmc_traffic_{args.dtype}_b{B}.json", f"r04_pmc_traffic_{args.dtype}_b{B}.json", f"r03_pmc_traffic_{args.dtype}_b{B}.json", f"r02_pmc_traffic_{args.dtype}_b{B}.json",
                      f"r01_pmc_traffic_b{B}.json" if args.dtype == "bf16" else ""):
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", name)))
