@@ -365,16 +365,28 @@ class _PointsGraph:
         # launches, each bracketed with a pair of timing events when asked to.  A measurement device (bench.py: the step replayed
         # from graphs AND its dominant kernel timed with events inside the timed region, which nodes of a graph do not allow);
         # same kernels, same buffers, same values as the one-graph form.
-        # Every capture is TWO graphs, cut where the counts are final (in front of the last SubM stage): replay() copies them to
+        # A probe capture is TWO graphs, cut where the counts are final (in front of the last SubM stage): replay() copies them to
         # pinned memory between the two and records counts_event there, so the host sizes the outputs while the second graph
-        # still runs (done_event marks its end).
+        # still runs (done_event marks its end).  Every other capture is one graph whose counts launch writes to the host itself
+        # (host_counts, below).
         # split_index (round 6, PointsPipeline's serial-convolution mode): the voxeliser and the whole index chain — everything that
         # reads coordinates only — are a graph of their own (graph_i) in front of the other two, so that replay() can issue them on the
         # slot's stream while every slot's convolutions go, in submission order, through ONE stream shared by the pipeline: batch
         # i + 1's latency-bound index kernels run under batch i's convolutions, and two convolutions never share the CUs.
+        # HOST COUNTS (round 6, every capture that is not a probe): the counts launch stores the counts into pinned host memory itself
+        # and its sequence number behind them (fnp_gather_counts_host); counts() polls for that number.  No event, no copy — and no
+        # cut: the convolutions are ONE graph, the last SubM stage follows the strided layer in front of it without the ~25 us a
+        # one-scene forward spent between two graph launches (end of graph, counts copy, event, start of graph).  FNP_HOST_COUNTS=0:
+        # the two-graph form with the copy between them.
+        self.host_counts = (not probe) and os.environ.get("FNP_HOST_COUNTS", "1") != "0"
+        self.counts_seq, self._replays = None, 0
         self.split_index, self.graph_i, self._index_cut = bool(split_index), None, False
         self.probe, self.deferred, self.graph_b = bool(probe), [], None
         self.counts_dev, self.counts_pin = None, None
+        if self.host_counts:    # (allocated and zeroed HERE: a fill issued during the capture would be a node of the graph)
+            self.counts_pin = torch.zeros((32,), dtype=torch.int32, pin_memory=True)
+            self._pin_np = self.counts_pin.numpy()
+            self.counts_seq = torch.zeros((1,), dtype=torch.int32, device=device)
         self.counts_event, self.done_event = torch.cuda.Event(), torch.cuda.Event()
         self._replayed = False
         self.engine, self.capacity, self.batch_size = engine, capacity, batch_size
@@ -415,6 +427,8 @@ class _PointsGraph:
             finally:
                 self._ctx.__exit__(None, None, None)
             assert self.counts_dev is not None and (self.deferred or not self.probe), "the engine did not reach its cut"
+            if self.host_counts:
+                self.graph_b = None     # (never begun: the capture was not cut)
             assert self._index_cut or not self.split_index, "the engine did not cut behind its index chain"
         finally:
             if gc_was_on:
@@ -430,10 +444,16 @@ class _PointsGraph:
         self._ctx = torch.cuda.graph(self.graph, pool=self.graph_i.pool())
         self._ctx.__enter__()
 
+    def counts_host(self):
+        """(pinned tensor, device sequence word) the engine's counts launch writes to, or None (two-graph form: replay() copies)"""
+        return (self.counts_pin, self.counts_seq) if self.host_counts else None
+
     def counts_ready(self, counts_dev):
         """called by the engine where the counts are final (every forked stream rejoined): ends the first graph's capture and
-        begins the second's on the same capture stream and memory pool"""
+        begins the second's on the same capture stream and memory pool (host counts: nothing to cut)"""
         self.counts_dev = counts_dev
+        if self.host_counts:
+            return
         self._ctx.__exit__(None, None, None)
         self._ctx = torch.cuda.graph(self.graph_b, pool=(self.graph_i if self.split_index else self.graph).pool())
         self._ctx.__enter__()
@@ -462,6 +482,11 @@ class _PointsGraph:
 
     def _replay_convs(self, profile):
         self.graph.replay()
+        if self.host_counts:
+            self._replays += 1
+            self.done_event.record()
+            self.engine._last_done = self.done_event
+            return
         if self.counts_pin is None:
             self.counts_pin = torch.empty((16,), dtype=torch.int32, pin_memory=True)
         self.counts_pin[:self.counts_dev.numel()].copy_(self.counts_dev, non_blocking=True)
@@ -481,7 +506,21 @@ class _PointsGraph:
         self.engine._last_done = self.done_event     # an eager forward issued next, on any stream, waits for this replay
 
     def counts(self):
-        """the host's copy of the last replay's counts (waits for the counts only, not for the second graph)"""
+        """the host's copy of the last replay's counts (waits for the counts only, not for the rest of the forward)"""
+        if self.host_counts:
+            # the counts launch of replay number r stores r behind the counts (after them, system scope): poll for it
+            want, word, t0 = self._replays & 0xffffffff, self._pin_np, None
+            spins = 0
+            while (int(word[16]) & 0xffffffff) != want:
+                spins += 1
+                if spins & 0xfff == 0:      # (~every millisecond: has the device stopped?)
+                    import time
+                    t0 = t0 or time.monotonic()
+                    if self.done_event.query() and (int(word[16]) & 0xffffffff) != want:
+                        raise RuntimeError("the forward ended without its counts launch (sequence %d, expected %d)" % (int(word[16]), want))
+                    if time.monotonic() - t0 > 60.0:
+                        raise RuntimeError("no counts from the device after 60 s")
+            return [int(v) for v in word[:self.counts_dev.numel()]]
         self.counts_event.synchronize()
         return self.counts_pin[:self.counts_dev.numel()].tolist()
 
@@ -678,16 +717,24 @@ class FusedResBackbone:
         _l.check(_l.load().fnp_spconv_tiled_aborts_copy(_l.ptr(t), _l.stream()), "fnp_spconv_tiled_aborts_copy")
         return t
 
-    def _counts_word(self, stage, ell_used, device):
+    def _counts_word(self, stage, ell_used, device, host=None):
         """enqueue ONE launch that collects what the host reads in a forward's one synchronisation — the five stage counts, the
-        library's time-out counter, the pool counters of the compact rulebooks, in that order — into a fresh int32 tensor"""
+        library's time-out counter, the pool counters of the compact rulebooks, in that order — into a fresh int32 tensor.
+        host = (pinned int32 tensor, device sequence word): the launch also stores them into the pinned tensor and its own number
+        behind them (fnp_gather_counts_host: the host polls for that number instead of waiting for an event)"""
         import ctypes
         from .. import lib as _l
         srcs = [s[2] for s in stage] + [None] + [u for u, _, _ in ell_used]
         arr = (ctypes.c_void_p * len(srcs))(*[None if t is None else t.data_ptr() for t in srcs])
         out = torch.empty((len(srcs),), dtype=torch.int32, device=device)
         reset = sum(1 << (len(stage) + 1 + i) for i in range(len(ell_used)))   # the pool counters are the engine's: zero for the next forward
-        _l.check(_l.load().fnp_gather_counts(ctypes.cast(arr, ctypes.c_void_p), len(srcs), reset, _l.ptr(out), _l.stream()), "fnp_gather_counts")
+        if host is not None:
+            pin, seq = host
+            assert pin.is_pinned() and pin.numel() > 16 and seq.is_cuda
+            _l.check(_l.load().fnp_gather_counts_host(ctypes.cast(arr, ctypes.c_void_p), len(srcs), reset, _l.ptr(out), ctypes.c_void_p(pin.data_ptr()),
+                                                      _l.ptr(seq), _l.stream()), "fnp_gather_counts_host")
+        else:
+            _l.check(_l.load().fnp_gather_counts(ctypes.cast(arr, ctypes.c_void_p), len(srcs), reset, _l.ptr(out), _l.stream()), "fnp_gather_counts")
         return out
 
     def _check_aborts(self, value):
@@ -767,7 +814,15 @@ class FusedResBackbone:
 
     def prepare(self):
         m = self.m
-        key = tuple((p.data_ptr(), p._version) for p in list(m.parameters()) + list(m.buffers())) + (self.act,)
+        # (the key is taken on EVERY forward — weights may have been loaded or trained in between —, so it must be cheap: the walk over
+        #  the module tree (m.parameters() + m.buffers(): ~0.1 ms of a 0.45 ms one-scene forward) is done once, what is read per call
+        #  are the (container, name) slots it found — .to() / load_state_dict replace the tensors IN those containers.  The module's
+        #  structure is fixed at construction.)
+        slots = getattr(self, "_prep_slots", None)
+        if slots is None:
+            slots = self._prep_slots = ([(mod._parameters, k) for mod in m.modules() for k, v in mod._parameters.items() if v is not None] +
+                                        [(mod._buffers, k) for mod in m.modules() for k, v in mod._buffers.items() if v is not None])
+        key = tuple([(t.data_ptr(), t._version) for t in [d[k] for d, k in slots]]) + (self.act,)
         if self._prep_key == key:
             return self._prep
         P = {}
@@ -1115,9 +1170,20 @@ class FusedResBackbone:
             books.append((down_key, blk_key, rbs, rb))
             idx_prev, n_prev, g_prev = rbs.out_indices, rbs.out_n, rbs.out_grid
         oconv = m.conv_out[0]
+        # HOST COUNTS (_PointsGraph.host_counts): the counts launch stores into pinned host memory itself, so it needs no cut and no
+        # event — and it can sit where the STAGE counts are final, at the end of the index chain (on the index branch), instead of behind the
+        # strided layer of stage 4: the host has its counts after ~half of a one-scene forward and sizes the outputs, returns, and
+        # issues the next frame while the convolutions still run.  (What is not final there is the tiled kernels' time-out counter: in
+        # this form a time-out — never seen; the protocol's guard against a hang — raises with the NEXT forward's counts.)
+        early_counts = probe is not None and getattr(probe, "host_counts", False)
+        counts_box = {}
         with _Index():
             rbo = S.rulebook_strided(idx_prev, n_prev, g_prev, oconv.kernel_size, oconv.stride, oconv.padding, caps[4],
                                      out_grid=grids[4], premarked=premarked)
+            if early_counts:
+                srcs = [(None, None, n1)] + [(None, None, b[2].out_n) for b in books] + [(None, None, rbo.out_n)]
+                counts_box['dev'] = self._counts_word(srcs, ell_used, dev, host=probe.counts_host())
+                probe.counts_ready(counts_box['dev'])
 
         # ---- convolutions -----------------------------------------------------------------------------------------------
         if probe is not None and getattr(probe, "split_index", False):
@@ -1155,11 +1221,11 @@ class FusedResBackbone:
         # host then waits for THAT event, sizes the outputs and returns while the GPU is still convolving; the caller's next
         # forward queues up behind it, and the ~0.1 ms the GPU used to idle between two forwards (copy back, Python, the first
         # launches of the next forward) is gone.  The returned tensors are ordinary stream-ordered torch tensors.
-        counts_box = {}
-
         def counts_now():
+            if early_counts:
+                return
             srcs = [(None, None, n1)] + [(None, None, b[2].out_n) for b in books] + [(None, None, rbo.out_n)]
-            cd = counts_box['dev'] = self._counts_word(srcs, ell_used, dev)
+            cd = counts_box['dev'] = self._counts_word(srcs, ell_used, dev, host=probe.counts_host() if probe is not None else None)
             if probe is not None:
                 probe.counts_ready(cd)          # (_PointsGraph: the first captured graph ends here)
             elif sync:

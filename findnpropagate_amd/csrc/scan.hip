@@ -3,6 +3,9 @@
 // and the rank-grid popcount prefix, which walks the summary level so that only occupied
 // blocks are read.
 #include "rankgrid.h"
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -90,6 +93,57 @@ __global__ __launch_bounds__(kThreads) void tile_scan_kernel(L load, long long n
     }
 }
 
+// SMALL INPUTS (one scene: the reference's extraction runs batch size 1, where a forward is a chain of ~50 launches of a few
+// microseconds each): up to kSmallTiles tiles in ONE launch.  Workgroup b sums everything in front of its tile itself (16-byte
+// loads, <= 60 per thread, all L2 hits) instead of waiting for a tile-sum pass and a scan of the tile sums, then scans its tile
+// four elements per thread and round; the last workgroup writes the grand total.  Same integers as the three-launch form.
+constexpr int kSmallTiles = 16;
+__global__ __launch_bounds__(kThreads) void small_scan_kernel(const int *__restrict__ in, int n, int *__restrict__ out, int *__restrict__ total_out) {
+    __shared__ unsigned wsum[4];
+    const int base = blockIdx.x * fnp_scan::kTile;
+    const int4 *in4 = reinterpret_cast<const int4 *>(in);
+    unsigned s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int c = threadIdx.x; c < base / 4; c += 4 * kThreads) {   // (base is a multiple of 4096: whole 16-byte chunks, all < n)
+        const int4 a = in4[c];
+        const int4 b = c + kThreads < base / 4 ? in4[c + kThreads] : make_int4(0, 0, 0, 0);
+        const int4 d = c + 2 * kThreads < base / 4 ? in4[c + 2 * kThreads] : make_int4(0, 0, 0, 0);
+        const int4 e = c + 3 * kThreads < base / 4 ? in4[c + 3 * kThreads] : make_int4(0, 0, 0, 0);
+        s0 += (unsigned)(a.x + a.y + a.z + a.w);
+        s1 += (unsigned)(b.x + b.y + b.z + b.w);
+        s2 += (unsigned)(d.x + d.y + d.z + d.w);
+        s3 += (unsigned)(e.x + e.y + e.z + e.w);
+    }
+    unsigned carry;
+    block_exclusive(s0 + s1 + s2 + s3, wsum, carry);   // (carry = the workgroup total = everything in front of the tile)
+    int4 v[kItems / 4];
+#pragma unroll
+    for (int j = 0; j < kItems / 4; ++j) {
+        const int i = base + (j * kThreads + threadIdx.x) * 4;
+        v[j] = make_int4(0, 0, 0, 0);
+        if (i + 3 < n) v[j] = in4[i >> 2];
+        else {
+            if (i < n) v[j].x = in[i];
+            if (i + 1 < n) v[j].y = in[i + 1];
+            if (i + 2 < n) v[j].z = in[i + 2];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kItems / 4; ++j) {
+        const int i = base + (j * kThreads + threadIdx.x) * 4;
+        unsigned tot;
+        const unsigned ex = carry + block_exclusive((unsigned)(v[j].x + v[j].y + v[j].z + v[j].w), wsum, tot);
+        const int4 o = make_int4((int)ex, (int)(ex + (unsigned)v[j].x), (int)(ex + (unsigned)(v[j].x + v[j].y)), (int)(ex + (unsigned)(v[j].x + v[j].y + v[j].z)));
+        if (i + 3 < n) reinterpret_cast<int4 *>(out)[i >> 2] = o;
+        else {
+            if (i < n) out[i] = o.x;
+            if (i + 1 < n) out[i + 1] = o.y;
+            if (i + 2 < n) out[i + 2] = o.z;
+        }
+        carry += tot;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = (int)carry;
+}
+
 template <class L, class TOut>
 int run_scan(L load, long long n, TOut *out, int *total, void *ws, hipStream_t s) {
     if (n < 0 || !total) return FNP_ERR_ARG;
@@ -98,6 +152,14 @@ int run_scan(L load, long long n, TOut *out, int *total, void *ws, hipStream_t s
     }
     if (!out || !ws) return FNP_ERR_ARG;
     const int tiles = fnp_divup(n, fnp_scan::kTile);
+    if constexpr (std::is_same<L, LoadInt>::value && std::is_same<TOut, int>::value) {
+        static const bool small_ok = [] { const char *e = getenv("FNP_SMALL_SCAN"); return !e || atoi(e) != 0; }();   // (development switch)
+        if (small_ok && tiles <= kSmallTiles && (const int *)out != load.p && (((uintptr_t)load.p | (uintptr_t)out) & 15) == 0) {   // (not in place: a workgroup reads the tiles in front of its own)
+            hipLaunchKernelGGL(small_scan_kernel, dim3(tiles), dim3(kThreads), 0, s, load.p, (int)n, out, total);
+            FNP_LAUNCH_CHECK();
+            return FNP_OK;
+        }
+    }
     unsigned *partial = (unsigned *)ws;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(tile_reduce_kernel<L>), dim3(tiles), dim3(kThreads), 0, s, load, n, partial);
     FNP_LAUNCH_CHECK();

@@ -1048,12 +1048,30 @@ struct GatherJobs {
     int *src[16];
     int n;
     unsigned reset_mask;
+    int *host;        // (fnp_gather_counts_host) pinned host memory: the counts and, behind them, the launch's sequence number
+    unsigned *seq;    // device word: launches so far
 };
-__global__ void gather_counts_kernel(GatherJobs j, int *__restrict__ dst) {
+// (one wave.)  The host form stores the counts into pinned host memory itself and then — behind a system-scope fence that every lane's
+// count store has passed — the number of this launch in word FNP_COUNTS_SEQ_SLOT: a host thread that polls that word knows the counts
+// are there without an event, a copy, or the end of the hipGraph the launch is a node of.
+__global__ __launch_bounds__(64) void gather_counts_kernel(GatherJobs j, int *__restrict__ dst) {
     const int t = threadIdx.x;
-    if (t >= j.n) return;
-    dst[t] = j.src[t] ? *j.src[t] : (int)g_tile_aborts;
-    if (j.src[t] && ((j.reset_mask >> t) & 1u)) *j.src[t] = 0;   // (a counter its owner wants at zero for the next forward)
+    int v = 0;
+    if (t < j.n) {
+        v = j.src[t] ? *j.src[t] : (int)g_tile_aborts;
+        dst[t] = v;
+        if (j.src[t] && ((j.reset_mask >> t) & 1u)) *j.src[t] = 0;   // (a counter its owner wants at zero for the next forward)
+    }
+    if (j.host) {
+        if (t < j.n) __hip_atomic_store(&j.host[t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __builtin_amdgcn_wave_barrier();
+        if (t == 0) {
+            const unsigned sq = *j.seq + 1u;
+            *j.seq = sq;
+            __hip_atomic_store(reinterpret_cast<unsigned *>(j.host) + FNP_COUNTS_SEQ_SLOT, sq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 extern "C" int fnp_gather_counts(int *const *srcs, int n, unsigned reset_mask, int *dst, fnp_stream_t stream) {
     if (!srcs || !dst || n <= 0 || n > 16) return FNP_ERR_ARG;
@@ -1061,6 +1079,20 @@ extern "C" int fnp_gather_counts(int *const *srcs, int n, unsigned reset_mask, i
     for (int i = 0; i < 16; ++i) j.src[i] = i < n ? srcs[i] : nullptr;
     j.n = n;
     j.reset_mask = reset_mask;
+    j.host = nullptr;
+    j.seq = nullptr;
+    hipLaunchKernelGGL(gather_counts_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, j, dst);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+extern "C" int fnp_gather_counts_host(int *const *srcs, int n, unsigned reset_mask, int *dst, int *host_dst, unsigned *seq, fnp_stream_t stream) {
+    if (!srcs || !dst || !host_dst || !seq || n <= 0 || n > 16) return FNP_ERR_ARG;
+    GatherJobs j;
+    for (int i = 0; i < 16; ++i) j.src[i] = i < n ? srcs[i] : nullptr;
+    j.n = n;
+    j.reset_mask = reset_mask;
+    j.host = host_dst;
+    j.seq = seq;
     hipLaunchKernelGGL(gather_counts_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, j, dst);
     FNP_LAUNCH_CHECK();
     return FNP_OK;

@@ -33,6 +33,7 @@ struct VoxWs {          // carve-up of the caller's workspace
     int *scene;         // (3*B + 4): fc_start[B+1], out_base[B+1], misc
     int *n_sorted;      // (1)
     int *n_first;       // (1)
+    int *fscan;         // (n) exclusive scan of the first-point flags (its own array: the one-launch scan of small inputs is not in-place)
     void *scan_ws;
 };
 
@@ -48,6 +49,7 @@ __host__ long long carve(VoxWs &w, char *base, long long n, int B, int cap, int 
     w.code = (long long *)take(8 * n);
     w.rank = (int *)take(4 * n);
     w.flag = (int *)take(4 * n);
+    w.fscan = (int *)take(4 * n);
     w.top = (int *)take(4ll * cap * maxp);
     w.cnt = (int *)take(4ll * cap + 4);   // (+ 1: "some cell is crowded", cleared with the counters)
     w.scene = (int *)take(4ll * (3 * B + 8));
@@ -580,19 +582,19 @@ extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets
     FNP_LAUNCH_CHECK();
     hipLaunchKernelGGL(vox_flag_kernel, dim3(pgrid), dim3(kThreads), 0, s, n, maxp, w.rank, w.top, (const int *)w.cnt, w.flag);
     FNP_LAUNCH_CHECK();
-    rc = fnp_scan::int32(w.flag, n, w.flag, w.n_first, w.scan_ws, s);
+    rc = fnp_scan::int32(w.flag, n, w.fscan, w.n_first, w.scan_ws, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(vox_scene_kernel, dim3(1), dim3(64), 0, s, batch_offsets, B, n, w.flag, w.n_first,
+    hipLaunchKernelGGL(vox_scene_kernel, dim3(1), dim3(64), 0, s, batch_offsets, B, n, w.fscan, w.n_first,
                        cfg->max_voxels, cap, w.scene, n_voxels);
     FNP_LAUNCH_CHECK();
     static const bool cell_form = [] { const char *e = getenv("FNP_VOX_EMIT"); return e && e[0] == 'c'; }();   // (development A/B)
     if (cell_form)
         hipLaunchKernelGGL(vox_emit_kernel, dim3(fnp_grid_for(n, kThreads)), dim3(kThreads), 0, s, points, C, maxp,
-                           batch_offsets, B, cfg->max_voxels, g.d, w.code, w.top, (const int *)w.cnt, w.flag, w.scene, w.n_sorted, n,
+                           batch_offsets, B, cfg->max_voxels, g.d, w.code, w.top, (const int *)w.cnt, w.fscan, w.scene, w.n_sorted, n,
                            g.perm, coords, num_points, mean_feats, voxels, n_cells, w.scene + 2 * (B + 1));
     else
         hipLaunchKernelGGL(vox_emit_points_kernel, dim3(pgrid), dim3(kThreads), 0, s, points, n, C, maxp, batch_offsets, B, cfg->max_voxels,
-                           g.d, w.code, (const int *)w.rank, w.top, (const int *)w.cnt, w.flag, (const int *)w.n_first, w.scene, w.n_sorted, n,
+                           g.d, w.code, (const int *)w.rank, w.top, (const int *)w.cnt, w.fscan, (const int *)w.n_first, w.scene, w.n_sorted, n,
                            g.perm, coords, num_points, mean_feats, voxels, n_cells, w.scene + 2 * (B + 1));
     FNP_LAUNCH_CHECK();
     return FNP_OK;

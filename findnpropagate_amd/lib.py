@@ -125,6 +125,7 @@ SIGNATURES = {
                                            P, P, c_int, c_int, c_int, P]),
     "fnp_spconv_tiled_aborts": (c_int, []),
     "fnp_gather_counts": (c_int, [P, c_int, c_uint, P, P]),
+    "fnp_gather_counts_host": (c_int, [P, c_int, c_uint, P, P, P, P]),
     "fnp_spconv_tiled_aborts_copy": (c_int, [P, P]),
     "fnp_debug_tile_hold": (c_int, [c_int]),
     "fnp_tile_rulebook_bytes": (c_int64, [c_int, c_int]),

@@ -307,6 +307,15 @@ int fnp_spconv_tiled_aborts_copy(int *dst, fnp_stream_t stream);
  * srcs[i] is NULL: what a forward hands to the host in its one synchronisation, in one launch (capturable).  Bit i of reset_mask:
  * *srcs[i] = 0 after it is read (a counter its owner keeps across forwards, e.g. fnp_rulebook_ell's pool_used). */
 int fnp_gather_counts(int *const *srcs, int n, unsigned reset_mask, int *dst, fnp_stream_t stream);
+/* The same launch, handing the counts to the HOST itself (ABI 14): besides dst (device) it stores them into host_dst — PINNED host
+ * memory of >= FNP_COUNTS_SEQ_SLOT + 1 words, addressed by the device through its host pointer — and then, behind a system-scope fence,
+ * ++*seq (a device word the caller zeroed once) into host_dst[FNP_COUNTS_SEQ_SLOT].  A host thread that has counted its launches polls that
+ * word and reads the counts when it arrives: no event, no device-to-host copy, and the launch may sit in the MIDDLE of a hipGraph — the
+ * captured forward is one graph, its counts leave where they are final (in front of the last SubM stage) and the host sizes the
+ * outputs while the rest of the graph runs.  The reference synchronises once per forward where spconv reads its pair counts
+ * (pcdet/models/backbones_3d/spconv_backbone.py:193-234 through spconv's indice-pair call). */
+#define FNP_COUNTS_SEQ_SLOT 16
+int fnp_gather_counts_host(int *const *srcs, int n, unsigned reset_mask, int *dst, int *host_dst, unsigned *seq, fnp_stream_t stream);
 int fnp_debug_tile_hold(int on);
 long long fnp_tile_rulebook_bytes(int cap_out, int channels);
 int fnp_tile_rulebook_build(const int *nbr, int nbr_stride, int K, const int *n_out, int cap_out, int channels,

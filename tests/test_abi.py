@@ -19,7 +19,7 @@ def test_header_table_and_exports_agree():
 
 def test_library_loads_and_reports_version():
     L = lib.load()
-    assert L.fnp_abi_version() == 13
+    assert L.fnp_abi_version() == 14
     assert b"gfx950" in L.fnp_version()
 
 

@@ -456,6 +456,56 @@ def test_graphed_forward_equals_eager(cuda):
 
 
 @pytest.mark.gpu
+def test_counts_launch_hands_the_counts_to_the_host_itself(cuda):
+    """fnp_gather_counts_host (include/fnp.h, ABI 14): the launch stores the counts into pinned host memory and, behind them, its own
+    sequence number; a host thread that polls for that number finds the counts — inside a replayed hipGraph too (no event, no copy):
+    how a captured forward hands its stage counts over in the middle of its one graph."""
+    import ctypes
+    import time
+    from findnpropagate_amd import lib as _lib
+    L = _lib.load()
+    a = torch.tensor([7], dtype=torch.int32, device=cuda)
+    b = torch.tensor([11], dtype=torch.int32, device=cuda)
+    pool = torch.tensor([5], dtype=torch.int32, device=cuda)      # (reset after it is read: bit 3)
+    dst = torch.zeros(4, dtype=torch.int32, device=cuda)
+    seq = torch.zeros(1, dtype=torch.int32, device=cuda)
+    pin = torch.zeros(32, dtype=torch.int32, pin_memory=True)
+    word = pin.numpy()
+    arr = (ctypes.c_void_p * 4)(a.data_ptr(), b.data_ptr(), None, pool.data_ptr())
+
+    def launch():
+        _lib.check(L.fnp_gather_counts_host(ctypes.cast(arr, ctypes.c_void_p), 4, 1 << 3, _lib.ptr(dst), ctypes.c_void_p(pin.data_ptr()), _lib.ptr(seq),
+                                            _lib.stream()), "fnp_gather_counts_host")
+
+    def wait(want):
+        t0 = time.monotonic()
+        while int(word[16]) != want:
+            assert time.monotonic() - t0 < 20.0, "the sequence number never arrived"
+
+    aborts = L.fnp_spconv_tiled_aborts()
+    launch()
+    wait(1)
+    assert [int(v) for v in word[:4]] == [7, 11, aborts, 5]
+    torch.cuda.synchronize()
+    assert dst.tolist() == [7, 11, aborts, 5] and int(pool.item()) == 0 and int(seq.item()) == 1
+    # as a node of a hipGraph, replayed: the sources change between replays, the sequence number counts the replays
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            a.add_(1)
+            launch()
+            b.mul_(2)       # (work behind the counts launch: the host does not wait for it)
+        for r in range(3):
+            g.replay()
+            wait(2 + r)
+            assert [int(v) for v in word[:4]] == [8 + r, 11 * 2 ** r, aborts, 0]
+    torch.cuda.synchronize()
+    assert L.fnp_gather_counts_host(None, 4, 0, _lib.ptr(dst), ctypes.c_void_p(pin.data_ptr()), _lib.ptr(seq), _lib.stream()) != 0
+    assert L.fnp_gather_counts_host(ctypes.cast(arr, ctypes.c_void_p), 17, 0, _lib.ptr(dst), ctypes.c_void_p(pin.data_ptr()), _lib.ptr(seq), _lib.stream()) != 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("depth", [1, 2, 3])
 def test_points_pipeline_equals_eager_frame_by_frame(cuda, depth):
     """PointsPipeline (one-scene frames, `depth` hipGraph replays in flight on their own streams, each slot with its own

@@ -139,3 +139,23 @@ def test_fused_mean_in_torchs_summation_order_for_other_shapes(cuda, oracle, rng
     c, num, vox, mean = _oracle([p], args, oracle)
     assert n == c.shape[0] and num.max() == max_points
     assert np.array_equal(got["voxels"], vox) and np.array_equal(got["mean"], mean)
+
+
+@pytest.mark.parametrize("n", [4095, 4096, 4097, 12288, 65535, 65536, 65537])
+def test_first_point_scan_forms_at_their_size_boundaries(cuda, oracle, rng, n):
+    """The first-point flags are scanned in ONE launch up to 16 tiles of 4,096 points (scan.hip small_scan_kernel: a workgroup sums
+    what lies in front of its tile itself) and by the three-launch tile scan above: same voxels, same first-come order, at the
+    tile boundaries of the first and the size boundary between the two."""
+    n0 = n // 3
+    scenes = []
+    for m in (n0, n - n0):
+        p = rng.uniform(-6, 6, size=(m, 5)).astype(np.float32)
+        p[:, 2] = rng.uniform(-1.0, 1.0, size=m)
+        p[::13, 0] = 99.0   # out of range
+        scenes.append(p)
+    args = ([0.1, 0.1, 0.25], [-5.0, -5.0, -1.0, 5.0, 5.0, 1.0], 5, 4, 60000)
+    got, nv = _run(scenes, args, cuda)
+    c, num, vox, mean = _oracle(scenes, args, oracle)
+    assert nv == c.shape[0] and nv > n // 4
+    assert np.array_equal(got["coords"], c) and np.array_equal(got["num_points"], num)
+    assert np.array_equal(got["voxels"], vox) and np.array_equal(got["mean"], mean)
