@@ -434,6 +434,20 @@ class _PointsGraph:
             if gc_was_on:
                 gc.enable()
 
+    def stage(self, points, batch_offsets):
+        """a frame into the static inputs (one launch on the current stream: the points, the padding behind them as far as the previous
+        frame reached, the scene offsets)"""
+        n = int(points.shape[0])
+        if (points.is_cuda and points.dtype == torch.float32 and points.is_contiguous() and batch_offsets.is_cuda
+                and batch_offsets.dtype == torch.int32 and batch_offsets.is_contiguous()):
+            S.stage_points(points, batch_offsets, self.pts, self.off, self.n_prev, self.FAR)
+        else:
+            self.pts[:n].copy_(points, non_blocking=True)
+            if self.n_prev > n:
+                self.pts[n:self.n_prev].fill_(self.FAR)
+            self.off.copy_(batch_offsets, non_blocking=True)
+        self.n_prev = n
+
     def index_ready(self):
         """called by the engine between its index chain and its first convolution (split_index captures only; the chain must be on
         the capture stream itself: no second branch): ends graph_i, begins the first convolution graph in the same pool"""
@@ -608,11 +622,7 @@ class PointsPipeline:
         st = self.streams[d]
         st.wait_stream(torch.cuda.current_stream(self.device))   # the caller produced `points` on its own stream
         with torch.cuda.stream(st):
-            g.pts[:n].copy_(points, non_blocking=True)
-            if g.n_prev > n:
-                g.pts[n:g.n_prev].fill_(_PointsGraph.FAR)
-            g.n_prev = n
-            g.off.copy_(batch_offsets, non_blocking=True)
+            g.stage(points, batch_offsets)
             # (copies the counts to pinned memory between its two convolution graphs; done_event at the end)
             g.replay(self.profile if self.probe else None, conv_stream=self.conv_stream)
         points.record_stream(st)
@@ -961,11 +971,7 @@ class FusedResBackbone:
                 finally:
                     self.profile = prof
                 self._graphs[key] = g
-            g.pts[:n].copy_(points)
-            if g.n_prev > n:
-                g.pts[n:g.n_prev].fill_(_PointsGraph.FAR)
-            g.n_prev = n
-            g.off.copy_(batch_offsets)
+            g.stage(points, batch_offsets)
             g.replay(self.profile if probe else None)
             stage, caps, shapes = g.res['stages'], g.res['caps'], g.res['shapes']
             counts = g.counts()   # the one host sync: the counts' copy between the two graphs
@@ -1189,7 +1195,12 @@ class FusedResBackbone:
         if probe is not None and getattr(probe, "split_index", False):
             assert not two, "a split capture keeps its index chain on the capture stream"
             probe.index_ready()      # (_PointsGraph: the voxeliser + index chain are a graph of their own)
-        joined = [False]
+        joined, cleared = [False], [None]
+
+        def clear_jobs():
+            jobs = [(grid1, indices, n_cells if n_cells is not None else n1)]
+            jobs += [(b[2].out_grid, b[2].out_indices, b[2].out_n) for b in books]
+            return jobs + [(rbo.out_grid, rbo.out_indices, rbo.out_n)]
 
         def ready(i):
             if two and not joined[0]:
@@ -1250,6 +1261,17 @@ class FusedResBackbone:
             if li == len(books) - 1:
                 ready(4)            # (every index kernel is behind us; a capture may end only with every forked stream rejoined)
                 joined[0] = True
+                if two and (probe is None or early_counts):   # (a two-graph capture is cut right here: no open branch across the cut)
+                    # the last reader of a rank grid has been issued (the strided layers resolve their neighbours in the input grid;
+                    # the layers behind this one run on tables): the sparse clear of all five grids goes to the index branch and runs
+                    # beside the last SubM stage instead of behind conv_out, at the end of the chain
+                    ev_c = torch.cuda.Event()
+                    ev_c.record(main)
+                    side.wait_event(ev_c)
+                    with torch.cuda.stream(side):
+                        S.clear_grids(clear_jobs())
+                        cleared[0] = torch.cuda.Event()
+                        cleared[0].record(side)
                 if probe is not None and probe.probe:
                     x = blocks_deferred(x, rb, rbs.out_n, P[blk_key])
                 else:
@@ -1263,7 +1285,10 @@ class FusedResBackbone:
         stage.append((f32_of(xo), rbo.out_indices, rbo.out_n, rbo.out_grid))
 
         # leave every persistent grid zeroed for the next call (O(rows) sparse clear, all five grids in one launch)
-        S.clear_grids([(g, idx, n_cells if (l == 0 and n_cells is not None) else n) for l, (_, idx, n, g) in enumerate(stage)])
+        if cleared[0] is not None:
+            main.wait_event(cleared[0])
+        else:
+            S.clear_grids(clear_jobs())
         self._dirty = False
         counts_dev = counts_box['dev']
         if feats.is_cuda and not capturing:

@@ -546,6 +546,32 @@ extern "C" int64_t fnp_voxelize_workspace_bytes(int64_t n_points, const fnp_voxe
     return carve(w, nullptr, n, grid->B, (int)n, cfg->max_points, (fnp_num_blocks(g) + 63) >> 6);
 }
 
+// A frame into the static inputs of a captured forward, in one launch: the points, the padding value behind them as far as the
+// previous frame reached, and the scene offsets (three stream operations before: a one-scene forward is a chain of ~50 launches).
+__global__ __launch_bounds__(kThreads) void stage_points_kernel(const float *__restrict__ src, long long n_words, long long n_prev_words, float pad,
+                                                                float *__restrict__ dst, const int *__restrict__ off_src, int n_off,
+                                                                int *__restrict__ off_dst) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i < n_words) dst[i] = src[i];
+    else if (i < n_prev_words) dst[i] = pad;
+    if (i < n_off) off_dst[i] = off_src[i];
+}
+extern "C" int fnp_stage_points(const float *points, int64_t n_points, int64_t n_prev_points, int num_features, float pad, float *dst_points,
+                                const int *batch_offsets, int n_offsets, int *dst_offsets, fnp_stream_t stream) {
+    if (n_points < 0 || n_prev_points < 0 || num_features <= 0 || !dst_points || n_offsets < 0 || (n_points > 0 && !points) ||
+        (n_offsets > 0 && (!batch_offsets || !dst_offsets)))
+        return FNP_ERR_ARG;
+    const long long nw = (long long)n_points * num_features, pw = (long long)n_prev_points * num_features;
+    const long long span = nw > pw ? nw : pw;
+    const long long items = span > n_offsets ? span : n_offsets;
+    if (items == 0) return FNP_OK;
+    if (items > (long long)kThreads * 0x7fffffff) return FNP_ERR_ARG;
+    hipLaunchKernelGGL(stage_points_kernel, dim3((unsigned)((items + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream, points, nw, pw, pad,
+                       dst_points, batch_offsets, n_offsets, dst_offsets);
+    FNP_LAUNCH_CHECK();
+    return FNP_OK;
+}
+
 extern "C" int fnp_voxelize(const float *points, int n, const int *batch_offsets, const fnp_voxel_cfg *cfg,
                             const fnp_rankgrid *grid, void *workspace, int64_t workspace_bytes, int *coords,
                             int *num_points, float *mean_feats, float *voxels, int *n_voxels, int *n_cells, int cap,

@@ -113,6 +113,7 @@ SIGNATURES = {
     "fnp_rankgrid_clear_multi": (c_int, [c_int, P, P, P, P, P]),
     "fnp_rankgrid_clear_summary": (c_int, [c_int, c_void_p, c_void_p]),
     "fnp_voxelize_workspace_bytes": (c_int64, [c_int64, POINTER(VoxelCfg), POINTER(RankGridC)]),
+    "fnp_stage_points": (c_int, [P, c_int64, c_int64, c_int, c_float, P, P, c_int, P, P]),
     "fnp_voxelize": (c_int, [P, c_int, P, POINTER(VoxelCfg), POINTER(RankGridC), P, c_int64,
                              P, P, P, P, P, P, c_int, P]),
     "fnp_host_voxelize": (c_int, [P, c_int, POINTER(VoxelCfg), P, P, P, c_int]),

@@ -121,6 +121,19 @@ def make_voxel_cfg(voxel_size, point_cloud_range, num_features, max_points, max_
     return cfg
 
 
+def stage_points(points, batch_offsets, dst_points, dst_offsets, n_prev, pad):
+    """one launch: dst_points[:n] = points, dst_points[n:n_prev] = pad, dst_offsets[:] = batch_offsets (fnp_stage_points: a frame into the
+    static inputs of a captured forward).  Everything on the device; the caller's stream."""
+    L = _l.load()
+    _l.require_device(points, batch_offsets, dst_points, dst_offsets)
+    assert points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous() and dst_points.is_contiguous()
+    assert dst_points.dtype == torch.float32 and dst_points.shape[1] == points.shape[1] and dst_points.shape[0] >= max(points.shape[0], n_prev)
+    assert batch_offsets.dtype == torch.int32 and dst_offsets.dtype == torch.int32 and dst_offsets.numel() == batch_offsets.numel()
+    assert batch_offsets.is_contiguous() and dst_offsets.is_contiguous()
+    _l.check(L.fnp_stage_points(_l.ptr(points) if points.shape[0] else None, points.shape[0], int(n_prev), points.shape[1], float(pad), _l.ptr(dst_points),
+                                _l.ptr(batch_offsets), batch_offsets.numel(), _l.ptr(dst_offsets), _l.stream()), "fnp_stage_points")
+
+
 def voxelize(points, batch_offsets, batch_size, cfg, grid=None, want_voxels=False, workspace=None):
     """points (N,C) f32 device, batch_offsets (B+1,) int32 device.
 

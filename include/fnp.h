@@ -193,6 +193,13 @@ typedef struct fnp_voxel_cfg {
  * spconv_backbone.py:191); grid->B is the number of scenes. */
 int64_t fnp_voxelize_workspace_bytes(int64_t n_points, const fnp_voxel_cfg *cfg, const fnp_rankgrid *grid);
 
+/* A frame into the STATIC inputs of a captured forward (a hipGraph reads fixed addresses), one launch: dst_points[0, n) = points,
+ * dst_points[n, n_prev) = pad in every column (rows the previous frame filled: pad lies outside every range, the voxeliser drops such
+ * points), dst_offsets = batch_offsets (n_offsets words).  All device pointers; (n, num_features) f32 rows, contiguous.
+ * The reference's loops hand a frame to the model through load_data_to_gpu (pcdet/models/__init__.py:23-37). */
+int fnp_stage_points(const float *points, int64_t n_points, int64_t n_prev_points, int num_features, float pad, float *dst_points,
+                     const int *batch_offsets, int n_offsets, int *dst_offsets, fnp_stream_t stream);
+
 /* points (N,C) f32, scenes concatenated; batch_offsets (B+1,) int32 device (scene b owns
  * points [off[b], off[b+1])).  Outputs, all capacity `cap` rows (cap >= N is always enough):
  *   coords (cap,4) int32 [b,z,y,x] in the sequential first-come order of the reference,
