@@ -591,6 +591,8 @@ class PointsPipeline:
         # those launches hold every CU's registers and LDS, the index kernels crawl (5 ms of kernel time) and the chain waits 1.7 ms.
         env = {"0": False, "1": True}.get(os.environ.get("FNP_PIPE_SERIAL", ""))
         self.serial_convs = self.depth > 1 and (bool(serial_convs) if serial_convs is not None else env if env is not None else self.batch_size >= 8)
+        # (measured, round 6: the convolution stream at a higher dispatch priority — torch.cuda.Stream(priority=-1) — starves the index
+        #  chains it waits for: 13.0-13.3 k -> 12.2-12.4 k scenes/s)
         self.conv_stream = torch.cuda.Stream(self.device) if self.serial_convs else None
         if self.serial_convs:
             for e in self.engines:
