@@ -550,6 +550,71 @@ class _PointsGraph:
         return vox, res
 
 
+def concurrent_streams(device, n, beside=(), tries=24, report=False):
+    """n HIP streams that really run BESIDE each other and beside the streams in `beside`.
+
+    HIP streams are spread over a few hardware queues (GPU_MAX_HW_QUEUES: 4 unless set before the runtime starts; this package asks for
+    8) when they are first used, and torch hands its streams out of a pool: which of them end up in the same hardware queue depends on
+    what the process did before.  Two streams of one queue run in order — a batch's index chain behind another batch's convolutions —
+    and nothing says so: the same pipeline measured 12.7 k or 13.3 k scenes/s at 128 scenes, 1.7 k or 3.0 k frames/s with two one-scene
+    frames in flight, by the order in which the process had created its pipelines.  So the streams are TESTED: a ~1 ms spin kernel on
+    one, an event on the other; the event completes at once unless the two share a queue.  Streams that fail against any already chosen
+    one are dropped (back into torch's pool) and the next is tried.  Falls back to untested streams after `tries` candidates
+    (report=True: returns (streams, whether every one of them passed))."""
+    import time
+    device = torch.device(device)
+    chosen, rejected = [], []
+    if device.type != "cuda" or n <= 0:
+        return chosen
+    with torch.cuda.device(device):
+        probe = torch.cuda.current_stream(device)
+        torch.cuda.synchronize(device)
+        # a spin of about a millisecond on this card (torch.cuda._sleep counts device clock ticks)
+        ticks = 100000
+        for _ in range(6):
+            t0 = time.perf_counter()
+            torch.cuda._sleep(ticks)
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            if dt >= 0.8e-3:
+                break
+            ticks = int(ticks * max(2.0, 1.0e-3 / max(dt, 1e-5)))
+        spin = max(dt, 0.8e-3)
+        word = torch.zeros((1,), dtype=torch.int32, device=device)
+
+        def aliased(a, b):
+            """does work on b wait for work on a (one hardware queue)?"""
+            if a == b:
+                return True
+            torch.cuda.synchronize(device)
+            with torch.cuda.stream(a):
+                torch.cuda._sleep(ticks)
+            ev = torch.cuda.Event()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(b):
+                word.fill_(1)        # (a real packet in b's queue: an event on an idle stream may complete without one)
+            ev.record(b)
+            ev.synchronize()
+            waited = time.perf_counter() - t0
+            torch.cuda.synchronize(device)
+            return waited > 0.4 * spin
+
+        others = [s for s in beside if s is not None]
+        for _ in range(max(tries, n)):
+            if len(chosen) == n:
+                break
+            c = torch.cuda.Stream(device)
+            if any(aliased(o, c) for o in others + chosen):
+                rejected.append(c)
+                continue
+            chosen.append(c)
+        complete = len(chosen) == n
+        while len(chosen) < n:      # (more streams asked for than the card has queues to give: take what there is)
+            chosen.append(rejected.pop(0) if rejected else torch.cuda.Stream(device))
+        del probe
+    return (chosen, complete) if report else chosen
+
+
 class PointsPipeline:
     """Frames that arrive ONE AT A TIME (the reference's extraction and evaluation loops run batch size 1) kept `depth` deep
     in flight: every slot owns an engine (its rank grids and workspaces), a captured hipGraph of forward_points and a HIP
@@ -559,7 +624,7 @@ class PointsPipeline:
     multiplies.  Results are the graphed path's, bit for bit.  The returned tensors are views of the slot's static buffers:
     valid until `depth` more frames have been submitted."""
 
-    def __init__(self, module, batch_size, voxel_cfg, depth=2, capacity=65536, n_feat=5, device=None, probe=False, serial_convs=None):
+    def __init__(self, module, batch_size, voxel_cfg, depth=2, capacity=65536, n_feat=5, device=None, probe=False, serial_convs=None, streams=None):
         # probe: every slot's capture is the two-graph PROBE form of _PointsGraph (the launches of the last SubM stage issued as plain
         # launches between the two graphs); with `self.profile` a list each of them is bracketed by a pair of timing events on the
         # slot's stream, (tag, start, end) appended — how bench.py times the dominant kernel inside its pipelined timed region
@@ -574,7 +639,25 @@ class PointsPipeline:
             # graph on top of that oversubscribes the hardware queues
             e.two_streams = self.depth == 1 or os.environ.get("FNP_PIPE_TWO", "0") == "1"
 
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.depth)]
+        # Which streams.  The free-for-all form (one-scene frames) takes streams that were SEEN to run beside each other and beside the
+        # caller's (concurrent_streams): 3.04 k / 3.7 k frames/s with two / three frames in flight every time, against 1.7-3.0 k / 2.2-3.5 k
+        # by the order in which the process happened to create its streams.  The serial form (batches of >= 8 scenes) keeps torch's next
+        # pool streams: whether a batch's index chain runs UNDER the other batch's convolutions (13.0-13.5 k scenes/s at 128 scenes) or
+        # after them (12.1-12.3 k) is decided by something the spin test does not see — in bench.py's process the tested set is the
+        # slow one, three runs out of three, in a fresh process both are fast, the convolutions on the CALLER's stream are always slow,
+        # and a trial of four candidate convolution streams at the first frame picked slow ones as often as not (DESIGN.md section 7:
+        # open).  FNP_TESTED_STREAMS=0 / 1 forces; `streams` hands in the caller's own.
+        env = {"0": False, "1": True}.get(os.environ.get("FNP_PIPE_SERIAL", ""))
+        self.serial_convs = self.depth > 1 and (bool(serial_convs) if serial_convs is not None else env if env is not None else self.batch_size >= 8)
+        if streams is not None:     # (the caller's own: depth slot streams, then the convolution stream of the serial form)
+            picked = list(streams)
+            assert len(picked) == self.depth + (1 if self.serial_convs else 0)
+        elif os.environ.get("FNP_TESTED_STREAMS", "0" if self.serial_convs else "1") != "0":
+            want = self.depth + (1 if self.serial_convs else 0)
+            picked = concurrent_streams(self.device, want, beside=[torch.cuda.current_stream(self.device)] if want < 4 else [])
+        else:
+            picked = [torch.cuda.Stream(self.device) for _ in range(self.depth + (1 if self.serial_convs else 0))]
+        self.streams = picked[:self.depth]
         # SERIAL CONVOLUTIONS (round 6).  With `depth` whole forwards in flight on `depth` streams the hardware interleaves them as
         # it likes: two 128 -> 128 launches share the CUs and each takes 1.8x as long (0.78 -> 1.37 ms at 128 scenes).  The gain of
         # the pipeline is elsewhere — a batch's voxeliser and index chain (latency- and atomics-bound, ~2 ms of a 10 ms step, a few
@@ -589,11 +672,9 @@ class PointsPipeline:
         # tile32 263 -> 340; the wide layers within 3 %): 8.76 ms of convolutions take 9.53.  Starting a batch's index chain only
         # where the batch before it reaches its 128 -> 128 launches (so that it meets matrix-bound kernels only) is WORSE, 12.2 k:
         # those launches hold every CU's registers and LDS, the index kernels crawl (5 ms of kernel time) and the chain waits 1.7 ms.
-        env = {"0": False, "1": True}.get(os.environ.get("FNP_PIPE_SERIAL", ""))
-        self.serial_convs = self.depth > 1 and (bool(serial_convs) if serial_convs is not None else env if env is not None else self.batch_size >= 8)
         # (measured, round 6: the convolution stream at a higher dispatch priority — torch.cuda.Stream(priority=-1) — starves the index
         #  chains it waits for: 13.0-13.3 k -> 12.2-12.4 k scenes/s)
-        self.conv_stream = torch.cuda.Stream(self.device) if self.serial_convs else None
+        self.conv_stream = picked[self.depth] if self.serial_convs else None
         if self.serial_convs:
             for e in self.engines:
                 e.two_streams = False      # (the index chain must sit on the capture stream itself: it becomes a graph of its own)

@@ -506,6 +506,43 @@ def test_counts_launch_hands_the_counts_to_the_host_itself(cuda):
 
 
 @pytest.mark.gpu
+def test_a_frame_is_staged_into_static_inputs_by_one_launch(cuda, rng):
+    """fnp_stage_points: rows [0, n) = the frame, rows [n, n_prev) = the padding value, the offsets copied — what three stream
+    operations did before a captured forward's replay."""
+    from findnpropagate_amd.backbones_3d.spconv_backbone import _PointsGraph
+    dst = torch.full((5000, 5), -7.0, dtype=torch.float32, device=cuda)
+    off_dst = torch.zeros(4, dtype=torch.int32, device=cuda)
+    for n, n_prev in ((3000, 0), (1200, 3000), (0, 1200), (4999, 0), (5000, 4999)):
+        pts = torch.from_numpy(rng.normal(size=(n, 5)).astype(np.float32)).to(cuda)
+        off = torch.tensor([0, n // 3, n // 2, n], dtype=torch.int32, device=cuda)
+        before = dst.clone()
+        S.stage_points(pts, off, dst, off_dst, n_prev, _PointsGraph.FAR)
+        want = before
+        want[:n] = pts
+        if n_prev > n:
+            want[n:n_prev] = _PointsGraph.FAR
+        assert torch.equal(dst, want) and torch.equal(off_dst, off), (n, n_prev)
+
+
+@pytest.mark.gpu
+def test_streams_are_tested_to_run_beside_each_other(cuda):
+    """concurrent_streams: distinct streams, none of them the caller's, each seen to make progress while a spin kernel holds another."""
+    from findnpropagate_amd.backbones_3d.spconv_backbone import concurrent_streams
+    caller = torch.cuda.current_stream(cuda)
+    st, ok = concurrent_streams(cuda, 3, beside=[caller], report=True)
+    assert len(st) == 3 and len({s.cuda_stream for s in st}) == 3 and all(s != caller for s in st)
+    assert isinstance(ok, bool)
+    x = torch.zeros(8, device=cuda)
+    for s in st:
+        with torch.cuda.stream(s):
+            x.add_(1)
+        torch.cuda.current_stream(cuda).wait_stream(s)
+    torch.cuda.synchronize()
+    assert float(x.sum()) == 24.0
+    assert concurrent_streams("cpu", 2) == []
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("depth", [1, 2, 3])
 def test_points_pipeline_equals_eager_frame_by_frame(cuda, depth):
     """PointsPipeline (one-scene frames, `depth` hipGraph replays in flight on their own streams, each slot with its own
