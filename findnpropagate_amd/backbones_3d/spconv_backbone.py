@@ -550,69 +550,7 @@ class _PointsGraph:
         return vox, res
 
 
-def concurrent_streams(device, n, beside=(), tries=24, report=False):
-    """n HIP streams that really run BESIDE each other and beside the streams in `beside`.
-
-    HIP streams are spread over a few hardware queues (GPU_MAX_HW_QUEUES: 4 unless set before the runtime starts; this package asks for
-    8) when they are first used, and torch hands its streams out of a pool: which of them end up in the same hardware queue depends on
-    what the process did before.  Two streams of one queue run in order — a batch's index chain behind another batch's convolutions —
-    and nothing says so: the same pipeline measured 12.7 k or 13.3 k scenes/s at 128 scenes, 1.7 k or 3.0 k frames/s with two one-scene
-    frames in flight, by the order in which the process had created its pipelines.  So the streams are TESTED: a ~1 ms spin kernel on
-    one, an event on the other; the event completes at once unless the two share a queue.  Streams that fail against any already chosen
-    one are dropped (back into torch's pool) and the next is tried.  Falls back to untested streams after `tries` candidates
-    (report=True: returns (streams, whether every one of them passed))."""
-    import time
-    device = torch.device(device)
-    chosen, rejected = [], []
-    if device.type != "cuda" or n <= 0:
-        return chosen
-    with torch.cuda.device(device):
-        probe = torch.cuda.current_stream(device)
-        torch.cuda.synchronize(device)
-        # a spin of about a millisecond on this card (torch.cuda._sleep counts device clock ticks)
-        ticks = 100000
-        for _ in range(6):
-            t0 = time.perf_counter()
-            torch.cuda._sleep(ticks)
-            torch.cuda.synchronize(device)
-            dt = time.perf_counter() - t0
-            if dt >= 0.8e-3:
-                break
-            ticks = int(ticks * max(2.0, 1.0e-3 / max(dt, 1e-5)))
-        spin = max(dt, 0.8e-3)
-        word = torch.zeros((1,), dtype=torch.int32, device=device)
-
-        def aliased(a, b):
-            """does work on b wait for work on a (one hardware queue)?"""
-            if a == b:
-                return True
-            torch.cuda.synchronize(device)
-            with torch.cuda.stream(a):
-                torch.cuda._sleep(ticks)
-            ev = torch.cuda.Event()
-            t0 = time.perf_counter()
-            with torch.cuda.stream(b):
-                word.fill_(1)        # (a real packet in b's queue: an event on an idle stream may complete without one)
-            ev.record(b)
-            ev.synchronize()
-            waited = time.perf_counter() - t0
-            torch.cuda.synchronize(device)
-            return waited > 0.4 * spin
-
-        others = [s for s in beside if s is not None]
-        for _ in range(max(tries, n)):
-            if len(chosen) == n:
-                break
-            c = torch.cuda.Stream(device)
-            if any(aliased(o, c) for o in others + chosen):
-                rejected.append(c)
-                continue
-            chosen.append(c)
-        complete = len(chosen) == n
-        while len(chosen) < n:      # (more streams asked for than the card has queues to give: take what there is)
-            chosen.append(rejected.pop(0) if rejected else torch.cuda.Stream(device))
-        del probe
-    return (chosen, complete) if report else chosen
+concurrent_streams = S.concurrent_streams     # (sparse.py: streams tested to run beside each other)
 
 
 class PointsPipeline:
@@ -639,22 +577,29 @@ class PointsPipeline:
             # graph on top of that oversubscribes the hardware queues
             e.two_streams = self.depth == 1 or os.environ.get("FNP_PIPE_TWO", "0") == "1"
 
-        # Which streams.  The free-for-all form (one-scene frames) takes streams that were SEEN to run beside each other and beside the
-        # caller's (concurrent_streams): 3.04 k / 3.7 k frames/s with two / three frames in flight every time, against 1.7-3.0 k / 2.2-3.5 k
-        # by the order in which the process happened to create its streams.  The serial form (batches of >= 8 scenes) keeps torch's next
-        # pool streams: whether a batch's index chain runs UNDER the other batch's convolutions (13.0-13.5 k scenes/s at 128 scenes) or
-        # after them (12.1-12.3 k) is decided by something the spin test does not see — in bench.py's process the tested set is the
-        # slow one, three runs out of three, in a fresh process both are fast, the convolutions on the CALLER's stream are always slow,
-        # and a trial of four candidate convolution streams at the first frame picked slow ones as often as not (DESIGN.md section 7:
-        # open).  FNP_TESTED_STREAMS=0 / 1 forces; `streams` hands in the caller's own.
+        # Which streams: ones that were SEEN to run beside each other and beside the caller's (concurrent_streams: the card's four
+        # hardware queues are shared out in the order streams are first used, and two streams of one queue run one after the other).
+        # tools/probe/queue_map.py, 128 scenes, one process: slots and convolutions on three queues, none the caller's 13.4 k scenes/s;
+        # a slot on the caller's stream 12.7-12.8 k; the convolutions on the caller's stream 12.2 k (nothing overlaps).  With more
+        # streams than queues (three slots + the convolution stream + the caller's) the CONVOLUTION stream is the one kept apart and the
+        # slots double up: their index chains run one after the other anyway.  FNP_TESTED_STREAMS=0: torch's next pool streams;
+        # `streams` hands in the caller's own.
         env = {"0": False, "1": True}.get(os.environ.get("FNP_PIPE_SERIAL", ""))
         self.serial_convs = self.depth > 1 and (bool(serial_convs) if serial_convs is not None else env if env is not None else self.batch_size >= 8)
         if streams is not None:     # (the caller's own: depth slot streams, then the convolution stream of the serial form)
             picked = list(streams)
             assert len(picked) == self.depth + (1 if self.serial_convs else 0)
-        elif os.environ.get("FNP_TESTED_STREAMS", "0" if self.serial_convs else "1") != "0":
-            want = self.depth + (1 if self.serial_convs else 0)
-            picked = concurrent_streams(self.device, want, beside=[torch.cuda.current_stream(self.device)] if want < 4 else [])
+        elif os.environ.get("FNP_TESTED_STREAMS", "1") != "0":
+            caller = torch.cuda.current_stream(self.device)
+            if self.serial_convs:
+                conv = concurrent_streams(self.device, 1, beside=[caller])
+                slots, ok = concurrent_streams(self.device, self.depth, beside=[caller] + conv, report=True)
+                if not ok:      # (not enough queues: the slots only have to stay clear of the convolutions)
+                    slots = concurrent_streams(self.device, min(self.depth, 2), beside=[caller] + conv)
+                    slots = [slots[i % len(slots)] for i in range(self.depth)]
+                picked = slots + conv
+            else:
+                picked = concurrent_streams(self.device, self.depth, beside=[caller])
         else:
             picked = [torch.cuda.Stream(self.device) for _ in range(self.depth + (1 if self.serial_convs else 0))]
         self.streams = picked[:self.depth]
@@ -1008,7 +953,13 @@ class FusedResBackbone:
         key = str(device)
         st = self._side.get(key)
         if st is None:
-            st = self._side[key] = torch.cuda.Stream(device)
+            # (eager two-stream forwards: a stream seen to run beside the caller's — sparse.concurrent_streams; inside a capture the
+            #  stream only names a branch, and the test, which synchronises, cannot run)
+            if torch.cuda.is_current_stream_capturing():
+                st = torch.cuda.Stream(device)
+            else:
+                st = S.concurrent_streams(device, 1, beside=[torch.cuda.current_stream(device)])[0]
+            self._side[key] = st
         return st
 
     def _ell_counter(self, which, device):

@@ -252,7 +252,13 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
     rec_local = {}
     rec_vec = torch.zeros((len(keys),), dtype=torch.int64, device=device)
     writer = _Writer(out_dir, dataset, resume, enabled=pipeline)
-    side = torch.cuda.Stream(device=device) if pipeline else None
+    # (a stream that was SEEN to run beside the caller's: HIP shares four hardware queues out in the order streams are first used, and
+    #  in a fresh process torch's first pool streams sit in the default stream's queue — the collective and the copy to the host would
+    #  then run behind the next scene's launch instead of beside it; sparse.concurrent_streams)
+    side = None
+    if pipeline:
+        from .sparse import concurrent_streams
+        side = concurrent_streams(device, 1, beside=[torch.cuda.current_stream(device)])[0]
     pending = None       # (host records, event) of the previous step
     head.eval()
 

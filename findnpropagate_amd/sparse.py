@@ -121,6 +121,66 @@ def make_voxel_cfg(voxel_size, point_cloud_range, num_features, max_points, max_
     return cfg
 
 
+def concurrent_streams(device, n, beside=(), tries=24, report=False):
+    """n HIP streams that really run BESIDE each other and beside the streams in `beside`.
+
+    HIP spreads its streams over a few hardware queues — 4 (GPU_MAX_HW_QUEUES) — in the order of their first use, torch hands its
+    streams out of a pool, and two streams of one hardware queue run strictly one after the other: a batch's index chain behind
+    another batch's convolutions.  Nothing says so: the same pipeline measured 12.2 k or 13.4 k scenes/s at 128 scenes, 1.7 k or 3.0 k
+    frames/s with two one-scene frames in flight, by what the process had done with streams before (in a fresh process the first
+    three pool streams share the queue of the default stream).  So candidate streams are TESTED: a run of chip-filling kernels
+    (matrix products, ~1 ms) goes to one stream, a one-word fill and an event to the other; the event completes at once unless the
+    two share a queue (0.02-0.3 ms against the whole run: tools/probe/queue_map.py sorts 14 pool streams into exactly four classes
+    this way, round robin in pool order).  A spin kernel of one thread does NOT show it.  Streams that fail against any already chosen
+    one are dropped (back into torch's pool) and the next is tried; after `tries` candidates the rest is filled with untested ones
+    (report=True: returns (streams, whether every one of them passed))."""
+    import time
+    device = torch.device(device)
+    chosen, rejected = [], []
+    if device.type != "cuda" or n <= 0:
+        return (chosen, True) if report else chosen
+    with torch.cuda.device(device):
+        a_mat = torch.zeros((4096, 4096), dtype=torch.bfloat16, device=device)
+        c_mat = torch.empty_like(a_mat)
+        word = torch.zeros((1,), dtype=torch.int32, device=device)
+        for _ in range(2):
+            torch.mm(a_mat, a_mat, out=c_mat)
+        torch.cuda.synchronize(device)
+
+        def shares_queue(a, b):
+            """does work on b wait for the work on a (one hardware queue)?"""
+            if a == b:
+                return True
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            with torch.cuda.stream(a):
+                for _ in range(10):
+                    torch.mm(a_mat, a_mat, out=c_mat)
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(b):
+                word.fill_(1)
+            ev.record(b)
+            ev.synchronize()
+            waited = time.perf_counter() - t0
+            torch.cuda.synchronize(device)
+            return waited > 0.5 * (time.perf_counter() - t0)
+
+        others = [s for s in beside if s is not None]
+        for _ in range(max(tries, n)):
+            if len(chosen) == n:
+                break
+            c = torch.cuda.Stream(device)
+            if any(shares_queue(o, c) for o in others + chosen):
+                rejected.append(c)
+                continue
+            chosen.append(c)
+        complete = len(chosen) == n
+        while len(chosen) < n:      # (more streams asked for than the card has queues to give: take what there is)
+            chosen.append(rejected.pop(0) if rejected else torch.cuda.Stream(device))
+        del a_mat, c_mat
+    return (chosen, complete) if report else chosen
+
+
 def stage_points(points, batch_offsets, dst_points, dst_offsets, n_prev, pad):
     """one launch: dst_points[:n] = points, dst_points[n:n_prev] = pad, dst_offsets[:] = batch_offsets (fnp_stage_points: a frame into the
     static inputs of a captured forward).  Everything on the device; the caller's stream."""

@@ -336,7 +336,13 @@ def end_of_backbone_forward(convs, indice_dict=None):
 def _side_stream(device):
     key = str(device)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device)
+        # (a stream SEEN to run beside the caller's: torch's first pool streams share the default stream's hardware queue in a fresh
+        #  process, and the prefetched rulebooks would be built behind the convolutions instead of beside them; sparse.concurrent_streams.
+        #  Not while a stream is capturing: the test synchronises.)
+        from .. import sparse as _S
+        if torch.cuda.is_current_stream_capturing():
+            return torch.cuda.Stream(device)
+        _SIDE[key] = _S.concurrent_streams(device, 1, beside=[torch.cuda.current_stream(device)])[0]
     return _SIDE[key]
 
 

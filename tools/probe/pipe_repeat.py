@@ -15,9 +15,16 @@ with torch.no_grad():
     for r in range(reps):
         pipe = net.points_pipeline(B, cfg, depth=depth, capacity=(pts.shape[0] + 65535) // 65536 * 65536)
         for _ in pipe.map([(pts, off)] * 6): pass
+        ts, tr = [], []
+        sub, resu = pipe.submit, pipe.result
+        def tsub(*a):
+            t = time.perf_counter(); sub(*a); ts.append(time.perf_counter() - t)
+        def tres():
+            t = time.perf_counter(); r = resu(); tr.append(time.perf_counter() - t); return r
+        pipe.submit, pipe.result = tsub, tres
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in pipe.map([(pts, off)] * K): pass
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
-        res.append(round(B / dt))
+        res.append((round(B / dt), "submit ms median %.2f max %.2f" % (1e3 * float(np.median(ts)), 1e3 * max(ts)), "result ms median %.2f" % (1e3 * float(np.median(tr)))))
         del pipe
 print(json.dumps({"scenes_per_batch": B, "depth": depth, "scenes_per_s": res}))

@@ -17,19 +17,22 @@ if ctx == "bench":     # what bench.py did before it built its pipeline: two-bra
     torch.cuda.synchronize()
 
 def aliased(a, b, ticks=200000):
-    """is b starved while a's queue is CONTINUOUSLY busy (a run of short kernels back to back for ~2 ms)?"""
+    """is b starved while a runs CHIP-FILLING kernels back to back (12 matrix products of ~0.5 ms)?"""
     if a == b:
         return True
     torch.cuda.synchronize()
     with torch.cuda.stream(a):
-        for _ in range(24): torch.cuda._sleep(20000)
+        for _ in range(12): torch.mm(aliased.A, aliased.A, out=aliased.C)
     ev = torch.cuda.Event(); t0 = time.perf_counter()
     with torch.cuda.stream(b): aliased.word.fill_(1)
     ev.record(b); ev.synchronize(); w = time.perf_counter() - t0
     torch.cuda.synchronize(); tot = time.perf_counter() - t0
     aliased.log.append((round(w * 1e3, 2), round(tot * 1e3, 2)))
-    return w > 0.5 * tot and tot > 1.0e-3
+    return w > 0.5 * tot
 aliased.log = []
+aliased.A = torch.randn(6144, 6144, device=dev, dtype=torch.bfloat16); aliased.C = torch.empty_like(aliased.A)
+for _ in range(3): torch.mm(aliased.A, aliased.A, out=aliased.C)
+torch.cuda.synchronize()
 aliased.word = torch.zeros(1, dtype=torch.int32, device=dev); aliased.word2 = torch.zeros(1, dtype=torch.int32, device=dev); aliased.helper = torch.cuda.Stream(dev)
 t0 = time.perf_counter(); torch.cuda._sleep(200000); torch.cuda.synchronize(); spin_ms = (time.perf_counter() - t0) * 1e3
 caller = torch.cuda.current_stream(dev)
@@ -41,7 +44,7 @@ for s in pool:
             c.append(s); break
     else:
         classes.append([s])
-out = {"test_ms_first6": aliased.log[:6], "scenes": B, "context": ctx, "spin_ms": round(spin_ms, 2), "classes": [len(c) for c in classes], "caller_class_size": len(classes[0])}
+out = {"test_ms": aliased.log[:40], "scenes": B, "context": ctx, "spin_ms": round(spin_ms, 2), "classes": [len(c) for c in classes], "class_of_pool": [next(i for i, c in enumerate(classes) if s_ in c) for s_ in pool], "caller_class_size": len(classes[0])}
 def q(i, j=0):      # j-th stream of class i (class 0 = the caller's; its member 0 is the caller's stream itself)
     c = classes[i]
     return c[min(j + (1 if i == 0 else 0), len(c) - 1)]
