@@ -129,7 +129,7 @@ def concurrent_streams(device, n, beside=(), tries=24, report=False):
     another batch's convolutions.  Nothing says so: the same pipeline measured 12.2 k or 13.4 k scenes/s at 128 scenes, 1.7 k or 3.0 k
     frames/s with two one-scene frames in flight, by what the process had done with streams before (in a fresh process the first
     three pool streams share the queue of the default stream).  So candidate streams are TESTED: a run of chip-filling kernels
-    (matrix products, ~1 ms) goes to one stream, a one-word fill and an event to the other; the event completes at once unless the
+    (twelve fills of 256 MB, ~0.8 ms) goes to one stream, a one-word fill and an event to the other; the event completes at once unless the
     two share a queue (0.02-0.3 ms against the whole run: tools/probe/queue_map.py sorts 14 pool streams into exactly four classes
     this way, round robin in pool order).  A spin kernel of one thread does NOT show it.  Streams that fail against any already chosen
     one are dropped (back into torch's pool) and the next is tried; after `tries` candidates the rest is filled with untested ones
@@ -140,11 +140,9 @@ def concurrent_streams(device, n, beside=(), tries=24, report=False):
     if device.type != "cuda" or n <= 0:
         return (chosen, True) if report else chosen
     with torch.cuda.device(device):
-        a_mat = torch.zeros((4096, 4096), dtype=torch.bfloat16, device=device)
-        c_mat = torch.empty_like(a_mat)
+        big = torch.empty((64 << 20,), dtype=torch.int32, device=device)     # 256 MB: a fill of it holds every CU for ~60 us
         word = torch.zeros((1,), dtype=torch.int32, device=device)
-        for _ in range(2):
-            torch.mm(a_mat, a_mat, out=c_mat)
+        big.zero_()
         torch.cuda.synchronize(device)
 
         def shares_queue(a, b):
@@ -154,8 +152,8 @@ def concurrent_streams(device, n, beside=(), tries=24, report=False):
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
             with torch.cuda.stream(a):
-                for _ in range(10):
-                    torch.mm(a_mat, a_mat, out=c_mat)
+                for _ in range(12):
+                    big.zero_()
             ev = torch.cuda.Event()
             with torch.cuda.stream(b):
                 word.fill_(1)
@@ -177,7 +175,7 @@ def concurrent_streams(device, n, beside=(), tries=24, report=False):
         complete = len(chosen) == n
         while len(chosen) < n:      # (more streams asked for than the card has queues to give: take what there is)
             chosen.append(rejected.pop(0) if rejected else torch.cuda.Stream(device))
-        del a_mat, c_mat
+        del big
     return (chosen, complete) if report else chosen
 
 
