@@ -523,17 +523,21 @@ class _PointsGraph:
         """the host's copy of the last replay's counts (waits for the counts only, not for the rest of the forward)"""
         if self.host_counts:
             # the counts launch of replay number r stores r behind the counts (after them, system scope): poll for it
+            # (a one-scene forward has them after ~0.2 ms: a pure spin; a 128-scene batch behind another after ~9 ms: past the first
+            #  ~0.3 ms the loop sleeps between looks, so that a long wait does not hold a core)
+            import time
             want, word, t0 = self._replays & 0xffffffff, self._pin_np, None
             spins = 0
             while (int(word[16]) & 0xffffffff) != want:
                 spins += 1
-                if spins & 0xfff == 0:      # (~every millisecond: has the device stopped?)
-                    import time
-                    t0 = t0 or time.monotonic()
-                    if self.done_event.query() and (int(word[16]) & 0xffffffff) != want:
-                        raise RuntimeError("the forward ended without its counts launch (sequence %d, expected %d)" % (int(word[16]), want))
-                    if time.monotonic() - t0 > 60.0:
-                        raise RuntimeError("no counts from the device after 60 s")
+                if spins > 3000:
+                    time.sleep(5.0e-5)
+                    if spins & 0x3f == 0:      # (every few milliseconds: has the device stopped?)
+                        t0 = t0 or time.monotonic()
+                        if self.done_event.query() and (int(word[16]) & 0xffffffff) != want:
+                            raise RuntimeError("the forward ended without its counts launch (sequence %d, expected %d)" % (int(word[16]), want))
+                        if time.monotonic() - t0 > 60.0:
+                            raise RuntimeError("no counts from the device after 60 s")
             return [int(v) for v in word[:self.counts_dev.numel()]]
         self.counts_event.synchronize()
         return self.counts_pin[:self.counts_dev.numel()].tolist()

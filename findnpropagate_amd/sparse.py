@@ -129,7 +129,7 @@ def concurrent_streams(device, n, beside=(), tries=24, report=False):
     another batch's convolutions.  Nothing says so: the same pipeline measured 12.2 k or 13.4 k scenes/s at 128 scenes, 1.7 k or 3.0 k
     frames/s with two one-scene frames in flight, by what the process had done with streams before (in a fresh process the first
     three pool streams share the queue of the default stream).  So candidate streams are TESTED: a run of chip-filling kernels
-    (twelve fills of 256 MB, ~0.8 ms) goes to one stream, a one-word fill and an event to the other; the event completes at once unless the
+    (twelve in-place adds over 128 MB, ~0.8 ms) goes to one stream, a one-word fill and an event to the other; the event completes at once unless the
     two share a queue (0.02-0.3 ms against the whole run: tools/probe/queue_map.py sorts 14 pool streams into exactly four classes
     this way, round robin in pool order).  A spin kernel of one thread does NOT show it.  Streams that fail against any already chosen
     one are dropped (back into torch's pool) and the next is tried; after `tries` candidates the rest is filled with untested ones
@@ -140,9 +140,12 @@ def concurrent_streams(device, n, beside=(), tries=24, report=False):
     if device.type != "cuda" or n <= 0:
         return (chosen, True) if report else chosen
     with torch.cuda.device(device):
-        big = torch.empty((64 << 20,), dtype=torch.int32, device=device)     # 256 MB: a fill of it holds every CU for ~60 us
-        word = torch.zeros((1,), dtype=torch.int32, device=device)
-        big.zero_()
+        # (elementwise KERNELS, never zero_(): that is hipMemsetAsync for a large tensor, and on this stack an eager memset changes what
+        #  the memset NODES of graphs captured earlier do when they are replayed — DESIGN.md section 2; with a 256 MB one in between,
+        #  the replay of a graph that torch had given a 4-byte memset node segfaulted)
+        big = torch.empty((32 << 20,), dtype=torch.int32, device=device)     # 128 MB: an add over it holds every CU for ~60 us
+        word = torch.ones((1,), dtype=torch.int32, device=device)
+        big.fill_(1)
         torch.cuda.synchronize(device)
 
         def shares_queue(a, b):
@@ -153,7 +156,7 @@ def concurrent_streams(device, n, beside=(), tries=24, report=False):
             t0 = time.perf_counter()
             with torch.cuda.stream(a):
                 for _ in range(12):
-                    big.zero_()
+                    big.add_(1)
             ev = torch.cuda.Event()
             with torch.cuda.stream(b):
                 word.fill_(1)
