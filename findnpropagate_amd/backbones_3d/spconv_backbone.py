@@ -331,13 +331,23 @@ class VoxelResBackBone8x(_BackboneBase):
         over (points, batch_offsets) pairs -> the dicts of forward_points, in order, with `depth` batches in flight (default TWO,
         round 6: the latency-bound index kernels of one batch run under the convolutions of the other — +5 to +7 % at 128 scenes
         per batch, 2x at one scene; results identical to forward_points batch by batch).  A returned dict's tensors are views of
-        a slot's static buffers: valid until `depth` more batches have been taken from the iterator.
+        a slot's static buffers: valid until `depth` more batches have been taken from the iterator — of this call or of the next one with
+        the same (batch_size, depth, capacity, voxel configuration): the pipeline of the last call is kept (its slots are captured
+        graphs and streams picked by test, ~0.5 s to make) and reused.
         capacity: point capacity of a slot (default: sized by the first batch, rounded up to 64 Ki points)."""
         pipe = None
         for pts, off in batches:
             if pipe is None:
                 cap = int(capacity) if capacity else max(65536, (int(pts.shape[0]) + 65535) // 65536 * 65536)
-                pipe = PointsPipeline(self, batch_size, voxel_cfg, depth=depth, capacity=cap, n_feat=int(pts.shape[1]))
+                key = (int(batch_size), int(depth), cap, int(pts.shape[1]), str(pts.device), bytes(voxel_cfg))
+                kept = self.__dict__.get("_iter_pipeline")
+                if kept is not None and kept[0] == key and int(pts.shape[0]) <= cap:
+                    pipe = kept[1]
+                    while pipe.pending:          # (an iterator of the last call that was dropped half-way)
+                        pipe.result()
+                else:
+                    pipe = PointsPipeline(self, batch_size, voxel_cfg, depth=depth, capacity=cap, n_feat=int(pts.shape[1]))
+                    self.__dict__["_iter_pipeline"] = (key, pipe)
             if len(pipe.pending) == pipe.depth:
                 yield pipe.result()
             pipe.submit(pts, off)

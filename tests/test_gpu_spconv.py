@@ -606,6 +606,21 @@ def test_batch_path_with_two_batches_in_flight_equals_forward_points(cuda):
                 assert torch.equal(got[k].features, want[i][k][0]) and torch.equal(got[k].indices, want[i][k][1]), (i, k)
             n += 1
         assert n == len(batches)
+        # a second call with the same configuration reuses the first call's pipeline (captured slots, tested streams) — also after an
+        # iterator that was dropped with batches still in flight — and a different configuration makes a new one
+        kept = net._iter_pipeline[1]
+        it = net.forward_points_iter(iter(batches), 2, cfg)
+        next(it)
+        del it
+        for i, got in enumerate(net.forward_points_iter(iter(batches[::-1]), 2, cfg)):
+            w_ = want[len(batches) - 1 - i]
+            assert got["counts"] == w_["counts"], i
+            for k in keys:
+                assert torch.equal(got[k].features, w_[k][0]) and torch.equal(got[k].indices, w_[k][1]), (i, k)
+        assert net._iter_pipeline[1] is kept and not kept.pending
+        for got in net.forward_points_iter(iter(batches[:1]), 2, cfg, depth=3):
+            assert got["counts"] == want[0]["counts"]
+        assert net._iter_pipeline[1] is not kept and net._iter_pipeline[1].depth == 3
         # serial_convs: every slot's capture cut behind its index chain, the convolution graphs of all slots on one stream (the
         # default from 8 scenes per batch on); False: whole forwards in flight side by side
         for serial, depth in ((True, 2), (False, 2), (True, 3)):
