@@ -151,6 +151,7 @@ class FrustumProposerOG(nn.Module):
             self.image_detector = self._default_detector(model_cfg, class_names)
         self.last_debug = None
         self._dev_tables = {}
+        self._ws_cache = {}      # (device, stream) -> the Box Seeker kernel's scratch buffer (launch)
         self._order_c = None
 
     @staticmethod
@@ -210,7 +211,7 @@ class FrustumProposerOG(nn.Module):
                                           float(self.nms_2d), float(self.score_thr), _l.ptr(rows), rows.shape[0])
         if n < 0:
             _l.check(n, "fnp_host_enumerate_frustums")
-        rows = rows[:n].clone()
+        rows = rows[:n]      # (a view of this call's own buffer)
         if self.box_fmt != 'xyxy':   # :596-601: [x, y, w, h] detections; the 2D NMS above ran on the raw numbers, as the reference's does
             rows[:, 4:6] += rows[:, 2:4]
         return rows
@@ -250,7 +251,11 @@ class FrustumProposerOG(nn.Module):
         """The same matrices made on the device by fnp_seeker_prepare_matrices from the batch's device tensors (no copy to the
         host, no synchronisation, no LAPACK call): (B,21), (B,6,45), and whether the batch carries an img_aug_matrix (applied
         whenever present, as the reference does: an identity changes no value)."""
-        f = lambda k: batch_dict[k].detach().to(dev, torch.float32, non_blocking=True).contiguous()
+        def f(k):   # (the collate hands out device f32 tensors already: three torch calls per matrix saved then)
+            t = batch_dict[k]
+            if t.device == dev and t.dtype == torch.float32 and t.is_contiguous() and not t.requires_grad:
+                return t
+            return t.detach().to(dev, torch.float32, non_blocking=True).contiguous()
         aug, l2i, c2l, K = f('lidar_aug_matrix'), f('lidar2image'), f('camera2lidar'), f('camera_intrinsics')
         ia = f('img_aug_matrix') if 'img_aug_matrix' in batch_dict else None
         B = aug.shape[0]
@@ -282,7 +287,8 @@ class FrustumProposerOG(nn.Module):
         L = _l.load()
         points = batch_dict['points']
         _l.require_device(points)
-        points = points.detach().float().contiguous()
+        if points.dtype != torch.float32 or not points.is_contiguous() or points.requires_grad:
+            points = points.detach().float().contiguous()
         dev = points.device
         B = int(batch_dict['batch_size'])
         frusts = self.enumerate_frustums(batch_dict)
@@ -296,14 +302,13 @@ class FrustumProposerOG(nn.Module):
         if pps is not None:
             assert len(pps) == B and sum(int(v) for v in pps) == points.shape[0]
             # scene offsets and the frustum table cross to the device in ONE pinned transfer (offsets as int32 bits in the f32 buffer)
+            # (filled through numpy views: a torch indexing call costs ~5 us of host time, and this loop is bound by the host)
             host = torch.empty((B + 1 + F * 8,), dtype=torch.float32, pin_memory=True)
-            ho = host[:B + 1].view(torch.int32)
-            acc = 0
+            hn = host.numpy()
+            ho = hn[:B + 1].view(np.int32)
             ho[0] = 0
-            for b, v in enumerate(pps):
-                acc += int(v)
-                ho[b + 1] = acc
-            host[B + 1:] = frusts.reshape(-1)
+            np.cumsum(np.asarray(pps, dtype=np.int64), out=ho[1:], dtype=np.int32) if B > 1 else ho.__setitem__(1, int(pps[0]))
+            hn[B + 1:] = frusts.numpy().reshape(-1)
             d_host = host.to(dev, non_blocking=True)
             offsets, d_fr = d_host[:B + 1].view(torch.int32), d_host[B + 1:].view(F, 8)
             max_pts = max(int(v) for v in pps)
@@ -322,7 +327,16 @@ class FrustumProposerOG(nn.Module):
         prm.has_img_aug = int(has_img_aug)
         NM, TK = max(int(self.num_mags), 1), int(self.topk)
         NC = NM * self.num_rotations * self.num_sizes
-        ws = torch.empty((int(L.fnp_boxseeker_workspace_bytes(F, max_pts)),), dtype=torch.uint8, device=dev)
+        # the kernel's scratch: one buffer per (device, stream), grown as needed — launches of a stream run in order, so the next one may
+        # have it (a debug launch hands views of it out and takes a buffer of its own)
+        need = int(L.fnp_boxseeker_workspace_bytes(F, max_pts))
+        if debug:
+            ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        else:
+            wkey = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+            ws = self._ws_cache.get(wkey)
+            if ws is None or ws.numel() < need:
+                ws = self._ws_cache[wkey] = torch.empty((max(need, 1 << 20),), dtype=torch.uint8, device=dev)
         # (every output element is written by the kernel, frustums without points included: no clearing launches)
         out_all = torch.empty((F * (1 + TK * 9),), dtype=torch.float32, device=dev)
         out_valid = out_all[:F].view(torch.int32)

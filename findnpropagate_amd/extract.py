@@ -158,9 +158,9 @@ def _records_from_launch(r, index_tags, device):
     tags = (ctypes.c_float * S)(*[float(t) for t in index_tags])
     if r is not None:
         fr = r["frustums"]                                   # host (F, 8)
-        per_scene = torch.bincount(fr[:, 0].long(), minlength=S)
-        if int(per_scene.max()) > K_MAX:
-            raise ValueError(f"{int(per_scene.max())} frustums in one scene exceed the exchange record ({K_MAX}); raise extract.K_MAX")
+        most = int(fr.shape[0]) if S == 1 else int(torch.bincount(fr[:, 0].long(), minlength=S).max())   # (one scene per step: the extraction script's)
+        if most > K_MAX:
+            raise ValueError(f"{most} frustums in one scene exceed the exchange record ({K_MAX}); raise extract.K_MAX")
         args = (_l.ptr(r["d_frustums"]), _l.ptr(r["out_valid"]), _l.ptr(r["out_box"]), int(fr.shape[0]))
     else:
         args = (None, None, None, 0)
@@ -239,6 +239,7 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
     rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
     world = dist.get_world_size() if (dist is not None and dist.is_initialized()) else 1
     os.makedirs(out_dir, exist_ok=True)
+    out_dir_s = os.fspath(out_dir)
     n = len(dataset)
     S = max(1, int(scenes_per_step))
     collate = collate or collate_scenes
@@ -282,7 +283,7 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
             scenes, tags, dup = [], [], []
             for slot, index in enumerate(idxs):
                 data = dataset[index]
-                skip = resume and frame_path(out_dir, data["frame_id"]).exists()
+                skip = resume and os.path.exists(os.path.join(out_dir_s, str(data["frame_id"]).replace('.', '_') + ".pth"))   # (frame_path, as a string)
                 if skip:
                     continue
                 scenes.append(data)
