@@ -103,6 +103,7 @@ def save_frame(out_dir, frame_id, pred_dict):
 
 
 RECALL_THRESH = (0.3, 0.5, 0.7)   # extract_pseudo_labels.py:108
+_SIDE_STREAMS = {}                # (device, caller's stream) -> the pipeline's side stream
 
 
 def recall_keys():
@@ -259,7 +260,11 @@ def extract_pseudo_labels(dataset, head, out_dir, device, dist=None, write="rank
     side = None
     if pipeline:
         from .sparse import concurrent_streams
-        side = concurrent_streams(device, 1, beside=[torch.cuda.current_stream(device)])[0]
+        cur0 = torch.cuda.current_stream(device)
+        skey = (str(device), cur0.cuda_stream)
+        side = _SIDE_STREAMS.get(skey)      # (tested once per process and caller stream: the test costs a few milliseconds)
+        if side is None:
+            side = _SIDE_STREAMS[skey] = concurrent_streams(device, 1, beside=[cur0])[0]
     pending = None       # (host records, event) of the previous step
     head.eval()
 

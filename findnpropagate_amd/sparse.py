@@ -129,7 +129,7 @@ def concurrent_streams(device, n, beside=(), tries=24, report=False):
     another batch's convolutions.  Nothing says so: the same pipeline measured 12.2 k or 13.4 k scenes/s at 128 scenes, 1.7 k or 3.0 k
     frames/s with two one-scene frames in flight, by what the process had done with streams before (in a fresh process the first
     three pool streams share the queue of the default stream).  So candidate streams are TESTED: a run of chip-filling kernels
-    (twelve in-place adds over 128 MB, ~0.8 ms) goes to one stream, a one-word fill and an event to the other; the event completes at once unless the
+    (48 in-place adds over 128 MB, ~1.8 ms) goes to one stream, a one-word fill and an event to the other; the event completes at once unless the
     two share a queue (0.02-0.3 ms against the whole run: tools/probe/queue_map.py sorts 14 pool streams into exactly four classes
     this way, round robin in pool order).  A spin kernel of one thread does NOT show it.  Streams that fail against any already chosen
     one are dropped (back into torch's pool) and the next is tried; after `tries` candidates the rest is filled with untested ones
@@ -155,7 +155,7 @@ def concurrent_streams(device, n, beside=(), tries=24, report=False):
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
             with torch.cuda.stream(a):
-                for _ in range(12):
+                for _ in range(48):      # (~1.8 ms: well above the ~0.2 ms the fill + event below cost the host on a free queue)
                     big.add_(1)
             ev = torch.cuda.Event()
             with torch.cuda.stream(b):
