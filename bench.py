@@ -54,6 +54,8 @@ def parse():
                          "are taken inside the timed region; 'graphs' = the same two-graph replay, one batch at a time (rounds 3-5's timed "
                          "step); 'stream' = every kernel a plain stream launch (rounds 1-3's)")
     ap.add_argument("--in-flight", type=int, default=2, help="batches in flight of --launch pipeline")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic (two rocprofv3 --pmc child runs of this script, ~1 min); "
+                    "the committed profile's value is quoted then")
     ap.add_argument("--no-sweep", action="store_true", help="skip the extra small-batch measurements (1 and 8 scenes per step)")
     return ap.parse_args()
 
@@ -283,6 +285,47 @@ def child_json(cmd, timeout):
     if not lines:
         raise RuntimeError((r.stderr or r.stdout)[-300:])
     return json.loads(lines[-1])
+
+
+def measured_traffic(kname, B, dtype, budget_s=110.0):
+    """HBM bytes per launch of kernel `kname`, MEASURED NOW: this script is run twice more as a child of rocprofv3 (3 steps each), once
+    with --pmc FETCH_SIZE and once with --pmc WRITE_SIZE (separate passes, --kernel-trace only, as MI355X_MICROARCH.md prescribes),
+    and the counters of the kernel's launches are averaged: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (KiB units; gfx950 FETCH_SIZE counts
+    64 B per 128-B request).  -> (bytes, launches, note) or raises."""
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic as PT
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        raise RuntimeError("rocprofv3 not found")
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="fnp_pmc_", dir="/tmp")
+        cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--batch", str(B), "--dtype", dtype, "--cpu-scenes", "0", "--no-sweep", "--no-secondary", "--no-traffic", "--steps", "3", "--warmup", "2",
+               "--reps", "1"]
+        p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                             start_new_session=True)
+        try:
+            p.wait(timeout=budget_s)
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(p.pid, signal.SIGKILL)     # (the exact process group this call started)
+            p.wait()
+            shutil.rmtree(d, ignore_errors=True)
+            raise RuntimeError(f"the {counter} pass did not finish in {budget_s:.0f} s")
+        try:
+            acc = PT.load(d, counter)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        hit = [v for k, v in acc.items() if PT.short(k) == kname]
+        if not hit:
+            raise RuntimeError(f"no launch of {kname} in the {counter} pass")
+        vals[counter] = hit[0]
+    f, w = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+    return (2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024.0, min(len(f), len(w))
 
 
 def main():
@@ -535,12 +578,19 @@ def main():
         # gfx950 FETCH_SIZE x2 correction applied: profiles/r0N_pmc_traffic_<dtype>_b<B>.json); null when no profile of
         # this kernel at this batch size is committed
         traffic, traffic_src = None, None
-        for name in (f"r06_pmc_traffic_{args.dtype}_b{B}.json", f"r05_pmc_traffic_{args.dtype}_b{B}.json", f"r04_pmc_traffic_{args.dtype}_b{B}.json", f"r03_pmc_traffic_{args.dtype}_b{B}.json", f"r02_pmc_traffic_{args.dtype}_b{B}.json",
-                     f"r01_pmc_traffic_b{B}.json" if args.dtype == "bf16" else ""):
+        if rank == 0 and world == 1 and not args.no_traffic and not args.no_secondary and not args.graph:
+            try:
+                traffic, n_l = measured_traffic(kname, B, args.dtype)
+                traffic_src = (f"measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) of `bench.py --batch {B} --steps 3` "
+                               f"as child processes, {n_l} launches of the kernel averaged, (2*FETCH_SIZE + WRITE_SIZE)*1024")
+            except Exception as e:
+                traffic, traffic_src = None, "live PMC passes failed (" + repr(e)[:160] + "); "
+        for name in (() if traffic else (f"r06_pmc_traffic_{args.dtype}_b{B}.json", f"r05_pmc_traffic_{args.dtype}_b{B}.json", f"r04_pmc_traffic_{args.dtype}_b{B}.json", f"r03_pmc_traffic_{args.dtype}_b{B}.json", f"r02_pmc_traffic_{args.dtype}_b{B}.json",
+                     f"r01_pmc_traffic_b{B}.json" if args.dtype == "bf16" else "")):
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if pj.get("batch") == B and kname in pj["kernels"]:
-                    traffic, traffic_src = pj["kernels"][kname]["hbm_bytes_corrected"], f"profiles/{name} (committed rocprofv3 --pmc passes of this command; not measured in this run)"
+                    traffic, traffic_src = pj["kernels"][kname]["hbm_bytes_corrected"], (traffic_src or "") + f"profiles/{name} (committed rocprofv3 --pmc passes of this command; not measured in this run)"
                     break
             except Exception:
                 continue
