@@ -573,10 +573,10 @@ def main():
         srt = ",sorted" if (args.dtype == "bf16" and K == 27 and S.sorted_by_default(cin, cout, torch.bfloat16, int(pts.shape[0] * eng.cap_factor[2]))) else ""
         kname = (f"spconv_mfma_kernel<{cin},{cout},{mb},{K if K == 27 else 0},{win},bf16{srt}>"
                  if args.dtype == "bf16" else f"spconv_mfma_f32_kernel<{cin},{cout},{mb32}>")
-        # HBM bytes per launch of that kernel: NOT measured in this run (PMC counters need rocprofv3 around the process) but
-        # read from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in separate runs,
-        # gfx950 FETCH_SIZE x2 correction applied: profiles/r0N_pmc_traffic_<dtype>_b<B>.json); null when no profile of
-        # this kernel at this batch size is committed
+        # HBM bytes per launch of that kernel: MEASURED in the default run (measured_traffic: PMC counters need rocprofv3 around a
+        # process, so this script is started twice more, 3 steps each, as a child of rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; gfx950
+        # FETCH_SIZE x2 correction applied).  Child runs (--no-secondary, --no-traffic) and a failed measurement quote the committed
+        # passes of the same command (profiles/r0N_pmc_traffic_<dtype>_b<B>.json); null when there is neither
         traffic, traffic_src = None, None
         if rank == 0 and world == 1 and not args.no_traffic and not args.no_secondary and not args.graph:
             try:
